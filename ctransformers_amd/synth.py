@@ -1,0 +1,392 @@
+"""Synthetic model files at real architecture shapes (no weights are downloadable here).
+
+* numpy block quantizers producing *valid* GGML blocks (layouts: reference models/ggml/ggml.c:888-925 for
+  Q4_0/Q8_0, models/ggml/k_quants.h:76-126 for Q4_K/Q5_K/Q6_K).  They are NOT the reference's quantizers
+  (k_quants.c:600-760 search for optimal scales); a model file is an *input* that both the reference and this
+  framework read, so any valid block stream is a fair test vector.  `dequantize()` restates the reference's
+  dequantize_row_* (k_quants.c:784-821, :984-1035, :1123-1170; ggml.c:1503-1560) and is checked against the
+  reference build in tests.
+* `write_llama_gguf()` / `write_falcon_gguf()`: GGUF v2 files the reference loader accepts (key list:
+  reference models/ggml/llama.cpp:1562-1680; tensor names :294-328; per-tensor type mix of the *_K_M ftypes
+  :4785-4850).
+"""
+import numpy as np
+
+from . import gguf as G
+
+QK_K = 256
+
+# ----------------------------------------------------------------------------------------------------------------------
+# quantizers (vectorised over blocks).  x: float32 [..., K]  ->  uint8 [..., K/block * block_bytes]
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _f16(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float16)
+
+
+def _pack_scales_k4(sc, mn):
+    """sc, mn: uint8 [nb, 8] (6-bit) -> uint8 [nb, 12]; inverse of get_scale_min_k4 (reference k_quants.c:306-314)."""
+    q = np.zeros(sc.shape[:-1] + (12,), dtype=np.uint8)
+    q[..., 0:4] = (sc[..., 0:4] & 63) | ((sc[..., 4:8] >> 4) << 6)
+    q[..., 4:8] = (mn[..., 0:4] & 63) | ((mn[..., 4:8] >> 4) << 6)
+    q[..., 8:12] = (sc[..., 4:8] & 0xF) | ((mn[..., 4:8] & 0xF) << 4)
+    return q
+
+
+def _unpack_scales_k4(q):
+    sc = np.zeros(q.shape[:-1] + (8,), dtype=np.uint8)
+    mn = np.zeros_like(sc)
+    sc[..., 0:4] = q[..., 0:4] & 63
+    mn[..., 0:4] = q[..., 4:8] & 63
+    sc[..., 4:8] = (q[..., 8:12] & 0xF) | ((q[..., 0:4] >> 6) << 4)
+    mn[..., 4:8] = (q[..., 8:12] >> 4) | ((q[..., 4:8] >> 6) << 4)
+    return sc, mn
+
+
+def _kquant_affine(x, levels):
+    """Shared Q4_K/Q5_K scale search: x [nb, 8, 32] -> d, dmin (f16), sc, mn (uint8 [nb,8]), L (uint8 [nb,8,32])."""
+    lo = np.minimum(x.min(axis=-1), 0.0)
+    hi = np.maximum(x.max(axis=-1), 0.0)
+    scale = (hi - lo) / levels
+    mins = -lo
+    d = _f16(scale.max(axis=-1) / 63.0)
+    dmin = _f16(mins.max(axis=-1) / 63.0)
+    df = d.astype(np.float32)[..., None]
+    dmf = dmin.astype(np.float32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(df > 0, np.rint(scale / df), 0).clip(0, 63).astype(np.uint8)
+        mn = np.where(dmf > 0, np.rint(mins / dmf), 0).clip(0, 63).astype(np.uint8)
+        es = (df * sc)[..., None]
+        em = (dmf * mn)[..., None]
+        L = np.where(es > 0, np.rint((x + em) / es), 0).clip(0, levels).astype(np.uint8)
+    return d, dmin, sc, mn, L
+
+
+def quantize_q4_K(x):
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 8, 32)
+    d, dmin, sc, mn, L = _kquant_affine(xb, 15)
+    nb = xb.shape[0]
+    out = np.zeros((nb, 144), dtype=np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = dmin.view(np.uint8).reshape(nb, 2)
+    out[:, 4:16] = _pack_scales_k4(sc, mn)
+    Lp = L.reshape(nb, 4, 2, 32)
+    out[:, 16:144] = (Lp[:, :, 0, :] | (Lp[:, :, 1, :] << 4)).reshape(nb, 128)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q5_K(x):
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 8, 32)
+    d, dmin, sc, mn, L = _kquant_affine(xb, 31)
+    nb = xb.shape[0]
+    out = np.zeros((nb, 176), dtype=np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = dmin.view(np.uint8).reshape(nb, 2)
+    out[:, 4:16] = _pack_scales_k4(sc, mn)
+    Lp = L.reshape(nb, 4, 2, 32)
+    hb = (Lp >> 4).astype(np.uint8)  # [nb, 4, 2, 32] high bits
+    qh = np.zeros((nb, 32), dtype=np.uint8)
+    for c in range(4):
+        qh |= (hb[:, c, 0, :] << (2 * c)) | (hb[:, c, 1, :] << (2 * c + 1))
+    out[:, 16:48] = qh
+    lo = Lp & 0xF
+    out[:, 48:176] = (lo[:, :, 0, :] | (lo[:, :, 1, :] << 4)).reshape(nb, 128)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q6_K(x):
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 16, 16)
+    nb = xb.shape[0]
+    amax = np.abs(xb).max(axis=-1)
+    s = amax / 31.0
+    d = _f16(s.max(axis=-1) / 127.0)
+    df = d.astype(np.float32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(df > 0, np.rint(s / df), 0).clip(0, 127).astype(np.int8)
+        es = (df * sc.astype(np.float32))[..., None]
+        q = np.where(es > 0, np.rint(xb / es), 0).clip(-32, 31).astype(np.int32)
+    L = (q + 32).astype(np.uint8).reshape(nb, 2, 4, 32)  # [half][group of 32 within 128][l]
+    out = np.zeros((nb, 210), dtype=np.uint8)
+    ql = np.zeros((nb, 2, 64), dtype=np.uint8)
+    ql[:, :, 0:32] = (L[:, :, 0, :] & 0xF) | ((L[:, :, 2, :] & 0xF) << 4)
+    ql[:, :, 32:64] = (L[:, :, 1, :] & 0xF) | ((L[:, :, 3, :] & 0xF) << 4)
+    qh = (L[:, :, 0, :] >> 4) | ((L[:, :, 1, :] >> 4) << 2) | ((L[:, :, 2, :] >> 4) << 4) | ((L[:, :, 3, :] >> 4) << 6)
+    out[:, 0:128] = ql.reshape(nb, 128)
+    out[:, 128:192] = qh.reshape(nb, 64)
+    out[:, 192:208] = sc.view(np.uint8)
+    out[:, 208:210] = d.view(np.uint8).reshape(nb, 2)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q8_0(x):
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 32)
+    nb = xb.shape[0]
+    d = _f16(np.abs(xb).max(axis=-1) / 127.0)
+    df = d.astype(np.float32)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(df > 0, np.rint(xb / df), 0).clip(-127, 127).astype(np.int8)
+    out = np.zeros((nb, 34), dtype=np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:34] = q.view(np.uint8)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q4_0(x):
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 32)
+    nb = xb.shape[0]
+    idx = np.abs(xb).argmax(axis=-1)
+    mx = xb[np.arange(nb), idx]
+    d = _f16(mx / -8.0)
+    df = d.astype(np.float32)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(df != 0, np.floor(xb / df + 8.5), 8).clip(0, 15).astype(np.uint8)
+    out = np.zeros((nb, 18), dtype=np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:18] = q[:, 0:16] | (q[:, 16:32] << 4)
+    return out.reshape(lead + (-1,))
+
+
+def quantize(x, ggml_type):
+    if ggml_type == G.F32:
+        return np.ascontiguousarray(x, dtype=np.float32).view(np.uint8).reshape(x.shape[:-1] + (-1,))
+    if ggml_type == G.F16:
+        return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).view(np.uint8).reshape(x.shape[:-1] + (-1,))
+    return {G.Q4_K: quantize_q4_K, G.Q5_K: quantize_q5_K, G.Q6_K: quantize_q6_K, G.Q8_0: quantize_q8_0,
+            G.Q4_0: quantize_q4_0}[ggml_type](x)
+
+
+def dequantize(raw, ggml_type, K):
+    """raw: uint8 [..., row_bytes] -> float32 [..., K]; same arithmetic order as the reference dequantize_row_*."""
+    raw = np.asarray(raw, dtype=np.uint8)
+    lead = raw.shape[:-1]
+    f32 = np.float32
+    if ggml_type == G.F32:
+        return raw.view(np.float32).reshape(lead + (K,))
+    if ggml_type == G.F16:
+        return raw.view(np.float16).astype(f32).reshape(lead + (K,))
+    be, bb = G.TYPE_BLOCK[ggml_type]
+    b = raw.reshape(-1, bb)
+    nb = b.shape[0]
+    if ggml_type == G.Q4_K or ggml_type == G.Q5_K:
+        d = b[:, 0:2].copy().view(np.float16).astype(f32).reshape(nb, 1)
+        dmin = b[:, 2:4].copy().view(np.float16).astype(f32).reshape(nb, 1)
+        sc, mn = _unpack_scales_k4(b[:, 4:16])
+        if ggml_type == G.Q4_K:
+            qs = b[:, 16:144].reshape(nb, 4, 32)
+            L = np.stack([qs & 0xF, qs >> 4], axis=2).astype(f32)  # [nb,4,2,32]
+        else:
+            qh = b[:, 16:48]
+            qs = b[:, 48:176].reshape(nb, 4, 32)
+            L = np.zeros((nb, 4, 2, 32), dtype=f32)
+            for c in range(4):
+                L[:, c, 0, :] = (qs[:, c, :] & 0xF) + (((qh >> (2 * c)) & 1) * 16)
+                L[:, c, 1, :] = (qs[:, c, :] >> 4) + (((qh >> (2 * c + 1)) & 1) * 16)
+        L = L.reshape(nb, 8, 32)
+        d1 = (d * sc.astype(f32))[..., None].astype(f32)
+        m1 = (dmin * mn.astype(f32))[..., None].astype(f32)
+        y = (d1 * L).astype(f32) - m1
+        return y.reshape(lead + (K,)).astype(f32)
+    if ggml_type == G.Q6_K:
+        ql = b[:, 0:128].reshape(nb, 2, 64)
+        qh = b[:, 128:192].reshape(nb, 2, 32)
+        sc = b[:, 192:208].copy().view(np.int8).astype(f32).reshape(nb, 2, 8)
+        d = b[:, 208:210].copy().view(np.float16).astype(f32).reshape(nb)
+        q = np.zeros((nb, 2, 4, 32), dtype=np.int32)
+        q[:, :, 0, :] = (ql[:, :, 0:32] & 0xF) | (((qh >> 0) & 3) << 4)
+        q[:, :, 1, :] = (ql[:, :, 32:64] & 0xF) | (((qh >> 2) & 3) << 4)
+        q[:, :, 2, :] = (ql[:, :, 0:32] >> 4) | (((qh >> 4) & 3) << 4)
+        q[:, :, 3, :] = (ql[:, :, 32:64] >> 4) | (((qh >> 6) & 3) << 4)
+        q = (q - 32).astype(f32).reshape(nb, 2, 4, 2, 16)
+        scr = sc.reshape(nb, 2, 4, 2)  # sc[is + 2*g], is = l/16
+        # reference: y = d * sc * q  (left to right)
+        y = ((d[:, None, None, None] * scr).astype(f32)[..., None] * q).astype(f32)
+        return y.reshape(lead + (K,))
+    if ggml_type == G.Q8_0:
+        d = b[:, 0:2].copy().view(np.float16).astype(f32).reshape(nb)
+        q = b[:, 2:34].copy().view(np.int8).astype(f32)
+        return (q * d[:, None]).astype(f32).reshape(lead + (K,))
+    if ggml_type == G.Q4_0:
+        d = b[:, 0:2].copy().view(np.float16).astype(f32).reshape(nb)
+        qs = b[:, 2:18]
+        q = np.concatenate([(qs & 0xF).astype(np.int32) - 8, (qs >> 4).astype(np.int32) - 8], axis=1).astype(f32)
+        return (q * d[:, None]).astype(f32).reshape(lead + (K,))
+    raise ValueError(ggml_type)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# architectures / file type mixes
+# ----------------------------------------------------------------------------------------------------------------------
+
+LLAMA_SHAPES = {
+    # name: n_vocab, n_embd, n_head, n_head_kv, n_layer, n_ff
+    "llama-2-7b": dict(n_vocab=32000, n_embd=4096, n_head=32, n_head_kv=32, n_layer=32, n_ff=11008),
+    "llama-2-70b": dict(n_vocab=32000, n_embd=8192, n_head=64, n_head_kv=8, n_layer=80, n_ff=28672),
+    # small shapes for parity tests (K-quants need K % 256 == 0)
+    "llama-tiny": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=2, n_layer=2, n_ff=512),
+    "llama-small": dict(n_vocab=1024, n_embd=512, n_head=8, n_head_kv=8, n_layer=3, n_ff=1280),
+    # two real-width 7B layers (per-layer kernels at their true shapes, cheap on the CPU side)
+    "llama-7b-2l": dict(n_vocab=32000, n_embd=4096, n_head=32, n_head_kv=32, n_layer=2, n_ff=11008),
+}
+
+
+def use_more_bits(i, n):
+    """reference models/ggml/llama.cpp:4723-4725"""
+    return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
+def llama_tensor_types(ftype, n_layer):
+    """name -> ggml type for every 2-D tensor of a llama GGUF under an ftype (reference llama.cpp:4785-4850)."""
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K}[ftype]
+    t = {"token_embd.weight": base, "output.weight": G.Q6_K if ftype in ("Q4_K_M", "Q5_K_M", "Q4_K_S", "Q6_K") else base}
+    if ftype == "Q4_0":
+        t["output.weight"] = G.Q6_K  # reference llama.cpp:4787-4790 (non-falcon: output is always Q6_K when k-quants on)
+    for i in range(n_layer):
+        more = ftype in ("Q4_K_M", "Q5_K_M") and use_more_bits(i, n_layer)
+        for nm in ("attn_q", "attn_k", "attn_output", "ffn_gate", "ffn_up"):
+            t["blk.%d.%s.weight" % (i, nm)] = base
+        t["blk.%d.attn_v.weight" % i] = G.Q6_K if more else base
+        t["blk.%d.ffn_down.weight" % i] = G.Q6_K if more else base
+    return t
+
+
+def make_vocab(n_vocab):
+    toks = [b"<unk>", b"<s>", b"</s>"] + [b"<0x%02X>" % i for i in range(256)]
+    types = [2, 3, 3] + [6] * 256
+    i = 0
+    while len(toks) < n_vocab:
+        toks.append(("▁t%d" % i).encode("utf-8"))
+        types.append(1)
+        i += 1
+    scores = [0.0] * 259 + [-float(j + 1) for j in range(len(toks) - 259)]
+    return toks[:n_vocab], scores[:n_vocab], types[:n_vocab]
+
+
+class BlockPool:
+    """Pre-quantized pool of blocks of one ggml type, drawn from N(0, sigma); tensors are assembled by sampling
+    blocks from the pool (fast path for multi-GB synthetic models; every block is a legal quantization of real
+    Gaussian data, every tensor is a different random sequence of them)."""
+
+    def __init__(self, ggml_type, sigma, rng, n_blocks=1 << 15):
+        be, bb = G.TYPE_BLOCK[ggml_type]
+        x = rng.standard_normal((n_blocks, be), dtype=np.float32) * np.float32(sigma)
+        self.blocks = quantize(x, ggml_type).reshape(n_blocks, bb)
+        self.n, self.bb, self.be = n_blocks, bb, be
+
+    def draw(self, rng, n_blocks):
+        idx = rng.integers(0, self.n, size=n_blocks, dtype=np.int32)
+        return self.blocks[idx]
+
+
+class _WeightSource:
+    def __init__(self, seed, pooled):
+        self.rng = np.random.default_rng(seed)
+        self.pooled = pooled
+        self.pools = {}
+
+    def matrix(self, rows, K, ggml_type, sigma):
+        """-> uint8 [rows * row_bytes]"""
+        if ggml_type in (G.F32, G.F16) or not self.pooled:
+            x = self.rng.standard_normal((rows, K), dtype=np.float32) * np.float32(sigma)
+            return quantize(x, ggml_type).reshape(-1)
+        key = (ggml_type, round(float(sigma), 9))
+        if key not in self.pools:
+            self.pools[key] = BlockPool(ggml_type, sigma, self.rng)
+        pool = self.pools[key]
+        return pool.draw(self.rng, rows * (K // pool.be)).reshape(-1)
+
+    def norm(self, n):
+        return (1.0 + 0.1 * self.rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+
+
+def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_train=4096, pooled=None,
+                     rope_freq_base=None, rms_eps=1e-5, overrides=None):
+    """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict."""
+    hp = dict(LLAMA_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
+    if overrides:
+        hp.update(overrides)
+    n_vocab, n_embd, n_head, n_head_kv = hp["n_vocab"], hp["n_embd"], hp["n_head"], hp["n_head_kv"]
+    n_layer, n_ff = hp["n_layer"], hp["n_ff"]
+    head_dim = n_embd // n_head
+    n_embd_gqa = head_dim * n_head_kv
+    if pooled is None:
+        pooled = n_embd >= 2048
+    src = _WeightSource(seed, pooled)
+    types = llama_tensor_types(ftype, n_layer)
+
+    w = G.GGUFWriter(path)
+    w.add_str("general.architecture", "llama")
+    w.add_str("general.name", "synthetic-%s-%s" % (shape if isinstance(shape, str) else "custom", ftype))
+    w.add_u32("llama.context_length", n_ctx_train)
+    w.add_u32("llama.embedding_length", n_embd)
+    w.add_u32("llama.block_count", n_layer)
+    w.add_u32("llama.feed_forward_length", n_ff)
+    w.add_u32("llama.rope.dimension_count", head_dim)
+    w.add_u32("llama.attention.head_count", n_head)
+    w.add_u32("llama.attention.head_count_kv", n_head_kv)
+    w.add_f32("llama.attention.layer_norm_rms_epsilon", rms_eps)
+    if rope_freq_base is not None:
+        w.add_f32("llama.rope.freq_base", rope_freq_base)
+    toks, scores, ttypes = make_vocab(n_vocab)
+    w.add_str("tokenizer.ggml.model", "llama")
+    w.add_arr("tokenizer.ggml.tokens", G.T_STR, toks)
+    w.add_arr("tokenizer.ggml.scores", G.T_F32, scores)
+    w.add_arr("tokenizer.ggml.token_type", G.T_I32, ttypes)
+    w.add_u32("tokenizer.ggml.bos_token_id", 1)
+    w.add_u32("tokenizer.ggml.eos_token_id", 2)
+    w.add_u32("tokenizer.ggml.unknown_token_id", 0)
+
+    def mat(name, rows, K, sigma):
+        t = types[name]
+        w.add_tensor(name, (K, rows), t, lambda: src.matrix(rows, K, t, sigma))
+
+    def vec(name, n):
+        w.add_tensor(name, (n,), G.F32, lambda: src.norm(n).view(np.uint8))
+
+    s_e = 1.0 / np.sqrt(n_embd)
+    s_f = 1.0 / np.sqrt(n_ff)
+    mat("token_embd.weight", n_vocab, n_embd, 1.0)
+    for i in range(n_layer):
+        p = "blk.%d." % i
+        vec(p + "attn_norm.weight", n_embd)
+        mat(p + "attn_q.weight", n_embd, n_embd, s_e)
+        mat(p + "attn_k.weight", n_embd_gqa, n_embd, s_e)
+        mat(p + "attn_v.weight", n_embd_gqa, n_embd, s_e)
+        mat(p + "attn_output.weight", n_embd, n_embd, s_e)
+        vec(p + "ffn_norm.weight", n_embd)
+        mat(p + "ffn_gate.weight", n_ff, n_embd, s_e)
+        mat(p + "ffn_down.weight", n_embd, n_ff, s_f)
+        mat(p + "ffn_up.weight", n_ff, n_embd, s_e)
+    vec("output_norm.weight", n_embd)
+    mat("output.weight", n_vocab, n_embd, s_e)
+    w.write()
+    hp.update(head_dim=head_dim, n_embd_gqa=n_embd_gqa, ftype=ftype, rms_eps=rms_eps)
+    return hp
+
+
+def prompt_tokens(n, n_vocab=32000):
+    """The benchmark prompt of BASELINE.md §3: [BOS] + [259 + (7*i mod 3000)], clipped into the vocab."""
+    span = min(3000, n_vocab - 259)
+    return [1] + [259 + (7 * i) % span for i in range(n - 1)]
+
+
+def weight_bytes_per_token(path):
+    """Algorithmic weight bytes one decoded token must read: every 2-D tensor except token_embd (one row of it)."""
+    f = G.GGUFFile(path)
+    total = 0
+    for name, (shape, t, data) in f.tensors.items():
+        if name == "token_embd.weight":
+            total += G.row_bytes(t, shape[0])
+        else:
+            total += data.size
+    return total
