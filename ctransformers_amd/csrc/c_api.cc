@@ -1,0 +1,105 @@
+// The 17-symbol C ABI (include/ctransformers_llm.h) over ctamd::Engine.
+#include "../../include/ctransformers_llm.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+struct ctransformers_llm {
+    ctamd::Engine engine;
+    std::string arch;
+    std::string piece;  // storage behind ctransformers_llm_detokenize
+};
+
+static bool file_is_gguf(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    uint32_t magic = 0;
+    const size_t n = fread(&magic, 1, 4, f);
+    fclose(f);
+    return n == 4 && magic == 0x46554747u;
+}
+
+extern "C" {
+
+ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* model_type,
+                                            struct ctransformers_config config) {
+    if (!model_path || !model_type) return nullptr;
+    std::string type;
+    for (const char* p = model_type; *p; ++p)
+        if (isalnum((unsigned char)*p)) type.push_back(*p);
+    if (!(type == "gguf" || file_is_gguf(model_path))) {
+        // Legacy (pre-GGUF) GGML architectures of the reference (models/llm.cc:47-65) are outside the hot-path scope.
+        fprintf(stderr, "Model type '%s' is not supported.\n", model_type);
+        return nullptr;
+    }
+    ctransformers_llm* llm = new ctransformers_llm;
+    std::string err;
+    if (!llm->engine.load(model_path, config.context_length, config.gpu_layers, err)) {
+        fprintf(stderr, "ctransformers_amd: failed to load '%s': %s\n", model_path, err.c_str());
+        delete llm;
+        return nullptr;
+    }
+    llm->arch = llm->engine.hparams().arch;
+    return llm;
+}
+
+void ctransformers_llm_delete(ctransformers_llm* llm) { delete llm; }
+
+int ctransformers_llm_tokenize(ctransformers_llm* llm, const char* text, bool add_bos_token, int* output) {
+    const std::vector<int> t = llm->engine.vocab().tokenize(text, add_bos_token);
+    std::copy(t.begin(), t.end(), output);
+    return (int)t.size();
+}
+
+const char* ctransformers_llm_detokenize(ctransformers_llm* llm, int token) {
+    llm->piece = llm->engine.vocab().piece(token);
+    return llm->piece.c_str();
+}
+
+bool ctransformers_llm_is_eos_token(ctransformers_llm* llm, int token) { return token == llm->engine.vocab().eos_id; }
+int ctransformers_llm_eos_token_id(ctransformers_llm* llm) { return llm->engine.vocab().eos_id; }
+int ctransformers_llm_bos_token_id(ctransformers_llm* llm) { return llm->engine.vocab().bos_id; }
+int ctransformers_llm_vocab_size(ctransformers_llm* llm) { return llm->engine.hparams().n_vocab; }
+int ctransformers_llm_context_length(ctransformers_llm* llm) { return llm->engine.n_ctx(); }
+const char* ctransformers_llm_architecture(ctransformers_llm* llm) { return llm->arch.c_str(); }
+
+bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, int batch_size,
+                                  int threads) {
+    (void)threads;
+    const int n_ctx = llm->engine.n_ctx();
+    batch_size = std::min(n_ctx, batch_size);
+    if (batch_size <= 0) return n_tokens <= 0;
+    for (int start = 0; start < n_tokens; start += batch_size) {
+        const int n = std::min(batch_size, n_tokens - start);
+        const int past = std::min(n_ctx - n, n_past);  // reference models/llm.h:126
+        std::string err;
+        if (!llm->engine.eval(tokens + start, n, past, err)) {
+            fprintf(stderr, "ctransformers_amd: eval failed: %s\n", err.c_str());
+            return false;
+        }
+        n_past += n;
+    }
+    return true;
+}
+
+float* ctransformers_llm_logits_data(ctransformers_llm* llm) { return llm->engine.logits(); }
+int ctransformers_llm_logits_size(ctransformers_llm* llm) { return llm->engine.logits_size(); }
+const float* ctransformers_llm_embeddings_data(ctransformers_llm* llm) { return llm->engine.embeddings(); }
+int ctransformers_llm_embeddings_size(ctransformers_llm* llm) { return llm->engine.embeddings_size(); }
+
+int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int n_last, int top_k, float top_p,
+                             float temperature, float repetition_penalty, int seed) {
+    if (llm->engine.logits_size() == 0) return llm->engine.vocab().eos_id;
+    return ctamd::sample_token(llm->engine.logits(), llm->engine.hparams().n_vocab, last_tokens, n_last, top_k, top_p,
+                               temperature, repetition_penalty, seed);
+}
+
+void ctransformers_llm_reset(ctransformers_llm* llm) { (void)llm; }
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+#include "engine.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+#include <thread>
+
+#include "gguf_reader.h"
+#include "kernels.h"
+
+namespace ctamd {
+
+#define HIP_OK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            err = std::string(#expr) + " failed: " + hipGetErrorString(e_);                                 \
+            return false;                                                                                    \
+        }                                                                                                    \
+    } while (0)
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+Engine::~Engine() { free_all(); }
+
+void Engine::free_all() {
+    for (void* p : dev_allocs_) (void)hipFree(p);
+    dev_allocs_.clear();
+    if (h_logits_) (void)hipHostFree(h_logits_);
+    if (h_emb_) (void)hipHostFree(h_emb_);
+    if (h_scalars_) (void)hipHostFree(h_scalars_);
+    h_logits_ = h_emb_ = nullptr;
+    h_scalars_ = nullptr;
+#ifndef CT_EMU
+    if (graph_step_) (void)hipGraphExecDestroy(graph_step_);
+    if (graph_step_head_) (void)hipGraphExecDestroy(graph_step_head_);
+    graph_step_ = graph_step_head_ = nullptr;
+#endif
+    if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+}
+
+template <class T> static bool dev_alloc(std::vector<void*>& pool, T** out, size_t n_elems, std::string& err) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n_elems * sizeof(T), 256);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc(") + std::to_string(bytes) + ") failed: " + hipGetErrorString(e);
+        return false;
+    }
+    pool.push_back(p);
+    *out = (T*)p;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Load-time repack of file-layout blocks into per-row byte planes (see quant.h).  Values are untouched.
+// ---------------------------------------------------------------------------------------------------------------------
+static void parallel_rows(int M, const std::function<void(int, int)>& fn) {
+    const int nt = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+    if (M < 4 * nt) { fn(0, M); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        const int r0 = (int)((long long)M * t / nt), r1 = (int)((long long)M * (t + 1) / nt);
+        th.emplace_back([=, &fn] { fn(r0, r1); });
+    }
+    for (auto& t : th) t.join();
+}
+
+bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::string& err) {
+    m.type = t->type;
+    m.K = (int)t->ne[0];
+    m.M = (int)t->ne[1];
+    const int be = ggml_block_elems(t->type), bb = ggml_block_bytes(t->type);
+    if (!(is_kquant(t->type) || t->type == GT_Q8_0 || t->type == GT_Q4_0)) {
+        err = "tensor " + t->name + ": weight type " + std::to_string(t->type) + " has no mat-vec kernel yet";
+        return false;
+    }
+    m.nb = m.K / be;
+    m.bytes = t->nbytes;
+    const int nb = m.nb, M = m.M;
+    int psz[4] = {0, 0, 0, 0};  // bytes per block in each plane
+    switch (t->type) {
+        case GT_Q4_K: psz[0] = 128; psz[1] = 16; break;
+        case GT_Q5_K: psz[0] = 128; psz[1] = 16; psz[2] = 32; break;
+        case GT_Q6_K: psz[0] = 128; psz[1] = 16; psz[2] = 64; psz[3] = 2; break;
+        case GT_Q8_0: psz[0] = 32; psz[3] = 2; break;
+        case GT_Q4_0: psz[0] = 16; psz[3] = 2; break;
+    }
+    std::vector<uint8_t> stage[4];
+    for (int k = 0; k < 4; ++k) stage[k].resize((size_t)psz[k] * nb * M);
+    const uint8_t* src = t->data;
+    const int type = t->type;
+    parallel_rows(M, [&](int r0, int r1) {
+        for (size_t i = (size_t)r0 * nb; i < (size_t)r1 * nb; ++i) {
+            const uint8_t* b = src + i * bb;
+            switch (type) {
+                case GT_Q4_K:
+                    memcpy(&stage[1][i * 16], b, 16);
+                    memcpy(&stage[0][i * 128], b + 16, 128);
+                    break;
+                case GT_Q5_K:
+                    memcpy(&stage[1][i * 16], b, 16);
+                    memcpy(&stage[2][i * 32], b + 16, 32);
+                    memcpy(&stage[0][i * 128], b + 48, 128);
+                    break;
+                case GT_Q6_K:
+                    memcpy(&stage[0][i * 128], b, 128);
+                    memcpy(&stage[2][i * 64], b + 128, 64);
+                    memcpy(&stage[1][i * 16], b + 192, 16);
+                    memcpy(&stage[3][i * 2], b + 208, 2);
+                    break;
+                case GT_Q8_0:
+                    memcpy(&stage[3][i * 2], b, 2);
+                    memcpy(&stage[0][i * 32], b + 2, 32);
+                    break;
+                case GT_Q4_0:
+                    memcpy(&stage[3][i * 2], b, 2);
+                    memcpy(&stage[0][i * 16], b + 2, 16);
+                    break;
+            }
+        }
+    });
+    for (int k = 0; k < 4; ++k) {
+        if (!psz[k]) continue;
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, stage[k].size() + 64, err)) return false;  // +64: tail slack for 16-B loads
+        HIP_OK(hipMemcpy(d, stage[k].data(), stage[k].size(), hipMemcpyHostToDevice));
+        m.p[k] = d;
+    }
+    if (keep_raw) {
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, t->nbytes, err)) return false;
+        HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
+        m.raw = d;
+    }
+    return true;
+}
+
+bool Engine::upload_f32(const GgufTensor* t, float** out, int n, std::string& err) {
+    if (!t) { err = "missing f32 tensor"; return false; }
+    if (t->type != GT_F32 || t->ne[0] != n) { err = "tensor " + t->name + " must be f32[" + std::to_string(n) + "]"; return false; }
+    if (!dev_alloc(dev_allocs_, out, (size_t)n, err)) return false;
+    HIP_OK(hipMemcpy(*out, t->data, (size_t)n * 4, hipMemcpyHostToDevice));
+    return true;
+}
+
+// fp16 lookup tables with the reference's exact contents (ggml.c:4318-4332, built with the host libm like the
+// reference does), and the RoPE cos/sin table with the reference's iterative theta (ggml.c:12482-12539).
+bool Engine::build_tables(std::string& err) {
+    std::vector<uint16_t> e(65536), s(65536), g(65536);
+    for (int i = 0; i < 65536; ++i) {
+        const float f = f16_bits_to_f32((uint16_t)i);
+        e[i] = f32_to_f16_bits(expf(f));
+        s[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));
+        g[i] = f32_to_f16_bits(0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f))));
+    }
+    if (!dev_alloc(dev_allocs_, &exp_tab_, 65536, err) || !dev_alloc(dev_allocs_, &silu_tab_, 65536, err) ||
+        !dev_alloc(dev_allocs_, &gelu_tab_, 65536, err))
+        return false;
+    HIP_OK(hipMemcpy(exp_tab_, e.data(), 65536 * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(silu_tab_, s.data(), 65536 * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(gelu_tab_, g.data(), 65536 * 2, hipMemcpyHostToDevice));
+
+    const int hd = hp_.head_dim(), half = hd / 2;
+    std::vector<float> cs((size_t)n_ctx_ * half * 2);
+    const float theta_scale = powf(hp_.rope_freq_base, -2.0f / (float)hp_.n_rot);
+    for (int p = 0; p < n_ctx_; ++p) {
+        float theta = hp_.rope_freq_scale * (float)p;
+        for (int i = 0; i < half; ++i) {
+            cs[((size_t)p * half + i) * 2 + 0] = cosf(theta);
+            cs[((size_t)p * half + i) * 2 + 1] = sinf(theta);
+            theta *= theta_scale;
+        }
+    }
+    if (!dev_alloc(dev_allocs_, &rope_cs_, cs.size(), err)) return false;
+    HIP_OK(hipMemcpy(rope_cs_, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    return true;
+}
+
+bool Engine::load(const std::string& path, int context_length, int gpu_layers, std::string& err) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
+        return false;
+    }
+    HIP_OK(hipSetDevice(0));
+    (void)gpu_layers;  // every layer lives on the GPU(s); the CPU/GPU split of the reference does not exist here
+    pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
+    max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 2048));
+
+    GgufFile f;
+    if (!f.open(path)) { err = f.error(); return false; }
+    if (!f.get_str("general.architecture", hp_.arch)) { err = "general.architecture missing"; return false; }
+    if (hp_.arch != "llama") { err = "architecture '" + hp_.arch + "' is not supported yet (llama only)"; return false; }
+    const std::string a = hp_.arch + ".";
+    uint32_t u;
+    auto need = [&](const char* key, int& out) {
+        if (!f.get_u32(a + key, u)) { err = "missing key " + a + key; return false; }
+        out = (int)u;
+        return true;
+    };
+    if (!need("context_length", hp_.n_ctx_train) || !need("embedding_length", hp_.n_embd) ||
+        !need("attention.head_count", hp_.n_head) || !need("block_count", hp_.n_layer) ||
+        !need("feed_forward_length", hp_.n_ff))
+        return false;
+    hp_.n_head_kv = hp_.n_head;
+    if (f.get_u32(a + "attention.head_count_kv", u)) hp_.n_head_kv = (int)u;
+    hp_.n_rot = hp_.n_embd / hp_.n_head;
+    if (f.get_u32(a + "rope.dimension_count", u)) hp_.n_rot = (int)u;
+    if (!f.get_f32(a + "attention.layer_norm_rms_epsilon", hp_.rms_eps)) { err = "missing rms epsilon"; return false; }
+    f.get_f32(a + "rope.freq_base", hp_.rope_freq_base);
+    float rs = 1.0f;
+    if (f.get_f32(a + "rope.scale_linear", rs) && rs != 0.0f) hp_.rope_freq_scale = 1.0f / rs;
+    if (hp_.n_rot != hp_.head_dim()) { err = "rope.dimension_count must equal head_dim"; return false; }
+    if (hp_.head_dim() % 8 || 64 % (hp_.head_dim() / 8)) { err = "unsupported head_dim"; return false; }
+    if (!vocab_.load(f, err)) return false;
+    hp_.n_vocab = vocab_.size();
+    // reference default n_ctx = 512 unless context_length is passed (llama.cpp:5281, llama.cc:90-92)
+    n_ctx_ = context_length > 0 ? context_length : 512;
+    if (n_ctx_ > kMaxCtx) { err = "context_length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
+
+    HIP_OK(hipStreamCreate(&stream_));
+    const GgufTensor* t;
+    auto mat = [&](const std::string& name, DevMat& m, int M, int K, bool raw = false) {
+        t = f.tensor(name);
+        if (!t) { err = "missing tensor " + name; return false; }
+        if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
+        if (!upload_matrix(t, m, raw, err)) return false;
+        weight_bytes_ += t->nbytes;
+        return true;
+    };
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, V = hp_.n_vocab;
+    t = f.tensor("token_embd.weight");
+    if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
+    {   // token_embd is only used by row lookup: keep the file layout, no planes
+        tok_embd_.type = t->type; tok_embd_.K = E; tok_embd_.M = V;
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, t->nbytes, err)) return false;
+        HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
+        tok_embd_.raw = d;
+    }
+    layers_.resize(hp_.n_layer);
+    for (int i = 0; i < hp_.n_layer; ++i) {
+        const std::string p = "blk." + std::to_string(i) + ".";
+        Layer& L = layers_[i];
+        if (!upload_f32(f.tensor(p + "attn_norm.weight"), &L.attn_norm, E, err)) return false;
+        if (!upload_f32(f.tensor(p + "ffn_norm.weight"), &L.ffn_norm, E, err)) return false;
+        if (!mat(p + "attn_q.weight", L.wq, E, E) || !mat(p + "attn_k.weight", L.wk, G, E) ||
+            !mat(p + "attn_v.weight", L.wv, G, E) || !mat(p + "attn_output.weight", L.wo, E, E) ||
+            !mat(p + "ffn_gate.weight", L.w_gate, F, E) || !mat(p + "ffn_up.weight", L.w_up, F, E) ||
+            !mat(p + "ffn_down.weight", L.w_down, E, F))
+            return false;
+        if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
+    }
+    if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
+    if (!mat("output.weight", output_, V, E)) return false;
+
+    const size_t kv_elems = (size_t)hp_.n_layer * n_ctx_ * G;
+    if (!dev_alloc(dev_allocs_, &kcache_, kv_elems, err) || !dev_alloc(dev_allocs_, &vcache_, kv_elems, err)) return false;
+    HIP_OK(hipMemset(kcache_, 0, kv_elems * 2));
+    HIP_OK(hipMemset(vcache_, 0, kv_elems * 2));
+    if (!dev_alloc(dev_allocs_, &x_, (size_t)E, err) || !dev_alloc(dev_allocs_, &attn_out_, (size_t)E, err) ||
+        !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
+        !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
+        !dev_alloc(dev_allocs_, &d_logits_, (size_t)V, err) || !dev_alloc(dev_allocs_, &d_emb_, (size_t)E, err) ||
+        !dev_alloc(dev_allocs_, &d_tokens_, (size_t)n_ctx_, err) || !dev_alloc(dev_allocs_, &d_state_, 4, err))
+        return false;
+    HIP_OK(hipHostMalloc(&h_logits_, (size_t)V * 4));
+    HIP_OK(hipHostMalloc(&h_emb_, (size_t)E * 4));
+    HIP_OK(hipHostMalloc(&h_scalars_, ((size_t)n_ctx_ + 16) * 4));
+    use_graph_ = env_int("CT_AMD_GRAPH", 1) != 0;
+    memset(h_logits_, 0, (size_t)V * 4);
+    memset(h_emb_, 0, (size_t)E * 4);
+    if (!build_tables(err)) return false;
+    HIP_OK(hipDeviceSynchronize());
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------------------
+static bool launch_matvec(MatvecArgs& a, int pairs_per_wave, int max_wgs, hipStream_t s, std::string& err) {
+    const int type0 = a.job[0].w.type;
+    if (!is_kquant(type0)) { err = "mat-vec kernel for weight type " + std::to_string(type0) + " not implemented yet"; return false; }
+    const int nb = a.job[0].w.nb;
+    const int need_i = (nb * 8 + 63) / 64;
+    constexpr int NT = 256, NW = NT / 64;
+    int waves = (a.n_pairs + pairs_per_wave - 1) / pairs_per_wave;
+    int wgs = std::max(1, std::min(max_wgs, (waves + NW - 1) / NW));
+    const dim3 grid((unsigned)wgs), block((unsigned)NT);
+    if (need_i <= 1) CT_LAUNCH((matvec_kq_kernel<NT, 1, 12288>), grid, block, s, a);
+    else if (need_i <= 2) CT_LAUNCH((matvec_kq_kernel<NT, 2, 12288>), grid, block, s, a);
+    else if (need_i <= 4) CT_LAUNCH((matvec_kq_kernel<NT, 4, 12288>), grid, block, s, a);
+    else if (need_i <= 6 && a.K <= 12288) CT_LAUNCH((matvec_kq_kernel<NT, 6, 12288>), grid, block, s, a);
+    else if (need_i <= 8) CT_LAUNCH((matvec_kq_kernel<NT, 8, 32768>), grid, block, s, a);
+    else { err = "mat-vec with K=" + std::to_string(a.K) + " not supported yet"; return false; }
+    return true;
+}
+
+static void set_jobs(MatvecArgs& a, std::initializer_list<std::pair<const DevMat*, int>> jobs) {
+    int j = 0, pair0 = 0;
+    for (auto& it : jobs) {
+        a.job[j].w = *it.first;
+        a.job[j].epi = it.second;
+        a.job[j].pair0 = pair0;
+        pair0 += (it.first->M + 1) / 2;
+        ++j;
+    }
+    a.njobs = j;
+    a.n_pairs = pair0;
+}
+
+bool Engine::token_step(bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+              (const int*)d_tokens_, (const int*)d_state_, x_);
+    MatvecArgs base = MatvecArgs();
+    base.rope_cs = rope_cs_;
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = G;
+    base.silu_tab = silu_tab_;
+    base.eps = hp_.rms_eps;
+    AttnArgs at = AttnArgs();
+    at.q_f16 = q_f16_;
+    at.scores = scores_;
+    at.out = attn_out_;
+    at.pos = d_pos;
+    at.exp_tab = exp_tab_;
+    at.n_head = hp_.n_head;
+    at.n_head_kv = hp_.n_head_kv;
+    at.head_dim = hd;
+    at.n_embd_gqa = G;
+    at.n_ctx = n_ctx_;
+    at.kq_scale = 1.0f / sqrtf((float)E / (float)hp_.n_head);
+    at.chunk = 64;
+    const int n_chunks = (n_ctx_ + at.chunk - 1) / at.chunk;
+    constexpr int DCH = 16;
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)il * n_ctx_ * G;
+        {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
+            a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
+            set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
+            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+        }
+        at.kcache = kc;
+        at.vcache = vc;
+        CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
+        CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
+        {   // Q8_K(attn) -> Wo -> + residual
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
+            set_jobs(a, {{&L.wo, EPI_ADD}});
+            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+        }
+        {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.ffn_norm; a.out = h_;
+            a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
+            a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
+            a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+        }
+        {   // Q8_K(h) -> W_down -> + residual
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
+            set_jobs(a, {{&L.w_down, EPI_ADD}});
+            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+        }
+    }
+    if (want_logits) {
+        CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
+                  hp_.rms_eps);
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+    }
+    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    return true;
+}
+
+// One token step is ~6 launches per layer; replaying it from a hipGraph removes the host launch cost (eager goes
+// host-bound below ~3 us per kernel — guide "graph-replay-floor").  Two graphs: with and without the lm_head tail.
+bool Engine::ensure_graphs(std::string& err) {
+#ifndef CT_EMU
+    if (graph_step_) return true;
+    for (int head = 0; head < 2; ++head) {
+        hipGraph_t g = nullptr;
+        HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+        const bool ok = token_step(head == 1, err);
+        hipError_t e = hipStreamEndCapture(stream_, &g);
+        if (!ok) return false;
+        if (e != hipSuccess) { err = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e); return false; }
+        hipGraphExec_t ex = nullptr;
+        HIP_OK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+        HIP_OK(hipGraphDestroy(g));
+        (head ? graph_step_head_ : graph_step_) = ex;
+    }
+#endif
+    (void)err;
+    return true;
+}
+
+bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
+    if (n <= 0) return true;
+    if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
+    for (int i = 0; i < n; ++i) {
+        if (tokens[i] < 0 || tokens[i] >= hp_.n_vocab) { err = "token id out of range"; return false; }
+        h_scalars_[2 + i] = tokens[i];
+    }
+    h_scalars_[0] = 0;       // step
+    h_scalars_[1] = n_past;  // position of the first token of this chunk
+    HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[2], (size_t)n * 4, hipMemcpyHostToDevice, stream_));
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 8, hipMemcpyHostToDevice, stream_));
+#ifndef CT_EMU
+    if (use_graph_) {
+        if (!ensure_graphs(err)) return false;
+        for (int i = 0; i < n; ++i) HIP_OK(hipGraphLaunch(i == n - 1 ? graph_step_head_ : graph_step_, stream_));
+    } else
+#endif
+    {
+        for (int i = 0; i < n; ++i)
+            if (!token_step(i == n - 1, err)) return false;
+    }
+    HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)hp_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(h_emb_, d_emb_, (size_t)hp_.n_embd * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipGetLastError());
+    have_logits_ = true;
+    return true;
+}
+
+bool Engine::run_matvec_test(int, int, int, const uint8_t*, const float*, const float*, float, float*, int, float*,
+                             std::string& err) {
+    err = "not implemented";
+    return false;
+}
+
+}  // namespace ctamd

@@ -1,0 +1,88 @@
+// Host layer of the MI355X inference core: model load (GGUF -> repacked device planes), per-context state (KV cache,
+// scratch, tables) and the per-token launch sequence that replaces the reference's llama_eval_internal
+// (models/ggml/llama.cpp:2835-2981) + llm_build_llama graph (:2162-2491) + ggml_graph_compute.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "gpu.h"
+#include "host_text.h"
+#include "quant.h"
+
+namespace ctamd {
+
+struct HParams {
+    std::string arch;
+    int n_vocab = 0, n_embd = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_ff = 0, n_rot = 0, n_ctx_train = 0;
+    float rms_eps = 1e-5f, rope_freq_base = 10000.0f, rope_freq_scale = 1.0f;
+    int head_dim() const { return n_embd / n_head; }
+    int n_embd_gqa() const { return head_dim() * n_head_kv; }
+};
+
+struct Layer {
+    float* attn_norm = nullptr;
+    float* ffn_norm = nullptr;
+    DevMat wq, wk, wv, wo, w_gate, w_up, w_down;
+};
+
+class Engine {
+   public:
+    Engine() {}
+    ~Engine();
+    // Loads the model onto the visible GPU(s).  Fails (false + message) when no HIP device is present: there is no
+    // CPU path in this library.
+    bool load(const std::string& path, int context_length, int gpu_layers, std::string& err);
+    // Evaluate `n` tokens at absolute positions n_past..n_past+n-1 (KV cache overwrite semantics); logits and the
+    // final-norm embedding of the LAST token land in the pinned host buffers.
+    bool eval(const int* tokens, int n, int n_past, std::string& err);
+
+    const HParams& hparams() const { return hp_; }
+    const Vocab& vocab() const { return vocab_; }
+    int n_ctx() const { return n_ctx_; }
+    float* logits() { return h_logits_; }
+    int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
+    const float* embeddings() const { return h_emb_; }
+    int embeddings_size() const { return have_logits_ ? hp_.n_embd : 0; }
+    size_t weight_bytes() const { return weight_bytes_; }
+
+    // test/bench hooks (exported through ctamd_* C symbols)
+    bool run_matvec_test(int type, int M, int K, const uint8_t* raw, const float* x, const float* norm_w, float eps,
+                         float* out, int iters, float* ms_per_iter, std::string& err);
+
+   private:
+    bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
+    bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
+    bool build_tables(std::string& err);
+    bool token_step(bool want_logits, std::string& err);
+    bool ensure_graphs(std::string& err);
+    void free_all();
+
+    HParams hp_;
+    Vocab vocab_;
+    int n_ctx_ = 0;
+    DevMat tok_embd_, output_;
+    float* output_norm_ = nullptr;
+    std::vector<Layer> layers_;
+    size_t weight_bytes_ = 0;
+
+    hipStream_t stream_ = nullptr;
+    uint16_t* kcache_ = nullptr;
+    uint16_t* vcache_ = nullptr;
+    float *x_ = nullptr, *attn_out_ = nullptr, *h_ = nullptr, *scores_ = nullptr, *d_logits_ = nullptr, *d_emb_ = nullptr;
+    uint16_t* q_f16_ = nullptr;
+    float* rope_cs_ = nullptr;
+    uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;
+    int *d_tokens_ = nullptr, *d_state_ = nullptr;  // token ids of the current chunk; {step, pos} cursor
+    float *h_logits_ = nullptr, *h_emb_ = nullptr;
+    int* h_scalars_ = nullptr;  // pinned staging for the token ids + cursor
+    bool use_graph_ = false;
+#ifndef CT_EMU
+    hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
+#endif
+    bool have_logits_ = false;
+    std::vector<void*> dev_allocs_;
+    int pairs_per_wave_ = 2, max_wgs_ = 2048;
+};
+
+}  // namespace ctamd

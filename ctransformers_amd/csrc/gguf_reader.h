@@ -1,0 +1,64 @@
+// GGUF v1/v2/v3 reader (mmap, zero-copy tensor views).  Restates the container format the reference parses in
+// models/ggml/ggml.c:19561-19880 (gguf_init_from_file): header :19473-19493, KV pairs :19626-19707 (value type ids
+// ggml.h:1830-1845), tensor infos :19709-19742, data section aligned to general.alignment (default 32) :19744-19759.
+#pragma once
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ctamd {
+
+enum GgufValueType : uint32_t {
+    GV_U8 = 0, GV_I8, GV_U16, GV_I16, GV_U32, GV_I32, GV_F32, GV_BOOL, GV_STR, GV_ARR, GV_U64, GV_I64, GV_F64,
+};
+
+struct GgufValue {
+    uint32_t type = 0;
+    uint32_t elem_type = 0;     // for arrays
+    uint64_t u = 0;             // integer / bool payload
+    double f = 0.0;             // float payload
+    std::string s;              // string payload
+    uint64_t n = 0;             // array length
+    const uint8_t* arr = nullptr;       // start of packed array payload (non-string arrays)
+    std::vector<std::string> strs;      // string arrays
+};
+
+struct GgufTensor {
+    std::string name;
+    int n_dims = 0;
+    int64_t ne[4] = {1, 1, 1, 1};
+    int type = 0;
+    uint64_t offset = 0;
+    const uint8_t* data = nullptr;
+    size_t nbytes = 0;
+};
+
+class GgufFile {
+   public:
+    ~GgufFile();
+    // returns false (and sets error()) on malformed input
+    bool open(const std::string& path);
+    const std::string& error() const { return err_; }
+    uint32_t version() const { return version_; }
+
+    const GgufValue* find(const std::string& key) const;
+    bool get_u32(const std::string& key, uint32_t& out) const;
+    bool get_f32(const std::string& key, float& out) const;
+    bool get_str(const std::string& key, std::string& out) const;
+    const GgufTensor* tensor(const std::string& name) const;
+    const std::vector<GgufTensor>& tensors() const { return tensors_; }
+
+   private:
+    bool fail(const std::string& m) { err_ = m; return false; }
+    std::string err_;
+    int fd_ = -1;
+    const uint8_t* map_ = nullptr;
+    size_t size_ = 0;
+    uint32_t version_ = 0;
+    std::map<std::string, GgufValue> kv_;
+    std::vector<GgufTensor> tensors_;
+    std::map<std::string, size_t> tindex_;
+};
+
+}  // namespace ctamd

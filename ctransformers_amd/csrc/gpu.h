@@ -1,0 +1,60 @@
+// Device dialect shared by every kernel in this directory.  Product build: hipcc --offload-arch=gfx950 (CDNA4,
+// wave64).  The only other build is the test-only CPU emulation (g++ -DCT_EMU, tests/emu/) which re-implements the
+// handful of names below so kernel logic can be checked without a GPU; nothing of it is linked into the product.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef CT_EMU
+#include "emu_runtime.h"
+#else
+#include <hip/hip_runtime.h>
+#define CT_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+#endif
+
+#define DEV __device__ __forceinline__
+constexpr int kWave = 64;  // CDNA wavefront width; hard-coded on purpose (MI355X_MICROARCH.md "wave = 64 not 32")
+
+// ---- fp16 bit conversions (IEEE binary16, round-to-nearest-even; == x86 F16C used by the reference build) -----------
+#ifdef CT_EMU
+static inline uint16_t f32_to_f16_bits(float f) { return (uint16_t)_cvtss_sh(f, 0); }
+static inline float f16_bits_to_f32(uint16_t h) { return _cvtsh_ss(h); }
+#else
+__host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32 on device, RNE on both sides
+    return __builtin_bit_cast(uint16_t, h);
+}
+__host__ __device__ __forceinline__ float f16_bits_to_f32(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+#endif
+
+DEV int lane_id() { return (int)(threadIdx.x & 63); }
+DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+
+template <class T> DEV T wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// ---- 16-byte streaming load (weights are read once per token: non-temporal, `nt-weights` row of the guide) ----------
+#ifdef CT_EMU
+struct u32x4 {
+    uint32_t v[4];
+    uint32_t operator[](int i) const { return v[i]; }
+};
+static inline u32x4 ld_stream16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }
+static inline u32x4 ld16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }
+#else
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+DEV u32x4 ld_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+DEV u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+#endif

@@ -1,0 +1,248 @@
+#include "host_text.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+#include <algorithm>
+#include <map>
+#include <queue>
+
+#include "gguf_reader.h"
+
+namespace ctamd {
+
+bool Vocab::load(const GgufFile& f, std::string& err) {
+    std::string model = "llama";
+    f.get_str("tokenizer.ggml.model", model);
+    if (model == "llama") {
+        type = VOCAB_SPM;
+        bos_id = 1; eos_id = 2; unk_id = 0;
+    } else if (model == "gpt2") {
+        type = VOCAB_BPE;
+        bos_id = 11; eos_id = 11; unk_id = -1;
+    } else {
+        err = "unknown tokenizer model '" + model + "'";
+        return false;
+    }
+    const GgufValue* toks = f.find("tokenizer.ggml.tokens");
+    if (!toks || toks->type != GV_ARR || toks->elem_type != GV_STR) { err = "tokenizer.ggml.tokens missing"; return false; }
+    const size_t n = toks->strs.size();
+    text = toks->strs;
+    score.assign(n, 0.0f);
+    ttype.assign(n, TT_NORMAL);
+    const GgufValue* sc = f.find("tokenizer.ggml.scores");
+    if (sc && sc->type == GV_ARR && sc->elem_type == GV_F32 && sc->n == n) memcpy(score.data(), sc->arr, n * 4);
+    const GgufValue* tt = f.find("tokenizer.ggml.token_type");
+    if (tt && tt->type == GV_ARR && (tt->elem_type == GV_I32 || tt->elem_type == GV_U32) && tt->n == n)
+        memcpy(ttype.data(), tt->arr, n * 4);
+    to_id.reserve(n * 2);
+    for (size_t i = 0; i < n; ++i) to_id[text[i]] = (int)i;
+    uint32_t v;
+    if (f.get_u32("tokenizer.ggml.bos_token_id", v)) bos_id = (int)v;
+    if (f.get_u32("tokenizer.ggml.eos_token_id", v)) eos_id = (int)v;
+    if (f.get_u32("tokenizer.ggml.unknown_token_id", v)) unk_id = (int)v;
+    return true;
+}
+
+namespace {
+size_t utf8_len(char c) {
+    static const size_t lookup[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4};
+    return lookup[(uint8_t)c >> 4];
+}
+void replace_all(std::string& s, const std::string& a, const std::string& b) {
+    std::string out;
+    size_t pos = 0;
+    for (;;) {
+        const size_t hit = s.find(a, pos);
+        if (hit == std::string::npos) { out.append(s, pos, std::string::npos); break; }
+        out.append(s, pos, hit - pos);
+        out += b;
+        pos = hit + a.size();
+    }
+    s.swap(out);
+}
+
+// Greedy highest-score bigram merging over a linked list of UTF-8 characters, then byte fallback for leftovers.
+struct Sym { int prev, next; const char* p; size_t n; };
+struct Bigram { int left, right; float score; size_t size; };
+struct BigramLess {
+    bool operator()(const Bigram& l, const Bigram& r) const {
+        return l.score < r.score || (l.score == r.score && l.left > r.left);
+    }
+};
+
+class SpmRun {
+   public:
+    explicit SpmRun(const Vocab& v) : v_(v) {}
+    void run(const std::string& text, std::vector<int>& out) {
+        size_t off = 0;
+        int idx = 0;
+        while (off < text.size()) {
+            size_t len = std::min(utf8_len(text[off]), text.size() - off);
+            Sym s{idx - 1, -1, text.data() + off, len};
+            off += len;
+            s.next = off == text.size() ? -1 : idx + 1;
+            syms_.push_back(s);
+            ++idx;
+        }
+        for (size_t i = 1; i < syms_.size(); ++i) try_add((int)i - 1, (int)i);
+        while (!q_.empty()) {
+            const Bigram b = q_.top();
+            q_.pop();
+            Sym& l = syms_[b.left];
+            Sym& r = syms_[b.right];
+            if (l.n == 0 || r.n == 0 || l.n + r.n != b.size) continue;
+            l.n += r.n;
+            r.n = 0;
+            l.next = r.next;
+            if (r.next >= 0) syms_[r.next].prev = b.left;
+            try_add(l.prev, b.left);
+            try_add(b.left, l.next);
+        }
+        if (syms_.empty()) return;
+        for (int i = 0; i != -1; i = syms_[i].next) emit(syms_[i], out);
+    }
+
+   private:
+    void emit(const Sym& s, std::vector<int>& out) {
+        const std::string t(s.p, s.n);
+        auto it = v_.to_id.find(t);
+        if (it != v_.to_id.end()) { out.push_back(it->second); return; }
+        auto rm = rev_.find(t);
+        if (rm == rev_.end()) {
+            for (size_t j = 0; j < s.n; ++j) {
+                char buf[8];
+                snprintf(buf, sizeof(buf), "<0x%02X>", (unsigned)(uint8_t)s.p[j]);
+                auto bt = v_.to_id.find(buf);
+                out.push_back(bt == v_.to_id.end() ? v_.unk_id : bt->second);
+            }
+            return;
+        }
+        emit(syms_[rm->second.first], out);
+        emit(syms_[rm->second.second], out);
+    }
+    void try_add(int left, int right) {
+        if (left == -1 || right == -1) return;
+        const std::string t(syms_[left].p, syms_[left].n + syms_[right].n);
+        auto it = v_.to_id.find(t);
+        if (it == v_.to_id.end() || it->second >= v_.size()) return;
+        q_.push(Bigram{left, right, v_.score[it->second], t.size()});
+        rev_[t] = std::make_pair(left, right);
+    }
+    const Vocab& v_;
+    std::vector<Sym> syms_;
+    std::priority_queue<Bigram, std::vector<Bigram>, BigramLess> q_;
+    std::map<std::string, std::pair<int, int>> rev_;
+};
+}  // namespace
+
+std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
+    std::vector<int> out;
+    if (add_bos && bos_id != -1) out.push_back(bos_id);
+    if (raw.empty()) return out;
+    if (type == VOCAB_SPM) {
+        std::string t = " " + raw;
+        replace_all(t, " ", "\xe2\x96\x81");
+        SpmRun run(*this);
+        run.run(t, out);
+    } else {
+        // BPE (Falcon) tokenizer is a §8(f) "next" row; until then fall back to byte-level lookup so ids are valid.
+        for (size_t off = 0; off < raw.size();) {
+            const size_t len = std::min(utf8_len(raw[off]), raw.size() - off);
+            auto it = to_id.find(raw.substr(off, len));
+            if (it != to_id.end()) out.push_back(it->second);
+            off += len;
+        }
+    }
+    return out;
+}
+
+std::string Vocab::piece(int token) const {
+    if (token < 0 || token >= size()) return std::string();
+    const int tt = ttype[token];
+    if (tt == TT_NORMAL) {
+        std::string r = text[token];
+        if (type == VOCAB_SPM) replace_all(r, "\xe2\x96\x81", " ");
+        return r;
+    }
+    if (tt == TT_UNKNOWN) return "\xe2\x96\x85";
+    if (tt == TT_BYTE) {
+        const std::string& t = text[token];  // "<0xXX>"
+        if (t.size() >= 5) return std::string(1, (char)strtol(t.substr(3, 2).c_str(), nullptr, 16));
+    }
+    return std::string();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Cand { int id; float logit; float p; };
+
+void softmax_sorted(std::vector<Cand>& c, size_t& size, bool& sorted) {
+    if (!sorted) {
+        std::sort(c.begin(), c.begin() + size, [](const Cand& a, const Cand& b) { return a.logit > b.logit; });
+        sorted = true;
+    }
+    const float max_l = c[0].logit;
+    float cum = 0.0f;
+    for (size_t i = 0; i < size; ++i) {
+        const float p = expf(c[i].logit - max_l);
+        c[i].p = p;
+        cum += p;
+    }
+    for (size_t i = 0; i < size; ++i) c[i].p /= cum;
+}
+}  // namespace
+
+int sample_token(const float* logits, int n_vocab, const int* last_tokens, int n_last, int top_k, float top_p,
+                 float temperature, float repetition_penalty, int seed) {
+    if (seed < 0) seed = (int)time(nullptr);
+    std::mt19937 rng;
+    rng.seed(seed);
+    std::vector<Cand> c((size_t)n_vocab);
+    for (int i = 0; i < n_vocab; ++i) c[i] = Cand{i, logits[i], 0.0f};
+    size_t size = c.size();
+    bool sorted = false;
+    // repetition penalty
+    if (n_last > 0 && repetition_penalty != 1.0f) {
+        for (size_t i = 0; i < size; ++i) {
+            if (std::find(last_tokens, last_tokens + n_last, c[i].id) == last_tokens + n_last) continue;
+            if (c[i].logit <= 0) c[i].logit *= repetition_penalty;
+            else c[i].logit /= repetition_penalty;
+        }
+        sorted = false;
+    }
+    // top-k (min_keep = 1)
+    {
+        int k = std::max(top_k, 1);
+        k = std::min(k, (int)size);
+        if (!sorted) {
+            auto comp = [](const Cand& a, const Cand& b) { return a.logit > b.logit; };
+            if (k == (int)size) std::sort(c.begin(), c.begin() + size, comp);
+            else std::partial_sort(c.begin(), c.begin() + k, c.begin() + size, comp);
+            sorted = true;
+        }
+        size = (size_t)k;
+    }
+    // top-p (min_keep = 1)
+    if (top_p < 1.0f) {
+        softmax_sorted(c, size, sorted);
+        float cum = 0.0f;
+        size_t last = size;
+        for (size_t i = 0; i < size; ++i) {
+            cum += c[i].p;
+            if (cum >= top_p && i + 1 >= 1) { last = i + 1; break; }
+        }
+        size = last;
+    }
+    // temperature
+    for (size_t i = 0; i < size; ++i) c[i].logit /= temperature;
+    // draw
+    softmax_sorted(c, size, sorted);
+    std::vector<float> probs(size);
+    for (size_t i = 0; i < size; ++i) probs[i] = c[i].p;
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return c[dist(rng)].id;
+}
+
+}  // namespace ctamd
