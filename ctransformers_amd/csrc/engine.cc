@@ -9,7 +9,7 @@
 #include <thread>
 
 #include "gguf_reader.h"
-#include "kernels.h"
+#include "kernels_exact.h"
 
 namespace ctamd {
 
@@ -85,6 +85,42 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     m.nb = m.K / be;
     m.bytes = t->nbytes;
     const int nb = m.nb, M = m.M;
+    if (exact_ && is_kquant(t->type)) {
+        // tile8 layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row.
+        m.layout = LAYOUT_TILE8;
+        const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
+        std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
+        const uint8_t* src = t->data;
+        parallel_rows(n_tiles, [&](int t0, int t1) {
+            for (int tl = t0; tl < t1; ++tl)
+                for (int b = 0; b < nb; ++b) {
+                    uint8_t* rp = &st[((size_t)tl * nb + b) * rec];
+                    for (int r = 0; r < 8; ++r) {
+                        const int row = tl * 8 + r;
+                        if (row >= M) continue;
+                        const uint8_t* blk = src + ((size_t)row * nb + b) * bb;
+                        if (type == GT_Q4_K) {
+                            memcpy(rp + r * 16, blk, 16);
+                            memcpy(rp + 128 + r * 128, blk + 16, 128);
+                        } else if (type == GT_Q5_K) {
+                            memcpy(rp + r * 16, blk, 16);
+                            memcpy(rp + 128 + r * 32, blk + 16, 32);
+                            memcpy(rp + 384 + r * 128, blk + 48, 128);
+                        } else {  // GT_Q6_K
+                            memcpy(rp + r * 2, blk + 208, 2);
+                            memcpy(rp + 16 + r * 16, blk + 192, 16);
+                            memcpy(rp + 144 + r * 64, blk + 128, 64);
+                            memcpy(rp + 656 + r * 128, blk, 128);
+                        }
+                    }
+                }
+        });
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, st.size() + 64, err)) return false;
+        HIP_OK(hipMemcpy(d, st.data(), st.size(), hipMemcpyHostToDevice));
+        m.p[0] = d;
+        return true;
+    }
     int psz[4] = {0, 0, 0, 0};  // bytes per block in each plane
     switch (t->type) {
         case GT_Q4_K: psz[0] = 128; psz[1] = 16; break;
@@ -193,6 +229,8 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     HIP_OK(hipSetDevice(0));
     (void)gpu_layers;  // every layer lives on the GPU(s); the CPU/GPU split of the reference does not exist here
     pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
+    exact_ = env_int("CT_AMD_EXACT", 1) != 0;
+    items_per_wave_ = std::max(1, env_int("CT_AMD_IPW", 1));
     max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 2048));
 
     GgufFile f;
@@ -219,7 +257,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     float rs = 1.0f;
     if (f.get_f32(a + "rope.scale_linear", rs) && rs != 0.0f) hp_.rope_freq_scale = 1.0f / rs;
     if (hp_.n_rot != hp_.head_dim()) { err = "rope.dimension_count must equal head_dim"; return false; }
-    if (hp_.head_dim() % 8 || 64 % (hp_.head_dim() / 8)) { err = "unsupported head_dim"; return false; }
+    if (hp_.head_dim() % 64 || hp_.head_dim() > 256) { err = "unsupported head_dim (need a multiple of 64)"; return false; }
     if (!vocab_.load(f, err)) return false;
     hp_.n_vocab = vocab_.size();
     // reference default n_ctx = 512 unless context_length is passed (llama.cpp:5281, llama.cc:90-92)
@@ -262,10 +300,11 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
     if (!mat("output.weight", output_, V, E)) return false;
 
-    const size_t kv_elems = (size_t)hp_.n_layer * n_ctx_ * G;
-    if (!dev_alloc(dev_allocs_, &kcache_, kv_elems, err) || !dev_alloc(dev_allocs_, &vcache_, kv_elems, err)) return false;
-    HIP_OK(hipMemset(kcache_, 0, kv_elems * 2));
-    HIP_OK(hipMemset(vcache_, 0, kv_elems * 2));
+    v_stride_ = (n_ctx_ + 31) / 32 * 32;  // V rows (one per channel) start 16-byte aligned
+    const size_t k_elems = (size_t)hp_.n_layer * n_ctx_ * G, v_elems = (size_t)hp_.n_layer * v_stride_ * G;
+    if (!dev_alloc(dev_allocs_, &kcache_, k_elems, err) || !dev_alloc(dev_allocs_, &vcache_, v_elems + 64, err)) return false;
+    HIP_OK(hipMemset(kcache_, 0, k_elems * 2));
+    HIP_OK(hipMemset(vcache_, 0, v_elems * 2));
     if (!dev_alloc(dev_allocs_, &x_, (size_t)E, err) || !dev_alloc(dev_allocs_, &attn_out_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
@@ -286,6 +325,25 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
 // ---------------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------------
+// Bit-exact path: work items are 8-row tiles.
+static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, hipStream_t s, std::string& err) {
+    // convert pair bookkeeping (set_jobs) into tile bookkeeping
+    int item0 = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        a.job[j].pair0 = a.gateup ? 0 : item0;
+        item0 += (a.job[j].w.M + 7) / 8;
+    }
+    a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
+    constexpr int NT = 256, NW = NT / 64;
+    const int waves = (a.n_pairs + items_per_wave - 1) / items_per_wave;
+    const int wgs = std::max(1, std::min(max_wgs, (waves + NW - 1) / NW));
+    const dim3 grid((unsigned)wgs), block((unsigned)NT);
+    if (a.K <= 12288) CT_LAUNCH((matvec_exact_kernel<NT, 12288, 4>), grid, block, s, a);
+    else if (a.K <= 32768) CT_LAUNCH((matvec_exact_kernel<NT, 32768, 4>), grid, block, s, a);
+    else { err = "mat-vec with K=" + std::to_string(a.K) + " not supported"; return false; }
+    return true;
+}
+
 static bool launch_matvec(MatvecArgs& a, int pairs_per_wave, int max_wgs, hipStream_t s, std::string& err) {
     const int type0 = a.job[0].w.type;
     if (!is_kquant(type0)) { err = "mat-vec kernel for weight type " + std::to_string(type0) + " not implemented yet"; return false; }
@@ -317,6 +375,11 @@ static void set_jobs(MatvecArgs& a, std::initializer_list<std::pair<const DevMat
     a.n_pairs = pair0;
 }
 
+bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
+    if (a.job[0].w.layout == LAYOUT_TILE8) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
+    return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
+}
+
 bool Engine::token_step(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
@@ -328,6 +391,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     base.n_ctx = n_ctx_;
     base.head_dim = hd;
     base.n_embd_gqa = G;
+    base.v_stride = v_stride_;
     base.silu_tab = silu_tab_;
     base.eps = hp_.rms_eps;
     AttnArgs at = AttnArgs();
@@ -341,6 +405,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     at.head_dim = hd;
     at.n_embd_gqa = G;
     at.n_ctx = n_ctx_;
+    at.v_stride = v_stride_;
     at.kq_scale = 1.0f / sqrtf((float)E / (float)hp_.n_head);
     at.chunk = 64;
     const int n_chunks = (n_ctx_ + at.chunk - 1) / at.chunk;
@@ -348,23 +413,32 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     for (int il = 0; il < hp_.n_layer; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * G;
-        uint16_t* vc = vcache_ + (size_t)il * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * G;
         {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
             a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
             set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
-            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+            if (!run_matvec(a, err)) return false;
         }
         at.kcache = kc;
         at.vcache = vc;
-        CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
-        CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
+        if (exact_) {
+            AttnArgsX ax = AttnArgsX();
+            ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
+            ax.exp_tab = exp_tab_; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
+            ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
+            CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
+            CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
+        } else {
+            CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
+            CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
+        }
         {   // Q8_K(attn) -> Wo -> + residual
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.wo, EPI_ADD}});
-            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+            if (!run_matvec(a, err)) return false;
         }
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
@@ -372,13 +446,13 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
-            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+            if (!run_matvec(a, err)) return false;
         }
         {   // Q8_K(h) -> W_down -> + residual
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
-            if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+            if (!run_matvec(a, err)) return false;
         }
     }
     if (want_logits) {
@@ -387,7 +461,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (!launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err)) return false;
+        if (!run_matvec(a, err)) return false;
     }
     CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     return true;

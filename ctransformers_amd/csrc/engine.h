@@ -10,6 +10,8 @@
 #include "host_text.h"
 #include "quant.h"
 
+struct MatvecArgs;
+
 namespace ctamd {
 
 struct HParams {
@@ -55,12 +57,13 @@ class Engine {
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
+    bool run_matvec(::MatvecArgs& a, std::string& err);
     bool ensure_graphs(std::string& err);
     void free_all();
 
     HParams hp_;
     Vocab vocab_;
-    int n_ctx_ = 0;
+    int n_ctx_ = 0, v_stride_ = 0;
     DevMat tok_embd_, output_;
     float* output_norm_ = nullptr;
     std::vector<Layer> layers_;
@@ -82,7 +85,8 @@ class Engine {
 #endif
     bool have_logits_ = false;
     std::vector<void*> dev_allocs_;
-    int pairs_per_wave_ = 2, max_wgs_ = 2048;
+    int pairs_per_wave_ = 2, max_wgs_ = 2048, items_per_wave_ = 1;
+    bool exact_ = true;
 };
 
 }  // namespace ctamd

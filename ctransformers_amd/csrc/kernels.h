@@ -64,7 +64,7 @@ struct MatvecArgs {
     uint16_t* vcache;       // this layer's V cache  [n_embd_gqa][n_ctx] fp16 (transposed, as the reference keeps it)
     const float* rope_cs;   // [n_ctx][head_dim/2][2] cos,sin (host-built with the reference's iterative theta)
     const int* pos;         // device scalar: position of this token
-    int n_ctx, head_dim, n_embd_gqa;
+    int n_ctx, head_dim, n_embd_gqa, v_stride;
     const uint16_t* silu_tab;  // 65536-entry fp16->fp16 table (reference ggml.c:4328-4332)
 };
 
@@ -355,14 +355,14 @@ __global__ void __launch_bounds__(NT) matvec_kq_kernel(const MatvecArgs a) {
                 a.out[rowA] = s * rB;
             } else if (epi == EPI_V) {
                 // V stored transposed, fp16 RNE (reference llama.cpp:2319-2329, ggml.c:8407)
-                a.vcache[(size_t)rowA * a.n_ctx + pos] = f32_to_f16_bits(rA);
-                if (hasB) a.vcache[(size_t)rowB * a.n_ctx + pos] = f32_to_f16_bits(rB);
+                a.vcache[(size_t)rowA * a.v_stride + pos] = f32_to_f16_bits(rA);
+                if (hasB) a.vcache[(size_t)rowB * a.v_stride + pos] = f32_to_f16_bits(rB);
             } else {  // EPI_ROPE_Q / EPI_ROPE_K: interleaved pairs (2i,2i+1), reference ggml.c:12522-12539
                 const int ip = (rowA % a.head_dim) >> 1;
                 const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
                 const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-                const float o0 = rA * cs - rB * sn;
-                const float o1 = rA * sn + rB * cs;
+                const float o0 = fmaf(rA, cs, -(rB * sn));  // as the reference build contracts it (oracle/mirror.c mir_rope)
+                const float o1 = fmaf(rB, cs, rA * sn);
                 if (epi == EPI_ROPE_Q) {
                     a.q_f16[rowA] = f32_to_f16_bits(o0);
                     a.q_f16[rowB] = f32_to_f16_bits(o1);
@@ -451,7 +451,7 @@ struct AttnArgs {
     float* out;              // [n_head*head_dim]
     const int* pos;
     const uint16_t* exp_tab;  // fp16 -> fp16 exp table (reference ggml.c:4332)
-    int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx;
+    int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
     float kq_scale;
     int chunk;               // positions per workgroup in phase 1
 };
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(NT) attn_softmax_pv_kernel(const AttnArgs a) {
     const int hk = h / (a.n_head / a.n_head_kv);
     for (int dd = wv; dd < DCH; dd += NW) {
         const int d = d0 + dd;
-        const uint16_t* vrow = a.vcache + ((size_t)hk * a.head_dim + d) * a.n_ctx;
+        const uint16_t* vrow = a.vcache + ((size_t)hk * a.head_dim + d) * a.v_stride;
         float acc = 0.0f;
         for (int i = lane; i < n_kv; i += 64) acc = fmaf(f16_bits_to_f32(vrow[i]), prob[i], acc);
         acc = wave_sum(acc);

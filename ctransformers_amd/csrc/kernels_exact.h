@@ -1,0 +1,430 @@
+// Bit-exact mat-vec: reproduces the f32 accumulation ORDER of the reference's AVX2 kernels, not just their
+// quantization points, so logits come out bit-identical to the reference CPU build and greedy decoding can never
+// drift.  (Without this, a 1e-7 summation-order difference occasionally flips one int8 rounding in the next Q8_K
+// activation quantization — ~10 flips per 7B token — and the logits wander at the 1e-4 level.)
+//
+// What the reference build computes per weight row (k_quants.c:2651-2720 Q4_K, :3183-3262 Q5_K, :3800-3872 Q6_K; all
+// use 8 f32 lanes `acc` updated ONCE PER 256-BLOCK, in block order):
+//     sumi[l] = sum over the block's 32-element sub-vectors s of  scale_s(l) * dot4(w_s[4l..4l+3], q8_s[4l..4l+3])   (int32)
+//     acc[l]  = fma(y.d * fp16(x.d), (float)sumi[l], acc[l])                          l = 0..7
+//   Q4_K min term: prod[t] = m[2t]*q8s[2t] + m[2t+1]*q8s[2t+1] (q8s[j] = bsums[2j]+bsums[2j+1]);
+//                  acc_m[t] = fma(-y.d*fp16(x.dmin), (float)prod[t], acc_m[t])        t = 0..3
+//   Q5_K min term: summs = fma(dmin, (float)(prod[0]+..+prod[3]), summs)              (scalar, gcc contracts it)
+//   result = hsum_float_8(acc) [+ (acc_m0+acc_m2)+(acc_m1+acc_m3) | + summs],
+//   hsum_float_8(x) = ((x0+x4)+(x2+x6)) + ((x1+x5)+(x3+x7))                           (k_quants.c:90-97)
+//
+// Mapping onto a wavefront: 8 lanes per weight row (8 rows per wave).  Lane g of a row owns the 16-byte unit g of each
+// 128-byte nibble block, i.e. bytes 4k..4k+3 (k = 0..3) of AVX half h of two sub-vectors; the four lanes with the same
+// h together cover all sub-vectors.  A 3-shuffle transpose-reduce over those four lanes leaves lane g holding the
+// block's complete integer sumi[l(g)], l(g) = 4*(g&1) + 2*((g>>1)&1) + (g>>2), and the lane then performs exactly
+// the reference's per-block fma on its own private accumulator.  Integer sums are exact in any order; every f32
+// operation is the reference's, in the reference's order.
+#pragma once
+#include "kernels.h"
+
+template <int MAXK> struct ActLdsX {
+    int q8[MAXK / 4];        // int8 quants, 4 per word
+    float yd[MAXK / 256];    // Q8_K block scale d
+    int bsums[MAXK / 16];    // sums of 16 quants
+    int sb[MAXK / 32];       // sums of 32 quants (= q8s[j] of the reference)
+    double red[16];
+};
+
+// Prologue: (RMSNorm ->) Q8_K into LDS, values held in registers between the two phases (one global read of x).
+// Reference k_quants.c:1191-1226 with `iscale*x[j] + 12582912.f` fused into one fma as the reference build does.
+template <int NT, int MAXK>
+DEV void prologue_q8k_exact(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
+                            float eps) {
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / 64;
+    constexpr int MAXB = (MAXK / 256 + NW - 1) / NW;  // blocks per wave
+    const int nblk = K >> 8;
+    float4 v[MAXB];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wv + i * NW;
+        if (b < nblk) {
+            v[i] = *(const float4*)(x + b * 256 + lane * 4);
+            if (pro == PRO_RMSNORM) {
+                s += (double)(v[i].x * v[i].x);
+                s += (double)(v[i].y * v[i].y);
+                s += (double)(v[i].z * v[i].z);
+                s += (double)(v[i].w * v[i].w);
+            }
+        }
+    }
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {
+        s = wave_sum(s);
+        if (lane == 0) L.red[wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wv + i * NW;
+        if (b < nblk) {  // wave-uniform
+            float4 t = v[i];
+            if (pro == PRO_RMSNORM) {
+                const float4 w4 = *(const float4*)(nw + b * 256 + lane * 4);
+                t.x = (t.x * scale) * w4.x;
+                t.y = (t.y * scale) * w4.y;
+                t.z = (t.z * scale) * w4.z;
+                t.w = (t.w * scale) * w4.w;
+            }
+            const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
+            const float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            const float amax = wave_max(am);
+            const unsigned long long hit = __ballot(am == amax);
+            const int first = __ffsll(hit) - 1;
+            const float mine = (a0 == amax) ? t.x : (a1 == amax) ? t.y : (a2 == amax) ? t.z : t.w;
+            const float maxv = __shfl(mine, first);
+            int packed = 0, s4 = 0;
+            float d = 0.0f;
+            if (amax != 0.0f) {
+                const float iscale = -128.f / maxv;
+                int q0 = ((int)f32_to_bits(fmaf(iscale, t.x, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q1 = ((int)f32_to_bits(fmaf(iscale, t.y, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q2 = ((int)f32_to_bits(fmaf(iscale, t.z, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q3 = ((int)f32_to_bits(fmaf(iscale, t.w, 12582912.f)) & 0x007fffff) - 0x00400000;
+                q0 = q0 > 127 ? 127 : q0;
+                q1 = q1 > 127 ? 127 : q1;
+                q2 = q2 > 127 ? 127 : q2;
+                q3 = q3 > 127 ? 127 : q3;
+                packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+                s4 = q0 + q1 + q2 + q3;
+                d = 1.0f / iscale;
+            }
+            L.q8[b * 64 + lane] = packed;
+            s4 += __shfl_xor(s4, 1);
+            s4 += __shfl_xor(s4, 2);
+            if ((lane & 3) == 0) L.bsums[b * 16 + (lane >> 2)] = s4;
+            s4 += __shfl_xor(s4, 4);
+            if ((lane & 7) == 0) L.sb[b * 8 + (lane >> 3)] = s4;
+            if (lane == 0) L.yd[b] = d;
+        }
+    }
+    __syncthreads();
+}
+
+// Transpose-reduce over the four lanes {g, g^2, g^4, g^6} (c = g>>1): in: 4 ints per lane, out: lane c holds the
+// 4-lane total of element kk(c) = 2*(c&1) + (c>>1).
+DEV int quad_transpose_reduce(int p0, int p1, int p2, int p3, int c) {
+    const bool odd = (c & 1) != 0;
+    const int send0 = odd ? p0 : p2, send1 = odd ? p1 : p3;
+    const int keep0 = odd ? p2 : p0, keep1 = odd ? p3 : p1;
+    const int q0 = keep0 + __shfl_xor(send0, 2);
+    const int q1 = keep1 + __shfl_xor(send1, 2);
+    const bool up = (c & 2) != 0;
+    const int send = up ? q0 : q1;
+    const int keep = up ? q1 : q0;
+    return keep + __shfl_xor(send, 4);
+}
+
+// hsum_float_8 of the 8 per-lane accumulators of one row, in the reference's association order (k_quants.c:90-97).
+// Lane g holds x[l(g)], l(g) = 4*(g&1) + 2*((g>>1)&1) + (g>>2).
+DEV float hsum8_exact(float acc) {
+    const float t = acc + __shfl_xor(acc, 1);  // x[k] + x[k+4]
+    const float u = t + __shfl_xor(t, 2);      // (r0+r2) or (r1+r3)
+    return u + __shfl_xor(u, 4);               // (r0+r2) + (r1+r3)
+}
+
+struct TileResult { float v; };
+
+// One 8-row tile (this lane: row r = lane>>3, unit g = lane&7) against the LDS-resident activation vector.
+// Returns the finished dot product of row r in every lane of the row's group.
+template <int MAXK, int UB>
+DEV float tile_dot_exact(const DevMat& w, int tile, const ActLdsX<MAXK>& L, int lane) {
+    const int nb = w.nb;
+    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
+    const int rec = tile8_record_bytes(w.type);
+    const uint8_t* base = w.p[0] + (size_t)tile * nb * rec;
+    float acc = 0.0f, accm = 0.0f;
+    if (w.type == GT_Q4_K || w.type == GT_Q5_K) {
+        const bool q5 = w.type == GT_Q5_K;
+        const int qh_off = 128, qs_off = q5 ? 128 + 256 : 128;
+        for (int b0 = 0; b0 < nb; b0 += UB) {
+            u32x4 qs[UB], hd[UB], qh[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int bb = (b0 + u < nb) ? b0 + u : nb - 1;
+                const uint8_t* rp = base + (size_t)bb * rec;
+                hd[u] = ld_stream16(rp + r * 16);
+                qs[u] = ld_stream16(rp + qs_off + r * 128 + g * 16);
+                if (q5) qh[u] = ld_stream16(rp + qh_off + r * 32 + h * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int b = b0 + u;
+                if (b < nb) {  // wave-uniform
+                    const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
+                    const int* ahi = alo + 8;
+                    int sc_lo, sc_hi, m_lo, m_hi;
+                    scale_min_pair(hd[u][1], hd[u][2], hd[u][3], c, sc_lo, sc_hi, m_lo, m_hi);
+                    int part[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t lo = qs[u][k] & 0x0F0F0F0Fu;
+                        uint32_t hi = (qs[u][k] >> 4) & 0x0F0F0F0Fu;
+                        if (q5) {
+                            lo |= ((qh[u][k] >> (2 * c)) & 0x01010101u) << 4;
+                            hi |= ((qh[u][k] >> (2 * c + 1)) & 0x01010101u) << 4;
+                        }
+                        part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
+                    }
+                    const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
+                    const float yd = L.yd[b];
+                    const float d = yd * f16_bits_to_f32((uint16_t)(hd[u][0] & 0xFFFF));
+                    const float dmin = -yd * f16_bits_to_f32((uint16_t)(hd[u][0] >> 16));
+                    acc = fmaf(d, (float)sumi, acc);
+                    // min term: this lane's chunk c owns sub-blocks 2c, 2c+1 => prod[c]; only the h == 0 lanes carry it
+                    int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
+                    if (q5) {  // scalar summs: all four prods are added as integers first
+                        prod += __shfl_xor(prod, 2);
+                        prod += __shfl_xor(prod, 4);
+                    }
+                    accm = fmaf(dmin, (float)prod, accm);
+                }
+            }
+        }
+        float tot = hsum8_exact(acc);
+        if (!q5) {
+            const float wsum = accm + __shfl_xor(accm, 4);   // (m0+m2) | (m1+m3)   [t = c, lanes with h == 0]
+            accm = wsum + __shfl_xor(wsum, 2);               // (m0+m2) + (m1+m3)
+        }
+        accm = __shfl(accm, lane & ~7);                      // lane g = 0 of the row (h == 0, c == 0)
+        tot = tot + accm;
+        return tot;
+    }
+    // ---- GT_Q6_K ----
+    {
+        const int n = g >> 2, gg = g & 3, hh = gg & 1, kq = gg >> 1;
+        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
+        for (int b0 = 0; b0 < nb; b0 += UB) {
+            u32x4 ql[UB], qh[UB], sc[UB];
+            uint16_t dd[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int bb = (b0 + u < nb) ? b0 + u : nb - 1;
+                const uint8_t* rp = base + (size_t)bb * rec;
+                dd[u] = *(const uint16_t*)(rp + r * 2);
+                sc[u] = ld_stream16(rp + 16 + r * 16);
+                qh[u] = ld_stream16(rp + 144 + r * 64 + n * 32 + hh * 16);
+                ql[u] = ld_stream16(rp + 656 + r * 128 + g * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int b = b0 + u;
+                if (b < nb) {
+                    const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
+                    const int* ahi = alo + 16;
+                    const uint32_t w_lo = n ? sc[u][2] : sc[u][0];
+                    const uint32_t w_hi = n ? sc[u][3] : sc[u][1];
+                    const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
+                    const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
+                    int part[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t lo = (ql[u][k] & 0x0F0F0F0Fu) | (((qh[u][k] >> s_lo) & 0x03030303u) << 4);
+                        const uint32_t hi = ((ql[u][k] >> 4) & 0x0F0F0F0Fu) | (((qh[u][k] >> s_hi) & 0x03030303u) << 4);
+                        const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
+                        const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
+                        part[k] = sc_lo * dl + sc_hi * dh;
+                    }
+                    const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
+                    const float d = L.yd[b] * f16_bits_to_f32(dd[u]);
+                    acc = fmaf(d, (float)sumi, acc);
+                }
+            }
+        }
+        return hsum8_exact(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused launch: prologue -> one 8-row tile per wave step -> epilogue.  Work item = tile index over the concatenated
+// jobs (gate/up mode: item t = gate tile t followed by up tile t).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int MAXK, int UB>
+__global__ void __launch_bounds__(NT) matvec_exact_kernel(const MatvecArgs a) {
+    __shared__ ActLdsX<MAXK> L;
+    const int lane = lane_id();
+    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    constexpr int NW = NT / 64;
+    const int gw = (int)blockIdx.x * NW + wave_id();
+    const int W = (int)gridDim.x * NW;
+    const int i_begin = (int)(((long long)a.n_pairs * gw) / W);  // n_pairs == number of work items (tiles) here
+    const int i_end = (int)(((long long)a.n_pairs * (gw + 1)) / W);
+    const int pos = a.pos ? *a.pos : 0;
+    const int r = lane >> 3, g = lane & 7;
+    for (int it = i_begin; it < i_end; ++it) {
+        int j = 0;
+        if (!a.gateup) {
+            if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
+            if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+        }
+        const MatJob& jb = a.job[j];
+        const int tile = it - jb.pair0;
+        const int row = tile * 8 + r;
+        float res = tile_dot_exact<MAXK, UB>(jb.w, tile, L, lane);
+        const int epi = a.gateup ? EPI_SILU_MUL : jb.epi;
+        if (epi == EPI_SILU_MUL) {
+            const float up = tile_dot_exact<MAXK, UB>(a.job[1].w, tile, L, lane);
+            if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
+        } else if (epi == EPI_STORE) {
+            if (g == 0 && row < jb.w.M) a.out[row] = res;
+        } else if (epi == EPI_ADD) {
+            if (g == 0 && row < jb.w.M) a.out[row] = res + a.res[row];
+        } else if (epi == EPI_V) {
+            if (g == 0 && row < jb.w.M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else {  // RoPE on the interleaved pair (row&~1, row|1): partner row lives in the neighbouring lane group
+            const float other = __shfl_xor(res, 8);
+            const int ip = (row % a.head_dim) >> 1;
+            const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+            const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+            // reference build: out0 = fma(x0, cos, -(x1*sin)), out1 = fma(x1, cos, x0*sin)  (how gcc contracts
+            // ggml.c:12536-12537; established against the reference's own rope op, see oracle/mirror.c mir_rope)
+            const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+            if (g == 0 && row < jb.w.M) {
+                if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+                else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Bit-exact decode attention.  The reference computes both attention mat-muls with ggml_vec_dot_f16 (ggml.c:2392-2425,
+// AVX: 4 accumulators x 8 f32 lanes, 32 elements per step, fma; reduce macro ggml.c:1964-1982):
+//     s_j[l] accumulates elements e = 32*step + 8*j + l, in step order          (j = 0..3, l = 0..7)
+//     S[l]   = (s_0[l] + s_2[l]) + (s_1[l] + s_3[l])
+//     t0[m]  = S[m] + S[m+4]  (m = 0..3);   res = (t0[0] + t0[1]) + (t0[2] + t0[3])
+//     leftovers (n % 32): sumf = (double)res; sumf += (double)(x[i]*y[i]) sequentially;  result = (float)sumf
+// A quad of lanes (j = lane&3) owns the four accumulator vectors: lane j reads the 16-byte chunks j, j+4, j+8, ... of
+// the row (8 halves = its 8 l-lanes for one step) and runs 8 independent fma chains; a 6-shuffle transpose-reduce
+// reproduces the reduction tree.
+// ------------------------------------------------------------------------------------------------------------------
+DEV void unpack8_f16(const u32x4 v, float* f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = f16_bits_to_f32((uint16_t)(v[k] & 0xFFFF));
+        f[2 * k + 1] = f16_bits_to_f32((uint16_t)(v[k] >> 16));
+    }
+}
+
+// in: acc[8] = s_j[0..7] of quad lane j; out (all 4 lanes): res of the reference's reduce.
+DEV float f16dot_reduce_exact(const float* acc, int j) {
+    // step A (partner j^2): keep l in {0,1,4,5} (j<2) or {2,3,6,7} (j>=2)
+    const bool hiA = (j & 2) != 0;
+    float kA[4], sA[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int l_lo = (t & 1) + 4 * (t >> 1);        // 0,1,4,5
+        const int l_hi = l_lo + 2;                      // 2,3,6,7
+        kA[t] = hiA ? acc[l_hi] : acc[l_lo];
+        sA[t] = hiA ? acc[l_lo] : acc[l_hi];
+    }
+    float a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = kA[t] + __shfl_xor(sA[t], 2);   // s_j[l] + s_{j^2}[l], l = base(t) (+2 if j>=2)
+    // a[] now holds l = {0,1,4,5} (+2 when j>=2).  step B (partner j^1): even j keeps t = {0,2} (l', l'+4 with l' even
+    // offset 0), odd j keeps t = {1,3}.
+    const bool odd = (j & 1) != 0;
+    const float k0 = odd ? a[1] : a[0], k1 = odd ? a[3] : a[2];
+    const float s0 = odd ? a[0] : a[1], s1 = odd ? a[2] : a[3];
+    const float S_lo = k0 + __shfl_xor(s0, 1);   // S[l'],   l' = j
+    const float S_hi = k1 + __shfl_xor(s1, 1);   // S[l'+4]
+    const float t0 = S_lo + S_hi;                // t0[j]
+    const float t1 = t0 + __shfl_xor(t0, 1);     // t0[0]+t0[1]  |  t0[2]+t0[3]
+    return t1 + __shfl_xor(t1, 2);
+}
+
+struct AttnArgsX {
+    const uint16_t* q_f16;
+    const uint16_t* kcache;  // layer base [n_ctx][n_embd_gqa]
+    const uint16_t* vcache;  // layer base [n_embd_gqa][v_stride]
+    float* scores;           // [n_head][n_ctx]
+    float* out;
+    const int* pos;
+    const uint16_t* exp_tab;
+    int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
+    float kq_scale;
+};
+
+// scores[h][p] = vec_dot_f16(K[p], Q[h]) * kq_scale.   grid (n_head, ceil(n_ctx/64)), 256 threads: quad per position.
+__global__ void __launch_bounds__(256) attn_scores_exact_kernel(const AttnArgsX a) {
+    const int h = (int)blockIdx.x;
+    const int n_kv = *a.pos + 1;
+    const int c0 = (int)blockIdx.y * 64;
+    if (c0 >= n_kv) return;
+    const int tid = (int)threadIdx.x, j = tid & 3;
+    const int p = c0 + (tid >> 2);
+    const bool ok = p < n_kv;
+    const int pp = ok ? p : c0;
+    const int hd = a.head_dim;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const uint16_t* krow = a.kcache + (size_t)pp * a.n_embd_gqa + (size_t)hk * hd;
+    const uint16_t* qrow = a.q_f16 + (size_t)h * hd;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e0 = 0; e0 < hd; e0 += 32) {
+        float kf[8], qf[8];
+        unpack8_f16(ld16(krow + e0 + 8 * j), kf);
+        unpack8_f16(ld16(qrow + e0 + 8 * j), qf);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+    }
+    const float res = f16dot_reduce_exact(acc, j);
+    if (ok && j == 0) a.scores[(size_t)h * a.n_ctx + p] = res * a.kq_scale;
+}
+
+// softmax (reference ggml.c:12047-12069) + out[h][d] = vec_dot_f16(V[d], P).   grid (n_head, head_dim/64), 256 threads.
+__global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnArgsX a) {
+    __shared__ float prob[kMaxCtx];
+    __shared__ double red[4];
+    __shared__ float redf[4];
+    const int h = (int)blockIdx.x;
+    const int n_kv = *a.pos + 1;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    const float* s = a.scores + (size_t)h * a.n_ctx;
+    float mx = -INFINITY;
+    for (int i = tid; i < n_kv; i += 256) mx = fmaxf(mx, s[i]);
+    mx = wave_max(mx);
+    if (lane == 0) redf[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double sum = 0.0;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(s[i] - mx)]);
+        prob[i] = e;
+        sum += (double)e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    const float inv = (float)(1.0 / tot);
+    for (int i = tid; i < n_kv; i += 256) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    __syncthreads();
+    const int j = tid & 3;
+    const int d = (int)blockIdx.y * 64 + (tid >> 2);
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const uint16_t* vrow = a.vcache + ((size_t)hk * a.head_dim + d) * a.v_stride;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int np = n_kv & ~31;
+    for (int i = 0; i < np; i += 32) {
+        float vf[8];
+        unpack8_f16(ld16(vrow + i + 8 * j), vf);
+        const float* pr = &prob[i + 8 * j];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+    }
+    const float res = f16dot_reduce_exact(acc, j);
+    double sumf = (double)res;
+    for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
+    if (j == 0) a.out[(size_t)h * a.head_dim + d] = (float)sumf;
+}

@@ -15,6 +15,14 @@
 //   Q8_0: p0 = qs[M][K]                                              p3 = d[M][K/32] (f16)
 //   Q4_0: p0 = qs[M][K/2]                                            p3 = d[M][K/32] (f16)
 // Total bytes are identical to the file (no padding inside planes), so the roofline byte count is unchanged.
+//
+// "tile8" layout (LAYOUT_TILE8, used by the bit-exact mat-vec): 8 consecutive rows form a tile; for every K-block b
+// the 8 rows' blocks are stored together as one record, fields grouped so that a wavefront (8 lanes per row) reads
+// each field with one fully-coalesced 16-byte-per-lane load, and a tile is one contiguous stream of nb records:
+//   Q4_K record 1152 B: hdr[8][16] | qs[8][128]
+//   Q5_K record 1408 B: hdr[8][16] | qh[8][32] | qs[8][128]
+//   Q6_K record 1680 B: d[8] f16 (16 B) | sc[8][16] | qh[8][64] | ql[8][128]
+// Record sizes are 8 x the file block size: bytes unchanged.  Rows beyond M in the last tile are zero blocks.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -41,6 +49,9 @@ CT_HD static inline int ggml_block_bytes(int t) {
 CT_HD static inline size_t ggml_row_bytes(int t, int64_t k) { return (size_t)(k / ggml_block_elems(t)) * ggml_block_bytes(t); }
 CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K || t == GT_Q6_K; }
 
+enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1 };
+CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
+
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
 struct DevMat {
     int type = -1;
@@ -48,5 +59,6 @@ struct DevMat {
     int nb = 0;                 // blocks per row (K/256 for K-quants, K/32 for Q4_0/Q8_0)
     const uint8_t* p[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
+    int layout = 0;                // LAYOUT_PLANES / LAYOUT_TILE8 (tile8 data lives in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };

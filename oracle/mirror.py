@@ -1,0 +1,169 @@
+"""TEST INFRASTRUCTURE ONLY — Python driver of the C restatement (oracle/mirror.c, built by oracle/Makefile into
+oracle/_build/libmirror.so).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_void_p
+
+import numpy as np
+
+from ctransformers_amd import gguf as G
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libmirror.so")
+_lib = None
+
+
+def available():
+    return os.path.isfile(LIB)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(LIB)
+        _lib.mir_f16_to_f32.argtypes = [ctypes.c_uint16]
+        _lib.mir_f16_to_f32.restype = c_float
+        _lib.mir_f32_to_f16.argtypes = [c_float]
+        _lib.mir_f32_to_f16.restype = ctypes.c_uint16
+        for n in ("q4_K_q8_K", "q5_K_q8_K", "q6_K_q8_K", "q8_0_q8_0", "q4_0_q8_0"):
+            f = getattr(_lib, "mir_vec_dot_" + n)
+            f.argtypes = [c_int, c_void_p, c_void_p]
+            f.restype = c_float
+        _lib.mir_matvec.argtypes = [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]
+        _lib.mir_dequantize_row.argtypes = [c_int, c_void_p, c_void_p, c_int]
+        _lib.mir_quantize_row_q8_K.argtypes = [c_void_p, c_void_p, c_int]
+        _lib.mir_quantize_row_q8_0.argtypes = [c_void_p, c_void_p, c_int]
+        _lib.mir_llama_eval.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+        _lib.mir_llama_eval.restype = c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+def quantize_q8_K(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.size // 256 * 292, dtype=np.uint8)
+    lib().mir_quantize_row_q8_K(_p(x), _p(out), x.size)
+    return out
+
+
+def quantize_q8_0(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.size // 32 * 34, dtype=np.uint8)
+    lib().mir_quantize_row_q8_0(_p(x), _p(out), x.size)
+    return out
+
+
+def dequantize(raw, ggml_type, K):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    rows = raw.reshape(-1, raw.shape[-1])
+    out = np.zeros((rows.shape[0], K), dtype=np.float32)
+    for r in range(rows.shape[0]):
+        row = np.ascontiguousarray(rows[r])
+        lib().mir_dequantize_row(int(ggml_type), _p(row), _p(out[r]), K)
+    return out
+
+
+def matvec(ggml_type, wraw, x, K):
+    w = np.ascontiguousarray(wraw, dtype=np.uint8)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    M = w.shape[0]
+    out = np.zeros(M, dtype=np.float32)
+    lib().mir_matvec(int(ggml_type), _p(w), M, K, _p(x), _p(out))
+    return out
+
+
+class _Model(Structure):
+    _fields_ = [("n_vocab", c_int), ("n_embd", c_int), ("n_head", c_int), ("n_head_kv", c_int), ("n_layer", c_int),
+                ("n_ff", c_int), ("n_ctx", c_int), ("rms_eps", c_float), ("rope_freq_base", c_float),
+                ("rope_freq_scale", c_float),
+                ("tok_embd", c_void_p), ("tok_embd_type", c_int), ("output_norm", c_void_p), ("output", c_void_p),
+                ("output_type", c_int), ("attn_norm", c_void_p), ("ffn_norm", c_void_p), ("wq", c_void_p),
+                ("wk", c_void_p), ("wv", c_void_p), ("wo", c_void_p), ("w_gate", c_void_p), ("w_up", c_void_p),
+                ("w_down", c_void_p), ("t_wq", c_void_p), ("t_wk", c_void_p), ("t_wv", c_void_p), ("t_wo", c_void_p),
+                ("t_gate", c_void_p), ("t_up", c_void_p), ("t_down", c_void_p), ("kcache", c_void_p),
+                ("vcache", c_void_p)]
+
+
+class MirrorLlama:
+    """The C restatement driven over a GGUF file: same eval(tokens, n_past) contract as the ABI's batch_eval."""
+
+    def __init__(self, path, context_length=512):
+        self.f = G.GGUFFile(path)
+        kv = self.f.kv
+        a = "llama."
+        self.n_embd = int(kv[a + "embedding_length"])
+        self.n_head = int(kv[a + "attention.head_count"])
+        self.n_head_kv = int(kv.get(a + "attention.head_count_kv", self.n_head))
+        self.n_layer = int(kv[a + "block_count"])
+        self.n_ff = int(kv[a + "feed_forward_length"])
+        self.n_vocab = len(kv["tokenizer.ggml.tokens"])
+        self.n_ctx = context_length
+        self._keep = []
+        m = _Model()
+        m.n_vocab, m.n_embd, m.n_head, m.n_head_kv = self.n_vocab, self.n_embd, self.n_head, self.n_head_kv
+        m.n_layer, m.n_ff, m.n_ctx = self.n_layer, self.n_ff, self.n_ctx
+        m.rms_eps = float(kv[a + "attention.layer_norm_rms_epsilon"])
+        m.rope_freq_base = float(kv.get(a + "rope.freq_base", 10000.0))
+        m.rope_freq_scale = 1.0
+
+        def tensor(name):
+            shape, t, data = self.f.tensors[name]
+            arr = np.ascontiguousarray(data)
+            self._keep.append(arr)
+            return arr.ctypes.data, t
+
+        m.tok_embd, m.tok_embd_type = tensor("token_embd.weight")
+        m.output_norm, _ = tensor("output_norm.weight")
+        m.output, m.output_type = tensor("output.weight")
+
+        def per_layer(fmt, types_field=None):
+            ptrs = (c_void_p * self.n_layer)()
+            types = (c_int * self.n_layer)()
+            for i in range(self.n_layer):
+                ptrs[i], types[i] = tensor(fmt % i)
+            self._keep += [ptrs, types]
+            return ctypes.cast(ptrs, c_void_p), ctypes.cast(types, c_void_p)
+
+        m.attn_norm, _ = per_layer("blk.%d.attn_norm.weight")
+        m.ffn_norm, _ = per_layer("blk.%d.ffn_norm.weight")
+        m.wq, m.t_wq = per_layer("blk.%d.attn_q.weight")
+        m.wk, m.t_wk = per_layer("blk.%d.attn_k.weight")
+        m.wv, m.t_wv = per_layer("blk.%d.attn_v.weight")
+        m.wo, m.t_wo = per_layer("blk.%d.attn_output.weight")
+        m.w_gate, m.t_gate = per_layer("blk.%d.ffn_gate.weight")
+        m.w_up, m.t_up = per_layer("blk.%d.ffn_up.weight")
+        m.w_down, m.t_down = per_layer("blk.%d.ffn_down.weight")
+        g = self.n_embd // self.n_head * self.n_head_kv
+        self.kc = np.zeros(self.n_layer * self.n_ctx * g, dtype=np.uint16)
+        self.vc = np.zeros(self.n_layer * self.n_ctx * g, dtype=np.uint16)
+        m.kcache, m.vcache = self.kc.ctypes.data, self.vc.ctypes.data
+        self.m = m
+        self.logits = np.zeros(self.n_vocab, dtype=np.float32)
+        self.embeddings = np.zeros(self.n_embd, dtype=np.float32)
+
+    def eval(self, tokens, n_past):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        lib().mir_llama_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits), _p(self.embeddings))
+        return self.logits
+
+
+# op-level entry points of the restatement (same semantics as oracle/ref.py GgmlOps, for cross-checks)
+def rms_norm_mul(x, w, eps):
+    x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
+    y = np.zeros_like(x)
+    L = lib()
+    L.mir_rms_norm_mul.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float]
+    L.mir_rms_norm_mul(_p(x), _p(w), _p(y), x.size, float(eps))
+    return y
+
+
+def rope(x, pos, freq_base=10000.0, freq_scale=1.0):
+    """x: [n_head, head_dim]"""
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    L = lib()
+    L.mir_rope.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_float]
+    L.mir_rope(_p(y), y.shape[0], y.shape[1], int(pos), float(freq_base), float(freq_scale))
+    return y

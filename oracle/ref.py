@@ -109,3 +109,92 @@ def open_llm(path, **cfg):
     from ctransformers_amd.llm import LLM, Config
     lib()  # existence check
     return LLM(path, config=Config(**cfg), lib=REF_LIB)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# op-level oracle through the reference's own graph executor (ggml.h public API, exported by the .so)
+# ---------------------------------------------------------------------------------------------------------------------
+class GgmlOps:
+    """Runs single ggml ops of the reference build on numpy data: rms_norm, rope, soft_max, scale, f16 mat-mul."""
+
+    def __init__(self, mem_mb=256):
+        L = lib()
+        self.L = L
+        vp = c_void_p
+        L.ggml_new_tensor_1d.argtypes = [vp, c_int, ctypes.c_int64]
+        L.ggml_new_tensor_2d.argtypes = [vp, c_int, ctypes.c_int64, ctypes.c_int64]
+        L.ggml_new_tensor_3d.argtypes = [vp, c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+        for f in (L.ggml_new_tensor_1d, L.ggml_new_tensor_2d, L.ggml_new_tensor_3d, L.ggml_get_data, L.ggml_new_graph,
+                  L.ggml_rms_norm, L.ggml_soft_max, L.ggml_scale, L.ggml_mul_mat, L.ggml_rope_custom_inplace,
+                  L.ggml_new_f32, L.ggml_mul, L.ggml_add, L.ggml_silu, L.ggml_cpy, L.ggml_diag_mask_inf):
+            f.restype = vp
+        L.ggml_get_data.argtypes = [vp]
+        L.ggml_new_graph.argtypes = [vp]
+        L.ggml_rms_norm.argtypes = [vp, vp, c_float]
+        L.ggml_soft_max.argtypes = [vp, vp]
+        L.ggml_scale.argtypes = [vp, vp, vp]
+        L.ggml_mul_mat.argtypes = [vp, vp, vp]
+        L.ggml_mul.argtypes = [vp, vp, vp]
+        L.ggml_add.argtypes = [vp, vp, vp]
+        L.ggml_cpy.argtypes = [vp, vp, vp]
+        L.ggml_silu.argtypes = [vp, vp]
+        L.ggml_new_f32.argtypes = [vp, c_float]
+        L.ggml_rope_custom_inplace.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_float, c_float]
+        L.ggml_build_forward_expand.argtypes = [vp, vp]
+        L.ggml_graph_compute_with_ctx.argtypes = [vp, vp, c_int]
+        L.ggml_free.argtypes = [vp]
+        self.mem = mem_mb << 20
+
+    def _ctx(self):
+        return self.L.ggml_init(_InitParams(self.mem, None, False))
+
+    def _tensor(self, ctx, arr, ggml_type=0):
+        arr = np.ascontiguousarray(arr)
+        shape = arr.shape[::-1]  # ggml order: ne[0] fastest
+        new = [self.L.ggml_new_tensor_1d, self.L.ggml_new_tensor_2d, self.L.ggml_new_tensor_3d][len(shape) - 1]
+        t = new(ctx, ggml_type, *[int(s) for s in shape])
+        ctypes.memmove(self.L.ggml_get_data(t), arr.ctypes.data, arr.nbytes)
+        return t
+
+    def _run(self, ctx, t, shape, dtype=np.float32, threads=1):
+        gf = self.L.ggml_new_graph(ctx)
+        self.L.ggml_build_forward_expand(gf, t)
+        self.L.ggml_graph_compute_with_ctx(ctx, gf, threads)
+        n = int(np.prod(shape))
+        out = np.empty(n, dtype=dtype)
+        ctypes.memmove(out.ctypes.data, self.L.ggml_get_data(t), out.nbytes)
+        self.L.ggml_free(ctx)
+        return out.reshape(shape)
+
+    def rms_norm_mul(self, x, w, eps):
+        ctx = self._ctx()
+        t = self.L.ggml_mul(ctx, self.L.ggml_rms_norm(ctx, self._tensor(ctx, x.astype(np.float32)), eps),
+                            self._tensor(ctx, w.astype(np.float32)))
+        return self._run(ctx, t, x.shape)
+
+    def rope(self, x, n_past, mode=0, freq_base=10000.0, freq_scale=1.0):
+        """x: [N, n_head, head_dim] f32 (numpy order) -> rotated copy."""
+        ctx = self._ctx()
+        t = self._tensor(ctx, x.astype(np.float32))
+        r = self.L.ggml_rope_custom_inplace(ctx, t, int(n_past), int(x.shape[-1]), mode, 0, freq_base, freq_scale)
+        return self._run(ctx, r, x.shape)
+
+    def scale_softmax(self, scores, scale):
+        """scores: [rows, n] f32 -> soft_max(scale * scores) rows."""
+        ctx = self._ctx()
+        t = self._tensor(ctx, scores.astype(np.float32))
+        s = self.L.ggml_scale(ctx, t, self.L.ggml_new_f32(ctx, float(scale)))
+        return self._run(ctx, self.L.ggml_soft_max(ctx, s), scores.shape)
+
+    def mul_mat_f16(self, a_f16, b_f32):
+        """a: [M, K] fp16 (uint16 bits / np.float16), b: [N, K] f32 -> [N, M] f32 = ggml_mul_mat(a, b)."""
+        ctx = self._ctx()
+        ta = self._tensor(ctx, np.ascontiguousarray(a_f16).view(np.uint16), 1)
+        tb = self._tensor(ctx, b_f32.astype(np.float32))
+        return self._run(ctx, self.L.ggml_mul_mat(ctx, ta, tb), (b_f32.shape[0], a_f16.shape[0]))
+
+    def silu_mul(self, g, u):
+        ctx = self._ctx()
+        t = self.L.ggml_mul(ctx, self.L.ggml_silu(ctx, self._tensor(ctx, g.astype(np.float32))),
+                            self._tensor(ctx, u.astype(np.float32)))
+        return self._run(ctx, t, g.shape)
