@@ -213,7 +213,9 @@ class LLM:
     def tokenize(self, text: str, add_bos_token: Optional[bool] = None) -> List[int]:
         if add_bos_token is None:
             add_bos_token = self.model_type == "llama"
-        out = (c_int * (len(text) + 1))()
+        # the reference allocates len(text)+1 ints (llm.py:335); byte-fallback vocabularies can need one id per UTF-8
+        # byte (+BOS, +the leading-space escape), so be generous — the callee does not bounds-check.
+        out = (c_int * (len(text.encode()) + 8))()
         n = self.ctransformers_llm_tokenize(text.encode(), add_bos_token, out)
         return out[:n]
 

@@ -1,0 +1,51 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libctransformers_emu.so")
+HIP_LIB = os.path.join(ROOT, "ctransformers_amd", "lib", "libctransformers.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """CPU emulation of the HIP kernels (tests/emu) — kernel-logic checks without a GPU."""
+    subprocess.run(["make"], cwd=os.path.join(ROOT, "tests", "emu"), check=True, stdout=subprocess.DEVNULL)
+    return EMU_LIB
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    if not os.path.isfile(HIP_LIB):
+        subprocess.run(["make"], cwd=os.path.join(ROOT, "ctransformers_amd", "csrc"), check=True, stdout=subprocess.DEVNULL)
+    return HIP_LIB
+
+
+@pytest.fixture(scope="session")
+def mirror():
+    from oracle import mirror as m
+    if not m.available():
+        subprocess.run(["make", "mirror_lib"], cwd=os.path.join(ROOT, "oracle"), check=True, stdout=subprocess.DEVNULL)
+    return m
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import ref as r
+    if not r.available():
+        pytest.skip("reference build oracle/_ref not present (needs /root/reference to build)")
+    return r

@@ -1,0 +1,87 @@
+"""Regenerates the committed golden vectors from the REAL reference build (oracle/_ref, built from /root/reference by
+oracle/Makefile).  Run in the build container:  python tests/golden/make_golden.py
+Outputs (small, committed):
+  tiny-q4km.gguf / tiny-q5km.gguf   synthetic llama-tiny models (the files themselves, so fixtures do not depend on numpy RNG)
+  tiny-*.npz                        reference logits / embeddings / greedy tokens / sampled tokens for those models
+  ops.npz                           op-level vectors: Q8_K/Q8_0 activation quantization, the five weight dot products,
+                                    rope, rms_norm*w, scale+softmax, fp16 mat-mul, silu*mul
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from ctransformers_amd import gguf as G, synth  # noqa: E402
+from oracle import ref  # noqa: E402
+
+
+def model_golden(name, ftype, seed):
+    path = os.path.join(HERE, name + ".gguf")
+    hp = synth.write_llama_gguf(path, "llama-tiny", ftype, seed=seed)
+    cfg = dict(context_length=96, batch_size=8, threads=4)
+    r = ref.open_llm(path, **cfg)
+    prompt = synth.prompt_tokens(11, hp["n_vocab"])
+    r.eval(prompt)
+    logits = [r.logits.to_numpy().copy()]
+    emb = [r.embeddings.to_numpy().copy()]
+    toks = []
+    for _ in range(40):
+        t = r.sample(top_k=1, repetition_penalty=1.0)
+        toks.append(t)
+        r.eval([t])
+        logits.append(r.logits.to_numpy().copy())
+        emb.append(r.embeddings.to_numpy().copy())
+    # sampler chain on the final logits (host-side path of the ABI)
+    samples = []
+    for seed_s, (k, p, temp, pen) in enumerate([(40, 0.95, 0.8, 1.1), (5, 0.5, 1.3, 1.0), (100, 1.0, 0.7, 1.3)]):
+        samples.append([k, p, temp, pen, seed_s + 11,
+                        r.sample(top_k=k, top_p=p, temperature=temp, repetition_penalty=pen, last_n_tokens=64, seed=seed_s + 11)])
+    # prefix-rollback: re-evaluate the last 5 tokens at their old positions -> same logits
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), prompt=np.array(prompt, dtype=np.int32),
+                        greedy=np.array(toks, dtype=np.int32), logits=np.array(logits), embeddings=np.array(emb),
+                        samples=np.array(samples, dtype=np.float64), context=np.array(list(r._context), dtype=np.int32))
+    print(name, "greedy head:", toks[:8])
+
+
+def ops_golden():
+    rng = np.random.default_rng(2024)
+    ops = ref.GgmlOps()
+    out = {}
+    K = 1024
+    x = (rng.standard_normal(K) * 1.7).astype(np.float32)
+    x[5] = -x[300]  # |x| tie inside one block with opposite signs
+    x[512:768] = 0.0  # an all-zero block
+    out["act_x"] = x
+    out["act_q8_K"], _ = ref.quantize_activation(x, G.Q4_K)
+    out["act_q8_0"], _ = ref.quantize_activation(x, G.Q8_0)
+    for t in (G.Q4_K, G.Q5_K, G.Q6_K, G.Q8_0, G.Q4_0):
+        w = rng.standard_normal((24, K), dtype=np.float32) * 0.2
+        raw = synth.quantize(w, t)
+        out["w_%s" % G.TYPE_NAMES[t]] = raw
+        out["y_%s" % G.TYPE_NAMES[t]] = ref.matvec(t, raw, x, K)
+        out["deq_%s" % G.TYPE_NAMES[t]] = ref.dequantize(raw[:2], t, K)
+    h = rng.standard_normal((3, 4, 64)).astype(np.float32)
+    out["rope_x"] = h
+    out["rope_pos"] = np.array([0, 17, 511], dtype=np.int32)
+    out["rope_y"] = np.stack([ops.rope(h[i][None], int(p))[0] for i, p in enumerate(out["rope_pos"])])
+    nx = rng.standard_normal(256).astype(np.float32) * 3
+    nw = (1 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    out["norm_x"], out["norm_w"], out["norm_y"] = nx, nw, ops.rms_norm_mul(nx, nw, 1e-5)
+    sc = rng.standard_normal((4, 77)).astype(np.float32) * 4
+    out["sm_x"], out["sm_scale"], out["sm_y"] = sc, np.float32(0.125), ops.scale_softmax(sc, 0.125)
+    a = (rng.standard_normal((5, 77)) * 0.5).astype(np.float16)
+    b = rng.random((2, 77)).astype(np.float32)
+    out["mm_a"], out["mm_b"], out["mm_y"] = a.view(np.uint16), b, ops.mul_mat_f16(a, b)
+    g, u = rng.standard_normal(300).astype(np.float32) * 3, rng.standard_normal(300).astype(np.float32)
+    out["silu_g"], out["silu_u"], out["silu_y"] = g, u, ops.silu_mul(g, u)
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
+
+
+if __name__ == "__main__":
+    model_golden("tiny-q4km", "Q4_K_M", 3)
+    model_golden("tiny-q5km", "Q5_K_M", 4)
+    ops_golden()
+    print("golden vectors written to", HERE)

@@ -1,0 +1,70 @@
+"""Pins the oracle: the C restatement (oracle/mirror.c) must be BIT-IDENTICAL to the committed golden vectors, which
+were produced by the real reference build (tests/golden/make_golden.py); where the reference build itself is present
+it is checked against the same vectors (guards against a drifting toolchain)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ctransformers_amd import gguf as G, synth
+
+OPS = np.load(os.path.join(GOLDEN, "ops.npz"))
+TYPES = [G.Q4_K, G.Q5_K, G.Q6_K, G.Q8_0, G.Q4_0]
+
+
+def test_activation_quantizers_bit_exact(mirror):
+    x = OPS["act_x"]
+    assert np.array_equal(mirror.quantize_q8_K(x), OPS["act_q8_K"])  # includes a sign tie and an all-zero block
+    assert np.array_equal(mirror.quantize_q8_0(x), OPS["act_q8_0"])
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_weight_dot_products_bit_exact(mirror, t):
+    name = G.TYPE_NAMES[t]
+    y = mirror.matvec(t, OPS["w_" + name], OPS["act_x"], OPS["act_x"].size)
+    assert np.array_equal(y, OPS["y_" + name])
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_dequantize_bit_exact(mirror, t):
+    name = G.TYPE_NAMES[t]
+    K = OPS["act_x"].size
+    assert np.array_equal(mirror.dequantize(OPS["w_" + name][:2], t, K), OPS["deq_" + name])
+    assert np.array_equal(synth.dequantize(OPS["w_" + name][:2], t, K), OPS["deq_" + name])  # numpy restatement
+
+
+def test_rope_and_rmsnorm_bit_exact(mirror):
+    for i, p in enumerate(OPS["rope_pos"]):
+        assert np.array_equal(mirror.rope(OPS["rope_x"][i], int(p)), OPS["rope_y"][i])
+    assert np.array_equal(mirror.rms_norm_mul(OPS["norm_x"], OPS["norm_w"], 1e-5), OPS["norm_y"])
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_whole_model_bit_exact(mirror, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = mirror.MirrorLlama(os.path.join(GOLDEN, name + ".gguf"), 96)
+    logits = m.eval(g["prompt"], 0)
+    assert np.array_equal(logits, g["logits"][0])
+    assert np.array_equal(m.embeddings, g["embeddings"][0])
+    pos = len(g["prompt"])
+    for i, t in enumerate(g["greedy"][:24]):
+        assert int(np.argmax(logits)) == int(t)
+        logits = m.eval([int(t)], pos + i)
+        assert np.array_equal(logits, g["logits"][i + 1]), "step %d" % i
+
+
+def test_reference_build_reproduces_golden(ref):
+    """The oracle/_ref binary in this checkout still produces the committed vectors."""
+    q, _ = ref.quantize_activation(OPS["act_x"], G.Q4_K)
+    assert np.array_equal(q, OPS["act_q8_K"])
+    for t in TYPES:
+        name = G.TYPE_NAMES[t]
+        assert np.array_equal(ref.matvec(t, OPS["w_" + name], OPS["act_x"], OPS["act_x"].size), OPS["y_" + name])
+    ops = ref.GgmlOps()
+    assert np.array_equal(ops.rope(OPS["rope_x"][1][None], int(OPS["rope_pos"][1]))[0], OPS["rope_y"][1])
+    assert np.array_equal(ops.scale_softmax(OPS["sm_x"], float(OPS["sm_scale"])), OPS["sm_y"])
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    r = ref.open_llm(os.path.join(GOLDEN, "tiny-q4km.gguf"), context_length=96, batch_size=8, threads=2)
+    r.eval(list(g["prompt"]))
+    assert np.array_equal(r.logits.to_numpy(), g["logits"][0])
