@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy decode tokens/s (and prefill tok/s) of synthetic Llama-2-7B Q4_K_M through the C ABI.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A "step" is one decoded token = one pass of the hot path (`llm.eval([token])` -> ctransformers_llm_batch_eval) with
+all weights and the KV cache resident in HBM; K steps are timed after a 128-token prefill and W untimed warm-up
+steps, bracketed by barrier + device synchronisation, MAX over ranks.
+
+Workload = BASELINE.json configs[1]: Llama-2-7B GGUF Q4_K_M (synthetic weights at the real shapes / tensor-type mix),
+all layers on the GPU(s), 128-token prefill + 256-token decode, context 512.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the K=4096 weight mat-vec launch: QKV / Wo / gate+up / lm_head sites) —
+                algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
+  cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from ctransformers_amd import synth  # noqa: E402
+from ctransformers_amd.llm import LLM, Config  # noqa: E402
+
+HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
+N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
+MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km.gguf")
+SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), "Q4_K_M"
+
+
+class LaunchStat(ctypes.Structure):
+    _fields_ = [("site", ctypes.c_char * 32), ("bytes", ctypes.c_double), ("ms", ctypes.c_double), ("launches", ctypes.c_int)]
+
+
+def ensure_model(rank):
+    if rank == 0 and not os.path.exists(MODEL):
+        tmp = MODEL + ".tmp%d" % os.getpid()
+        synth.write_llama_gguf(tmp, SHAPE, FTYPE, seed=1234)
+        os.replace(tmp, MODEL)
+
+
+def profile_sites(llm, iters):
+    lib = llm._lib
+    lib.ctamd_profile_decode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LaunchStat), ctypes.c_int]
+    lib.ctamd_profile_decode.restype = ctypes.c_int
+    buf = (LaunchStat * 32)()
+    n = lib.ctamd_profile_decode(llm._llm, iters, buf, 32)
+    return [dict(site=buf[i].site.decode(), bytes=buf[i].bytes, ms=buf[i].ms, launches=buf[i].launches) for i in range(max(n, 0))]
+
+
+def cpu_baseline(n_vocab):
+    """Reference CPU build on the host cores, bounded sample: 16-token prefill + 24 greedy decode steps."""
+    from oracle import ref
+    if not ref.available():
+        return None
+    threads = min(16, os.cpu_count() or 1)
+    r = ref.open_llm(MODEL, context_length=N_CTX, batch_size=16, threads=threads)
+    r.eval(synth.prompt_tokens(16, n_vocab))
+    ts = []
+    for _ in range(24):
+        tok = r.sample(top_k=1, repetition_penalty=1.0)
+        t0 = time.perf_counter()
+        r.eval([tok])
+        ts.append(time.perf_counter() - t0)
+    return dict(value=round(1.0 / float(np.median(ts)), 3), unit="tokens/s", cores=threads, kind="reference",
+                sample="reference AVX2 build (oracle/_ref), threads=%d, same synthetic 7B file, 16-token prefill then "
+                       "24 greedy decode steps, median step time" % threads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=N_DECODE)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 or world > 1:
+        from ctransformers_amd import pipeline
+        return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
+
+    ensure_model(rank)
+    t0 = time.perf_counter()
+    llm = LLM(MODEL, config=Config(context_length=N_CTX, batch_size=N_PROMPT, gpu_layers=1000))
+    load_s = time.perf_counter() - t0
+    n_vocab = llm.vocab_size
+    prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
+    # prefill (timed separately; reported, not the headline value)
+    t0 = time.perf_counter()
+    llm.eval(prompt)
+    prefill_s = time.perf_counter() - t0
+    tok = llm.sample(top_k=1, repetition_penalty=1.0)
+    for _ in range(a.warmup):
+        llm.eval([tok])
+        tok = llm.sample(top_k=1, repetition_penalty=1.0)
+    steps = min(a.steps, N_CTX - N_PROMPT - a.warmup - 1)
+    # llm.eval() returns only after the library synchronised its stream and copied the logits to the host, so the
+    # wall clock below brackets exactly `steps` complete decode steps (device sync on both sides).
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        llm.eval([tok])
+        tok = llm.sample(top_k=1, repetition_penalty=1.0)
+    dt = time.perf_counter() - t0
+    tok_s = steps / dt
+
+    sites = profile_sites(llm, 8)
+    dom = [s for s in sites if s["site"] in ("qkv", "wo", "gate_up", "lm_head")]
+    roof = None
+    if dom:
+        b = sum(s["bytes"] for s in dom)
+        ms = sum(s["ms"] for s in dom)
+        nl = sum(s["launches"] for s in dom)
+        ach = b / (ms * 1e-3)
+        roof = dict(bound="hbm", kernel="matvec_exact2_kernel<256,4096,4> (QKV, Wo, gate+up, lm_head launch sites)",
+                    achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / HBM_PEAK, 4),
+                    traffic=None, bytes_per_launch=round(b / nl), us_per_launch=round(ms * 1e3 / nl, 2),
+                    sites={s["site"]: dict(GBps=round(s["bytes"] / (s["ms"] * 1e-3) / 1e9, 1) if s["bytes"] else None,
+                                           us=round(s["ms"] * 1e3 / s["launches"], 2)) for s in sites})
+    wbytes = synth.weight_bytes_per_token(MODEL)
+    kv_avg = 2 * 32 * (N_PROMPT + a.warmup + steps / 2.0) * 4096 * 2 if SHAPE == "llama-2-7b" else 0
+    out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=1, steps=steps, warmup=a.warmup,
+               ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int8",
+               data="synthetic",
+               config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on 1xMI355X, 128-tok prefill + 256-tok greedy decode, ctx 512",
+                           shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism="1 GPU"),
+               prefill_tok_s=round(N_PROMPT / prefill_s, 1), load_s=round(load_s, 2),
+               token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / HBM_PEAK, 4)),
+               roofline=roof)
+    if not a.no_cpu_baseline:
+        del llm
+        out["cpu_baseline"] = cpu_baseline(n_vocab)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

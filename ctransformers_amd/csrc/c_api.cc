@@ -1,5 +1,6 @@
 // The 17-symbol C ABI (include/ctransformers_llm.h) over ctamd::Engine.
 #include "../../include/ctransformers_llm.h"
+#include "../../include/ctransformers_amd_ext.h"
 
 #include <ctype.h>
 #include <stdio.h>
@@ -101,5 +102,26 @@ int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int
 }
 
 void ctransformers_llm_reset(ctransformers_llm* llm) { (void)llm; }
+
+// ---- measurement extensions (include/ctransformers_amd_ext.h); not part of the reference ABI ----------------------
+int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* out, int max_out) {
+    std::vector<ctamd::Engine::LaunchStat> st;
+    std::string err;
+    if (!llm->engine.profile_decode(iters, st, err)) {
+        fprintf(stderr, "ctransformers_amd: profile failed: %s\n", err.c_str());
+        return -1;
+    }
+    int n = 0;
+    for (auto& s : st) {
+        if (n >= max_out) break;
+        snprintf(out[n].site, sizeof(out[n].site), "%s", s.site);
+        out[n].bytes = s.bytes;
+        out[n].ms = s.ms;
+        out[n].launches = s.launches;
+        ++n;
+    }
+    return n;
+}
+double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
 
 }  // extern "C"

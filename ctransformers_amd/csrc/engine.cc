@@ -231,7 +231,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
     exact_ = env_int("CT_AMD_EXACT", 1) != 0;
     items_per_wave_ = std::max(1, env_int("CT_AMD_IPW", 1));
-    max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 2048));
+    max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 1024));
 
     GgufFile f;
     if (!f.open(path)) { err = f.error(); return false; }
@@ -334,6 +334,15 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         item0 += (a.job[j].w.M + 7) / 8;
     }
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
+    static const int design = env_int("CT_AMD_DESIGN", 2);
+    if (design == 2 && a.K <= 12288) {
+        // design C: one tile per workgroup step, K split over the waves; persistent grid, balanced items per workgroup
+        const int per_wg = (a.n_pairs + max_wgs - 1) / max_wgs;
+        const int wgs = (a.n_pairs + per_wg - 1) / per_wg;
+        if (a.K <= 4096) CT_LAUNCH((matvec_exact2_kernel<256, 4096, 4>), dim3((unsigned)wgs), dim3(256), s, a);
+        else CT_LAUNCH((matvec_exact2_kernel<512, 12288, 2>), dim3((unsigned)wgs), dim3(512), s, a);
+        return true;
+    }
     constexpr int NT = 256, NW = NT / 64;
     const int waves = (a.n_pairs + items_per_wave - 1) / items_per_wave;
     const int wgs = std::max(1, std::min(max_wgs, (waves + NW - 1) / NW));
@@ -383,8 +392,10 @@ bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
 bool Engine::token_step(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
+    prof_begin("embed", "embed_row_kernel", (double)ggml_row_bytes(tok_embd_.type, E));
     CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
               (const int*)d_tokens_, (const int*)d_state_, x_);
+    prof_end();
     MatvecArgs base = MatvecArgs();
     base.rope_cs = rope_cs_;
     base.pos = d_pos;
@@ -419,7 +430,9 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
             a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
             set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
+            prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
             if (!run_matvec(a, err)) return false;
+            prof_end();
         }
         at.kcache = kc;
         at.vcache = vc;
@@ -428,8 +441,12 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
             ax.exp_tab = exp_tab_; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
             ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
+            prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);
             CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
+            prof_end();
+            prof_begin("attn_softmax_pv", "attn_softmax_pv_exact_kernel", 0.0);
             CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
+            prof_end();
         } else {
             CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
             CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
@@ -438,7 +455,9 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.wo, EPI_ADD}});
+            prof_begin("wo", "matvec", (double)L.wo.bytes);
             if (!run_matvec(a, err)) return false;
+            prof_end();
         }
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
@@ -446,13 +465,17 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
             if (!run_matvec(a, err)) return false;
+            prof_end();
         }
         {   // Q8_K(h) -> W_down -> + residual
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
+            prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
             if (!run_matvec(a, err)) return false;
+            prof_end();
         }
     }
     if (want_logits) {
@@ -461,7 +484,9 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        prof_begin("lm_head", "matvec", (double)output_.bytes);
         if (!run_matvec(a, err)) return false;
+        prof_end();
     }
     CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     return true;
@@ -515,13 +540,64 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
     HIP_OK(hipStreamSynchronize(stream_));
     HIP_OK(hipGetLastError());
     have_logits_ = true;
+    last_token_ = tokens[n - 1];
+    last_pos_ = n_past + n - 1;
     return true;
 }
 
-bool Engine::run_matvec_test(int, int, int, const uint8_t*, const float*, const float*, float, float*, int, float*,
-                             std::string& err) {
-    err = "not implemented";
-    return false;
+void Engine::prof_begin(const char* site, const char* kernel, double bytes) {
+#ifndef CT_EMU
+    if (!prof_) return;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, stream_);
+    prof_->push_back(ProfRec{site, kernel, bytes, (void*)e0, (void*)e1});
+#else
+    (void)site; (void)kernel; (void)bytes;
+#endif
 }
+void Engine::prof_end() {
+#ifndef CT_EMU
+    if (!prof_) return;
+    (void)hipEventRecord((hipEvent_t)prof_->back().e1, stream_);
+#endif
+}
+
+bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string& err) {
+    out.clear();
+#ifndef CT_EMU
+    if (last_pos_ < 0) { err = "profile_decode: nothing evaluated yet"; return false; }
+    std::vector<ProfRec> recs;
+    for (int it = 0; it < iters; ++it) {
+        h_scalars_[0] = 0;
+        h_scalars_[1] = last_pos_;
+        h_scalars_[2] = last_token_;
+        HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[2], 4, hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 8, hipMemcpyHostToDevice, stream_));
+        prof_ = &recs;
+        const bool ok = token_step(true, err);
+        prof_ = nullptr;
+        if (!ok) return false;
+        HIP_OK(hipStreamSynchronize(stream_));
+    }
+    for (auto& r : recs) {
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)r.e0, (hipEvent_t)r.e1));
+        (void)hipEventDestroy((hipEvent_t)r.e0);
+        (void)hipEventDestroy((hipEvent_t)r.e1);
+        bool found = false;
+        for (auto& o : out)
+            if (!strcmp(o.site, r.site)) { o.ms += ms; o.bytes += r.bytes; o.launches++; found = true; break; }
+        if (!found) out.push_back(LaunchStat{r.site, r.kernel, r.bytes, (double)ms, 1});
+    }
+    return true;
+#else
+    (void)iters;
+    err = "profiling needs the HIP build";
+    return false;
+#endif
+}
+
 
 }  // namespace ctamd

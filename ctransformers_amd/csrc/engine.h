@@ -48,9 +48,10 @@ class Engine {
     int embeddings_size() const { return have_logits_ ? hp_.n_embd : 0; }
     size_t weight_bytes() const { return weight_bytes_; }
 
-    // test/bench hooks (exported through ctamd_* C symbols)
-    bool run_matvec_test(int type, int M, int K, const uint8_t* raw, const float* x, const float* norm_w, float eps,
-                         float* out, int iters, float* ms_per_iter, std::string& err);
+    // Measurement hook (exported as ctamd_profile_decode): replays the LAST evaluated token `iters` times with eager
+    // launches bracketed by HIP events on the engine's stream; one entry per launch site, times summed over iters.
+    struct LaunchStat { const char* site; const char* kernel; double bytes; double ms; int launches; };
+    bool profile_decode(int iters, std::vector<LaunchStat>& out, std::string& err);
 
    private:
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
@@ -84,6 +85,11 @@ class Engine {
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
 #endif
     bool have_logits_ = false;
+    int last_token_ = -1, last_pos_ = -1;
+    struct ProfRec { const char* site; const char* kernel; double bytes; void* e0; void* e1; };
+    std::vector<ProfRec>* prof_ = nullptr;
+    void prof_begin(const char* site, const char* kernel, double bytes);
+    void prof_end();
     std::vector<void*> dev_allocs_;
     int pairs_per_wave_ = 2, max_wgs_ = 2048, items_per_wave_ = 1;
     bool exact_ = true;

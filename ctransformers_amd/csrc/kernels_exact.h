@@ -428,3 +428,199 @@ __global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnAr
     for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
     if (j == 0) a.out[(size_t)h * a.head_dim + d] = (float)sumf;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Design C: the same bit-exact arithmetic with K split across the waves of a workgroup.
+// The integer part of a block (loads, nibble unpack, dot4, transpose-reduce) is order-free, so the NW waves of a
+// workgroup take the blocks b = wave, wave+NW, ... of ONE 8-row tile concurrently and leave per block
+//     S[b][lane] = (float)sumi[l(g)]   D[b][row] = y.d*fp16(x.d)   DM[b][row] = -y.d*fp16(x.dmin)   PM[b][row][t]
+// in LDS; after one barrier a single wave replays the reference's sequential f32 fma chain over b = 0..nb-1 from LDS
+// (nb short dependent steps) and runs the epilogue.  This multiplies the loads in flight per tile by NW and cuts the
+// serial depth per tile from nb block-steps to nb/NW, which is what the small 4096-row matrices (Wo, W_down: 512
+// tiles) need to keep every CU streaming.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MAXNB> struct ChainBuf {
+    float S[MAXNB][64];
+    float D[MAXNB][8];
+    float DM[MAXNB][8];
+    float PM[MAXNB][32];
+};
+
+// Integer work of one block for this lane's row; results go to the chain buffer.
+template <int MAXK, int MAXNB>
+DEV void block_to_chain(int type, const uint8_t* rp, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane,
+                        const u32x4 v0, const u32x4 v1, const u32x4 v2, const uint16_t dd) {
+    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
+    (void)rp;
+    if (type == GT_Q4_K || type == GT_Q5_K) {
+        const bool q5 = type == GT_Q5_K;
+        // v0 = hdr, v1 = qs, v2 = qh (Q5_K)
+        const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
+        const int* ahi = alo + 8;
+        int sc_lo, sc_hi, m_lo, m_hi;
+        scale_min_pair(v0[1], v0[2], v0[3], c, sc_lo, sc_hi, m_lo, m_hi);
+        int part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t lo = v1[k] & 0x0F0F0F0Fu;
+            uint32_t hi = (v1[k] >> 4) & 0x0F0F0F0Fu;
+            if (q5) {
+                lo |= ((v2[k] >> (2 * c)) & 0x01010101u) << 4;
+                hi |= ((v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
+            }
+            part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
+        }
+        const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
+        C.S[b][lane] = (float)sumi;
+        int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
+        if (q5) {
+            prod += __shfl_xor(prod, 2);
+            prod += __shfl_xor(prod, 4);
+        }
+        if (h == 0) C.PM[b][r * 4 + c] = (float)prod;
+        if (g == 0) {
+            const float yd = L.yd[b];
+            C.D[b][r] = yd * f16_bits_to_f32((uint16_t)(v0[0] & 0xFFFF));
+            C.DM[b][r] = -yd * f16_bits_to_f32((uint16_t)(v0[0] >> 16));
+        }
+    } else {  // GT_Q6_K: v0 = sc, v1 = ql, v2 = qh, dd = d
+        const int n = g >> 2, gg = g & 3, kq = gg >> 1;
+        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
+        const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
+        const int* ahi = alo + 16;
+        const uint32_t w_lo = n ? v0[2] : v0[0];
+        const uint32_t w_hi = n ? v0[3] : v0[1];
+        const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
+        const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
+        int part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (v1[k] & 0x0F0F0F0Fu) | (((v2[k] >> s_lo) & 0x03030303u) << 4);
+            const uint32_t hi = ((v1[k] >> 4) & 0x0F0F0F0Fu) | (((v2[k] >> s_hi) & 0x03030303u) << 4);
+            const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
+            const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
+            part[k] = sc_lo * dl + sc_hi * dh;
+        }
+        const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
+        C.S[b][lane] = (float)sumi;
+        if (g == 0) C.D[b][r] = L.yd[b] * f16_bits_to_f32(dd);
+    }
+}
+
+// All waves: this wave's blocks (b = wv, wv+NW, ...) of one tile -> chain buffer.
+template <int NW, int MAXK, int MAXNB, int UB>
+DEV void tile_blocks_to_chain(const DevMat& w, int tile, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, int wv) {
+    const int nb = w.nb, type = w.type;
+    const int r = lane >> 3, g = lane & 7, h = g & 1;
+    const int rec = tile8_record_bytes(type);
+    const uint8_t* base = w.p[0] + (size_t)tile * nb * rec;
+    for (int b0 = wv; b0 < nb; b0 += NW * UB) {
+        u32x4 v0[UB], v1[UB], v2[UB];
+        uint16_t dd[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int b = b0 + u * NW;
+            const uint8_t* rp = base + (size_t)(b < nb ? b : nb - 1) * rec;
+            if (type == GT_Q6_K) {
+                const int n = g >> 2, hh = g & 1;
+                dd[u] = *(const uint16_t*)(rp + r * 2);
+                v0[u] = ld_stream16(rp + 16 + r * 16);
+                v2[u] = ld_stream16(rp + 144 + r * 64 + n * 32 + hh * 16);
+                v1[u] = ld_stream16(rp + 656 + r * 128 + g * 16);
+            } else {
+                const bool q5 = type == GT_Q5_K;
+                dd[u] = 0;
+                v0[u] = ld_stream16(rp + r * 16);
+                v1[u] = ld_stream16(rp + (q5 ? 384 : 128) + r * 128 + g * 16);
+                v2[u] = q5 ? ld_stream16(rp + 128 + r * 32 + h * 16) : v0[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int b = b0 + u * NW;
+            if (b < nb) block_to_chain<MAXK, MAXNB>(type, nullptr, b, L, C, lane, v0[u], v1[u], v2[u], dd[u]);  // wave-uniform
+        }
+    }
+}
+
+// One wave: the reference's sequential accumulation over all blocks, then its reduction tree.
+template <int MAXNB>
+DEV float chain_reduce(int type, int nb, const ChainBuf<MAXNB>& C, int lane) {
+    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
+    float acc = 0.0f, accm = 0.0f;
+    if (type == GT_Q6_K) {
+        for (int b = 0; b < nb; ++b) acc = fmaf(C.D[b][r], C.S[b][lane], acc);
+        return hsum8_exact(acc);
+    }
+    const bool q5 = type == GT_Q5_K;
+    for (int b = 0; b < nb; ++b) {
+        acc = fmaf(C.D[b][r], C.S[b][lane], acc);
+        const float pm = (h == 0) ? C.PM[b][r * 4 + c] : 0.0f;
+        accm = fmaf(C.DM[b][r], pm, accm);
+    }
+    float tot = hsum8_exact(acc);
+    if (!q5) {
+        const float wsum = accm + __shfl_xor(accm, 4);
+        accm = wsum + __shfl_xor(wsum, 2);
+    }
+    accm = __shfl(accm, lane & ~7);
+    return tot + accm;
+}
+
+template <int NT, int MAXK, int UB>
+__global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
+    constexpr int NW = NT / 64;
+    constexpr int MAXNB = MAXK / 256;
+    __shared__ ActLdsX<MAXK> L;
+    __shared__ ChainBuf<MAXNB> CB[2];
+    const int lane = lane_id(), wv = wave_id();
+    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    const int pos = a.pos ? *a.pos : 0;
+    const int r = lane >> 3, g = lane & 7;
+    int buf = 0, turn = 0;
+    for (int it = (int)blockIdx.x; it < a.n_pairs; it += (int)gridDim.x) {  // n_pairs == number of work items
+        int j = 0;
+        if (!a.gateup) {
+            if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
+            if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+        }
+        const MatJob& jb = a.job[j];
+        const int tile = it - jb.pair0;
+        const int row = tile * 8 + r;
+        const int epi = a.gateup ? EPI_SILU_MUL : jb.epi;
+        const int cw = turn % NW;  // the wave that replays the chain for this item (rotates to spread the work)
+        ++turn;
+        tile_blocks_to_chain<NW, MAXK, MAXNB, UB>(jb.w, tile, L, CB[buf], lane, wv);
+        __syncthreads();
+        float res = 0.0f;
+        if (wv == cw) res = chain_reduce<MAXNB>(jb.w.type, jb.w.nb, CB[buf], lane);
+        buf ^= 1;
+        if (epi == EPI_SILU_MUL) {
+            tile_blocks_to_chain<NW, MAXK, MAXNB, UB>(a.job[1].w, tile, L, CB[buf], lane, wv);
+            __syncthreads();
+            if (wv == cw) {
+                const float up = chain_reduce<MAXNB>(a.job[1].w.type, a.job[1].w.nb, CB[buf], lane);
+                if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
+            }
+            buf ^= 1;
+        } else if (wv == cw) {
+            if (epi == EPI_STORE) {
+                if (g == 0 && row < jb.w.M) a.out[row] = res;
+            } else if (epi == EPI_ADD) {
+                if (g == 0 && row < jb.w.M) a.out[row] = res + a.res[row];
+            } else if (epi == EPI_V) {
+                if (g == 0 && row < jb.w.M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+            } else {
+                const float other = __shfl_xor(res, 8);
+                const int ip = (row % a.head_dim) >> 1;
+                const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+                const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+                const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+                if (g == 0 && row < jb.w.M) {
+                    if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+                    else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,112 @@
+"""GPU parity tests proper (run with -m gpu on the MI355X box).  Everything goes through the C ABI of the HIP library
+(ctransformers_amd/lib/libctransformers.so via the Python host mirror).  Bar: BIT-IDENTICAL logits to the reference CPU
+build — checked (a) against the committed golden vectors and (b) against the reference .so itself (oracle/_ref, which
+travels with the snapshot) on freshly generated models, plus size-independent properties at the full 7B size."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ctransformers_amd import synth
+from ctransformers_amd.llm import LLM, Config
+
+pytestmark = pytest.mark.gpu
+
+
+def open_hip(path, **kw):
+    cfg = dict(context_length=96, batch_size=8)
+    cfg.update(kw)
+    return LLM(path, config=Config(**cfg))  # default lib = the HIP build; raises if missing / no GPU
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_golden_logits_bit_identical(name, graph, monkeypatch):
+    monkeypatch.setenv("CT_AMD_GRAPH", graph)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_hip(os.path.join(GOLDEN, name + ".gguf"))
+    m.eval(list(g["prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    for i, t in enumerate(g["greedy"]):
+        assert m.sample(top_k=1, repetition_penalty=1.0) == int(t)
+        m.eval([int(t)])
+        assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
+
+
+def test_abi_semantics_on_gpu():
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = open_hip(os.path.join(GOLDEN, "tiny-q4km.gguf"))
+    prompt = list(g["prompt"])
+    m.eval(prompt, batch_size=4)  # chunked == one shot
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    m.logits[7] = -55.25  # in-place mutation persists (reference tests/test_model.py:10-16)
+    assert m.logits[7] == -55.25
+    m._context = m._context[:-3]  # KV overwrite at an earlier n_past
+    m.eval(prompt[-3:])
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    for k, p, temp, pen, seed, expect in g["samples"][:1]:
+        pass  # sampler parity is covered on the CPU suite (host code, identical binary path)
+
+
+@pytest.mark.parametrize("shape,ftype,n_prompt,n_decode", [
+    ("llama-small", "Q4_K_M", 20, 60),   # MHA 8/8, head_dim 64, K = 512 / 1280 (odd block counts)
+    ("llama-tiny", "Q5_K_M", 5, 80),     # GQA 4/2, runs past 64 positions (fp16 dot leftovers + full 32-steps)
+    ("llama-7b-2l", "Q4_K_M", 33, 12),   # two layers at the real 7B shapes incl. the 32000x4096 Q6_K head
+])
+def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, shape, ftype, seed=21)
+    ctx = n_prompt + n_decode + 8
+    r = ref.open_llm(p, context_length=ctx, batch_size=64, threads=8)
+    m = open_hip(p, context_length=ctx, batch_size=64)
+    toks = synth.prompt_tokens(n_prompt, hp["n_vocab"])
+    r.eval(toks)
+    m.eval(toks)
+    for i in range(n_decode):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
+    assert np.array_equal(r.embeddings.to_numpy(), m.embeddings.to_numpy())
+
+
+@pytest.fixture(scope="module")
+def model_7b(tmp_path_factory):
+    p = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km.gguf")
+    if not os.path.exists(p):
+        synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
+    return p
+
+
+def test_full_7b_properties_and_reference(ref, model_7b):
+    """BASELINE.json's full-size config: parity vs the reference CPU build on a short prompt + greedy steps, and
+    size-independent properties (determinism across instances, chunking invariance, KV rollback)."""
+    toks = synth.prompt_tokens(24, 32000)
+    m = open_hip(model_7b, context_length=512, batch_size=128)
+    m.eval(toks)
+    first = m.logits.to_numpy().copy()
+    r = ref.open_llm(model_7b, context_length=512, batch_size=128, threads=16)
+    r.eval(toks)
+    assert np.array_equal(r.logits.to_numpy(), first)
+    seq = []
+    for i in range(8):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "7B step %d" % i
+        t = int(a.argmax())
+        seq.append(t)
+        r.eval([t])
+        m.eval([t])
+    del r
+    last = m.logits.to_numpy().copy()
+    # rollback: drop the last 5 evaluated tokens and replay them -> same logits (KV overwrite semantics)
+    replay = m._context[-5:]
+    m._context = m._context[:-5]
+    m.eval(replay, batch_size=2)
+    assert np.array_equal(m.logits.to_numpy(), last)
+    # a second, independent instance is bit-deterministic
+    m2 = open_hip(model_7b, context_length=512, batch_size=8)
+    m2.eval(toks)  # chunks of 8
+    assert np.array_equal(m2.logits.to_numpy(), first)
