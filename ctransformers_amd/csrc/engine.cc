@@ -315,6 +315,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     HIP_OK(hipHostMalloc(&h_emb_, (size_t)E * 4));
     HIP_OK(hipHostMalloc(&h_scalars_, ((size_t)n_ctx_ + 16) * 4));
     use_graph_ = env_int("CT_AMD_GRAPH", 1) != 0;
+    dump_dir_ = getenv("CT_AMD_DUMP");
+    if (dump_dir_ && !*dump_dir_) dump_dir_ = nullptr;
+    if (dump_dir_) use_graph_ = false;
     memset(h_logits_, 0, (size_t)V * 4);
     memset(h_emb_, 0, (size_t)E * 4);
     if (!build_tables(err)) return false;
@@ -384,6 +387,34 @@ static void set_jobs(MatvecArgs& a, std::initializer_list<std::pair<const DevMat
     a.n_pairs = pair0;
 }
 
+// Debug aid (CT_AMD_DUMP=<dir>): after every launch of a token step, synchronise and write the scratch buffers to
+// <dir>/t<eval#>_l<layer>_<site>.bin so two builds (HIP vs the CPU emulation of the same sources) can be diffed.
+void Engine::debug_dump(const char* site, int layer) {
+    if (!dump_dir_) return;
+    (void)hipStreamSynchronize(stream_);
+    const int E = hp_.n_embd, F = hp_.n_ff;
+    std::vector<float> buf((size_t)E * 2 + F + (size_t)hp_.n_head * n_ctx_ + E);
+    size_t o = 0;
+    (void)hipMemcpy(&buf[o], x_, (size_t)E * 4, hipMemcpyDeviceToHost); o += E;
+    (void)hipMemcpy(&buf[o], attn_out_, (size_t)E * 4, hipMemcpyDeviceToHost); o += E;
+    (void)hipMemcpy(&buf[o], h_, (size_t)F * 4, hipMemcpyDeviceToHost); o += F;
+    (void)hipMemcpy(&buf[o], scores_, (size_t)hp_.n_head * n_ctx_ * 4, hipMemcpyDeviceToHost); o += (size_t)hp_.n_head * n_ctx_;
+    (void)hipMemcpy(&buf[o], q_f16_, (size_t)E * 2, hipMemcpyDeviceToHost);
+    char name[512];
+    snprintf(name, sizeof(name), "%s/t%04d_l%02d_%s.bin", dump_dir_, dump_seq_, layer, site);
+    FILE* f = fopen(name, "wb");
+    if (f) { fwrite(buf.data(), 4, buf.size(), f); fclose(f); }
+    if (!strcmp(site, "2attn")) {  // also the layer's K/V cache
+        const int G = hp_.n_embd_gqa();
+        std::vector<uint16_t> kv((size_t)n_ctx_ * G + (size_t)v_stride_ * G);
+        (void)hipMemcpy(kv.data(), kcache_ + (size_t)layer * n_ctx_ * G, (size_t)n_ctx_ * G * 2, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(kv.data() + (size_t)n_ctx_ * G, vcache_ + (size_t)layer * v_stride_ * G, (size_t)v_stride_ * G * 2, hipMemcpyDeviceToHost);
+        snprintf(name, sizeof(name), "%s/t%04d_l%02d_kv.bin", dump_dir_, dump_seq_, layer);
+        f = fopen(name, "wb");
+        if (f) { fwrite(kv.data(), 2, kv.size(), f); fclose(f); }
+    }
+}
+
 bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
     if (a.job[0].w.layout == LAYOUT_TILE8) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
     return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
@@ -433,6 +464,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
             if (!run_matvec(a, err)) return false;
             prof_end();
+            debug_dump("1qkv", il);
         }
         at.kcache = kc;
         at.vcache = vc;
@@ -447,6 +479,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_begin("attn_softmax_pv", "attn_softmax_pv_exact_kernel", 0.0);
             CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
             prof_end();
+            debug_dump("2attn", il);
         } else {
             CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
             CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
@@ -458,6 +491,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_begin("wo", "matvec", (double)L.wo.bytes);
             if (!run_matvec(a, err)) return false;
             prof_end();
+            debug_dump("3wo", il);
         }
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
@@ -468,6 +502,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
             if (!run_matvec(a, err)) return false;
             prof_end();
+            debug_dump("4gateup", il);
         }
         {   // Q8_K(h) -> W_down -> + residual
             MatvecArgs a = base;
@@ -476,6 +511,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
             if (!run_matvec(a, err)) return false;
             prof_end();
+            debug_dump("5down", il);
         }
     }
     if (want_logits) {
@@ -489,6 +525,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         prof_end();
     }
     CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (dump_dir_) ++dump_seq_;
     return true;
 }
 

@@ -61,6 +61,9 @@ class Engine {
     bool run_matvec(::MatvecArgs& a, std::string& err);
     bool ensure_graphs(std::string& err);
     void free_all();
+    void debug_dump(const char* site, int layer);
+    const char* dump_dir_ = nullptr;
+    int dump_seq_ = 0;
 
     HParams hp_;
     Vocab vocab_;

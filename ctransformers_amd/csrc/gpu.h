@@ -21,6 +21,13 @@ static inline uint16_t f32_to_f16_bits(float f) { return (uint16_t)_cvtss_sh(f, 
 static inline float f16_bits_to_f32(uint16_t h) { return _cvtsh_ss(h); }
 #else
 __host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Pin the f32 value in a VGPR first: without this hipcc (ROCm 7.2) folds `(half)(a*b)` / `(half)fma(a,b,c)` into
+    // v_fma_mixlo_f16, which rounds the EXACT product once to fp16 instead of f32-then-fp16 like the reference's
+    // F16C conversion; the two differ exactly when the f32 result is an fp16 tie (seen on hardware: a softmax
+    // probability 0x3cd9b000 came out 0x26cd instead of 0x26ce).  -ffp-contract=off does not stop this fold.
+    asm volatile("" : "+v"(f));
+#endif
     _Float16 h = (_Float16)f;  // v_cvt_f16_f32 on device, RNE on both sides
     return __builtin_bit_cast(uint16_t, h);
 }
