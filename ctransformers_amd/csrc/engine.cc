@@ -471,7 +471,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         if (exact_) {
             AttnArgsX ax = AttnArgsX();
             ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
-            ax.exp_tab = exp_tab_; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
+            ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
             ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
             prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);
             CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
@@ -556,12 +556,13 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
     if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
     for (int i = 0; i < n; ++i) {
         if (tokens[i] < 0 || tokens[i] >= hp_.n_vocab) { err = "token id out of range"; return false; }
-        h_scalars_[2 + i] = tokens[i];
+        h_scalars_[4 + i] = tokens[i];
     }
-    h_scalars_[0] = 0;       // step
-    h_scalars_[1] = n_past;  // position of the first token of this chunk
-    HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[2], (size_t)n * 4, hipMemcpyHostToDevice, stream_));
-    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 8, hipMemcpyHostToDevice, stream_));
+    h_scalars_[0] = 0;           // step
+    h_scalars_[1] = n_past;      // position of the first token of this chunk
+    h_scalars_[2] = n_past + n;  // n_total: the reference runs this chunk as ONE batch (see attn_softmax_pv_exact_kernel)
+    HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], (size_t)n * 4, hipMemcpyHostToDevice, stream_));
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 12, hipMemcpyHostToDevice, stream_));
 #ifndef CT_EMU
     if (use_graph_) {
         if (!ensure_graphs(err)) return false;
@@ -609,9 +610,10 @@ bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string
     for (int it = 0; it < iters; ++it) {
         h_scalars_[0] = 0;
         h_scalars_[1] = last_pos_;
-        h_scalars_[2] = last_token_;
-        HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[2], 4, hipMemcpyHostToDevice, stream_));
-        HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 8, hipMemcpyHostToDevice, stream_));
+        h_scalars_[2] = last_pos_ + 1;
+        h_scalars_[4] = last_token_;
+        HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], 4, hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 12, hipMemcpyHostToDevice, stream_));
         prof_ = &recs;
         const bool ok = token_step(true, err);
         prof_ = nullptr;

@@ -565,6 +565,7 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 
 // Device-side cursor {step, pos}: lets N token steps (eager launches or hipGraph replays) be queued back to back with
 // no host round trip — every kernel reads the position from memory, this one advances it.
+// state = {step, pos, n_total}; n_total (= n_past + N of the chunk) stays fixed for the whole chunk.
 __global__ void advance_state_kernel(int* state) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state[0] += 1;

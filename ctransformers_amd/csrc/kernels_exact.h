@@ -351,6 +351,7 @@ struct AttnArgsX {
     float* scores;           // [n_head][n_ctx]
     float* out;
     const int* pos;
+    const int* n_total;      // device scalar: n_past + N of the batch this token belongs to (see attn_softmax_pv_exact_kernel)
     const uint16_t* exp_tab;
     int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
     float kq_scale;
@@ -383,6 +384,10 @@ __global__ void __launch_bounds__(256) attn_scores_exact_kernel(const AttnArgsX 
 }
 
 // softmax (reference ggml.c:12047-12069) + out[h][d] = vec_dot_f16(V[d], P).   grid (n_head, head_dim/64), 256 threads.
+// Batch structure matters for bit-identity: the reference evaluates a chunk of N tokens as one graph, so every query row
+// of the chunk runs vec_dot_f16 over ALL n_total = n_past + N columns (masked columns hold P = 0): the split between the
+// 32-wide fma part and the scalar double-precision leftovers is taken at n_total & ~31, not at this token's own length.
+// fma(v, 0, acc) == acc, so only the split point has to be reproduced.
 __global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnArgsX a) {
     __shared__ float prob[kMaxCtx];
     __shared__ double red[4];
@@ -409,13 +414,15 @@ __global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnAr
     const double tot = ((red[0] + red[1]) + red[2]) + red[3];
     const float inv = (float)(1.0 / tot);
     for (int i = tid; i < n_kv; i += 256) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    const int n_tot = *a.n_total;
+    const int np = n_tot & ~31;
+    for (int i = n_kv + tid; i < np; i += 256) prob[i] = 0.0f;  // masked columns of this batch
     __syncthreads();
     const int j = tid & 3;
     const int d = (int)blockIdx.y * 64 + (tid >> 2);
     const int hk = h / (a.n_head / a.n_head_kv);
     const uint16_t* vrow = a.vcache + ((size_t)hk * a.head_dim + d) * a.v_stride;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int np = n_kv & ~31;
     for (int i = 0; i < np; i += 32) {
         float vf[8];
         unpack8_f16(ld16(vrow + i + 8 * j), vf);

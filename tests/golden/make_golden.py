@@ -39,10 +39,20 @@ def model_golden(name, ftype, seed):
     for seed_s, (k, p, temp, pen) in enumerate([(40, 0.95, 0.8, 1.1), (5, 0.5, 1.3, 1.0), (100, 1.0, 0.7, 1.3)]):
         samples.append([k, p, temp, pen, seed_s + 11,
                         r.sample(top_k=k, top_p=p, temperature=temp, repetition_penalty=pen, last_n_tokens=64, seed=seed_s + 11)])
-    # prefix-rollback: re-evaluate the last 5 tokens at their old positions -> same logits
+    # batch structure: a 45-token prompt as ONE batch vs in chunks of 8 (the reference's default batch_size) — the
+    # results differ in the last bits once n_past+N crosses 32 (vec_dot_f16's fma/leftover split), both are golden.
+    long_prompt = synth.prompt_tokens(45, hp["n_vocab"])
+    r2 = ref.open_llm(path, context_length=96, batch_size=64, threads=4)
+    r2.eval(long_prompt)
+    long_one = r2.logits.to_numpy().copy()
+    r3 = ref.open_llm(path, context_length=96, batch_size=8, threads=4)
+    r3.eval(long_prompt)
+    long_chunked = r3.logits.to_numpy().copy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), prompt=np.array(prompt, dtype=np.int32),
                         greedy=np.array(toks, dtype=np.int32), logits=np.array(logits), embeddings=np.array(emb),
-                        samples=np.array(samples, dtype=np.float64), context=np.array(list(r._context), dtype=np.int32))
+                        samples=np.array(samples, dtype=np.float64), context=np.array(list(r._context), dtype=np.int32),
+                        long_prompt=np.array(long_prompt, dtype=np.int32), long_one=long_one, long_chunked=long_chunked)
+    print(name, 'one-batch vs chunked identical:', np.array_equal(long_one, long_chunked))
     print(name, "greedy head:", toks[:8])
 
 

@@ -32,6 +32,17 @@ def test_logits_bit_identical_to_reference(emu_lib, name, steps):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
 
 
+def test_batch_structure(emu_lib):
+    """One 45-token batch vs chunks of 8 (reference default batch_size): both bit-identical to the reference."""
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = open_emu(emu_lib, "tiny-q4km", batch_size=64)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_one"])
+    m = open_emu(emu_lib, "tiny-q4km", batch_size=8)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
+
+
 def test_abi_semantics(emu_lib):
     g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
     m = open_emu(emu_lib, "tiny-q4km")

@@ -35,6 +35,17 @@ def test_golden_logits_bit_identical(name, graph, monkeypatch):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
 
 
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_batch_structure_on_gpu(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_hip(os.path.join(GOLDEN, name + ".gguf"), batch_size=64)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_one"])
+    m = open_hip(os.path.join(GOLDEN, name + ".gguf"), batch_size=8)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
+
+
 def test_abi_semantics_on_gpu():
     g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
     m = open_hip(os.path.join(GOLDEN, "tiny-q4km.gguf"))

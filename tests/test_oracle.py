@@ -54,6 +54,19 @@ def test_whole_model_bit_exact(mirror, name):
         assert np.array_equal(logits, g["logits"][i + 1]), "step %d" % i
 
 
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_batch_structure_bit_exact(mirror, name):
+    """45-token prompt as one batch and in chunks of 8: the fma/leftover split of vec_dot_f16 follows the batch."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    lp = g["long_prompt"]
+    m = mirror.MirrorLlama(os.path.join(GOLDEN, name + ".gguf"), 96)
+    assert np.array_equal(m.eval(lp, 0), g["long_one"])
+    m = mirror.MirrorLlama(os.path.join(GOLDEN, name + ".gguf"), 96)
+    for s in range(0, len(lp), 8):
+        out = m.eval(lp[s:s + 8], s)
+    assert np.array_equal(out, g["long_chunked"])
+
+
 def test_reference_build_reproduces_golden(ref):
     """The oracle/_ref binary in this checkout still produces the committed vectors."""
     q, _ = ref.quantize_activation(OPS["act_x"], G.Q4_K)

@@ -25,6 +25,11 @@ def run(shape, ft, n_prompt, n, env, seed=7, threads=4):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "b":
+        run("llama-7b-2l", "Q4_K_M", 1, 6, {}, seed=11, threads=16)
+        run("llama-7b-2l", "Q4_K_M", 1, 6, {"CT_AMD_DESIGN": 1}, seed=11, threads=16)
+        run("llama-7b-2l", "Q4_K_M", 1, 6, {"CT_AMD_GRAPH": 0, "CT_AMD_MAXWG": 1}, seed=11, threads=16)
+        run("llama-7b-2l", "Q4_K_M", 8, 6, {}, seed=11, threads=16)
     if which == "a":
         run("llama-small", "Q4_K_M", 12, 40, {})
         run("llama-small", "Q4_K_M", 12, 40, {"CT_AMD_DESIGN": 1})

@@ -7,10 +7,11 @@ from ctransformers_amd.llm import LLM, Config
 out, lib, n = sys.argv[1], (sys.argv[2] if sys.argv[2] != "hip" else None), int(sys.argv[3])
 os.makedirs(out, exist_ok=True)
 os.environ["CT_AMD_DUMP"] = out
-p = "/tmp/dump-small.gguf"
-hp = synth.write_llama_gguf(p, "llama-small", "Q4_K_M", seed=7)
+shape = os.environ.get("DUMP_SHAPE", "llama-small")
+p = "/tmp/dump-%s.gguf" % shape
+hp = synth.write_llama_gguf(p, shape, "Q4_K_M", seed=int(os.environ.get("DUMP_SEED", "7")))
 m = LLM(p, config=Config(context_length=64, batch_size=64), lib=lib)
-toks = synth.prompt_tokens(12, hp["n_vocab"])
+toks = synth.prompt_tokens(int(os.environ.get("DUMP_PROMPT", "12")), hp["n_vocab"])
 m.eval(toks)
 seq = [int(x) for x in os.environ.get("DUMP_TOKENS", "").split(",") if x]
 for i in range(n):
