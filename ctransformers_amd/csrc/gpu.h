@@ -65,3 +65,50 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 DEV u32x4 ld_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 DEV u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 #endif
+
+// ---- cross-lane moves without the LDS crossbar where the ISA allows it ----------------------------------------------
+// __shfl_xor always lowers to ds_bpermute_b32 (address VGPR + LDS pipe, ~100 cycles dependent latency).  Butterflies
+// inside a row of 16 lanes can use DPP modifiers instead: quad_perm for xor 1/2, row_half_mirror o quad_perm(3,2,1,0)
+// for xor 4 (7-p then 3-q  ==  p^4), row_ror:8 for xor 8.  xor 16 uses ds_swizzle (no address register), xor 32 bpermute.
+#ifdef CT_EMU
+template <class T> static inline T lane_xor1(T v) { return __shfl_xor(v, 1); }
+template <class T> static inline T lane_xor2(T v) { return __shfl_xor(v, 2); }
+template <class T> static inline T lane_xor4(T v) { return __shfl_xor(v, 4); }
+template <class T> static inline T lane_xor8(T v) { return __shfl_xor(v, 8); }
+template <class T> static inline T lane_xor16(T v) { return __shfl_xor(v, 16); }
+template <class T> static inline T lane_xor32(T v) { return __shfl_xor(v, 32); }
+#else
+template <int CTRL> DEV int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <class T, int CTRL> DEV T dpp_any(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dpp payload");
+    if constexpr (sizeof(T) == 4) {
+        int i = __builtin_bit_cast(int, v);
+        i = dpp_i32<CTRL>(i);
+        return __builtin_bit_cast(T, i);
+    } else {
+        long long l = __builtin_bit_cast(long long, v);
+        int lo = (int)(l & 0xffffffffll), hi = (int)(l >> 32);
+        lo = dpp_i32<CTRL>(lo);
+        hi = dpp_i32<CTRL>(hi);
+        l = ((long long)hi << 32) | (unsigned)lo;
+        return __builtin_bit_cast(T, l);
+    }
+}
+template <class T> DEV T lane_xor1(T v) { return dpp_any<T, 0xB1>(v); }                      // quad_perm [1,0,3,2]
+template <class T> DEV T lane_xor2(T v) { return dpp_any<T, 0x4E>(v); }                      // quad_perm [2,3,0,1]
+template <class T> DEV T lane_xor4(T v) { return dpp_any<T, 0x1B>(dpp_any<T, 0x141>(v)); }  // row_half_mirror, then quad_perm [3,2,1,0]
+template <class T> DEV T lane_xor8(T v) { return dpp_any<T, 0x128>(v); }                     // row_ror:8
+template <class T> DEV T lane_xor16(T v) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // bit mode: xor 16
+    } else {
+        return __shfl_xor(v, 16);
+    }
+}
+template <class T> DEV T lane_xor32(T v) { return __shfl_xor(v, 32); }
+#endif
+
+template <class T> DEV T wave_sum_fast(T v) {
+    v += lane_xor1(v); v += lane_xor2(v); v += lane_xor4(v); v += lane_xor8(v); v += lane_xor16(v); v += lane_xor32(v);
+    return v;
+}

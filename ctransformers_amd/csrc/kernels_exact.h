@@ -514,66 +514,248 @@ DEV void block_to_chain(int type, const uint8_t* rp, int b, const ActLdsX<MAXK>&
     }
 }
 
-// All waves: this wave's blocks (b = wv, wv+NW, ...) of one tile -> chain buffer.
-template <int NW, int MAXK, int MAXNB, int UB>
-DEV void tile_blocks_to_chain(const DevMat& w, int tile, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, int wv) {
+// Prologue, 16 lanes per 256-block: lane `sub` owns 16 consecutive elements, so the per-block reductions are 4 DPP
+// steps inside a row of 16 lanes and all 16 (32) blocks of a round proceed at once.  Same arithmetic as
+// prologue_q8k_exact (reference k_quants.c:1191-1226 with the fused fma; RMSNorm ggml.c:10700-10716).
+template <int NT, int MAXK>
+DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
+                              float eps) {
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, sub = tid & 15, grp = tid >> 4;
+    constexpr int NW = NT / 64, NG = NT / 16;
+    constexpr int ROUNDS = (MAXK / 256 + NG - 1) / NG;
+    const int nblk = K >> 8;
+    float4 v[ROUNDS][4];
+    double s = 0.0;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int b = grp + rd * NG;
+        if (b < nblk) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
+                if (pro == PRO_RMSNORM) {
+                    s += (double)(v[rd][k].x * v[rd][k].x);
+                    s += (double)(v[rd][k].y * v[rd][k].y);
+                    s += (double)(v[rd][k].z * v[rd][k].z);
+                    s += (double)(v[rd][k].w * v[rd][k].w);
+                }
+            }
+        }
+    }
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {
+        s = wave_sum_fast(s);
+        if (lane == 0) L.red[wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + eps);
+    }
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int b = grp + rd * NG;
+        const bool live = b < nblk;            // uniform within a 16-lane row, may differ between rows of a wave
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
+            if (live && pro == PRO_RMSNORM) {
+                const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                q.x = (q.x * scale) * w4.x;
+                q.y = (q.y * scale) * w4.y;
+                q.z = (q.z * scale) * w4.z;
+                q.w = (q.w * scale) * w4.w;
+            }
+            t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
+        }
+        float am = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+        float amax = am;
+        amax = fmaxf(amax, lane_xor1(amax));
+        amax = fmaxf(amax, lane_xor2(amax));
+        amax = fmaxf(amax, lane_xor4(amax));
+        amax = fmaxf(amax, lane_xor8(amax));
+        // first element (lowest index) attaining amax keeps its sign
+        const unsigned long long hit = __ballot(am == amax);
+        const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
+        const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
+        float mine = 0.0f;
+#pragma unroll
+        for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
+        const float maxv = __shfl(mine, first);
+        int packed[4] = {0, 0, 0, 0}, s16 = 0;
+        float d = 0.0f;
+        if (amax != 0.0f) {
+            const float iscale = -128.f / maxv;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int q = ((int)f32_to_bits(fmaf(iscale, t[e], 12582912.f)) & 0x007fffff) - 0x00400000;
+                q = q > 127 ? 127 : q;
+                packed[e >> 2] |= (q & 0xff) << (8 * (e & 3));
+                s16 += q;
+            }
+            d = 1.0f / iscale;
+        }
+        const int s32 = s16 + lane_xor1(s16);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) L.q8[b * 64 + sub * 4 + k] = packed[k];
+            L.bsums[b * 16 + sub] = s16;
+            if ((sub & 1) == 0) L.sb[b * 8 + (sub >> 1)] = s32;
+            if (sub == 0) L.yd[b] = d;
+        }
+    }
+    __syncthreads();
+}
+
+// DPP form of quad_transpose_reduce (lanes g, g^2, g^4, g^6 of a row).
+DEV int quad_transpose_reduce_dpp(int p0, int p1, int p2, int p3, int c) {
+    const bool odd = (c & 1) != 0;
+    const int send0 = odd ? p0 : p2, send1 = odd ? p1 : p3;
+    const int keep0 = odd ? p2 : p0, keep1 = odd ? p3 : p1;
+    const int q0 = keep0 + lane_xor2(send0);
+    const int q1 = keep1 + lane_xor2(send1);
+    const bool up = (c & 2) != 0;
+    const int send = up ? q0 : q1;
+    const int keep = up ? q1 : q0;
+    return keep + lane_xor4(send);
+}
+DEV float hsum8_exact_dpp(float acc) {
+    const float t = acc + lane_xor1(acc);
+    const float u = t + lane_xor2(t);
+    return u + lane_xor4(u);
+}
+
+// Register image of one chunk (UB blocks of this wave) of one tile.
+// One block image (this lane's pieces of one K-block of an 8-row tile) in named registers — no arrays, so the
+// compiler keeps the 4-deep load pipeline in VGPRs (an array-of-vectors image was demoted to scratch by hipcc).
+struct BlockRegs {
+    u32x4 v0, v1, v2;
+    uint32_t dd;
+};
+
+DEV BlockRegs block_load(const DevMat& w, int tile, int b, int lane) {
     const int nb = w.nb, type = w.type;
     const int r = lane >> 3, g = lane & 7, h = g & 1;
     const int rec = tile8_record_bytes(type);
-    const uint8_t* base = w.p[0] + (size_t)tile * nb * rec;
-    for (int b0 = wv; b0 < nb; b0 += NW * UB) {
-        u32x4 v0[UB], v1[UB], v2[UB];
-        uint16_t dd[UB];
+    const uint8_t* rp = w.p[0] + ((size_t)tile * nb + (size_t)(b < nb ? b : nb - 1)) * rec;
+    BlockRegs R;
+    if (type == GT_Q6_K) {
+        const int n = g >> 2;
+        R.dd = *(const uint16_t*)(rp + r * 2);
+        R.v0 = ld_stream16(rp + 16 + r * 16);
+        R.v2 = ld_stream16(rp + 144 + r * 64 + n * 32 + h * 16);
+        R.v1 = ld_stream16(rp + 656 + r * 128 + g * 16);
+    } else {
+        const bool q5 = type == GT_Q5_K;
+        R.dd = 0;
+        R.v0 = ld_stream16(rp + r * 16);
+        R.v1 = ld_stream16(rp + (q5 ? 384 : 128) + r * 128 + g * 16);
+        R.v2 = ld_stream16(rp + (q5 ? 128 + r * 32 + h * 16 : r * 16));
+    }
+    return R;
+}
+
+// Integer work of one block (DPP transposes), results into the chain buffer.
+template <int MAXK, int MAXNB>
+DEV void block_to_chain2(int type, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, const u32x4 v0,
+                         const u32x4 v1, const u32x4 v2, const uint16_t dd) {
+    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
+    if (type == GT_Q4_K || type == GT_Q5_K) {
+        const bool q5 = type == GT_Q5_K;
+        const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
+        const int* ahi = alo + 8;
+        int sc_lo, sc_hi, m_lo, m_hi;
+        scale_min_pair(v0[1], v0[2], v0[3], c, sc_lo, sc_hi, m_lo, m_hi);
+        int part[4];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int b = b0 + u * NW;
-            const uint8_t* rp = base + (size_t)(b < nb ? b : nb - 1) * rec;
-            if (type == GT_Q6_K) {
-                const int n = g >> 2, hh = g & 1;
-                dd[u] = *(const uint16_t*)(rp + r * 2);
-                v0[u] = ld_stream16(rp + 16 + r * 16);
-                v2[u] = ld_stream16(rp + 144 + r * 64 + n * 32 + hh * 16);
-                v1[u] = ld_stream16(rp + 656 + r * 128 + g * 16);
-            } else {
-                const bool q5 = type == GT_Q5_K;
-                dd[u] = 0;
-                v0[u] = ld_stream16(rp + r * 16);
-                v1[u] = ld_stream16(rp + (q5 ? 384 : 128) + r * 128 + g * 16);
-                v2[u] = q5 ? ld_stream16(rp + 128 + r * 32 + h * 16) : v0[u];
+        for (int k = 0; k < 4; ++k) {
+            uint32_t lo = v1[k] & 0x0F0F0F0Fu;
+            uint32_t hi = (v1[k] >> 4) & 0x0F0F0F0Fu;
+            if (q5) {
+                lo |= ((v2[k] >> (2 * c)) & 0x01010101u) << 4;
+                hi |= ((v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
             }
+            part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
         }
+        const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
+        C.S[b][lane] = (float)sumi;
+        int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
+        if (q5) {
+            prod += lane_xor2(prod);
+            prod += lane_xor4(prod);
+        }
+        if (h == 0) C.PM[b][r * 4 + c] = (float)prod;
+        if (g == 0) {
+            const float yd = L.yd[b];
+            C.D[b][r] = yd * f16_bits_to_f32((uint16_t)(v0[0] & 0xFFFF));
+            C.DM[b][r] = -yd * f16_bits_to_f32((uint16_t)(v0[0] >> 16));
+        }
+    } else {
+        const int n = g >> 2, gg = g & 3, kq = gg >> 1;
+        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
+        const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
+        const int* ahi = alo + 16;
+        const uint32_t w_lo = n ? v0[2] : v0[0];
+        const uint32_t w_hi = n ? v0[3] : v0[1];
+        const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
+        const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
+        int part[4];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int b = b0 + u * NW;
-            if (b < nb) block_to_chain<MAXK, MAXNB>(type, nullptr, b, L, C, lane, v0[u], v1[u], v2[u], dd[u]);  // wave-uniform
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (v1[k] & 0x0F0F0F0Fu) | (((v2[k] >> s_lo) & 0x03030303u) << 4);
+            const uint32_t hi = ((v1[k] >> 4) & 0x0F0F0F0Fu) | (((v2[k] >> s_hi) & 0x03030303u) << 4);
+            const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
+            const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
+            part[k] = sc_lo * dl + sc_hi * dh;
         }
+        const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
+        C.S[b][lane] = (float)sumi;
+        if (g == 0) C.D[b][r] = L.yd[b] * f16_bits_to_f32(dd);
     }
 }
 
-// One wave: the reference's sequential accumulation over all blocks, then its reduction tree.
+// One wave: the reference's sequential accumulation over all blocks (operands preloaded 16 blocks at a time so the
+// dependent part is a bare fma chain), then its reduction tree.
 template <int MAXNB>
-DEV float chain_reduce(int type, int nb, const ChainBuf<MAXNB>& C, int lane) {
+DEV float chain_reduce2(int type, int nb, const ChainBuf<MAXNB>& C, int lane) {
     const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
     float acc = 0.0f, accm = 0.0f;
-    if (type == GT_Q6_K) {
-        for (int b = 0; b < nb; ++b) acc = fmaf(C.D[b][r], C.S[b][lane], acc);
-        return hsum8_exact(acc);
+    const bool mins = type != GT_Q6_K;
+    for (int b0 = 0; b0 < nb; b0 += 16) {
+        float dv[16], sv[16], mv[16], pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = (b0 + u < nb) ? b0 + u : nb - 1;
+            dv[u] = C.D[b][r];
+            sv[u] = C.S[b][lane];
+            mv[u] = mins ? C.DM[b][r] : 0.0f;
+            pv[u] = (mins && h == 0) ? C.PM[b][r * 4 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (b0 + u < nb) {
+                acc = fmaf(dv[u], sv[u], acc);
+                accm = fmaf(mv[u], pv[u], accm);
+            }
+        }
     }
-    const bool q5 = type == GT_Q5_K;
-    for (int b = 0; b < nb; ++b) {
-        acc = fmaf(C.D[b][r], C.S[b][lane], acc);
-        const float pm = (h == 0) ? C.PM[b][r * 4 + c] : 0.0f;
-        accm = fmaf(C.DM[b][r], pm, accm);
-    }
-    float tot = hsum8_exact(acc);
-    if (!q5) {
-        const float wsum = accm + __shfl_xor(accm, 4);
-        accm = wsum + __shfl_xor(wsum, 2);
+    float tot = hsum8_exact_dpp(acc);
+    if (!mins) return tot;
+    if (type == GT_Q4_K) {
+        const float wsum = accm + lane_xor4(accm);
+        accm = wsum + lane_xor2(wsum);
     }
     accm = __shfl(accm, lane & ~7);
     return tot + accm;
 }
 
+// Fused launch, design C: persistent workgroups; software pipeline over (unit, chunk): the loads of chunk q+1 are in
+// flight while chunk q is unpacked; a unit (one 8-row tile of one matrix) ends with a barrier, after which a rotating
+// wave replays the f32 chain from LDS and runs the epilogue while the others continue with the next unit.
 template <int NT, int MAXK, int UB>
 __global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
     constexpr int NW = NT / 64;
@@ -581,53 +763,90 @@ __global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
     __shared__ ActLdsX<MAXK> L;
     __shared__ ChainBuf<MAXNB> CB[2];
     const int lane = lane_id(), wv = wave_id();
-    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
-    const int pos = a.pos ? *a.pos : 0;
     const int r = lane >> 3, g = lane & 7;
-    int buf = 0, turn = 0;
-    for (int it = (int)blockIdx.x; it < a.n_pairs; it += (int)gridDim.x) {  // n_pairs == number of work items
+    const int nb = a.job[0].w.nb;                       // all jobs of a launch share K
+    const int cpu = (nb + NW - 1) / NW;                  // block steps per unit for every wave (tail blocks masked)
+    const int upi = a.gateup ? 2 : 1;                   // units per item
+    const int first_item = (int)blockIdx.x, stride = (int)gridDim.x;
+    const int n_items_wg = first_item < a.n_pairs ? (a.n_pairs - first_item + stride - 1) / stride : 0;
+    const int T = n_items_wg * upi * cpu;               // block steps this workgroup will process
+
+    // (matrix, tile, block) of step q
+    auto unit_of = [&](int q, const DevMat*& w, int& tile, int& chunk, int& item, int& part) __attribute__((always_inline)) {
+        const int uidx = q / cpu;
+        chunk = q - uidx * cpu;
+        const int it = first_item + (uidx / upi) * stride;
+        part = uidx % upi;
+        item = it;
         int j = 0;
         if (!a.gateup) {
             if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
             if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
         }
-        const MatJob& jb = a.job[j];
-        const int tile = it - jb.pair0;
-        const int row = tile * 8 + r;
-        const int epi = a.gateup ? EPI_SILU_MUL : jb.epi;
-        const int cw = turn % NW;  // the wave that replays the chain for this item (rotates to spread the work)
-        ++turn;
-        tile_blocks_to_chain<NW, MAXK, MAXNB, UB>(jb.w, tile, L, CB[buf], lane, wv);
+        w = a.gateup ? &a.job[part].w : &a.job[j].w;
+        tile = it - (a.gateup ? 0 : a.job[j].pair0);
+    };
+    auto load_step = [&](int q) __attribute__((always_inline)) -> BlockRegs {
+        const DevMat* w; int tile, chunk, item, part;
+        unit_of(q < T ? q : T - 1, w, tile, chunk, item, part);
+        return block_load(*w, tile, wv + chunk * NW, lane);
+    };
+
+    BlockRegs R0, R1, R2, R3;
+    if (T > 0) { R0 = load_step(0); R1 = load_step(1); R2 = load_step(2); R3 = load_step(3); }
+    prologue_q8k_exact16<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    const int pos = a.pos ? *a.pos : 0;
+    float res_gate = 0.0f;
+
+    auto finish_unit = [&](int q) __attribute__((always_inline)) {  // called by every wave after the last chunk of a unit
+        const DevMat* w; int tile, chunk, item, part;
+        unit_of(q, w, tile, chunk, item, part);
+        const int uidx = q / cpu;
         __syncthreads();
-        float res = 0.0f;
-        if (wv == cw) res = chain_reduce<MAXNB>(jb.w.type, jb.w.nb, CB[buf], lane);
-        buf ^= 1;
-        if (epi == EPI_SILU_MUL) {
-            tile_blocks_to_chain<NW, MAXK, MAXNB, UB>(a.job[1].w, tile, L, CB[buf], lane, wv);
-            __syncthreads();
-            if (wv == cw) {
-                const float up = chain_reduce<MAXNB>(a.job[1].w.type, a.job[1].w.nb, CB[buf], lane);
-                if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
-            }
-            buf ^= 1;
-        } else if (wv == cw) {
-            if (epi == EPI_STORE) {
-                if (g == 0 && row < jb.w.M) a.out[row] = res;
-            } else if (epi == EPI_ADD) {
-                if (g == 0 && row < jb.w.M) a.out[row] = res + a.res[row];
-            } else if (epi == EPI_V) {
-                if (g == 0 && row < jb.w.M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
-            } else {
-                const float other = __shfl_xor(res, 8);
-                const int ip = (row % a.head_dim) >> 1;
-                const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
-                const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-                const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-                if (g == 0 && row < jb.w.M) {
-                    if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                    else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
-                }
+        const int cw = (uidx / upi) % NW;
+        if (wv != cw) return;
+        const float res = chain_reduce2<MAXNB>(w->type, w->nb, CB[uidx & 1], lane);
+        const int row = tile * 8 + r;
+        if (a.gateup) {
+            if (part == 0) { res_gate = res; return; }
+            if (g == 0 && row < w->M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res_gate)]) * res;
+            return;
+        }
+        int j = 0;
+        if (a.njobs > 1 && item >= a.job[1].pair0) j = 1;
+        if (a.njobs > 2 && item >= a.job[2].pair0) j = 2;
+        const int epi = a.job[j].epi;
+        if (epi == EPI_STORE) {
+            if (g == 0 && row < w->M) a.out[row] = res;
+        } else if (epi == EPI_ADD) {
+            if (g == 0 && row < w->M) a.out[row] = res + a.res[row];
+        } else if (epi == EPI_V) {
+            if (g == 0 && row < w->M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else {
+            const float other = lane_xor8(res);
+            const int ip = (row % a.head_dim) >> 1;
+            const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+            const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+            const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+            if (g == 0 && row < w->M) {
+                if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+                else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
             }
         }
+    };
+
+    auto compute_step = [&](const BlockRegs& R, int q) __attribute__((always_inline)) {
+        if (q >= T) return;
+        const DevMat* w; int tile, chunk, item, part;
+        unit_of(q, w, tile, chunk, item, part);
+        const int b = wv + chunk * NW;
+        if (b < w->nb) block_to_chain2<MAXK, MAXNB>(w->type, b, L, CB[(q / cpu) & 1], lane, R.v0, R.v1, R.v2, (uint16_t)R.dd);
+        if (chunk == cpu - 1) finish_unit(q);
+    };
+    for (int q = 0; q < T; q += 4) {
+        compute_step(R0, q);     R0 = load_step(q + 4);
+        compute_step(R1, q + 1); R1 = load_step(q + 5);
+        compute_step(R2, q + 2); R2 = load_step(q + 6);
+        compute_step(R3, q + 3); R3 = load_step(q + 7);
     }
 }

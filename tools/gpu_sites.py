@@ -1,0 +1,26 @@
+"""Per-launch-site decode timings (HIP events inside the library) for the synthetic 7B model. Usage: gpu_sites.py [tag] [ENV=VAL ...]"""
+import ctypes, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); os.environ[k] = v
+from ctransformers_amd import synth
+from ctransformers_amd.llm import LLM, Config
+import bench
+p = "/tmp/l7b.gguf"
+if not os.path.exists(p):
+    synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
+m = LLM(p, config=Config(context_length=512, batch_size=64))
+m.eval(synth.prompt_tokens(64, 32000))
+tok = m.sample(top_k=1, repetition_penalty=1.0)
+for _ in range(8):
+    m.eval([tok]); tok = m.sample(top_k=1, repetition_penalty=1.0)
+t0 = time.perf_counter()
+for _ in range(64):
+    m.eval([tok]); tok = m.sample(top_k=1, repetition_penalty=1.0)
+dt = (time.perf_counter() - t0) / 64
+sites = bench.profile_sites(m, 10)
+tot = sum(s["ms"] for s in sites) / 10
+print(json.dumps(dict(tag=sys.argv[1] if len(sys.argv) > 1 else "", ms_per_token=round(dt * 1e3, 3), tok_s=round(1 / dt, 1),
+                      eager_sum_ms=round(tot, 3),
+                      sites={s["site"]: round(s["ms"] * 1e3 / s["launches"], 2) for s in sites})))
