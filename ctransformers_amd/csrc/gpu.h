@@ -51,6 +51,16 @@ DEV float wave_max(float v) {
 }
 
 DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+// 24-bit integer multiply (full rate; v_mul_lo_u32 is quarter rate).  All products on the hot path fit: |a|,|b| < 2^23.
+#ifdef CT_EMU
+static inline int mul24(int a, int b) { return a * b; }
+static inline int uniform_int(int v) { return v; }
+#else
+DEV int mul24(int a, int b) { return __builtin_amdgcn_mul_i24(a, b); }
+// Tell the compiler a value is wave-uniform (it is: derived from the wave index) so it lives in an SGPR and branches on
+// it are scalar (guide T20: anything derived from threadIdx is divergent to the compiler).
+DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 
 // ---- 16-byte streaming load (weights are read once per token: non-temporal, `nt-weights` row of the guide) ----------
 #ifdef CT_EMU

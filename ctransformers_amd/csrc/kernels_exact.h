@@ -637,84 +637,117 @@ struct BlockRegs {
     uint32_t dd;
 };
 
-DEV BlockRegs block_load(const DevMat& w, int tile, int b, int lane) {
-    const int nb = w.nb, type = w.type;
-    const int r = lane >> 3, g = lane & 7, h = g & 1;
-    const int rec = tile8_record_bytes(type);
-    const uint8_t* rp = w.p[0] + ((size_t)tile * nb + (size_t)(b < nb ? b : nb - 1)) * rec;
+// Per-lane constants of the tile geometry (computed once per kernel).
+struct LaneGeom {
+    int r, g, c, h;           // row in tile, unit in block, chunk, AVX half
+    uint32_t off_hdr, off_qs, off_qh5;     // Q4_K / Q5_K byte offsets inside a record
+    uint32_t off6_d, off6_sc, off6_qh, off6_ql;  // Q6_K byte offsets inside a record
+    int a45, a6;              // LDS word offsets of this lane's activation bytes inside a block (Q4/5_K, Q6_K)
+    int sh16;                 // 16*(c&1): which half of the packed scale words
+    int s_lo6, s_hi6, sc_sh6; // Q6_K shifts
+};
+DEV LaneGeom lane_geom(int lane) {
+    LaneGeom G;
+    G.r = lane >> 3; G.g = lane & 7; G.c = G.g >> 1; G.h = G.g & 1;
+    G.off_hdr = G.r * 16;
+    G.off_qs = G.r * 128 + G.g * 16;
+    G.off_qh5 = 128 + G.r * 32 + G.h * 16;
+    const int n = G.g >> 2, gg = G.g & 3, kq = gg >> 1;
+    G.off6_d = G.r * 2;
+    G.off6_sc = 16 + G.r * 16;
+    G.off6_qh = 144 + G.r * 64 + n * 32 + G.h * 16;
+    G.off6_ql = 656 + G.r * 128 + G.g * 16;
+    G.a45 = 16 * G.c + 4 * G.h;
+    G.a6 = 32 * n + 4 * gg;
+    G.sh16 = 16 * (G.c & 1);
+    G.s_lo6 = 2 * kq; G.s_hi6 = 4 + 2 * kq; G.sc_sh6 = 8 * gg;
+    return G;
+}
+
+// rec_base: wave-uniform pointer to the (tile, block) record.
+DEV BlockRegs block_load2(int type, const uint8_t* rec_base, const LaneGeom& G) {
     BlockRegs R;
     if (type == GT_Q6_K) {
-        const int n = g >> 2;
-        R.dd = *(const uint16_t*)(rp + r * 2);
-        R.v0 = ld_stream16(rp + 16 + r * 16);
-        R.v2 = ld_stream16(rp + 144 + r * 64 + n * 32 + h * 16);
-        R.v1 = ld_stream16(rp + 656 + r * 128 + g * 16);
-    } else {
-        const bool q5 = type == GT_Q5_K;
+        R.dd = *(const uint16_t*)(rec_base + G.off6_d);
+        R.v0 = ld_stream16(rec_base + G.off6_sc);
+        R.v2 = ld_stream16(rec_base + G.off6_qh);
+        R.v1 = ld_stream16(rec_base + G.off6_ql);
+    } else if (type == GT_Q5_K) {
         R.dd = 0;
-        R.v0 = ld_stream16(rp + r * 16);
-        R.v1 = ld_stream16(rp + (q5 ? 384 : 128) + r * 128 + g * 16);
-        R.v2 = ld_stream16(rp + (q5 ? 128 + r * 32 + h * 16 : r * 16));
+        R.v0 = ld_stream16(rec_base + G.off_hdr);
+        R.v1 = ld_stream16(rec_base + 384 + G.off_qs);
+        R.v2 = ld_stream16(rec_base + G.off_qh5);
+    } else {
+        R.dd = 0;
+        R.v0 = ld_stream16(rec_base + G.off_hdr);
+        R.v1 = ld_stream16(rec_base + G.off_qs + 128);
+        R.v2 = R.v0;
     }
     return R;
 }
 
-// Integer work of one block (DPP transposes), results into the chain buffer.
+// Integer work of one block (DPP transposes, 24-bit multiplies), results into the chain buffer.
 template <int MAXK, int MAXNB>
-DEV void block_to_chain2(int type, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, const u32x4 v0,
-                         const u32x4 v1, const u32x4 v2, const uint16_t dd) {
-    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
+DEV void block_to_chain3(int type, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, const LaneGeom& G,
+                         const BlockRegs& R) {
+    const int c = G.c;
     if (type == GT_Q4_K || type == GT_Q5_K) {
         const bool q5 = type == GT_Q5_K;
-        const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
+        const int* alo = &L.q8[b * 64 + G.a45];
         const int* ahi = alo + 8;
-        int sc_lo, sc_hi, m_lo, m_hi;
-        scale_min_pair(v0[1], v0[2], v0[3], c, sc_lo, sc_hi, m_lo, m_hi);
+        // 6-bit scales/mins of sub-blocks 2c, 2c+1 as byte pairs (reference get_scale_min_k4, k_quants.c:306-314)
+        const uint32_t A = R.v0[1] >> G.sh16, B = R.v0[2] >> G.sh16, C3 = R.v0[3] >> G.sh16;
+        const uint32_t scL = A & 0x3F3Fu, mL = B & 0x3F3Fu;
+        const uint32_t scH = (C3 & 0x0F0Fu) | ((A >> 2) & 0x3030u);
+        const uint32_t mH = ((C3 >> 4) & 0x0F0Fu) | ((B >> 2) & 0x3030u);
+        const uint32_t scp = c < 2 ? scL : scH, mp = c < 2 ? mL : mH;
+        const int sc_lo = (int)(scp & 0xFF), sc_hi = (int)(scp >> 8), m_lo = (int)(mp & 0xFF), m_hi = (int)(mp >> 8);
         int part[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t lo = v1[k] & 0x0F0F0F0Fu;
-            uint32_t hi = (v1[k] >> 4) & 0x0F0F0F0Fu;
+            uint32_t lo = R.v1[k] & 0x0F0F0F0Fu;
+            uint32_t hi = (R.v1[k] >> 4) & 0x0F0F0F0Fu;
             if (q5) {
-                lo |= ((v2[k] >> (2 * c)) & 0x01010101u) << 4;
-                hi |= ((v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
+                lo |= ((R.v2[k] >> (2 * c)) & 0x01010101u) << 4;
+                hi |= ((R.v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
             }
-            part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
+            part[k] = mul24(sc_lo, sdot4((int)lo, alo[k], 0)) + mul24(sc_hi, sdot4((int)hi, ahi[k], 0));
         }
         const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
         C.S[b][lane] = (float)sumi;
-        int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
+        int prod = mul24(m_lo, L.sb[b * 8 + 2 * c]) + mul24(m_hi, L.sb[b * 8 + 2 * c + 1]);
+        if (G.h != 0) prod = 0;
         if (q5) {
             prod += lane_xor2(prod);
             prod += lane_xor4(prod);
         }
-        if (h == 0) C.PM[b][r * 4 + c] = (float)prod;
-        if (g == 0) {
+        if (G.h == 0) C.PM[b][G.r * 4 + c] = (float)prod;
+        if (G.g == 0) {
             const float yd = L.yd[b];
-            C.D[b][r] = yd * f16_bits_to_f32((uint16_t)(v0[0] & 0xFFFF));
-            C.DM[b][r] = -yd * f16_bits_to_f32((uint16_t)(v0[0] >> 16));
+            C.D[b][G.r] = yd * f16_bits_to_f32((uint16_t)(R.v0[0] & 0xFFFF));
+            C.DM[b][G.r] = -yd * f16_bits_to_f32((uint16_t)(R.v0[0] >> 16));
         }
     } else {
-        const int n = g >> 2, gg = g & 3, kq = gg >> 1;
-        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
-        const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
+        const int n = G.g >> 2;
+        const int* alo = &L.q8[b * 64 + G.a6];
         const int* ahi = alo + 16;
-        const uint32_t w_lo = n ? v0[2] : v0[0];
-        const uint32_t w_hi = n ? v0[3] : v0[1];
-        const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
-        const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
+        const uint32_t w_lo = n ? R.v0[2] : R.v0[0];
+        const uint32_t w_hi = n ? R.v0[3] : R.v0[1];
+        const int sc_lo = (int)(int8_t)((w_lo >> G.sc_sh6) & 0xFF);
+        const int sc_hi = (int)(int8_t)((w_hi >> G.sc_sh6) & 0xFF);
         int part[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = (v1[k] & 0x0F0F0F0Fu) | (((v2[k] >> s_lo) & 0x03030303u) << 4);
-            const uint32_t hi = ((v1[k] >> 4) & 0x0F0F0F0Fu) | (((v2[k] >> s_hi) & 0x03030303u) << 4);
-            const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
-            const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
-            part[k] = sc_lo * dl + sc_hi * dh;
+            const uint32_t lo = (R.v1[k] & 0x0F0F0F0Fu) | (((R.v2[k] >> G.s_lo6) & 0x03030303u) << 4);
+            const uint32_t hi = ((R.v1[k] >> 4) & 0x0F0F0F0Fu) | (((R.v2[k] >> G.s_hi6) & 0x03030303u) << 4);
+            // (q - 32) . a  ==  q . a - 32 * sum(a): fold the -32 into the dot4 chain with a constant operand
+            const int dl = sdot4((int)lo, alo[k], sdot4((int)0xE0E0E0E0u, alo[k], 0));
+            const int dh = sdot4((int)hi, ahi[k], sdot4((int)0xE0E0E0E0u, ahi[k], 0));
+            part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
         }
         const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
         C.S[b][lane] = (float)sumi;
-        if (g == 0) C.D[b][r] = L.yd[b] * f16_bits_to_f32(dd);
+        if (G.g == 0) C.D[b][G.r] = L.yd[b] * f16_bits_to_f32((uint16_t)R.dd);
     }
 }
 
@@ -753,100 +786,129 @@ DEV float chain_reduce2(int type, int nb, const ChainBuf<MAXNB>& C, int lane) {
     return tot + accm;
 }
 
-// Fused launch, design C: persistent workgroups; software pipeline over (unit, chunk): the loads of chunk q+1 are in
-// flight while chunk q is unpacked; a unit (one 8-row tile of one matrix) ends with a barrier, after which a rotating
-// wave replays the f32 chain from LDS and runs the epilogue while the others continue with the next unit.
+// Work cursor of a persistent workgroup: walks items -> units (matrix, tile) -> block steps with adds and compares
+// only (no integer divisions; everything here is wave-uniform and lives in SGPRs).
+struct StepCursor {
+    int item, part, chunk;     // current item, unit inside the item (gate/up), block step inside the unit
+    int j, tile, unit_seq;     // job index, tile index inside the job's matrix, running unit number (chain buffer parity)
+    int type, nb, M;
+    const uint8_t* tile_base;  // first record of the tile
+    uint32_t rec;
+    bool valid;
+};
+DEV void cursor_set_unit(StepCursor& c, const MatvecArgs& a) {
+    int j = 0;
+    if (!a.gateup) {
+        if (a.njobs > 1 && c.item >= a.job[1].pair0) j = 1;
+        if (a.njobs > 2 && c.item >= a.job[2].pair0) j = 2;
+    }
+    c.j = j;
+    const DevMat& w = a.gateup ? a.job[c.part].w : a.job[j].w;
+    c.tile = c.item - (a.gateup ? 0 : a.job[j].pair0);
+    c.type = w.type; c.nb = w.nb; c.M = w.M;
+    c.rec = (uint32_t)tile8_record_bytes(w.type);
+    c.tile_base = w.p[0] + (size_t)c.tile * w.nb * c.rec;
+}
+DEV void cursor_init(StepCursor& c, const MatvecArgs& a, int first_item) {
+    c.item = first_item; c.part = 0; c.chunk = 0; c.unit_seq = 0;
+    c.valid = first_item < a.n_pairs;
+    if (c.valid) cursor_set_unit(c, a);
+}
+DEV void cursor_next(StepCursor& c, const MatvecArgs& a, int cpu, int upi, int stride) {
+    if (!c.valid) return;
+    if (++c.chunk < cpu) return;
+    c.chunk = 0;
+    ++c.unit_seq;
+    if (++c.part >= upi) {
+        c.part = 0;
+        c.item += stride;
+        if (c.item >= a.n_pairs) { c.valid = false; return; }
+    }
+    cursor_set_unit(c, a);
+}
+
+// Fused launch, design C: persistent workgroups; the loads of the next four block steps are in flight while the current
+// one is unpacked; a unit (one 8-row tile of one matrix) ends with a barrier, after which a rotating wave replays the
+// f32 chain from LDS and runs the epilogue while the others continue with the next unit.
 template <int NT, int MAXK, int UB>
 __global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
     constexpr int NW = NT / 64;
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
     __shared__ ChainBuf<MAXNB> CB[2];
-    const int lane = lane_id(), wv = wave_id();
-    const int r = lane >> 3, g = lane & 7;
-    const int nb = a.job[0].w.nb;                       // all jobs of a launch share K
-    const int cpu = (nb + NW - 1) / NW;                  // block steps per unit for every wave (tail blocks masked)
-    const int upi = a.gateup ? 2 : 1;                   // units per item
-    const int first_item = (int)blockIdx.x, stride = (int)gridDim.x;
-    const int n_items_wg = first_item < a.n_pairs ? (a.n_pairs - first_item + stride - 1) / stride : 0;
-    const int T = n_items_wg * upi * cpu;               // block steps this workgroup will process
+    const int lane = lane_id();
+    const int wv = uniform_int(wave_id());
+    const LaneGeom G = lane_geom(lane);
+    const int nb0 = a.job[0].w.nb;                      // all jobs of a launch share K
+    const int cpu = (nb0 + NW - 1) / NW;                // block steps per unit for every wave (tail blocks masked)
+    const int upi = a.gateup ? 2 : 1;
+    const int stride = (int)gridDim.x;
 
-    // (matrix, tile, block) of step q
-    auto unit_of = [&](int q, const DevMat*& w, int& tile, int& chunk, int& item, int& part) __attribute__((always_inline)) {
-        const int uidx = q / cpu;
-        chunk = q - uidx * cpu;
-        const int it = first_item + (uidx / upi) * stride;
-        part = uidx % upi;
-        item = it;
-        int j = 0;
-        if (!a.gateup) {
-            if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
-            if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+    StepCursor lc, cc;                                  // load cursor (4 steps ahead) and compute cursor
+    cursor_init(lc, a, (int)blockIdx.x);
+    cursor_init(cc, a, (int)blockIdx.x);
+    auto load_step = [&]() __attribute__((always_inline)) -> BlockRegs {
+        BlockRegs R;
+        if (lc.valid) {
+            int b = wv + lc.chunk * NW;
+            b = b < lc.nb ? b : lc.nb - 1;
+            R = block_load2(lc.type, lc.tile_base + (size_t)b * lc.rec, G);
+        } else {
+            R.v0 = R.v1 = R.v2 = u32x4{0, 0, 0, 0};
+            R.dd = 0;
         }
-        w = a.gateup ? &a.job[part].w : &a.job[j].w;
-        tile = it - (a.gateup ? 0 : a.job[j].pair0);
-    };
-    auto load_step = [&](int q) __attribute__((always_inline)) -> BlockRegs {
-        const DevMat* w; int tile, chunk, item, part;
-        unit_of(q < T ? q : T - 1, w, tile, chunk, item, part);
-        return block_load(*w, tile, wv + chunk * NW, lane);
+        cursor_next(lc, a, cpu, upi, stride);
+        return R;
     };
 
-    BlockRegs R0, R1, R2, R3;
-    if (T > 0) { R0 = load_step(0); R1 = load_step(1); R2 = load_step(2); R3 = load_step(3); }
+    BlockRegs R0 = load_step(), R1 = load_step(), R2 = load_step(), R3 = load_step();
     prologue_q8k_exact16<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
     const int pos = a.pos ? *a.pos : 0;
     float res_gate = 0.0f;
 
-    auto finish_unit = [&](int q) __attribute__((always_inline)) {  // called by every wave after the last chunk of a unit
-        const DevMat* w; int tile, chunk, item, part;
-        unit_of(q, w, tile, chunk, item, part);
-        const int uidx = q / cpu;
+    auto finish_unit = [&]() __attribute__((always_inline)) {  // every wave, after the last block step of a unit
         __syncthreads();
-        const int cw = (uidx / upi) % NW;
+        const int item_seq = a.gateup ? (cc.unit_seq >> 1) : cc.unit_seq;
+        const int cw = item_seq & (NW - 1);
         if (wv != cw) return;
-        const float res = chain_reduce2<MAXNB>(w->type, w->nb, CB[uidx & 1], lane);
-        const int row = tile * 8 + r;
+        const float res = chain_reduce2<MAXNB>(cc.type, cc.nb, CB[cc.unit_seq & 1], lane);
+        const int row = cc.tile * 8 + G.r;
+        const bool own = G.g == 0 && row < cc.M;
         if (a.gateup) {
-            if (part == 0) { res_gate = res; return; }
-            if (g == 0 && row < w->M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res_gate)]) * res;
+            if (cc.part == 0) { res_gate = res; return; }
+            if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res_gate)]) * res;
             return;
         }
-        int j = 0;
-        if (a.njobs > 1 && item >= a.job[1].pair0) j = 1;
-        if (a.njobs > 2 && item >= a.job[2].pair0) j = 2;
-        const int epi = a.job[j].epi;
+        const int epi = a.job[cc.j].epi;
         if (epi == EPI_STORE) {
-            if (g == 0 && row < w->M) a.out[row] = res;
+            if (own) a.out[row] = res;
         } else if (epi == EPI_ADD) {
-            if (g == 0 && row < w->M) a.out[row] = res + a.res[row];
+            if (own) a.out[row] = res + a.res[row];
         } else if (epi == EPI_V) {
-            if (g == 0 && row < w->M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+            if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;
             const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
             const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-            const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-            if (g == 0 && row < w->M) {
+            const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+            if (own) {
                 if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
                 else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
             }
         }
     };
-
-    auto compute_step = [&](const BlockRegs& R, int q) __attribute__((always_inline)) {
-        if (q >= T) return;
-        const DevMat* w; int tile, chunk, item, part;
-        unit_of(q, w, tile, chunk, item, part);
-        const int b = wv + chunk * NW;
-        if (b < w->nb) block_to_chain2<MAXK, MAXNB>(w->type, b, L, CB[(q / cpu) & 1], lane, R.v0, R.v1, R.v2, (uint16_t)R.dd);
-        if (chunk == cpu - 1) finish_unit(q);
+    auto compute_step = [&](const BlockRegs& R) __attribute__((always_inline)) {
+        if (!cc.valid) return;
+        const int b = wv + cc.chunk * NW;
+        if (b < cc.nb) block_to_chain3<MAXK, MAXNB>(cc.type, b, L, CB[cc.unit_seq & 1], lane, G, R);
+        if (cc.chunk == cpu - 1) finish_unit();
+        cursor_next(cc, a, cpu, upi, stride);
     };
-    for (int q = 0; q < T; q += 4) {
-        compute_step(R0, q);     R0 = load_step(q + 4);
-        compute_step(R1, q + 1); R1 = load_step(q + 5);
-        compute_step(R2, q + 2); R2 = load_step(q + 6);
-        compute_step(R3, q + 3); R3 = load_step(q + 7);
+    while (cc.valid) {
+        compute_step(R0); R0 = load_step();
+        compute_step(R1); R1 = load_step();
+        compute_step(R2); R2 = load_step();
+        compute_step(R3); R3 = load_step();
     }
 }
