@@ -56,7 +56,7 @@ DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, fals
 static inline int mul24(int a, int b) { return a * b; }
 static inline int uniform_int(int v) { return v; }
 #else
-DEV int mul24(int a, int b) { return __builtin_amdgcn_mul_i24(a, b); }
+DEV int mul24(int a, int b) { return __mul24(a, b); }
 // Tell the compiler a value is wave-uniform (it is: derived from the wave index) so it lives in an SGPR and branches on
 // it are scalar (guide T20: anything derived from threadIdx is divergent to the compiler).
 DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
