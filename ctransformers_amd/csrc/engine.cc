@@ -9,7 +9,7 @@
 #include <thread>
 
 #include "gguf_reader.h"
-#include "kernels_exact.h"
+#include "kernels_v4.h"
 
 namespace ctamd {
 
@@ -87,7 +87,8 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     const int nb = m.nb, M = m.M;
     if (exact_ && is_kquant(t->type)) {
         // tile8 layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row.
-        m.layout = LAYOUT_TILE8;
+        const bool v4 = design_ == 4 && m.K <= 12288;
+        m.layout = v4 ? LAYOUT_TILE8S : LAYOUT_TILE8;
         const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
         std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
         const uint8_t* src = t->data;
@@ -99,11 +100,27 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
                         const int row = tl * 8 + r;
                         if (row >= M) continue;
                         const uint8_t* blk = src + ((size_t)row * nb + b) * bb;
+                        uint8_t hdr[16];
+                        if (type != GT_Q6_K) {
+                            memcpy(hdr, blk, 16);
+                            if (v4) {  // re-encode the 6-bit scale/min field (reference packing: k_quants.c:306-314)
+                                const uint8_t* q = blk + 4;
+                                uint8_t sc[8], mn[8];
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
+                                    else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
+                                }
+                                for (int cc = 0; cc < 4; ++cc) {
+                                    const uint32_t g24 = sc[2 * cc] | (sc[2 * cc + 1] << 6) | (mn[2 * cc] << 12) | (mn[2 * cc + 1] << 18);
+                                    hdr[4 + 3 * cc] = g24 & 0xFF; hdr[5 + 3 * cc] = (g24 >> 8) & 0xFF; hdr[6 + 3 * cc] = (g24 >> 16) & 0xFF;
+                                }
+                            }
+                        }
                         if (type == GT_Q4_K) {
-                            memcpy(rp + r * 16, blk, 16);
+                            memcpy(rp + r * 16, hdr, 16);
                             memcpy(rp + 128 + r * 128, blk + 16, 128);
                         } else if (type == GT_Q5_K) {
-                            memcpy(rp + r * 16, blk, 16);
+                            memcpy(rp + r * 16, hdr, 16);
                             memcpy(rp + 128 + r * 32, blk + 16, 32);
                             memcpy(rp + 384 + r * 128, blk + 48, 128);
                         } else {  // GT_Q6_K
@@ -230,6 +247,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     (void)gpu_layers;  // every layer lives on the GPU(s); the CPU/GPU split of the reference does not exist here
     pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
     exact_ = env_int("CT_AMD_EXACT", 1) != 0;
+    design_ = env_int("CT_AMD_DESIGN", 4);
     items_per_wave_ = std::max(1, env_int("CT_AMD_IPW", 1));
     max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 1024));
 
@@ -337,6 +355,19 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         item0 += (a.job[j].w.M + 7) / 8;
     }
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
+    if (a.job[0].w.layout == LAYOUT_TILE8S) {
+        // generation 4: one 1024-thread workgroup per CU, two tiles per barrier round
+        static const int n_cu = [] { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); return n > 0 ? n : 256; }();
+        static const int cap = env_int("CT_AMD_V4_WGS", 0);
+        const int rounds_total = a.gateup ? a.n_pairs : (a.n_pairs + 1) / 2;
+        const int max_w = cap > 0 ? cap : n_cu;
+        const int per_wg = (rounds_total + max_w - 1) / max_w;
+        const int wgs = std::max(1, (rounds_total + per_wg - 1) / per_wg);
+        // every workgroup must own at least one item: wgs <= n_pairs holds because rounds_total <= n_pairs
+        if (a.K <= 4096) CT_LAUNCH((matvec_v4_kernel<4096, 1, 2>), dim3((unsigned)wgs), dim3(1024), s, a);
+        else CT_LAUNCH((matvec_v4_kernel<12288, 3, 1>), dim3((unsigned)wgs), dim3(1024), s, a);
+        return true;
+    }
     static const int design = env_int("CT_AMD_DESIGN", 2);
     if (design == 2 && a.K <= 12288) {
         // design C: one tile per workgroup step, K split over the waves; persistent grid, balanced items per workgroup
@@ -416,7 +447,7 @@ void Engine::debug_dump(const char* site, int layer) {
 }
 
 bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
-    if (a.job[0].w.layout == LAYOUT_TILE8) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
+    if (a.job[0].w.layout != LAYOUT_PLANES) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
     return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
 }
 

@@ -96,6 +96,7 @@ class Engine {
     std::vector<void*> dev_allocs_;
     int pairs_per_wave_ = 2, max_wgs_ = 2048, items_per_wave_ = 1;
     bool exact_ = true;
+    int design_ = 4;
 };
 
 }  // namespace ctamd

@@ -55,7 +55,11 @@ DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, fals
 #ifdef CT_EMU
 static inline int mul24(int a, int b) { return a * b; }
 static inline int uniform_int(int v) { return v; }
+static inline uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31)); }
+static inline uint32_t bfe32(uint32_t v, int off, int width) { return (v >> off) & ((1u << width) - 1u); }
 #else
+DEV uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+DEV uint32_t bfe32(uint32_t v, int off, int width) { return __builtin_amdgcn_ubfe(v, off, width); }
 DEV int mul24(int a, int b) { return __mul24(a, b); }
 // Tell the compiler a value is wave-uniform (it is: derived from the wave index) so it lives in an SGPR and branches on
 // it are scalar (guide T20: anything derived from threadIdx is divergent to the compiler).

@@ -49,7 +49,9 @@ CT_HD static inline int ggml_block_bytes(int t) {
 CT_HD static inline size_t ggml_row_bytes(int t, int64_t k) { return (size_t)(k / ggml_block_elems(t)) * ggml_block_bytes(t); }
 CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K || t == GT_Q6_K; }
 
-enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1 };
+// LAYOUT_TILE8S = tile8 with the 12-byte 6-bit scale/min field of Q4_K/Q5_K headers re-encoded (losslessly, same size) as
+// four 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
+enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1, LAYOUT_TILE8S = 2 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).

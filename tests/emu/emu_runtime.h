@@ -90,3 +90,5 @@ template <class P> static inline hipError_t hipHostMalloc(P** p, size_t n, unsig
 
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+enum { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 4; return hipSuccess; }  // emulate a 4-CU chip
