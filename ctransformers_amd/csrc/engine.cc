@@ -9,7 +9,7 @@
 #include <thread>
 
 #include "gguf_reader.h"
-#include "kernels_v4.h"
+#include "kernels_v5.h"
 
 namespace ctamd {
 
@@ -364,6 +364,31 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         const int per_wg = (rounds_total + max_w - 1) / max_w;
         const int wgs = std::max(1, (rounds_total + per_wg - 1) / per_wg);
         // every workgroup must own at least one item: wgs <= n_pairs holds because rounds_total <= n_pairs
+        static const int gen = env_int("CT_AMD_GEN", 5);
+        // generation 5: type-specialised kernels; job groups must be (TA...)(TB...) with TB == Q6_K or absent
+        int ta = a.job[0].w.type, tb = 0, na = 0;
+        bool ok5 = gen == 5;
+        for (int j = 0; j < a.njobs && ok5; ++j) {
+            const int tj = a.job[j].w.type;
+            const int items = a.gateup ? (j == 0 ? a.n_pairs : 0) : (a.job[j].w.M + 7) / 8;
+            if (tj == ta && tb == 0) na += items;
+            else if (tb == 0 && tj == GT_Q6_K) tb = tj;
+            else if (tj != tb) ok5 = false;
+        }
+        if (a.gateup) { na = a.n_pairs; tb = 0; ok5 = ok5 && a.job[0].w.type == a.job[1].w.type; }
+        if (ok5) {
+            a.n_groupA = na;
+            const dim3 g5((unsigned)std::max(1, std::min(max_w, a.n_pairs))), b5(1024);
+#define V5(MK, SS, TT, NB) \
+            if (ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0>), g5, b5, s, a); \
+            else if (ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0>), g5, b5, s, a); \
+            else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0>), g5, b5, s, a); \
+            else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K>), g5, b5, s, a); \
+            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K>), g5, b5, s, a);
+            if (a.K <= 4096) { V5(4096, 1, 4, 2) } else { V5(12288, 3, 2, 1) }
+#undef V5
+            return true;
+        }
         if (a.K <= 4096) CT_LAUNCH((matvec_v4_kernel<4096, 1, 2>), dim3((unsigned)wgs), dim3(1024), s, a);
         else CT_LAUNCH((matvec_v4_kernel<12288, 3, 1>), dim3((unsigned)wgs), dim3(1024), s, a);
         return true;
@@ -467,6 +492,8 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     base.v_stride = v_stride_;
     base.silu_tab = silu_tab_;
     base.eps = hp_.rms_eps;
+    base.dbg = env_int("CT_AMD_DBG", 0);
+    base.dbg_sink = scores_;
     AttnArgs at = AttnArgs();
     at.q_f16 = q_f16_;
     at.scores = scores_;

@@ -50,6 +50,7 @@ struct MatvecArgs {
     MatJob job[3];
     int njobs;
     int n_pairs;        // total pairs over all jobs
+    int n_groupA;       // generation-5 kernels: items of the first type-homogeneous job group (rest = group B)
     int gateup;         // 1: job[0]=gate, job[1]=up, pair t = (gate row t, up row t), epilogue SiLU(gate)*up
     int K;              // input length
     int pro;            // PRO_*
@@ -66,6 +67,8 @@ struct MatvecArgs {
     const int* pos;         // device scalar: position of this token
     int n_ctx, head_dim, n_embd_gqa, v_stride;
     const uint16_t* silu_tab;  // 65536-entry fp16->fp16 table (reference ggml.c:4328-4332)
+    float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
+    int dbg;                   // measurement only (CT_AMD_DBG): 1 skip prologue, 2 skip block math, 4 skip chain+epilogue, 8 skip weight loads, 16 return at once
 };
 
 // Per-lane copy of the activation bytes that pair with this lane's weight units.

@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(1024) matvec_v4_kernel(const MatvecArgs a) {
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
     __shared__ ChainBuf4<MAXNB> CB[NBUF][2];
+    if (a.dbg & 16) return;
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(1024) matvec_v4_kernel(const MatvecArgs a) {
         }
     };
     auto load_blk = [&](const UnitInfo& u, int i) __attribute__((always_inline)) -> BlockRegs {
+        if (a.dbg & 8) { BlockRegs Z; Z.v0 = Z.v1 = Z.v2 = u32x4{1, 2, 3, 4}; Z.dd = 0; return Z; }
         int b = wv + i * NW;
         b = b < u.nb ? b : u.nb - 1;
         return block_load2(u.type, u.base + (size_t)b * u.rec, G);
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(1024) matvec_v4_kernel(const MatvecArgs a) {
         RA[i] = load_blk(cA, i);   // cA.valid is guaranteed by the launch (grid <= items)
         RB[i] = load_blk(cB.valid ? cB : cA, i);
     }
-    prologue_q8k_exact16<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if (!(a.dbg & 1)) prologue_q8k_exact16<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
     const int pos = a.pos ? *a.pos : 0;
 
     for (int p = 0; cA.valid; ++p) {
@@ -206,14 +208,16 @@ __global__ void __launch_bounds__(1024) matvec_v4_kernel(const MatvecArgs a) {
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int b = wv + i * NW;
-            if (b < cA.nb) block_to_chain4<MAXK, MAXNB>(cA.type, b, L, CA, lane, G, RA[i]);
+            if (b < cA.nb && !(a.dbg & 2)) block_to_chain4<MAXK, MAXNB>(cA.type, b, L, CA, lane, G, RA[i]);
             if (nA.valid) RA[i] = load_blk(nA, i);
-            if (cB.valid && b < cB.nb) block_to_chain4<MAXK, MAXNB>(cB.type, b, L, CBb, lane, G, RB[i]);
+            if (cB.valid && b < cB.nb && !(a.dbg & 2)) block_to_chain4<MAXK, MAXNB>(cB.type, b, L, CBb, lane, G, RB[i]);
             if (nB.valid) RB[i] = load_blk(nB, i);
         }
         __syncthreads();
         const int wA = (2 * p) & (NW - 1), wB = (2 * p + 1) & (NW - 1);
-        if (a.gateup) {
+        if (a.dbg & 4) {
+            if ((a.dbg & 2) && lane == 0 && wv == 0) a.dbg_sink[0] = (float)(RA[0].v1[0] + RB[0].v1[1]);  // keep the loads alive
+        } else if (a.gateup) {
             if (wv == wA) {
                 const float gate = chain_reduce4<MAXK, MAXNB>(cA.type, cA.nb, L, CA, lane, G);
                 const float up = chain_reduce4<MAXK, MAXNB>(cB.type, cB.nb, L, CBb, lane, G);
