@@ -123,5 +123,10 @@ int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* o
     return n;
 }
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
+int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
+    std::string err;
+    if (!llm->engine.trace_site(site, out, n, err)) { fprintf(stderr, "ctransformers_amd: trace failed: %s\n", err.c_str()); return -1; }
+    return 0;
+}
 
 }  // extern "C"

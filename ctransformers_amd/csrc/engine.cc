@@ -327,7 +327,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
         !dev_alloc(dev_allocs_, &d_logits_, (size_t)V, err) || !dev_alloc(dev_allocs_, &d_emb_, (size_t)E, err) ||
-        !dev_alloc(dev_allocs_, &d_tokens_, (size_t)n_ctx_, err) || !dev_alloc(dev_allocs_, &d_state_, 4, err))
+        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_tokens_, (size_t)n_ctx_, err) || !dev_alloc(dev_allocs_, &d_state_, 4, err))
         return false;
     HIP_OK(hipHostMalloc(&h_logits_, (size_t)V * 4));
     HIP_OK(hipHostMalloc(&h_emb_, (size_t)E * 4));
@@ -471,6 +471,13 @@ void Engine::debug_dump(const char* site, int layer) {
     }
 }
 
+void Engine::apply_trace(MatvecArgs& a, const char* site) {
+    if (trace_site_ && !strcmp(site, trace_site_)) {
+        a.dbg |= 32;
+        a.dbg_sink = (float*)trace_buf_;
+    }
+}
+
 bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
     if (a.job[0].w.layout != LAYOUT_PLANES) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
     return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
@@ -519,6 +526,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
             a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
             set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
+            apply_trace(a, "qkv");
             prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
             if (!run_matvec(a, err)) return false;
             prof_end();
@@ -546,6 +554,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.wo, EPI_ADD}});
+            apply_trace(a, "wo");
             prof_begin("wo", "matvec", (double)L.wo.bytes);
             if (!run_matvec(a, err)) return false;
             prof_end();
@@ -557,6 +566,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            apply_trace(a, "gate_up");
             prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
             if (!run_matvec(a, err)) return false;
             prof_end();
@@ -566,6 +576,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
+            apply_trace(a, "down");
             prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
             if (!run_matvec(a, err)) return false;
             prof_end();
@@ -578,6 +589,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        apply_trace(a, "lm_head");
         prof_begin("lm_head", "matvec", (double)output_.bytes);
         if (!run_matvec(a, err)) return false;
         prof_end();
@@ -657,6 +669,24 @@ void Engine::prof_end() {
 #ifndef CT_EMU
     if (!prof_) return;
     (void)hipEventRecord((hipEvent_t)prof_->back().e1, stream_);
+#endif
+}
+
+bool Engine::trace_site(const char* site, unsigned long long* out, int n, std::string& err) {
+#ifndef CT_EMU
+    if (last_pos_ < 0) { err = "nothing evaluated yet"; return false; }
+    h_scalars_[0] = 0; h_scalars_[1] = last_pos_; h_scalars_[2] = last_pos_ + 1; h_scalars_[4] = last_token_;
+    HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], 4, hipMemcpyHostToDevice, stream_));
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 12, hipMemcpyHostToDevice, stream_));
+    trace_site_ = site;
+    const bool ok = token_step(true, err);
+    trace_site_ = nullptr;
+    if (!ok) return false;
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipMemcpy(out, trace_buf_, (size_t)std::min(n, 256) * 8, hipMemcpyDeviceToHost));
+    return true;
+#else
+    (void)site; (void)out; (void)n; err = "needs the HIP build"; return false;
 #endif
 }
 

@@ -52,6 +52,11 @@ class Engine {
     // launches bracketed by HIP events on the engine's stream; one entry per launch site, times summed over iters.
     struct LaunchStat { const char* site; const char* kernel; double bytes; double ms; int launches; };
     bool profile_decode(int iters, std::vector<LaunchStat>& out, std::string& err);
+    // measurement only: run ONE launch site of the last token with in-kernel timestamps (CT_AMD_DBG=32) and copy them out
+    bool trace_site(const char* site, unsigned long long* out, int n, std::string& err);
+    const char* trace_site_ = nullptr;
+    unsigned long long* trace_buf_ = nullptr;
+    void apply_trace(::MatvecArgs& a, const char* site);
 
    private:
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);

@@ -126,3 +126,9 @@ template <class T> DEV T wave_sum_fast(T v) {
     v += lane_xor1(v); v += lane_xor2(v); v += lane_xor4(v); v += lane_xor8(v); v += lane_xor16(v); v += lane_xor32(v);
     return v;
 }
+
+#ifdef CT_EMU
+static inline unsigned long long clock64_dev() { return 0; }
+#else
+DEV unsigned long long clock64_dev() { return __builtin_amdgcn_s_memtime(); }
+#endif

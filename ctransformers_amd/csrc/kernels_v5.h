@@ -177,8 +177,12 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
 #pragma unroll
         for (int i = 0; i < S; ++i) R[t][i] = load_img(cur[t], i);
     }
+    const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
+    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
+    if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
     if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if (trace) tr[2] = clock64_dev();
     const int n_rounds = (n_units + T - 1) / T;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
         const int par = round_seq % NBUF;
@@ -202,7 +206,9 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
                 R[t][i] = load_img(nxt[t], i);
             }
         }
+        if (trace && rd == 0) tr[3] = clock64_dev();
         __syncthreads();
+        if (trace && rd == 0) tr[4] = clock64_dev();
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             if (wv != ((round_seq * T + t) & (NW - 1)) || !cur[t].valid) continue;
@@ -235,6 +241,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
                 }
             }
         }
+        if (trace && rd == 0) tr[5] = clock64_dev();
         if (NBUF == 1) __syncthreads();
 #pragma unroll
         for (int t = 0; t < T; ++t) cur[t] = nxt[t];
@@ -251,9 +258,11 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
+    if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0) ((unsigned long long*)a.dbg_sink)[16 * wv] = clock64_dev();
     const int pos = a.pos ? *a.pos : 0;
     int round_seq = 0;
     run_group<TA, MAXK, S, T, NBUF, true>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
     if constexpr (TB != 0)
         run_group<TB, MAXK, S, T, NBUF, false>(a, a.n_groupA, a.n_pairs - a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
+    if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0) ((unsigned long long*)a.dbg_sink)[16 * wv + 6] = clock64_dev();
 }

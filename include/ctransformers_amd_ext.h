@@ -17,6 +17,9 @@ typedef struct {
  * sites written to `out`, or -1. */
 int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* out, int max_out);
 double ctamd_weight_bytes(ctransformers_llm* llm);
+/* In-kernel s_memtime stamps of workgroup 0 of the last launch of `site` (16 waves x 16 slots of uint64; slots: 0 entry,
+ * 1 first loads issued, 2 prologue done, 3 round-0 block math done, 4 barrier passed, 5 chain+epilogue done, 6 exit). */
+int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n);
 #ifdef __cplusplus
 }
 #endif

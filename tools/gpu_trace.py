@@ -1,0 +1,23 @@
+"""In-kernel timeline (s_memtime) of workgroup 0 for each mat-vec launch site of one decode step."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ctransformers_amd import synth
+from ctransformers_amd.llm import LLM, Config
+p = "/tmp/l7b.gguf"
+if not os.path.exists(p):
+    synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
+m = LLM(p, config=Config(context_length=512, batch_size=64))
+m.eval(synth.prompt_tokens(64, 32000))
+lib = m._lib
+lib.ctamd_trace_site.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+buf = (ctypes.c_uint64 * 256)()
+for site in ("qkv", "wo", "gate_up", "down", "lm_head"):
+    for rep in range(2):
+        lib.ctamd_trace_site(m._llm, site.encode(), buf, 256)
+    rows = [[buf[16 * w + k] for k in range(7)] for w in range(16)]
+    t0 = min(r[0] for r in rows if r[0])
+    print(site)
+    for w in (0, 1, 5, 15):
+        r = rows[w]
+        print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "loads", "prolog", "math", "barrier", "chain", "exit"))))
