@@ -385,7 +385,8 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0>), g5, b5, s, a); \
             else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K>), g5, b5, s, a); \
             else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K>), g5, b5, s, a);
-            if (a.K <= 4096) { V5(4096, 1, 4, 2) } else { V5(12288, 3, 2, 1) }
+            const int units_per_wg = ((a.n_pairs + (int)g5.x - 1) / (int)g5.x) * (a.gateup ? 2 : 1);
+            if (a.K <= 4096) { if (units_per_wg <= 2) { V5(4096, 1, 2, 2) } else { V5(4096, 1, 4, 2) } } else { V5(12288, 3, 2, 1) }
 #undef V5
             return true;
         }
@@ -479,6 +480,9 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
 }
 
 bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
+    static const int repeat = env_int("CT_AMD_REPEAT", 1);  // measurement only (breaks results): relaunch to see warm-cache timing
+    for (int r = 1; r < repeat; ++r)
+        if (!launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err)) return false;
     if (a.job[0].w.layout != LAYOUT_PLANES) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
     return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
 }

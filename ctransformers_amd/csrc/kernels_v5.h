@@ -9,6 +9,93 @@
 #pragma once
 #include "kernels_v4.h"
 
+// Prologue for 1024-thread workgroups: one wave per 256-block (lane = 4 consecutive elements), so every wave of the
+// workgroup takes part and a thread touches 4 values instead of 16.  Arithmetic identical to prologue_q8k_exact16.
+template <int MAXK>
+DEV void prologue_q8k_wave(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
+                           float eps, int lane, int wv) {
+    constexpr int NW = 16;
+    constexpr int MAXB = (MAXK / 256 + NW - 1) / NW;
+    const int nblk = K >> 8;
+    float4 v[MAXB];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wv + i * NW;
+        if (b < nblk) {
+            v[i] = *(const float4*)(x + b * 256 + lane * 4);
+            if (pro == PRO_RMSNORM) {
+                s += (double)(v[i].x * v[i].x);
+                s += (double)(v[i].y * v[i].y);
+                s += (double)(v[i].z * v[i].z);
+                s += (double)(v[i].w * v[i].w);
+            }
+        }
+    }
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {
+        s = wave_sum_fast(s);
+        if (lane == 0) L.red[wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int b = wv + i * NW;
+        if (b < nblk) {  // wave-uniform
+            float4 t = v[i];
+            if (pro == PRO_RMSNORM) {
+                const float4 w4 = *(const float4*)(nw + b * 256 + lane * 4);
+                t.x = (t.x * scale) * w4.x;
+                t.y = (t.y * scale) * w4.y;
+                t.z = (t.z * scale) * w4.z;
+                t.w = (t.w * scale) * w4.w;
+            }
+            const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
+            const float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            float amax = am;
+            amax = fmaxf(amax, lane_xor1(amax));
+            amax = fmaxf(amax, lane_xor2(amax));
+            amax = fmaxf(amax, lane_xor4(amax));
+            amax = fmaxf(amax, lane_xor8(amax));
+            amax = fmaxf(amax, lane_xor16(amax));
+            amax = fmaxf(amax, lane_xor32(amax));
+            const unsigned long long hit = __ballot(am == amax);
+            const int first = __ffsll(hit) - 1;
+            const float mine = (a0 == amax) ? t.x : (a1 == amax) ? t.y : (a2 == amax) ? t.z : t.w;
+            const float maxv = __shfl(mine, first);
+            int packed = 0, s4 = 0;
+            float d = 0.0f;
+            if (amax != 0.0f) {
+                const float iscale = -128.f / maxv;
+                int q0 = ((int)f32_to_bits(fmaf(iscale, t.x, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q1 = ((int)f32_to_bits(fmaf(iscale, t.y, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q2 = ((int)f32_to_bits(fmaf(iscale, t.z, 12582912.f)) & 0x007fffff) - 0x00400000;
+                int q3 = ((int)f32_to_bits(fmaf(iscale, t.w, 12582912.f)) & 0x007fffff) - 0x00400000;
+                q0 = q0 > 127 ? 127 : q0;
+                q1 = q1 > 127 ? 127 : q1;
+                q2 = q2 > 127 ? 127 : q2;
+                q3 = q3 > 127 ? 127 : q3;
+                packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+                s4 = q0 + q1 + q2 + q3;
+                d = 1.0f / iscale;
+            }
+            L.q8[b * 64 + lane] = packed;
+            s4 += lane_xor1(s4);
+            s4 += lane_xor2(s4);
+            if ((lane & 3) == 0) L.bsums[b * 16 + (lane >> 2)] = s4;
+            s4 += lane_xor4(s4);
+            if ((lane & 7) == 0) L.sb[b * 8 + (lane >> 3)] = s4;
+            if (lane == 0) L.yd[b] = d;
+        }
+    }
+    __syncthreads();
+}
+
 template <int TYPE> struct BlkImg;
 template <> struct BlkImg<GT_Q4_K> { u32x4 hdr, qs; };
 template <> struct BlkImg<GT_Q5_K> { u32x4 hdr, qs, qh; };
@@ -94,10 +181,11 @@ template <int TYPE, int MAXK, int MAXNB>
 DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C, int lane, const LaneGeom& G) {
     float acc = 0.0f, accm = 0.0f;
     constexpr bool mins = TYPE != GT_Q6_K;
-    for (int b0 = 0; b0 < nb; b0 += 8) {
-        float dv[8], sv[8], mv[8], pv[8];
+    constexpr int CH = MAXNB <= 16 ? 16 : 8;   // operands of CH blocks are fetched before the dependent fma chain starts
+    for (int b0 = 0; b0 < nb; b0 += CH) {
+        float dv[CH], sv[CH], mv[CH], pv[CH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int b = (b0 + u < nb) ? b0 + u : nb - 1;
             const uint32_t hw = C.H[b][G.r];
             const float yd = L.yd[b];
@@ -109,7 +197,7 @@ DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C,
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CH; ++u) {
             if (b0 + u < nb) {
                 acc = fmaf(dv[u], sv[u], acc);
                 if constexpr (mins) accm = fmaf(mv[u], pv[u], accm);   // lanes with h == 1 carry garbage here; never read
@@ -141,7 +229,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     const int n_loc = first < n_items ? (n_items - first + stride - 1) / stride : 0;
     const int n_units = n_loc * upi;
     if (n_units == 0) {
-        if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+        if constexpr (WITH_PROLOGUE) prologue_q8k_wave<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, lane, wv);
         return;
     }
     const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
@@ -181,7 +269,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if constexpr (WITH_PROLOGUE) prologue_q8k_wave<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, lane, wv);
     if (trace) tr[2] = clock64_dev();
     const int n_rounds = (n_units + T - 1) / T;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
