@@ -181,7 +181,7 @@ template <int TYPE, int MAXK, int MAXNB>
 DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C, int lane, const LaneGeom& G) {
     float acc = 0.0f, accm = 0.0f;
     constexpr bool mins = TYPE != GT_Q6_K;
-    constexpr int CH = MAXNB <= 16 ? 16 : 8;   // operands of CH blocks are fetched before the dependent fma chain starts
+    constexpr int CH = 8;   // operands of CH blocks are fetched before the dependent fma chain starts
     for (int b0 = 0; b0 < nb; b0 += CH) {
         float dv[CH], sv[CH], mv[CH], pv[CH];
 #pragma unroll
@@ -229,7 +229,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     const int n_loc = first < n_items ? (n_items - first + stride - 1) / stride : 0;
     const int n_units = n_loc * upi;
     if (n_units == 0) {
-        if constexpr (WITH_PROLOGUE) prologue_q8k_wave<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, lane, wv);
+        if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
         return;
     }
     const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
@@ -269,7 +269,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    if constexpr (WITH_PROLOGUE) prologue_q8k_wave<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, lane, wv);
+    if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
     if (trace) tr[2] = clock64_dev();
     const int n_rounds = (n_units + T - 1) / T;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
