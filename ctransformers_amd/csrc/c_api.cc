@@ -122,6 +122,34 @@ int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* o
     }
     return n;
 }
+ctransformers_llm* ctamd_stage_create(const char* model_path, int context_length, int layer_begin, int layer_end,
+                                      int device) {
+    if (!model_path) return nullptr;
+    ctransformers_llm* llm = new ctransformers_llm;
+    std::string err;
+    if (!llm->engine.load(model_path, context_length, 1000, err, layer_begin, layer_end, device)) {
+        fprintf(stderr, "ctransformers_amd: failed to load stage [%d,%d) of '%s': %s\n", layer_begin, layer_end, model_path,
+                err.c_str());
+        delete llm;
+        return nullptr;
+    }
+    llm->arch = llm->engine.hparams().arch;
+    return llm;
+}
+
+int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
+                     void* x_out_dev) {
+    std::string err;
+    if (!llm->engine.eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err)) {
+        fprintf(stderr, "ctransformers_amd: stage eval failed: %s\n", err.c_str());
+        return -1;
+    }
+    return 0;
+}
+
+int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine.hparams().n_layer; }
+int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine.hparams().n_embd; }
+
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
     std::string err;

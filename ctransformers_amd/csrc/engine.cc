@@ -237,13 +237,16 @@ bool Engine::build_tables(std::string& err) {
     return true;
 }
 
-bool Engine::load(const std::string& path, int context_length, int gpu_layers, std::string& err) {
+bool Engine::load(const std::string& path, int context_length, int gpu_layers, std::string& err, int layer_begin,
+                  int layer_end, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
         return false;
     }
-    HIP_OK(hipSetDevice(0));
+    if (device < 0 || device >= ndev) { err = "HIP device ordinal out of range"; return false; }
+    device_ = device;
+    HIP_OK(hipSetDevice(device_));
     (void)gpu_layers;  // every layer lives on the GPU(s); the CPU/GPU split of the reference does not exist here
     pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
     exact_ = env_int("CT_AMD_EXACT", 1) != 0;
@@ -293,9 +296,12 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         return true;
     };
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, V = hp_.n_vocab;
+    l0_ = layer_begin < 0 ? 0 : layer_begin;
+    l1_ = layer_end < 0 ? hp_.n_layer : layer_end;
+    if (l0_ >= l1_ || l1_ > hp_.n_layer) { err = "bad pipeline stage layer range"; return false; }
     t = f.tensor("token_embd.weight");
     if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
-    {   // token_embd is only used by row lookup: keep the file layout, no planes
+    if (l0_ == 0) {   // token_embd is only used by row lookup: keep the file layout, no planes
         tok_embd_.type = t->type; tok_embd_.K = E; tok_embd_.M = V;
         uint8_t* d = nullptr;
         if (!dev_alloc(dev_allocs_, &d, t->nbytes, err)) return false;
@@ -303,7 +309,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         tok_embd_.raw = d;
     }
     layers_.resize(hp_.n_layer);
-    for (int i = 0; i < hp_.n_layer; ++i) {
+    for (int i = l0_; i < l1_; ++i) {
         const std::string p = "blk." + std::to_string(i) + ".";
         Layer& L = layers_[i];
         if (!upload_f32(f.tensor(p + "attn_norm.weight"), &L.attn_norm, E, err)) return false;
@@ -315,11 +321,15 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
             return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
     }
-    if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
-    if (!mat("output.weight", output_, V, E)) return false;
+    if (l1_ == hp_.n_layer) {
+        if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
+        if (!mat("output.weight", output_, V, E)) return false;
+    }
+    if (l0_ > 0 || l1_ < hp_.n_layer)
+        if (!dev_alloc(dev_allocs_, &xio_, (size_t)n_ctx_ * E, err)) return false;
 
     v_stride_ = (n_ctx_ + 31) / 32 * 32;  // V rows (one per channel) start 16-byte aligned
-    const size_t k_elems = (size_t)hp_.n_layer * n_ctx_ * G, v_elems = (size_t)hp_.n_layer * v_stride_ * G;
+    const size_t k_elems = (size_t)(l1_ - l0_) * n_ctx_ * G, v_elems = (size_t)(l1_ - l0_) * v_stride_ * G;
     if (!dev_alloc(dev_allocs_, &kcache_, k_elems, err) || !dev_alloc(dev_allocs_, &vcache_, v_elems + 64, err)) return false;
     HIP_OK(hipMemset(kcache_, 0, k_elems * 2));
     HIP_OK(hipMemset(vcache_, 0, v_elems * 2));
@@ -490,10 +500,15 @@ bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
 bool Engine::token_step(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
-    prof_begin("embed", "embed_row_kernel", (double)ggml_row_bytes(tok_embd_.type, E));
-    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
-              (const int*)d_tokens_, (const int*)d_state_, x_);
-    prof_end();
+    if (l0_ == 0) {
+        prof_begin("embed", "embed_row_kernel", (double)ggml_row_bytes(tok_embd_.type, E));
+        CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+                  (const int*)d_tokens_, (const int*)d_state_, x_);
+        prof_end();
+    } else {  // inner stage: this token's residual-stream row was handed over by the previous stage
+        CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)xio_, x_, E,
+                  (const int*)d_state_, 0);
+    }
     MatvecArgs base = MatvecArgs();
     base.rope_cs = rope_cs_;
     base.pos = d_pos;
@@ -521,10 +536,10 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     at.chunk = 64;
     const int n_chunks = (n_ctx_ + at.chunk - 1) / at.chunk;
     constexpr int DCH = 16;
-    for (int il = 0; il < hp_.n_layer; ++il) {
+    for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
-        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * G;
-        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * G;
+        uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
@@ -587,7 +602,10 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             debug_dump("5down", il);
         }
     }
-    if (want_logits) {
+    if (l1_ < hp_.n_layer) {  // hand this token's residual-stream row to the next stage
+        CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)x_, xio_, E,
+                  (const int*)d_state_, 1);
+    } else if (want_logits) {
         CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
                   hp_.rms_eps);
         MatvecArgs a = base;
@@ -626,12 +644,24 @@ bool Engine::ensure_graphs(std::string& err) {
 }
 
 bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
+    if (l0_ != 0 || l1_ != hp_.n_layer) { err = "this handle is a pipeline stage: use eval_stage"; return false; }
+    return eval_stage(tokens, n, n_past, nullptr, nullptr, err);
+}
+
+bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err) {
     if (n <= 0) return true;
     if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
+    if (l0_ > 0 && !x_in_dev) { err = "stage with layer_begin > 0 needs x_in"; return false; }
+    if (l1_ < hp_.n_layer && !x_out_dev) { err = "stage with layer_end < n_layer needs x_out"; return false; }
+    HIP_OK(hipSetDevice(device_));
     for (int i = 0; i < n; ++i) {
-        if (tokens[i] < 0 || tokens[i] >= hp_.n_vocab) { err = "token id out of range"; return false; }
-        h_scalars_[4 + i] = tokens[i];
+        const int tk = (l0_ == 0 && tokens) ? tokens[i] : 0;
+        if (tk < 0 || tk >= hp_.n_vocab) { err = "token id out of range"; return false; }
+        h_scalars_[4 + i] = tk;
     }
+    if (l0_ == 0 && !tokens) { err = "first stage needs token ids"; return false; }
+    const size_t xbytes = (size_t)n * hp_.n_embd * sizeof(float);
+    if (l0_ > 0) HIP_OK(hipMemcpyAsync(xio_, x_in_dev, xbytes, hipMemcpyDeviceToDevice, stream_));
     h_scalars_[0] = 0;           // step
     h_scalars_[1] = n_past;      // position of the first token of this chunk
     h_scalars_[2] = n_past + n;  // n_total: the reference runs this chunk as ONE batch (see attn_softmax_pv_exact_kernel)
@@ -647,12 +677,16 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
         for (int i = 0; i < n; ++i)
             if (!token_step(i == n - 1, err)) return false;
     }
-    HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)hp_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(h_emb_, d_emb_, (size_t)hp_.n_embd * 4, hipMemcpyDeviceToHost, stream_));
+    if (l1_ == hp_.n_layer) {
+        HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)hp_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(h_emb_, d_emb_, (size_t)hp_.n_embd * 4, hipMemcpyDeviceToHost, stream_));
+    } else {
+        HIP_OK(hipMemcpyAsync(x_out_dev, xio_, xbytes, hipMemcpyDeviceToDevice, stream_));
+    }
     HIP_OK(hipStreamSynchronize(stream_));
     HIP_OK(hipGetLastError());
-    have_logits_ = true;
-    last_token_ = tokens[n - 1];
+    have_logits_ = l1_ == hp_.n_layer;
+    last_token_ = h_scalars_[4 + n - 1];
     last_pos_ = n_past + n - 1;
     return true;
 }

@@ -34,10 +34,19 @@ class Engine {
     ~Engine();
     // Loads the model onto the visible GPU(s).  Fails (false + message) when no HIP device is present: there is no
     // CPU path in this library.
-    bool load(const std::string& path, int context_length, int gpu_layers, std::string& err);
+    // layer_begin/layer_end select a pipeline STAGE (layers [begin, end) only; -1/-1 = the whole model): a stage with
+    // begin > 0 has no embedding table, a stage with end < n_layer has no output head.  `device` is the HIP ordinal.
+    bool load(const std::string& path, int context_length, int gpu_layers, std::string& err, int layer_begin = -1,
+              int layer_end = -1, int device = 0);
     // Evaluate `n` tokens at absolute positions n_past..n_past+n-1 (KV cache overwrite semantics); logits and the
     // final-norm embedding of the LAST token land in the pinned host buffers.
     bool eval(const int* tokens, int n, int n_past, std::string& err);
+    // Stage form: x_in_dev / x_out_dev are DEVICE pointers to [n][n_embd] f32 residual-stream rows (the hand-off between
+    // pipeline stages).  x_in_dev is required iff layer_begin > 0, x_out_dev iff layer_end < n_layer.
+    bool eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err);
+    int layer_begin() const { return l0_; }
+    int layer_end() const { return l1_; }
+    bool has_head() const { return l1_ == hp_.n_layer; }
 
     const HParams& hparams() const { return hp_; }
     const Vocab& vocab() const { return vocab_; }
@@ -73,6 +82,8 @@ class Engine {
     HParams hp_;
     Vocab vocab_;
     int n_ctx_ = 0, v_stride_ = 0;
+    int l0_ = 0, l1_ = 0, device_ = 0;
+    float* xio_ = nullptr;  // [n_ctx][n_embd] residual-stream rows handed between pipeline stages (partial stages only)
     DevMat tok_embd_, output_;
     float* output_norm_ = nullptr;
     std::vector<Layer> layers_;

@@ -569,6 +569,16 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 // Device-side cursor {step, pos}: lets N token steps (eager launches or hipGraph replays) be queued back to back with
 // no host round trip — every kernel reads the position from memory, this one advances it.
 // state = {step, pos, n_total}; n_total (= n_past + N of the chunk) stays fixed for the whole chunk.
+// Pipeline-stage hand-off: row `step` of the [n_ctx][E] stage buffer <-> the working residual stream.
+// to_rows == 0: dst[i] = src[step*E + i] (stage input); to_rows == 1: dst[step*E + i] = src[i] (stage output).
+__global__ void stage_row_kernel(const float* src, float* dst, int E, const int* state, int to_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const size_t off = (size_t)state[0] * E;
+    if (to_rows) dst[off + i] = src[i];
+    else dst[i] = src[off + i];
+}
+
 __global__ void advance_state_kernel(int* state) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state[0] += 1;

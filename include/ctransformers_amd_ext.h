@@ -20,6 +20,21 @@ double ctamd_weight_bytes(ctransformers_llm* llm);
 /* In-kernel s_memtime stamps of workgroup 0 of the last launch of `site` (16 waves x 16 slots of uint64; slots: 0 entry,
  * 1 first loads issued, 2 prologue done, 3 round-0 block math done, 4 barrier passed, 5 chain+epilogue done, 6 exit). */
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n);
+
+/* ---- multi-GPU layer pipeline (DESIGN.md row e): one process per GPU, each owning a contiguous layer range ------------
+ * The reference has no multi-GPU path in this ABI (its cuBLAS offload splits tensors inside one process,
+ * models/ggml/llama.cpp:1938-2070 `tensor_split`); the MI355X design shards LAYERS across ranks instead and hands the
+ * [n_tokens][n_embd] f32 residual stream from stage to stage (RCCL send/recv, ctransformers_amd/pipeline.py).
+ * A stage handle is a normal ctransformers_llm*: on the last stage logits_data / sample / embeddings work as usual. */
+ctransformers_llm* ctamd_stage_create(const char* model_path, int context_length, int layer_begin, int layer_end,
+                                      int device);
+/* tokens: host ids (used by the first stage only, may be NULL elsewhere); x_in_dev / x_out_dev: DEVICE pointers to
+ * [n_tokens][n_embd] f32 rows (x_in required iff layer_begin > 0, x_out iff layer_end < n_layer).  Returns 0 / -1.
+ * The call returns after the stage's stream has drained, so x_out may be handed to a collective on any stream. */
+int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
+                     void* x_out_dev);
+int ctamd_n_layer(ctransformers_llm* llm);
+int ctamd_n_embd(ctransformers_llm* llm);
 #ifdef __cplusplus
 }
 #endif

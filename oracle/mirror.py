@@ -35,6 +35,9 @@ def lib():
         _lib.mir_quantize_row_q8_0.argtypes = [c_void_p, c_void_p, c_int]
         _lib.mir_llama_eval.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
         _lib.mir_llama_eval.restype = c_int
+        _lib.mir_llama_eval_range.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p]
+        _lib.mir_llama_eval_range.restype = c_int
     return _lib
 
 
@@ -151,6 +154,17 @@ class MirrorLlama:
 
 
 # op-level entry points of the restatement (same semantics as oracle/ref.py GgmlOps, for cross-checks)
+
+    def eval_range(self, tokens, n_past, l0, l1, x_in=None):
+        """Layers [l0, l1) only (pipeline stage oracle): returns x_out [n, n_embd] for an inner stage, logits for the last."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        xi = None if x_in is None else np.ascontiguousarray(x_in, dtype=np.float32)
+        xo = np.zeros((len(t), self.n_embd), dtype=np.float32)
+        lib().mir_llama_eval_range(ctypes.byref(self.m), _p(t), len(t), int(n_past), int(l0), int(l1),
+                                   None if xi is None else _p(xi), _p(xo), _p(self.logits), _p(self.embeddings))
+        return self.logits if l1 == self.n_layer else xo
+
+
 def rms_norm_mul(x, w, eps):
     x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
     y = np.zeros_like(x)

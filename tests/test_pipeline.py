@@ -1,0 +1,98 @@
+"""Row (e): the multi-GPU layer pipeline.  CPU coverage of the N > 1 path: stage entry points of the C library (emulator
+build of the HIP sources), the layer partition, and a world_size-2 gloo run of the real Pipeline driver."""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from ctransformers_amd import pipeline
+
+
+def test_partition_layers():
+    for n_layer, world in [(32, 1), (32, 2), (32, 4), (32, 8), (80, 8), (60, 4), (2, 2), (3, 2)]:
+        b = pipeline.partition_layers(n_layer, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == n_layer
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1)) and all(e > s for s, e in b)
+        sizes = [e - s for s, e in b]
+        assert max(sizes) - min(sizes) <= 1
+        if world > 1 and n_layer % world:
+            assert sizes[-1] == min(sizes)  # the stage that also streams the lm_head gets the short end
+    assert pipeline.partition_layers(32, 8) == [(4 * i, 4 * i + 4) for i in range(8)]
+    with pytest.raises(ValueError):
+        pipeline.partition_layers(2, 3)
+
+
+def test_stage_chain_equals_whole_model(emu_lib, mirror):
+    """stage[0,1) -> stage[1,2) through the C stage API == the whole model, bit for bit; the hand-off rows equal the
+    oracle's residual stream after layer 0."""
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    lib = ctypes.CDLL(emu_lib)
+    s0 = pipeline.HipStage(path, 0, 1, context_length=96, device="cpu", lib=lib)
+    s1 = pipeline.HipStage(path, 1, 2, context_length=96, device="cpu", lib=lib)
+    assert s0.first and not s0.last and s1.last and not s1.first and s0.n_layer == 2
+    prompt = [int(t) for t in g["prompt"]]
+    x = s0.forward(prompt, 0)
+    orc = mirror.MirrorLlama(path, 96)
+    assert np.array_equal(x.numpy(), orc.eval_range(prompt, 0, 0, 1))
+    logits = s1.forward([0] * len(prompt), 0, x)
+    assert np.array_equal(logits.numpy(), g["logits"][0])
+    for i in range(3):  # decode steps through the two stages
+        t = int(g["greedy"][i])
+        logits = s1.forward([0], len(prompt) + i, s0.forward([t], len(prompt) + i))
+        assert np.array_equal(logits.numpy(), g["logits"][i + 1])
+    # misuse is refused loudly
+    with pytest.raises(ValueError):
+        s1.forward([0], 0, None)
+    # a stage handle refuses the whole-model entry point
+    lib.ctransformers_llm_batch_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int]
+    lib.ctransformers_llm_batch_eval.restype = ctypes.c_bool
+    assert not lib.ctransformers_llm_batch_eval(s1._h, (ctypes.c_int * 1)(1), 1, 0, 8, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gloo_pipeline_world2(emu_lib, tmp_path, mirror):
+    """Two processes, gloo, 127.0.0.1.  Micro-batched prefill through the pipeline is bit-identical to the REFERENCE's
+    single-process result for the same chunking (golden long_chunked = batch 8); greedy decode returns the same ids on
+    rank 0 and on the last rank, equal to the oracle's, with bit-identical final logits."""
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pipeline_worker.py"), path, emu_lib,
+                                       str(tmp_path), "8", "3"], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert recs[0]["layers"] == [0, 1] and recs[1]["layers"] == [1, 2]
+    assert np.array_equal(np.load(tmp_path / "prefill_logits.npy"), g["long_chunked"])
+    assert recs[0]["tokens"] == recs[1]["tokens"] and len(recs[0]["tokens"]) == 3
+    orc = mirror.MirrorLlama(path, 96)
+    prompt = [int(t) for t in g["long_prompt"]]
+    for s in range(0, len(prompt), 8):
+        lg = orc.eval(prompt[s:s + 8], s)
+    want, pos = [], len(prompt)
+    for _ in range(3):
+        t = int(np.argmax(lg))
+        want.append(t)
+        lg = orc.eval([t], pos)
+        pos += 1
+    assert recs[1]["tokens"] == want
+    assert np.array_equal(np.load(tmp_path / "logits.npy"), lg)
