@@ -15,7 +15,6 @@ Extra objects on the JSON line:
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,17 +25,12 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from ctransformers_amd import synth  # noqa: E402
+from ctransformers_amd import measure, synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
-HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
 MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km.gguf")
 SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), "Q4_K_M"
-
-
-class LaunchStat(ctypes.Structure):
-    _fields_ = [("site", ctypes.c_char * 32), ("bytes", ctypes.c_double), ("ms", ctypes.c_double), ("launches", ctypes.c_int)]
 
 
 def ensure_model(rank):
@@ -44,15 +38,6 @@ def ensure_model(rank):
         tmp = MODEL + ".tmp%d" % os.getpid()
         synth.write_llama_gguf(tmp, SHAPE, FTYPE, seed=1234)
         os.replace(tmp, MODEL)
-
-
-def profile_sites(llm, iters):
-    lib = llm._lib
-    lib.ctamd_profile_decode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LaunchStat), ctypes.c_int]
-    lib.ctamd_profile_decode.restype = ctypes.c_int
-    buf = (LaunchStat * 32)()
-    n = lib.ctamd_profile_decode(llm._llm, iters, buf, 32)
-    return [dict(site=buf[i].site.decode(), bytes=buf[i].bytes, ms=buf[i].ms, launches=buf[i].launches) for i in range(max(n, 0))]
 
 
 def cpu_baseline(n_vocab):
@@ -111,19 +96,8 @@ def main():
     dt = time.perf_counter() - t0
     tok_s = steps / dt
 
-    sites = profile_sites(llm, 8)
-    dom = [s for s in sites if s["site"] in ("qkv", "wo", "gate_up", "lm_head")]
-    roof = None
-    if dom:
-        b = sum(s["bytes"] for s in dom)
-        ms = sum(s["ms"] for s in dom)
-        nl = sum(s["launches"] for s in dom)
-        ach = b / (ms * 1e-3)
-        roof = dict(bound="hbm", kernel="matvec_exact2_kernel<256,4096,4> (QKV, Wo, gate+up, lm_head launch sites)",
-                    achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / HBM_PEAK, 4),
-                    traffic=None, bytes_per_launch=round(b / nl), us_per_launch=round(ms * 1e3 / nl, 2),
-                    sites={s["site"]: dict(GBps=round(s["bytes"] / (s["ms"] * 1e-3) / 1e9, 1) if s["bytes"] else None,
-                                           us=round(s["ms"] * 1e3 / s["launches"], 2)) for s in sites})
+    sites = measure.profile_sites(llm._lib, llm._llm, 8)
+    roof = measure.roofline(sites)
     wbytes = synth.weight_bytes_per_token(MODEL)
     kv_avg = 2 * 32 * (N_PROMPT + a.warmup + steps / 2.0) * 4096 * 2 if SHAPE == "llama-2-7b" else 0
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=1, steps=steps, warmup=a.warmup,
@@ -132,7 +106,7 @@ def main():
                config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on 1xMI355X, 128-tok prefill + 256-tok greedy decode, ctx 512",
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism="1 GPU"),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), load_s=round(load_s, 2),
-               token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / HBM_PEAK, 4)),
+               token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4)),
                roofline=roof)
     if not a.no_cpu_baseline:
         del llm

@@ -251,6 +251,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
     exact_ = env_int("CT_AMD_EXACT", 1) != 0;
     design_ = env_int("CT_AMD_DESIGN", 4);
+    fused_attn_ = env_int("CT_AMD_FUSED_ATTN", 1) != 0;
     items_per_wave_ = std::max(1, env_int("CT_AMD_IPW", 1));
     max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 1024));
 
@@ -356,6 +357,11 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
 // ---------------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------------
+static int chip_cus() {
+    static const int n_cu = [] { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); return n > 0 ? n : 256; }();
+    return n_cu;
+}
+
 // Bit-exact path: work items are 8-row tiles.
 static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, hipStream_t s, std::string& err) {
     // convert pair bookkeeping (set_jobs) into tile bookkeeping
@@ -367,7 +373,7 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
     if (a.job[0].w.layout == LAYOUT_TILE8S) {
         // generation 4: one 1024-thread workgroup per CU, two tiles per barrier round
-        static const int n_cu = [] { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); return n > 0 ? n : 256; }();
+        const int n_cu = chip_cus();
         static const int cap = env_int("CT_AMD_V4_WGS", 0);
         const int rounds_total = a.gateup ? a.n_pairs : (a.n_pairs + 1) / 2;
         const int max_w = cap > 0 ? cap : n_cu;
@@ -558,12 +564,21 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
             ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
             ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
-            prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);
-            CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
-            prof_end();
-            prof_begin("attn_softmax_pv", "attn_softmax_pv_exact_kernel", 0.0);
-            CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
-            prof_end();
+            if (fused_attn_) {
+                prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+                const int nt = env_int("CT_AMD_ATTN_NT", 512);
+                if (nt == 256) CT_LAUNCH((attn_fused_exact_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
+                else if (nt == 512) CT_LAUNCH((attn_fused_exact_kernel<512>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(512), stream_, ax);
+                else CT_LAUNCH((attn_fused_exact_kernel<1024>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(1024), stream_, ax);
+                prof_end();
+            } else {
+                prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);
+                CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
+                prof_end();
+                prof_begin("attn_softmax_pv", "attn_softmax_pv_exact_kernel", 0.0);
+                CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
+                prof_end();
+            }
             debug_dump("2attn", il);
         } else {
             CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);

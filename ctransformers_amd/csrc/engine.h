@@ -111,7 +111,7 @@ class Engine {
     void prof_end();
     std::vector<void*> dev_allocs_;
     int pairs_per_wave_ = 2, max_wgs_ = 2048, items_per_wave_ = 1;
-    bool exact_ = true;
+    bool exact_ = true, fused_attn_ = true;
     int design_ = 4;
 };
 

@@ -436,6 +436,83 @@ __global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnAr
     if (j == 0) a.out[(size_t)h * a.head_dim + d] = (float)sumf;
 }
 
+// Fused form of the two kernels above (one launch per layer instead of two): grid (n_head, head_dim/64), 1024 threads.
+// Every workgroup recomputes the (cheap) score row of its head into LDS — 256 positions per pass, a quad per position —
+// then runs the softmax and its 64 channels of V*P exactly as attn_softmax_pv_exact_kernel does.  The double-precision
+// exp sum is order-free here: the addends are fp16 values in (0, 1] (multiples of 2^-24), so any summation order of up
+// to 8192 of them is exact in binary64.
+template <int NT>
+__global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
+    constexpr int NWV = NT / 64;
+    __shared__ float prob[kMaxCtx];
+    __shared__ double red[NWV];
+    __shared__ float redf[NWV];
+    const int h = (int)blockIdx.x;
+    const int n_kv = *a.pos + 1;
+    const int n_tot = *a.n_total;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3;
+    const int hd = a.head_dim;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const uint16_t* qrow = a.q_f16 + (size_t)h * hd;
+    float mx = -INFINITY;
+    for (int base = 0; base < n_kv; base += NT / 4) {
+        const int p = base + (tid >> 2);
+        const bool ok = p < n_kv;
+        const uint16_t* krow = a.kcache + (size_t)(ok ? p : base) * a.n_embd_gqa + (size_t)hk * hd;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e0 = 0; e0 < hd; e0 += 32) {
+            float kf[8], qf[8];
+            unpack8_f16(ld16(krow + e0 + 8 * j), kf);
+            unpack8_f16(ld16(qrow + e0 + 8 * j), qf);
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+        }
+        const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+        if (ok) {
+            mx = fmaxf(mx, sc);
+            if (j == 0) prob[p] = sc;
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) redf[wv] = mx;
+    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+    double sum = 0.0;
+    for (int i = tid; i < n_kv; i += NT) {
+        const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]);
+        prob[i] = e;
+        sum += (double)e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) tot += red[w];
+    const float inv = (float)(1.0 / tot);
+    for (int i = tid; i < n_kv; i += NT) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    const int np = n_tot & ~31;
+    for (int i = n_kv + tid; i < np; i += NT) prob[i] = 0.0f;  // masked columns of this batch
+    __syncthreads();
+    if (tid >= 256) return;
+    const int d = (int)blockIdx.y * 64 + (tid >> 2);
+    const uint16_t* vrow = a.vcache + ((size_t)hk * hd + d) * a.v_stride;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < np; i += 32) {
+        float vf[8];
+        unpack8_f16(ld16(vrow + i + 8 * j), vf);
+        const float* pr = &prob[i + 8 * j];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+    }
+    const float res = f16dot_reduce_exact(acc, j);
+    double sumf = (double)res;
+    for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
+    if (j == 0) a.out[(size_t)h * hd + d] = (float)sumf;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Design C: the same bit-exact arithmetic with K split across the waves of a workgroup.
 // The integer part of a block (loads, nibble unpack, dot4, transpose-reduce) is order-free, so the NW waves of a
@@ -525,87 +602,101 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
     constexpr int NW = NT / 64, NG = NT / 16;
     constexpr int ROUNDS = (MAXK / 256 + NG - 1) / NG;
     const int nblk = K >> 8;
+    // A wave whose four 16-lane rows are all past the last block has nothing to quantize: it must SKIP the arithmetic
+    // (wave-uniform branches), not run it predicated off — the prologue is VALU-issue bound (about 250 wave
+    // instructions), and for K = 4096 only 4 of the 16 waves (one per SIMD) are live.
+    const bool wave_live = uniform_int(wv * 4) < nblk;
     float4 v[ROUNDS][4];
     double s = 0.0;
+    if (wave_live) {
 #pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int b = grp + rd * NG;
-        if (b < nblk) {
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int b = grp + rd * NG;
+            if (b < nblk) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
-                if (pro == PRO_RMSNORM) {
-                    s += (double)(v[rd][k].x * v[rd][k].x);
-                    s += (double)(v[rd][k].y * v[rd][k].y);
-                    s += (double)(v[rd][k].z * v[rd][k].z);
-                    s += (double)(v[rd][k].w * v[rd][k].w);
+                for (int k = 0; k < 4; ++k) {
+                    v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
+                    if (pro == PRO_RMSNORM) {
+                        s += (double)(v[rd][k].x * v[rd][k].x);
+                        s += (double)(v[rd][k].y * v[rd][k].y);
+                        s += (double)(v[rd][k].z * v[rd][k].z);
+                        s += (double)(v[rd][k].w * v[rd][k].w);
+                    }
                 }
             }
         }
     }
     float scale = 1.0f;
     if (pro == PRO_RMSNORM) {
-        s = wave_sum_fast(s);
-        if (lane == 0) L.red[wv] = s;
+        if (wave_live) {
+            s = wave_sum_fast(s);
+            if (lane == 0) L.red[wv] = s;
+        } else if (lane == 0) {
+            L.red[wv] = 0.0;
+        }
         __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += L.red[w];
-        const float mean = (float)(tot / (double)K);
-        scale = 1.0f / sqrtf(mean + eps);
+        if (wave_live) {
+            double tot = 0.0;
+            for (int w = 0; w < NW; ++w) tot += L.red[w];
+            const float mean = (float)(tot / (double)K);
+            scale = 1.0f / sqrtf(mean + eps);
+        }
     }
+    if (wave_live) {
 #pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int b = grp + rd * NG;
-        const bool live = b < nblk;            // uniform within a 16-lane row, may differ between rows of a wave
-        float t[16];
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int b = grp + rd * NG;
+            const bool live = b < nblk;            // uniform within a 16-lane row, may differ between rows of a wave
+            float t[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
-            if (live && pro == PRO_RMSNORM) {
-                const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
-                q.x = (q.x * scale) * w4.x;
-                q.y = (q.y * scale) * w4.y;
-                q.z = (q.z * scale) * w4.z;
-                q.w = (q.w * scale) * w4.w;
+            for (int k = 0; k < 4; ++k) {
+                float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
+                if (live && pro == PRO_RMSNORM) {
+                    const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                    q.x = (q.x * scale) * w4.x;
+                    q.y = (q.y * scale) * w4.y;
+                    q.z = (q.z * scale) * w4.z;
+                    q.w = (q.w * scale) * w4.w;
+                }
+                t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
             }
-            t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
-        }
-        float am = 0.0f;
+            float am = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
-        float amax = am;
-        amax = fmaxf(amax, lane_xor1(amax));
-        amax = fmaxf(amax, lane_xor2(amax));
-        amax = fmaxf(amax, lane_xor4(amax));
-        amax = fmaxf(amax, lane_xor8(amax));
-        // first element (lowest index) attaining amax keeps its sign
-        const unsigned long long hit = __ballot(am == amax);
-        const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
-        const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
-        float mine = 0.0f;
+            for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+            float amax = am;
+            amax = fmaxf(amax, lane_xor1(amax));
+            amax = fmaxf(amax, lane_xor2(amax));
+            amax = fmaxf(amax, lane_xor4(amax));
+            amax = fmaxf(amax, lane_xor8(amax));
+            // first element (lowest index) attaining amax keeps its sign
+            const unsigned long long hit = __ballot(am == amax);
+            const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
+            const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
+            float mine = 0.0f;
 #pragma unroll
-        for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
-        const float maxv = __shfl(mine, first);
-        int packed[4] = {0, 0, 0, 0}, s16 = 0;
-        float d = 0.0f;
-        if (amax != 0.0f) {
-            const float iscale = -128.f / maxv;
+            for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
+            const float maxv = __shfl(mine, first);
+            int packed[4] = {0, 0, 0, 0}, s16 = 0;
+            float d = 0.0f;
+            if (amax != 0.0f) {
+                const float iscale = -128.f / maxv;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int q = ((int)f32_to_bits(fmaf(iscale, t[e], 12582912.f)) & 0x007fffff) - 0x00400000;
-                q = q > 127 ? 127 : q;
-                packed[e >> 2] |= (q & 0xff) << (8 * (e & 3));
-                s16 += q;
+                for (int e = 0; e < 16; ++e) {
+                    int q = ((int)f32_to_bits(fmaf(iscale, t[e], 12582912.f)) & 0x007fffff) - 0x00400000;
+                    q = q > 127 ? 127 : q;
+                    packed[e >> 2] |= (q & 0xff) << (8 * (e & 3));
+                    s16 += q;
+                }
+                d = 1.0f / iscale;
             }
-            d = 1.0f / iscale;
-        }
-        const int s32 = s16 + lane_xor1(s16);
-        if (live) {
+            const int s32 = s16 + lane_xor1(s16);
+            if (live) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) L.q8[b * 64 + sub * 4 + k] = packed[k];
-            L.bsums[b * 16 + sub] = s16;
-            if ((sub & 1) == 0) L.sb[b * 8 + (sub >> 1)] = s32;
-            if (sub == 0) L.yd[b] = d;
+                for (int k = 0; k < 4; ++k) L.q8[b * 64 + sub * 4 + k] = packed[k];
+                L.bsums[b * 16 + sub] = s16;
+                if ((sub & 1) == 0) L.sb[b * 8 + (sub >> 1)] = s32;
+                if (sub == 0) L.yd[b] = d;
+            }
         }
     }
     __syncthreads();

@@ -266,7 +266,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
         for (int i = 0; i < S; ++i) R[t][i] = load_img(cur[t], i);
     }
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
-    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
+    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (WITH_PROLOGUE ? 0 : 6);
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
     if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
@@ -290,8 +290,8 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
             for (int i = 0; i < S; ++i) {
                 int b = wv + i * NW;
                 b = b < cur[t].nb ? b : cur[t].nb - 1;
-                img_to_chain<TYPE, MAXK, MAXNB>(R[t][i], b, L, CB[par][t], lane, G);
-                R[t][i] = load_img(nxt[t], i);
+                if (cur[t].valid) img_to_chain<TYPE, MAXK, MAXNB>(R[t][i], b, L, CB[par][t], lane, G);   // tail rounds: skip
+                if (nxt[t].valid) R[t][i] = load_img(nxt[t], i);                                        // the padding units
             }
         }
         if (trace && rd == 0) tr[3] = clock64_dev();

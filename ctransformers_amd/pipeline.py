@@ -120,12 +120,16 @@ class Pipeline:
     """SPMD driver: every rank calls the same methods with the same arguments.  `stage` is any object with
     first/last/n_embd and forward(tokens, n_past, x_in) (HipStage in the product; the tests also inject the oracle)."""
 
-    def __init__(self, stage, rank, world, device, group=None):
+    def __init__(self, stage, rank, world, device, group=None, stage_device=None):
+        # `device`: where the tensors handed to torch.distributed live (cuda:<local rank> for RCCL, cpu for gloo).
+        # `stage_device`: where the stage wants its rows; differs from `device` only when a gloo group drives HIP stages
+        # (hand-off staged through host memory: the 1-GPU CI form of the N-GPU run).
         self.stage, self.rank, self.world, self.device, self.group = stage, rank, world, torch.device(device), group
+        self.stage_device = torch.device(stage_device) if stage_device is not None else self.device
 
     def _sync(self):
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
+        if self.stage_device.type == "cuda":
+            torch.cuda.current_stream(self.stage_device).synchronize()
 
     def eval_chunk(self, tokens, n_past):
         """One chunk through this rank's stage.  Returns logits on the last rank, None elsewhere."""
@@ -134,9 +138,11 @@ class Pipeline:
         if self.rank > 0:
             x_in = torch.empty((n, self.stage.n_embd), dtype=torch.float32, device=self.device)
             dist.recv(x_in, src=self.rank - 1, group=self.group)
+            x_in = x_in.to(self.stage_device)
             self._sync()  # the stage runs on the library's own stream: the hand-off must have landed
         out = self.stage.forward(tokens, n_past, x_in)
         if self.rank < self.world - 1:
+            out = out.to(self.device)
             dist.send(out, dst=self.rank + 1, group=self.group)
             self._keep = out  # keep the buffer alive until the next call has synchronised
             return None
@@ -236,7 +242,10 @@ def bench_main(args, model_path, shape, ftype, n_prompt=128, n_ctx=512):
         logits = pipe.eval_chunk([tok], pos)
         pos += 1
     barrier_sync()
-    dt = torch.tensor([time.perf_counter() - t0, prefill_s, load_s], dtype=torch.float64, device=device)
+    dt_local = time.perf_counter() - t0
+    from . import measure
+    roof = measure.roofline(measure.profile_sites(stage._lib, stage._h, 8)) if rank == 0 else None  # after the timed region
+    dt = torch.tensor([dt_local, prefill_s, load_s], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt_s, prefill_s, load_s = [float(v) for v in dt.tolist()]
     if rank == 0:
@@ -251,7 +260,7 @@ def bench_main(args, model_path, shape, ftype, n_prompt=128, n_ctx=512):
                    prefill_tok_s=round(n_prompt / prefill_s, 1), load_s=round(load_s, 2),
                    token_roofline=dict(bytes_per_token=int(wbytes), frac_of_8TBps=round(steps / dt_s * wbytes / 8.0e12, 4),
                                        note="stages are serial for one sequence: the denominator stays ONE GPU's HBM"),
-                   roofline=None, cpu_baseline=None)
+                   roofline=roof, cpu_baseline=None)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

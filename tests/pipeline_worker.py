@@ -18,8 +18,12 @@ def main():
     rank, world, _, device = pipeline.init_distributed("gloo")
     dims = pipeline.model_dims(model)
     l0, l1 = pipeline.partition_layers(dims["n_layer"], world)[rank]
-    stage = pipeline.HipStage(model, l0, l1, context_length=96, device="cpu", lib=ctypes.CDLL(emu))
-    pipe = pipeline.Pipeline(stage, rank, world, device)
+    if emu == "hip":  # GPU box, one GPU: both ranks put their stage on cuda:0, gloo hand-off staged through the host
+        stage = pipeline.HipStage(model, l0, l1, context_length=96, device="cuda:0")
+        pipe = pipeline.Pipeline(stage, rank, world, device, stage_device="cuda:0")
+    else:
+        stage = pipeline.HipStage(model, l0, l1, context_length=96, device="cpu", lib=ctypes.CDLL(emu))
+        pipe = pipeline.Pipeline(stage, rank, world, device)
     g = np.load(os.path.splitext(model)[0] + ".npz")
     prompt = [int(t) for t in g["long_prompt"]]
     pre = pipe.prefill(prompt, 0, micro_batch=micro)

@@ -121,3 +121,54 @@ def test_full_7b_properties_and_reference(ref, model_7b):
     m2 = open_hip(model_7b, context_length=512, batch_size=8)
     m2.eval(toks)  # chunks of 8
     assert np.array_equal(m2.logits.to_numpy(), first)
+
+
+def test_pipeline_stages_on_gpu():
+    """Row (e) on hardware: two layer stages of the HIP library chained through device-resident hand-off rows are
+    bit-identical to the reference goldens (prefill in chunks of 8 + greedy decode)."""
+    import torch
+    from ctransformers_amd import pipeline
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    s0 = pipeline.HipStage(path, 0, 1, context_length=96, device="cuda:0")
+    s1 = pipeline.HipStage(path, 1, 2, context_length=96, device="cuda:0")
+    prompt = [int(t) for t in g["long_prompt"]]
+    for s in range(0, len(prompt), 8):
+        c = prompt[s:s + 8]
+        x = s0.forward(c, s)
+        assert x.is_cuda and tuple(x.shape) == (len(c), s0.n_embd)
+        logits = s1.forward([0] * len(c), s, x)
+    torch.cuda.synchronize()
+    assert np.array_equal(logits.numpy(), g["long_chunked"])
+    s0b = pipeline.HipStage(path, 0, 1, context_length=96, device="cuda:0")
+    s1b = pipeline.HipStage(path, 1, 2, context_length=96, device="cuda:0")
+    p = [int(t) for t in g["prompt"]]
+    logits = s1b.forward([0] * len(p), 0, s0b.forward(p, 0))
+    assert np.array_equal(logits.numpy(), g["logits"][0])
+    for i, t in enumerate(g["greedy"][:4]):
+        logits = s1b.forward([0], len(p) + i, s0b.forward([int(t)], len(p) + i))
+        assert np.array_equal(logits.numpy(), g["logits"][i + 1])
+
+
+def test_pipeline_two_processes_one_gpu(tmp_path):
+    """The N > 1 driver on the 1-GPU box: two ranks (gloo rendezvous on 127.0.0.1, hand-off staged through the host), each
+    with its HIP stage on cuda:0.  Same assertions as the CPU gloo test, against the reference goldens."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from test_pipeline import _free_port
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pipeline_worker.py"), path, "hip",
+                                       str(tmp_path), "8", "3"], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert np.array_equal(np.load(tmp_path / "prefill_logits.npy"), g["long_chunked"])
+    assert recs[0]["tokens"] == recs[1]["tokens"] and len(recs[0]["tokens"]) == 3

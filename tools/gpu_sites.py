@@ -6,7 +6,7 @@ for kv in sys.argv[2:]:
     k, v = kv.split("="); os.environ[k] = v
 from ctransformers_amd import synth
 from ctransformers_amd.llm import LLM, Config
-import bench
+
 p = "/tmp/l7b.gguf"
 if not os.path.exists(p):
     synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
@@ -19,7 +19,8 @@ t0 = time.perf_counter()
 for _ in range(64):
     m.eval([tok]); tok = m.sample(top_k=1, repetition_penalty=1.0)
 dt = (time.perf_counter() - t0) / 64
-sites = bench.profile_sites(m, 10)
+from ctransformers_amd import measure
+sites = measure.profile_sites(m._lib, m._llm, 10)
 tot = sum(s["ms"] for s in sites) / 10
 print(json.dumps(dict(tag=sys.argv[1] if len(sys.argv) > 1 else "", ms_per_token=round(dt * 1e3, 3), tok_s=round(1 / dt, 1),
                       eager_sum_ms=round(tot, 3),
