@@ -336,6 +336,138 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     }
 }
 
+// One type-homogeneous group of a launch, as seen by one workgroup: its units (local items k = 0.. with
+// item = item0 + blockIdx + k*gridDim, times 2 for gate/up pairs), the units of the current round and their block
+// images in registers.
+template <int TYPE, int S, int T> struct GroupState {
+    int item0, first, stride, n_units;
+    UnitInfo cur[T];
+    BlkImg<TYPE> R[T][S];
+};
+
+template <int TYPE, int S, int T>
+DEV void group_unit_of(const MatvecArgs& a, const GroupState<TYPE, S, T>& g, int u, UnitInfo& U) {   // u clamps to the last unit
+    const int uu = u < g.n_units ? u : g.n_units - 1;
+    const int k = a.gateup ? (uu >> 1) : uu;
+    const int part = a.gateup ? (uu & 1) : 0;
+    const int it = g.item0 + g.first + k * g.stride;
+    int j = 0;
+    if (!a.gateup) {
+        if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
+        if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+    }
+    const DevMat& w = a.gateup ? a.job[part].w : a.job[j].w;
+    const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
+    U.valid = u < g.n_units;
+    U.j = j;
+    U.tile = it - (a.gateup ? 0 : a.job[j].pair0);
+    U.type = TYPE; U.nb = w.nb; U.M = w.M; U.rec = rec;
+    U.base = w.p[0] + (size_t)U.tile * w.nb * rec;
+}
+
+template <int TYPE, int S>
+DEV BlkImg<TYPE> group_load_img(const UnitInfo& U, int i, int wv, const LaneGeom& G) {
+    int b = wv + i * 16;
+    b = b < U.nb ? b : U.nb - 1;
+    return img_load<TYPE>(U.base + (size_t)b * U.rec, G);
+}
+
+// Sets the group up and issues the loads of its first round.
+template <int TYPE, int S, int T>
+DEV void group_begin(const MatvecArgs& a, int item0, int n_items, GroupState<TYPE, S, T>& g, int wv, const LaneGeom& G) {
+    g.item0 = item0;
+    g.stride = (int)gridDim.x;
+    g.first = (int)blockIdx.x;
+    const int n_loc = g.first < n_items ? (n_items - g.first + g.stride - 1) / g.stride : 0;
+    g.n_units = n_loc * (a.gateup ? 2 : 1);
+    if (g.n_units == 0) return;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        group_unit_of<TYPE, S, T>(a, g, t, g.cur[t]);
+        if (g.cur[t].valid) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) g.R[t][i] = group_load_img<TYPE, S>(g.cur[t], i, wv, G);
+        }
+    }
+}
+
+// Every wave of the workgroup walks the group's units in rounds of T.  `hook` runs once, in the last round after this
+// wave's block math and before the barrier: the kernel uses it to issue the NEXT group's first loads, so the weight
+// stream does not stop while this group's last chains are replayed.
+template <int TYPE, int MAXK, int S, int T, int TCB, int NBUF, bool GROUP_B, class Hook>
+DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MAXK>& L, ChainBuf4<MAXK / 256> (&CB)[NBUF][TCB],
+                      int lane, int wv, const LaneGeom& G, int pos, int& round_seq, Hook hook) {
+    constexpr int NW = 16, MAXNB = MAXK / 256;
+    const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
+    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (GROUP_B ? 6 : 0);
+    const int n_rounds = (g.n_units + T - 1) / T;
+    if (n_rounds == 0) { hook(); return; }
+    UnitInfo nxt[T];
+    for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
+        const int par = round_seq % NBUF;
+        // the wave that will replay unit t's chain starts the dependent residual load now
+        float res_in = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !a.gateup && a.job[g.cur[t].j].epi == EPI_ADD) {
+                const int row = g.cur[t].tile * 8 + G.r;
+                if (row < g.cur[t].M) res_in = a.res[row];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            group_unit_of<TYPE, S, T>(a, g, (rd + 1) * T + t, nxt[t]);
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                int b = wv + i * NW;
+                b = b < g.cur[t].nb ? b : g.cur[t].nb - 1;
+                if (g.cur[t].valid) img_to_chain<TYPE, MAXK, MAXNB>(g.R[t][i], b, L, CB[par][t], lane, G);   // tail rounds: skip
+                if (nxt[t].valid) g.R[t][i] = group_load_img<TYPE, S>(nxt[t], i, wv, G);                     // the padding units
+            }
+        }
+        if (rd == n_rounds - 1) hook();
+        if (trace && rd == 0) tr[3] = clock64_dev();
+        __syncthreads();
+        if (trace && rd == 0) tr[4] = clock64_dev();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (wv != ((round_seq * T + t) & (NW - 1)) || !g.cur[t].valid) continue;
+            if (a.gateup && (t & 1)) continue;                       // the gate wave also replays the up chain
+            const UnitInfo& U = g.cur[t];
+            const float res = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t], lane, G);
+            const int row = U.tile * 8 + G.r;
+            const bool own = G.g == 0 && row < U.M;
+            if (a.gateup) {
+                const float up = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t + 1 < T ? t + 1 : t], lane, G);
+                if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
+            } else {
+                const int epi = a.job[U.j].epi;
+                if (epi == EPI_ADD) {
+                    if (own) a.out[row] = res + res_in;
+                } else if (epi == EPI_STORE) {
+                    if (own) a.out[row] = res;
+                } else if (epi == EPI_V) {
+                    if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+                } else {
+                    const float other = lane_xor8(res);
+                    const int ip = (row % a.head_dim) >> 1;
+                    const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+                    const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+                    const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+                    if (own) {
+                        if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+                        else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                    }
+                }
+            }
+        }
+        if (trace && rd == 0) tr[5] = clock64_dev();
+        if (NBUF == 1) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) g.cur[t] = nxt[t];
+    }
+}
+
 // TA / TB: weight types of the two job groups (TB == 0: single group).  a.n_groupA = number of items in group A.
 template <int MAXK, int S, int T, int NBUF, int TA, int TB>
 __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
@@ -346,11 +478,34 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
-    if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0) ((unsigned long long*)a.dbg_sink)[16 * wv] = clock64_dev();
+    const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
+    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
+    if (trace) tr[0] = clock64_dev();
     const int pos = a.pos ? *a.pos : 0;
     int round_seq = 0;
-    run_group<TA, MAXK, S, T, NBUF, true>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
-    if constexpr (TB != 0)
-        run_group<TB, MAXK, S, T, NBUF, false>(a, a.n_groupA, a.n_pairs - a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
-    if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0) ((unsigned long long*)a.dbg_sink)[16 * wv + 6] = clock64_dev();
+    if constexpr (TB == 0) {   // single type: the plain loop (the compiler schedules it better than the group-state form)
+        run_group<TA, MAXK, S, T, NBUF, true>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
+        if (trace) tr[6] = clock64_dev();
+        return;
+    }
+    GroupState<TA, S, T> ga;
+    group_begin<TA, S, T>(a, 0, a.n_groupA, ga, wv, G);
+    if (trace) tr[1] = clock64_dev();
+    // the first weight loads are in flight while the activation vector is normalised / quantized
+    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if (trace) tr[2] = clock64_dev();
+    if constexpr (TB != 0) {
+        // group B (the Q6_K matrix of a mixed launch) is the small one: two units per round keep its preloaded
+        // images within the 128-VGPR budget of a 1024-thread workgroup
+        constexpr int T2 = T > 2 ? 2 : T;
+        GroupState<TB, S, T2> gb;
+        group_rounds<TA, MAXK, S, T, T, NBUF, false>(a, ga, L, CB, lane, wv, G, pos, round_seq, [&]() __attribute__((always_inline)) {
+            group_begin<TB, S, T2>(a, a.n_groupA, a.n_pairs - a.n_groupA, gb, wv, G);
+            if (trace) tr[7] = clock64_dev();
+        });
+        group_rounds<TB, MAXK, S, T2, T, NBUF, true>(a, gb, L, CB, lane, wv, G, pos, round_seq, []() {});
+    } else {
+        group_rounds<TA, MAXK, S, T, T, NBUF, false>(a, ga, L, CB, lane, wv, G, pos, round_seq, []() {});
+    }
+    if (trace) tr[6] = clock64_dev();
 }
