@@ -564,12 +564,17 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
             ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
             ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
+            if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
             if (fused_attn_) {
                 prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
                 const int nt = env_int("CT_AMD_ATTN_NT", 512);
-                if (nt == 256) CT_LAUNCH((attn_fused_exact_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
-                else if (nt == 512) CT_LAUNCH((attn_fused_exact_kernel<512>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(512), stream_, ax);
-                else CT_LAUNCH((attn_fused_exact_kernel<1024>), dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(1024), stream_, ax);
+                const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
+#define ATT(NTV, HDV) CT_LAUNCH((attn_fused_exact_kernel<NTV, HDV>), ag, dim3(NTV), stream_, ax)
+                if (hd == 128) { if (nt == 256) ATT(256, 128); else if (nt == 1024) ATT(1024, 128); else ATT(512, 128); }
+                else if (hd == 64) ATT(512, 64);
+                else if (hd == 192) ATT(512, 192);
+                else ATT(512, 256);
+#undef ATT
                 prof_end();
             } else {
                 prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);

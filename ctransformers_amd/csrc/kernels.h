@@ -46,6 +46,14 @@ struct MatJob {
     int pair0;  // first global pair index of this job
 };
 
+// K cache layout: [kv_head][n_ctx][head_dim] fp16 — position-major inside a head, so the decode attention workgroup of a
+// head streams ONE contiguous region (the reference keeps [pos][n_embd_gqa], llama.cpp:2342-2347, which at decode time
+// is a 256-byte read every 8 KB per head).  The layout is internal; the numerics do not depend on it.
+DEV size_t kcache_off(int pos, int row, int head_dim, int n_ctx) {
+    const int hk = row / head_dim;
+    return ((size_t)hk * n_ctx + pos) * head_dim + (size_t)(row - hk * head_dim);
+}
+
 struct MatvecArgs {
     MatJob job[3];
     int njobs;
@@ -61,7 +69,7 @@ struct MatvecArgs {
     float* out;             // EPI_STORE / EPI_ADD / EPI_SILU_MUL destination
     const float* res;       // EPI_ADD residual
     uint16_t* q_f16;        // EPI_ROPE_Q destination (fp16 query, n_head*head_dim)
-    uint16_t* kcache;       // this layer's K cache  [n_ctx][n_embd_gqa] fp16
+    uint16_t* kcache;       // this layer's K cache  [n_head_kv][n_ctx][head_dim] fp16 (kcache_off)
     uint16_t* vcache;       // this layer's V cache  [n_embd_gqa][n_ctx] fp16 (transposed, as the reference keeps it)
     const float* rope_cs;   // [n_ctx][head_dim/2][2] cos,sin (host-built with the reference's iterative theta)
     const int* pos;         // device scalar: position of this token
@@ -370,8 +378,8 @@ __global__ void __launch_bounds__(NT) matvec_kq_kernel(const MatvecArgs a) {
                     a.q_f16[rowA] = f32_to_f16_bits(o0);
                     a.q_f16[rowB] = f32_to_f16_bits(o1);
                 } else {
-                    a.kcache[(size_t)pos * a.n_embd_gqa + rowA] = f32_to_f16_bits(o0);
-                    a.kcache[(size_t)pos * a.n_embd_gqa + rowB] = f32_to_f16_bits(o1);
+                    a.kcache[kcache_off(pos, rowA, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o0);
+                    a.kcache[kcache_off(pos, rowB, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o1);
                 }
             }
         }
@@ -448,7 +456,7 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------------------------------
 struct AttnArgs {
     const uint16_t* q_f16;   // [n_head*head_dim]
-    const uint16_t* kcache;  // layer base [n_ctx][n_embd_gqa]
+    const uint16_t* kcache;  // layer base [n_head_kv][n_ctx][head_dim] (kcache_off)
     const uint16_t* vcache;  // layer base [n_embd_gqa][n_ctx]
     float* scores;           // [n_head][n_ctx]
     float* out;              // [n_head*head_dim]
@@ -485,7 +493,7 @@ __global__ void __launch_bounds__(NT) attn_scores_kernel(const AttnArgs a) {
         const int p = base + pl;
         const bool ok = p < c1;
         const int pp = ok ? p : c0;
-        const u32x4 kv = ld16(a.kcache + (size_t)pp * a.n_embd_gqa + (size_t)hk * hd + sub * 8);
+        const u32x4 kv = ld16(a.kcache + ((size_t)hk * a.n_ctx + pp) * hd + sub * 8);
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(NT) matvec_exact_kernel(const MatvecArgs a) {
             const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
             if (g == 0 && row < jb.w.M) {
                 if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
             }
         }
     }
@@ -346,7 +346,7 @@ DEV float f16dot_reduce_exact(const float* acc, int j) {
 
 struct AttnArgsX {
     const uint16_t* q_f16;
-    const uint16_t* kcache;  // layer base [n_ctx][n_embd_gqa]
+    const uint16_t* kcache;  // layer base [n_head_kv][n_ctx][head_dim] (kcache_off)
     const uint16_t* vcache;  // layer base [n_embd_gqa][v_stride]
     float* scores;           // [n_head][n_ctx]
     float* out;
@@ -355,6 +355,7 @@ struct AttnArgsX {
     const uint16_t* exp_tab;
     int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
     float kq_scale;
+    unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
 };
 
 // scores[h][p] = vec_dot_f16(K[p], Q[h]) * kq_scale.   grid (n_head, ceil(n_ctx/64)), 256 threads: quad per position.
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(256) attn_scores_exact_kernel(const AttnArgsX 
     const int pp = ok ? p : c0;
     const int hd = a.head_dim;
     const int hk = h / (a.n_head / a.n_head_kv);
-    const uint16_t* krow = a.kcache + (size_t)pp * a.n_embd_gqa + (size_t)hk * hd;
+    const uint16_t* krow = a.kcache + ((size_t)hk * a.n_ctx + pp) * hd;
     const uint16_t* qrow = a.q_f16 + (size_t)h * hd;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int e0 = 0; e0 < hd; e0 += 32) {
@@ -441,44 +442,78 @@ __global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnAr
 // then runs the softmax and its 64 channels of V*P exactly as attn_softmax_pv_exact_kernel does.  The double-precision
 // exp sum is order-free here: the addends are fp16 values in (0, 1] (multiples of 2^-24), so any summation order of up
 // to 8192 of them is exact in binary64.
-template <int NT>
+template <int NT, int HD>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
-    constexpr int NWV = NT / 64;
+    constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
+    constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
+    constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
+    constexpr int VB = 8;                       // V chunks (32 positions each) in flight together
     __shared__ float prob[kMaxCtx];
     __shared__ double red[NWV];
     __shared__ float redf[NWV];
     const int h = (int)blockIdx.x;
+    const bool trace = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0;
+    unsigned long long* tr = a.trace + 16 * (threadIdx.x >> 6);
+    if (trace) tr[0] = clock64_dev();
     const int n_kv = *a.pos + 1;
     const int n_tot = *a.n_total;
+    const int np = n_tot & ~31;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3;
-    const int hd = a.head_dim;
     const int hk = h / (a.n_head / a.n_head_kv);
-    const uint16_t* qrow = a.q_f16 + (size_t)h * hd;
-    float mx = -INFINITY;
-    for (int base = 0; base < n_kv; base += NT / 4) {
-        const int p = base + (tid >> 2);
-        const bool ok = p < n_kv;
-        const uint16_t* krow = a.kcache + (size_t)(ok ? p : base) * a.n_embd_gqa + (size_t)hk * hd;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int e0 = 0; e0 < hd; e0 += 32) {
-            float kf[8], qf[8];
-            unpack8_f16(ld16(krow + e0 + 8 * j), kf);
-            unpack8_f16(ld16(qrow + e0 + 8 * j), qf);
+    if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
+    const uint16_t* qrow = a.q_f16 + (size_t)h * HD;
+    const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
+    const bool pv_thread = tid < 256;           // 64 channels x 4 lanes run the V*P part
+    const int d = (int)blockIdx.y * 64 + ((tid & 255) >> 2);
+    const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
+    // The V rows do not depend on the probabilities: their first VB chunks are requested now, so that their latency
+    // overlaps the score and softmax phases instead of following them.
+    u32x4 vv[VB];
+    u32x4 qv[NC];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+    for (int c = 0; c < NC; ++c) qv[c] = ld16(qrow + 32 * c + 8 * j);
+    float mx = -INFINITY;
+    for (int base = 0; base < n_kv; base += NQ * PB) {
+        u32x4 kv[PB][NC];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * NQ + (tid >> 2);
+            const uint16_t* krow = kbase + (size_t)p * HD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)   // no clamping: hundreds of idle quads re-reading one row serialise in the L1
+                kv[u][c] = (p < n_kv) ? ld16(krow + 32 * c) : u32x4{0u, 0u, 0u, 0u};
         }
-        const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
-        if (ok) {
-            mx = fmaxf(mx, sc);
-            if (j == 0) prob[p] = sc;
+        if (base == 0) {   // after the K requests (the critical path), before anything waits on them
+#pragma unroll
+            for (int u = 0; u < VB; ++u) vv[u] = (pv_thread && 32 * u < np) ? ld16(vrow + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * NQ + (tid >> 2);
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float kf[8], qf[8];
+                unpack8_f16(kv[u][c], kf);
+                unpack8_f16(qv[c], qf);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+            }
+            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if (p < n_kv) {
+                mx = fmaxf(mx, sc);
+                if (j == 0) prob[p] = sc;
+            }
         }
     }
+    if (trace) tr[2] = clock64_dev();
     mx = wave_max(mx);
     if (lane == 0) redf[wv] = mx;
     __syncthreads();
     mx = redf[0];
 #pragma unroll
     for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+    if (trace) tr[3] = clock64_dev();
     double sum = 0.0;
     for (int i = tid; i < n_kv; i += NT) {
         const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]);
@@ -493,24 +528,34 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     for (int w = 1; w < NWV; ++w) tot += red[w];
     const float inv = (float)(1.0 / tot);
     for (int i = tid; i < n_kv; i += NT) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
-    const int np = n_tot & ~31;
     for (int i = n_kv + tid; i < np; i += NT) prob[i] = 0.0f;  // masked columns of this batch
     __syncthreads();
-    if (tid >= 256) return;
-    const int d = (int)blockIdx.y * 64 + (tid >> 2);
-    const uint16_t* vrow = a.vcache + ((size_t)hk * hd + d) * a.v_stride;
+    if (trace) tr[4] = clock64_dev();
+    if (!pv_thread) return;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < np; i += 32) {
-        float vf[8];
-        unpack8_f16(ld16(vrow + i + 8 * j), vf);
-        const float* pr = &prob[i + 8 * j];
+    for (int i0 = 0; i0 < np; i0 += 32 * VB) {
+        if (i0 > 0) {
 #pragma unroll
-        for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            for (int u = 0; u < VB; ++u)
+                if (i0 + 32 * u < np) vv[u] = ld16(vrow + i0 + 32 * u + 8 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            if (i0 + 32 * u < np) {
+                float vf[8];
+                unpack8_f16(vv[u], vf);
+                const float* pr = &prob[i0 + 32 * u + 8 * j];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            }
+        }
     }
     const float res = f16dot_reduce_exact(acc, j);
     double sumf = (double)res;
+    if (trace) tr[5] = clock64_dev();
     for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
-    if (j == 0) a.out[(size_t)h * hd + d] = (float)sumf;
+    if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
+    if (trace) tr[6] = clock64_dev();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -985,7 +1030,7 @@ __global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
             const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
             if (own) {
                 if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
             }
         }
     };

@@ -152,7 +152,7 @@ DEV void epilogue4(const MatvecArgs& a, const UnitInfo& u, float res, int lane, 
         const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
         if (own) {
             if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-            else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+            else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
         }
     }
 }

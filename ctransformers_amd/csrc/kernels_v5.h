@@ -324,7 +324,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
                     const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
                     if (own) {
                         if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                        else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                        else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
                     }
                 }
             }
@@ -456,7 +456,7 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
                     const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
                     if (own) {
                         if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                        else a.kcache[(size_t)pos * a.n_embd_gqa + row] = f32_to_f16_bits(o);
+                        else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
                     }
                 }
             }

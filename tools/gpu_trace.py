@@ -7,8 +7,8 @@ from ctransformers_amd.llm import LLM, Config
 p = "/tmp/l7b.gguf"
 if not os.path.exists(p):
     synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
-m = LLM(p, config=Config(context_length=512, batch_size=64))
-m.eval(synth.prompt_tokens(64, 32000))
+m = LLM(p, config=Config(context_length=512, batch_size=512))
+m.eval(synth.prompt_tokens(int(os.environ.get("SITES_PROMPT", "64")), 32000))
 lib = m._lib
 lib.ctamd_trace_site.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 buf = (ctypes.c_uint64 * 256)()
@@ -21,3 +21,11 @@ for site in ("qkv", "wo", "gate_up", "down", "lm_head"):
     for w in (0, 1, 5, 15):
         r = rows[w]
         print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "loads", "prolog", "math", "barrier", "chain", "exit", "Bloads", "Bprolog", "Bmath", "Bbarrier", "Bchain", "x"))))
+for rep in range(2):
+    lib.ctamd_trace_site(m._llm, b"attn", buf, 256)
+rows = [[buf[16 * w + k] for k in range(8)] for w in range(16)]
+t0 = rows[0][0]
+print("attn (n_kv=%d)" % rows[0][7])
+for w in (0, 1, 3):
+    r = rows[w]
+    print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "pos", "scores", "max", "softmax", "pv_fma", "exit"))))

@@ -1,3 +1,3 @@
 cd /root/repo
-python tools/gpu_sites.py "$1" 2>/dev/null
-python tools/gpu_trace.py 2>/dev/null | grep -A4 -E "^(gate_up)"
+SITES_PROMPT=384 python tools/gpu_trace.py 2>/dev/null | grep -A5 "^attn"
+python tools/gpu_sites.py p384 SITES_PROMPT=384 2>/dev/null
