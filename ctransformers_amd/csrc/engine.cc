@@ -396,13 +396,17 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             a.n_groupA = na;
             const dim3 g5((unsigned)std::max(1, std::min(max_w, a.n_pairs))), b5(1024);
 #define V5(MK, SS, TT, NB) \
-            if (ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0>), g5, b5, s, a); \
-            else if (ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0>), g5, b5, s, a); \
-            else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0>), g5, b5, s, a); \
-            else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K>), g5, b5, s, a); \
-            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K>), g5, b5, s, a);
+            if (a.gateup && ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, true>), g5, b5, s, a); \
+            else if (a.gateup && ta == GT_Q5_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, true>), g5, b5, s, a); \
+            else if (a.gateup) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, true>), g5, b5, s, a); \
+            else if (ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, false>), g5, b5, s, a); \
+            else if (ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, false>), g5, b5, s, a); \
+            else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, false>), g5, b5, s, a); \
+            else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false>), g5, b5, s, a); \
+            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false>), g5, b5, s, a);
             const int units_per_wg = ((a.n_pairs + (int)g5.x - 1) / (int)g5.x) * (a.gateup ? 2 : 1);
-            if (a.K <= 4096) { if (units_per_wg <= 2) { V5(4096, 1, 2, 2) } else { V5(4096, 1, 4, 2) } } else { V5(12288, 3, 2, 1) }
+            static const int mixed_t = env_int("CT_AMD_MIXED_T", 4);
+            if (a.K <= 4096) { if (units_per_wg <= 2 || (tb != 0 && mixed_t == 2)) { V5(4096, 1, 2, 2) } else { V5(4096, 1, 4, 2) } } else { V5(12288, 3, 2, 1) }
 #undef V5
             return true;
         }

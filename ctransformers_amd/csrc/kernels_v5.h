@@ -214,17 +214,68 @@ DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C,
     return tot + accm;
 }
 
+// Two independent chains (the gate and the up tile of one item) replayed together: same arithmetic per chain as
+// chain_typed, but the LDS fetches and the two dependent fma sequences interleave instead of running back to back.
+template <int TYPE, int MAXK, int MAXNB>
+DEV void chain_typed2(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C0, const ChainBuf4<MAXNB>& C1, int lane,
+                      const LaneGeom& G, float& out0, float& out1) {
+    float acc0 = 0.0f, accm0 = 0.0f, acc1 = 0.0f, accm1 = 0.0f;
+    constexpr bool mins = TYPE != GT_Q6_K;
+    constexpr int CH = 8;
+    for (int b0 = 0; b0 < nb; b0 += CH) {
+        float dv0[CH], sv0[CH], mv0[CH], pv0[CH], dv1[CH], sv1[CH], mv1[CH], pv1[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int b = (b0 + u < nb) ? b0 + u : nb - 1;
+            const uint32_t h0 = C0.H[b][G.r], h1 = C1.H[b][G.r];
+            const float yd = L.yd[b];
+            dv0[u] = yd * f16_bits_to_f32((uint16_t)(h0 & 0xFFFF));
+            dv1[u] = yd * f16_bits_to_f32((uint16_t)(h1 & 0xFFFF));
+            sv0[u] = C0.S[b][lane];
+            sv1[u] = C1.S[b][lane];
+            if constexpr (mins) {
+                mv0[u] = -yd * f16_bits_to_f32((uint16_t)(h0 >> 16));
+                mv1[u] = -yd * f16_bits_to_f32((uint16_t)(h1 >> 16));
+                pv0[u] = C0.PM[b][G.r * 4 + G.c];
+                pv1[u] = C1.PM[b][G.r * 4 + G.c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (b0 + u < nb) {
+                acc0 = fmaf(dv0[u], sv0[u], acc0);
+                acc1 = fmaf(dv1[u], sv1[u], acc1);
+                if constexpr (mins) {
+                    accm0 = fmaf(mv0[u], pv0[u], accm0);
+                    accm1 = fmaf(mv1[u], pv1[u], accm1);
+                }
+            }
+        }
+    }
+    const float tot0 = hsum8_exact_dpp(acc0), tot1 = hsum8_exact_dpp(acc1);
+    if constexpr (!mins) { out0 = tot0; out1 = tot1; return; }
+    if constexpr (TYPE == GT_Q4_K) {
+        const float w0 = accm0 + lane_xor4(accm0), w1 = accm1 + lane_xor4(accm1);
+        accm0 = w0 + lane_xor2(w0);
+        accm1 = w1 + lane_xor2(w1);
+    }
+    accm0 = __shfl(accm0, lane & ~7);
+    accm1 = __shfl(accm1, lane & ~7);
+    out0 = tot0 + accm0;
+    out1 = tot1 + accm1;
+}
+
 struct GroupInfo {           // one type-homogeneous group of jobs of a launch
     int item0, n_items;      // item range of the group inside the launch's concatenated item list
 };
 
 // One group: every wave of the workgroup walks the group's units in rounds of T.
-template <int TYPE, int MAXK, int S, int T, int NBUF, bool WITH_PROLOGUE>
+template <int TYPE, int MAXK, int S, int T, int NBUF, bool WITH_PROLOGUE, bool GU>
 DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L,
                    ChainBuf4<MAXK / 256> (&CB)[NBUF][T], int lane, int wv, const LaneGeom& G, int pos, int& round_seq) {
     constexpr int NW = 16, MAXNB = MAXK / 256;
     const int stride = (int)gridDim.x, first = (int)blockIdx.x;
-    const int upi = a.gateup ? 2 : 1;
+    const int upi = GU ? 2 : 1;
     // units of this workgroup inside the group: local items k = 0.. with item = item0 + first + k*stride
     const int n_loc = first < n_items ? (n_items - first + stride - 1) / stride : 0;
     const int n_units = n_loc * upi;
@@ -236,18 +287,18 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
 
     auto unit_of = [&](int u, UnitInfo& U) __attribute__((always_inline)) {   // u is clamped to the last valid unit
         const int uu = u < n_units ? u : n_units - 1;
-        const int k = a.gateup ? (uu >> 1) : uu;
-        const int part = a.gateup ? (uu & 1) : 0;
+        const int k = GU ? (uu >> 1) : uu;
+        const int part = GU ? (uu & 1) : 0;
         const int it = item0 + first + k * stride;
         int j = 0;
-        if (!a.gateup) {
+        if (!GU) {
             if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
             if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
         }
-        const DevMat& w = a.gateup ? a.job[part].w : a.job[j].w;
+        const DevMat& w = GU ? a.job[part].w : a.job[j].w;
         U.valid = u < n_units;
         U.j = j;
-        U.tile = it - (a.gateup ? 0 : a.job[j].pair0);
+        U.tile = it - (GU ? 0 : a.job[j].pair0);
         U.type = TYPE; U.nb = w.nb; U.M = w.M; U.rec = rec;
         U.base = w.p[0] + (size_t)U.tile * w.nb * rec;
     };
@@ -278,7 +329,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
         float res_in = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (wv == ((round_seq * T + t) & (NW - 1)) && cur[t].valid && !a.gateup && a.job[cur[t].j].epi == EPI_ADD) {
+            if (wv == ((round_seq * T + t) & (NW - 1)) && cur[t].valid && !GU && a.job[cur[t].j].epi == EPI_ADD) {
                 const int row = cur[t].tile * 8 + G.r;
                 if (row < cur[t].M) res_in = a.res[row];
             }
@@ -300,15 +351,16 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             if (wv != ((round_seq * T + t) & (NW - 1)) || !cur[t].valid) continue;
-            if (a.gateup && (t & 1)) continue;                       // the gate wave also replays the up chain
+            if (GU && (t & 1)) continue;                       // the gate wave also replays the up chain
             const UnitInfo& U = cur[t];
-            const float res = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t], lane, G);
             const int row = U.tile * 8 + G.r;
             const bool own = G.g == 0 && row < U.M;
-            if (a.gateup) {
-                const float up = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t + 1 < T ? t + 1 : t], lane, G);
+            if (GU) {
+                float res, up;
+                chain_typed2<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t], CB[par][t + 1 < T ? t + 1 : t], lane, G, res, up);
                 if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
             } else {
+                const float res = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t], lane, G);
                 const int epi = a.job[U.j].epi;
                 if (epi == EPI_ADD) {
                     if (own) a.out[row] = res + res_in;
@@ -339,37 +391,42 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
 // One type-homogeneous group of a launch, as seen by one workgroup: its units (local items k = 0.. with
 // item = item0 + blockIdx + k*gridDim, times 2 for gate/up pairs), the units of the current round and their block
 // images in registers.
+struct UnitRef {            // wave-uniform; kept small so that T of them stay in SGPRs
+    const uint8_t* base;    // first record of the tile
+    int tile, j;            // tile index inside its matrix, job index
+    bool valid;
+};
 template <int TYPE, int S, int T> struct GroupState {
     int item0, first, stride, n_units;
-    UnitInfo cur[T];
+    UnitRef cur[T];
     BlkImg<TYPE> R[T][S];
 };
 
 template <int TYPE, int S, int T>
-DEV void group_unit_of(const MatvecArgs& a, const GroupState<TYPE, S, T>& g, int u, UnitInfo& U) {   // u clamps to the last unit
+DEV void group_unit_of(const MatvecArgs& a, const GroupState<TYPE, S, T>& g, int u, UnitRef& U) {   // u clamps to the last unit
     const int uu = u < g.n_units ? u : g.n_units - 1;
-    const int k = a.gateup ? (uu >> 1) : uu;
-    const int part = a.gateup ? (uu & 1) : 0;
+    const int k = false ? (uu >> 1) : uu;
+    const int part = false ? (uu & 1) : 0;
     const int it = g.item0 + g.first + k * g.stride;
     int j = 0;
-    if (!a.gateup) {
+    if (!false) {
         if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
         if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
     }
-    const DevMat& w = a.gateup ? a.job[part].w : a.job[j].w;
-    const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
+    const DevMat& w = false ? a.job[part].w : a.job[j].w;
+    constexpr uint32_t rec = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
     U.valid = u < g.n_units;
-    U.j = j;
-    U.tile = it - (a.gateup ? 0 : a.job[j].pair0);
-    U.type = TYPE; U.nb = w.nb; U.M = w.M; U.rec = rec;
-    U.base = w.p[0] + (size_t)U.tile * w.nb * rec;
+    U.j = false ? part : j;
+    U.tile = it - (false ? 0 : a.job[j].pair0);
+    U.base = w.p[0] + (size_t)U.tile * (uint32_t)(a.K >> 8) * rec;
 }
 
 template <int TYPE, int S>
-DEV BlkImg<TYPE> group_load_img(const UnitInfo& U, int i, int wv, const LaneGeom& G) {
+DEV BlkImg<TYPE> group_load_img(const UnitRef& U, int nb, int i, int wv, const LaneGeom& G) {
+    constexpr uint32_t rec = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
     int b = wv + i * 16;
-    b = b < U.nb ? b : U.nb - 1;
-    return img_load<TYPE>(U.base + (size_t)b * U.rec, G);
+    b = b < nb ? b : nb - 1;
+    return img_load<TYPE>(U.base + (size_t)b * rec, G);
 }
 
 // Sets the group up and issues the loads of its first round.
@@ -379,14 +436,14 @@ DEV void group_begin(const MatvecArgs& a, int item0, int n_items, GroupState<TYP
     g.stride = (int)gridDim.x;
     g.first = (int)blockIdx.x;
     const int n_loc = g.first < n_items ? (n_items - g.first + g.stride - 1) / g.stride : 0;
-    g.n_units = n_loc * (a.gateup ? 2 : 1);
+    g.n_units = n_loc * (false ? 2 : 1);
     if (g.n_units == 0) return;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         group_unit_of<TYPE, S, T>(a, g, t, g.cur[t]);
         if (g.cur[t].valid) {
 #pragma unroll
-            for (int i = 0; i < S; ++i) g.R[t][i] = group_load_img<TYPE, S>(g.cur[t], i, wv, G);
+            for (int i = 0; i < S; ++i) g.R[t][i] = group_load_img<TYPE, S>(g.cur[t], a.K >> 8, i, wv, G);
         }
     }
 }
@@ -402,16 +459,17 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (GROUP_B ? 6 : 0);
     const int n_rounds = (g.n_units + T - 1) / T;
     if (n_rounds == 0) { hook(); return; }
-    UnitInfo nxt[T];
+    UnitRef nxt[T];
+    const int nb = a.K >> 8;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
         const int par = round_seq % NBUF;
         // the wave that will replay unit t's chain starts the dependent residual load now
         float res_in = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !a.gateup && a.job[g.cur[t].j].epi == EPI_ADD) {
+            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !false && a.job[g.cur[t].j].epi == EPI_ADD) {
                 const int row = g.cur[t].tile * 8 + G.r;
-                if (row < g.cur[t].M) res_in = a.res[row];
+                if (row < a.job[g.cur[t].j].w.M) res_in = a.res[row];
             }
         }
 #pragma unroll
@@ -420,9 +478,9 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 int b = wv + i * NW;
-                b = b < g.cur[t].nb ? b : g.cur[t].nb - 1;
+                b = b < nb ? b : nb - 1;
                 if (g.cur[t].valid) img_to_chain<TYPE, MAXK, MAXNB>(g.R[t][i], b, L, CB[par][t], lane, G);   // tail rounds: skip
-                if (nxt[t].valid) g.R[t][i] = group_load_img<TYPE, S>(nxt[t], i, wv, G);                     // the padding units
+                if (nxt[t].valid) g.R[t][i] = group_load_img<TYPE, S>(nxt[t], nb, i, wv, G);                     // the padding units
             }
         }
         if (rd == n_rounds - 1) hook();
@@ -432,15 +490,16 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             if (wv != ((round_seq * T + t) & (NW - 1)) || !g.cur[t].valid) continue;
-            if (a.gateup && (t & 1)) continue;                       // the gate wave also replays the up chain
-            const UnitInfo& U = g.cur[t];
-            const float res = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t], lane, G);
+            if (false && (t & 1)) continue;                       // the gate wave also replays the up chain
+            const UnitRef& U = g.cur[t];
             const int row = U.tile * 8 + G.r;
-            const bool own = G.g == 0 && row < U.M;
-            if (a.gateup) {
-                const float up = chain_typed<TYPE, MAXK, MAXNB>(U.nb, L, CB[par][t + 1 < T ? t + 1 : t], lane, G);
+            const bool own = G.g == 0 && row < a.job[U.j].w.M;
+            if (false) {
+                float res, up;
+                chain_typed2<TYPE, MAXK, MAXNB>(nb, L, CB[par][t], CB[par][t + 1 < T ? t + 1 : t], lane, G, res, up);
                 if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
             } else {
+                const float res = chain_typed<TYPE, MAXK, MAXNB>(nb, L, CB[par][t], lane, G);
                 const int epi = a.job[U.j].epi;
                 if (epi == EPI_ADD) {
                     if (own) a.out[row] = res + res_in;
@@ -469,7 +528,7 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: single group).  a.n_groupA = number of items in group A.
-template <int MAXK, int S, int T, int NBUF, int TA, int TB>
+template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU>
 __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
@@ -484,7 +543,7 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     const int pos = a.pos ? *a.pos : 0;
     int round_seq = 0;
     if constexpr (TB == 0) {   // single type: the plain loop (the compiler schedules it better than the group-state form)
-        run_group<TA, MAXK, S, T, NBUF, true>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
+        run_group<TA, MAXK, S, T, NBUF, true, GU>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
         if (trace) tr[6] = clock64_dev();
         return;
     }

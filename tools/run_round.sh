@@ -1,3 +1,5 @@
 cd /root/repo
-SITES_PROMPT=384 python tools/gpu_trace.py 2>/dev/null | grep -A5 "^attn"
-python tools/gpu_sites.py p384 SITES_PROMPT=384 2>/dev/null
+for i in 1 2; do
+python tools/gpu_sites.py base SITES_LIB=/root/repo/ctransformers_amd/lib/libbase.so 2>/dev/null
+python tools/gpu_sites.py new 2>/dev/null
+done
