@@ -96,6 +96,16 @@ DEV void prologue_q8k_wave(ActLdsX<MAXK>& L, const float* __restrict__ x, const 
     __syncthreads();
 }
 
+// Chain storage of generation 5: like ChainBuf4, but the block scales arrive already multiplied out
+// (D = y.d * fp16(x.d), DM = -y.d * fp16(x.dmin)): those products are order-free, so the block step that holds the
+// header does them and the replay — the serial part of a round — is left with LDS fetches and the fma chain only.
+template <int MAXNB> struct ChainBuf5 {
+    float S[MAXNB][64];
+    float D[MAXNB][8];
+    float DM[MAXNB][8];
+    float PM[MAXNB][32];
+};
+
 template <int TYPE> struct BlkImg;
 template <> struct BlkImg<GT_Q4_K> { u32x4 hdr, qs; };
 template <> struct BlkImg<GT_Q5_K> { u32x4 hdr, qs, qh; };
@@ -126,7 +136,7 @@ template <> DEV BlkImg<GT_Q6_K> img_load<GT_Q6_K>(const uint8_t* rec, const Lane
 
 // Integer work of one block -> chain storage (see block_to_chain4 for the arithmetic; this is its per-type form).
 template <int TYPE, int MAXK, int MAXNB>
-DEV void img_to_chain(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, ChainBuf4<MAXNB>& C, int lane, const LaneGeom& G) {
+DEV void img_to_chain(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, ChainBuf5<MAXNB>& C, int lane, const LaneGeom& G) {
     const int c = G.c;
     if constexpr (TYPE == GT_Q4_K || TYPE == GT_Q5_K) {
         const int* alo = &L.q8[b * 64 + G.a45];
@@ -154,7 +164,11 @@ DEV void img_to_chain(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, Chai
             prod += lane_xor4(prod);
         }
         if (G.h == 0) C.PM[b][G.r * 4 + c] = (float)prod;
-        if (G.g == 0) C.H[b][G.r] = R.hdr[0];
+        if (G.g == 0) {
+            const float yd = L.yd[b];
+            C.D[b][G.r] = yd * f16_bits_to_f32((uint16_t)(R.hdr[0] & 0xFFFF));
+            C.DM[b][G.r] = -yd * f16_bits_to_f32((uint16_t)(R.hdr[0] >> 16));
+        }
     } else {
         const int n = G.g >> 2;
         const int* alo = &L.q8[b * 64 + G.a6];
@@ -173,12 +187,12 @@ DEV void img_to_chain(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, Chai
             part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
         }
         C.S[b][lane] = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
-        if (G.g == 0) C.H[b][G.r] = R.d;
+        if (G.g == 0) C.D[b][G.r] = L.yd[b] * f16_bits_to_f32((uint16_t)(R.d & 0xFFFF));
     }
 }
 
 template <int TYPE, int MAXK, int MAXNB>
-DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C, int lane, const LaneGeom& G) {
+DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf5<MAXNB>& C, int lane, const LaneGeom& G) {
     float acc = 0.0f, accm = 0.0f;
     constexpr bool mins = TYPE != GT_Q6_K;
     constexpr int CH = 8;   // operands of CH blocks are fetched before the dependent fma chain starts
@@ -187,12 +201,10 @@ DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C,
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int b = (b0 + u < nb) ? b0 + u : nb - 1;
-            const uint32_t hw = C.H[b][G.r];
-            const float yd = L.yd[b];
-            dv[u] = yd * f16_bits_to_f32((uint16_t)(hw & 0xFFFF));
+            dv[u] = C.D[b][G.r];
             sv[u] = C.S[b][lane];
             if constexpr (mins) {
-                mv[u] = -yd * f16_bits_to_f32((uint16_t)(hw >> 16));
+                mv[u] = C.DM[b][G.r];
                 pv[u] = C.PM[b][G.r * 4 + G.c];
             }
         }
@@ -217,7 +229,7 @@ DEV float chain_typed(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C,
 // Two independent chains (the gate and the up tile of one item) replayed together: same arithmetic per chain as
 // chain_typed, but the LDS fetches and the two dependent fma sequences interleave instead of running back to back.
 template <int TYPE, int MAXK, int MAXNB>
-DEV void chain_typed2(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C0, const ChainBuf4<MAXNB>& C1, int lane,
+DEV void chain_typed2(int nb, const ActLdsX<MAXK>& L, const ChainBuf5<MAXNB>& C0, const ChainBuf5<MAXNB>& C1, int lane,
                       const LaneGeom& G, float& out0, float& out1) {
     float acc0 = 0.0f, accm0 = 0.0f, acc1 = 0.0f, accm1 = 0.0f;
     constexpr bool mins = TYPE != GT_Q6_K;
@@ -227,15 +239,13 @@ DEV void chain_typed2(int nb, const ActLdsX<MAXK>& L, const ChainBuf4<MAXNB>& C0
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int b = (b0 + u < nb) ? b0 + u : nb - 1;
-            const uint32_t h0 = C0.H[b][G.r], h1 = C1.H[b][G.r];
-            const float yd = L.yd[b];
-            dv0[u] = yd * f16_bits_to_f32((uint16_t)(h0 & 0xFFFF));
-            dv1[u] = yd * f16_bits_to_f32((uint16_t)(h1 & 0xFFFF));
+            dv0[u] = C0.D[b][G.r];
+            dv1[u] = C1.D[b][G.r];
             sv0[u] = C0.S[b][lane];
             sv1[u] = C1.S[b][lane];
             if constexpr (mins) {
-                mv0[u] = -yd * f16_bits_to_f32((uint16_t)(h0 >> 16));
-                mv1[u] = -yd * f16_bits_to_f32((uint16_t)(h1 >> 16));
+                mv0[u] = C0.DM[b][G.r];
+                mv1[u] = C1.DM[b][G.r];
                 pv0[u] = C0.PM[b][G.r * 4 + G.c];
                 pv1[u] = C1.PM[b][G.r * 4 + G.c];
             }
@@ -272,7 +282,7 @@ struct GroupInfo {           // one type-homogeneous group of jobs of a launch
 // One group: every wave of the workgroup walks the group's units in rounds of T.
 template <int TYPE, int MAXK, int S, int T, int NBUF, bool WITH_PROLOGUE, bool GU>
 DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L,
-                   ChainBuf4<MAXK / 256> (&CB)[NBUF][T], int lane, int wv, const LaneGeom& G, int pos, int& round_seq) {
+                   ChainBuf5<MAXK / 256> (&CB)[NBUF][T], int lane, int wv, const LaneGeom& G, int pos, int& round_seq) {
     constexpr int NW = 16, MAXNB = MAXK / 256;
     const int stride = (int)gridDim.x, first = (int)blockIdx.x;
     const int upi = GU ? 2 : 1;
@@ -452,7 +462,7 @@ DEV void group_begin(const MatvecArgs& a, int item0, int n_items, GroupState<TYP
 // wave's block math and before the barrier: the kernel uses it to issue the NEXT group's first loads, so the weight
 // stream does not stop while this group's last chains are replayed.
 template <int TYPE, int MAXK, int S, int T, int TCB, int NBUF, bool GROUP_B, class Hook>
-DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MAXK>& L, ChainBuf4<MAXK / 256> (&CB)[NBUF][TCB],
+DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MAXK>& L, ChainBuf5<MAXK / 256> (&CB)[NBUF][TCB],
                       int lane, int wv, const LaneGeom& G, int pos, int& round_seq, Hook hook) {
     constexpr int NW = 16, MAXNB = MAXK / 256;
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
@@ -532,7 +542,7 @@ template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU>
 __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
-    __shared__ ChainBuf4<MAXNB> CB[NBUF][T];
+    __shared__ ChainBuf5<MAXNB> CB[NBUF][T];
     if (a.dbg & 16) return;
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
