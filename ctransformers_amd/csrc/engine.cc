@@ -511,10 +511,12 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
+        if (site_on("embed")) {
         prof_begin("embed", "embed_row_kernel", (double)ggml_row_bytes(tok_embd_.type, E));
         CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
                   (const int*)d_tokens_, (const int*)d_state_, x_);
         prof_end();
+        }
     } else {  // inner stage: this token's residual-stream row was handed over by the previous stage
         CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)xio_, x_, E,
                   (const int*)d_state_, 0);
@@ -556,9 +558,11 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
             set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
             apply_trace(a, "qkv");
-            prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
-            if (!run_matvec(a, err)) return false;
-            prof_end();
+            if (site_on("qkv")) {
+                prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
             debug_dump("1qkv", il);
         }
         at.kcache = kc;
@@ -569,7 +573,8 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
             ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
             if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
-            if (fused_attn_) {
+            if (!site_on("attn_fused")) {
+            } else if (fused_attn_) {
                 prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
                 const int nt = env_int("CT_AMD_ATTN_NT", 512);
                 const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
@@ -598,9 +603,11 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.wo, EPI_ADD}});
             apply_trace(a, "wo");
-            prof_begin("wo", "matvec", (double)L.wo.bytes);
-            if (!run_matvec(a, err)) return false;
-            prof_end();
+            if (site_on("wo")) {
+                prof_begin("wo", "matvec", (double)L.wo.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
             debug_dump("3wo", il);
         }
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
@@ -610,9 +617,11 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
             apply_trace(a, "gate_up");
-            prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
-            if (!run_matvec(a, err)) return false;
-            prof_end();
+            if (site_on("gate_up")) {
+                prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
             debug_dump("4gateup", il);
         }
         {   // Q8_K(h) -> W_down -> + residual
@@ -620,9 +629,11 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
             apply_trace(a, "down");
-            prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
-            if (!run_matvec(a, err)) return false;
-            prof_end();
+            if (site_on("down")) {
+                prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
             debug_dump("5down", il);
         }
     }
@@ -630,17 +641,20 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)x_, xio_, E,
                   (const int*)d_state_, 1);
     } else if (want_logits) {
-        CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
-                  hp_.rms_eps);
+        if (!only_site_)
+            CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
+                      hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
         apply_trace(a, "lm_head");
-        prof_begin("lm_head", "matvec", (double)output_.bytes);
-        if (!run_matvec(a, err)) return false;
-        prof_end();
+        if (site_on("lm_head")) {
+            prof_begin("lm_head", "matvec", (double)output_.bytes);
+            if (!run_matvec(a, err)) return false;
+            prof_end();
+        }
     }
-    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     if (dump_dir_) ++dump_seq_;
     return true;
 }
@@ -770,6 +784,45 @@ bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string
         if (!ok) return false;
         HIP_OK(hipStreamSynchronize(stream_));
     }
+    // Second view, "sweep": for each launch site, the kernels of ALL layers back to back between ONE pair of events
+    // (different weights every launch, so HBM-cold like the real step; no per-launch event, so the ~6.6 us eager
+    // event floor is paid once per sweep, not per kernel).  This is the per-launch cost inside a graph replay.
+    static const char* kSweep[] = {"qkv", "attn_fused", "wo", "gate_up", "down", "lm_head"};
+    struct Sweep { const char* site; float ms; int launches; };
+    std::vector<Sweep> sweeps;
+    for (const char* site : kSweep) {
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        float ms_tot = 0.0f;
+        int n_tot = 0;
+        for (int it = 0; it < iters; ++it) {
+            h_scalars_[0] = 0; h_scalars_[1] = last_pos_; h_scalars_[2] = last_pos_ + 1; h_scalars_[4] = last_token_;
+            HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], 4, hipMemcpyHostToDevice, stream_));
+            HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 12, hipMemcpyHostToDevice, stream_));
+            if (!strcmp(site, "lm_head")) {   // one launch per step: evict its weights from the memory-side cache first
+                only_site_ = "gate_up";
+                const bool okf = token_step(true, err);
+                only_site_ = nullptr;
+                if (!okf) return false;
+            }
+            only_site_ = site;
+            site_launches_ = 0;
+            HIP_OK(hipEventRecord(e0, stream_));
+            const bool ok = token_step(true, err);
+            HIP_OK(hipEventRecord(e1, stream_));
+            only_site_ = nullptr;
+            if (!ok) return false;
+            HIP_OK(hipStreamSynchronize(stream_));
+            float ms = 0.0f;
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            ms_tot += ms;
+            n_tot += site_launches_;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (n_tot > 0) sweeps.push_back(Sweep{site, ms_tot, n_tot});
+    }
     for (auto& r : recs) {
         float ms = 0.0f;
         HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)r.e0, (hipEvent_t)r.e1));
@@ -779,6 +832,16 @@ bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string
         for (auto& o : out)
             if (!strcmp(o.site, r.site)) { o.ms += ms; o.bytes += r.bytes; o.launches++; found = true; break; }
         if (!found) out.push_back(LaunchStat{r.site, r.kernel, r.bytes, (double)ms, 1});
+    }
+    static std::vector<std::string> names;   // storage behind the "<site>@sweep" labels
+    names.clear();
+    names.reserve(sweeps.size());
+    for (auto& w : sweeps) {
+        double bytes = 0.0;
+        for (auto& o : out)
+            if (!strcmp(o.site, w.site)) bytes = o.bytes / o.launches * w.launches;
+        names.push_back(std::string(w.site) + "@sweep");
+        out.push_back(LaunchStat{names.back().c_str(), "sweep", bytes, (double)w.ms, w.launches});
     }
     return true;
 #else

@@ -3,6 +3,7 @@
 // (models/ggml/llama.cpp:2835-2981) + llm_build_llama graph (:2162-2491) + ggml_graph_compute.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,14 @@ class Engine {
     const char* trace_site_ = nullptr;
     unsigned long long* trace_buf_ = nullptr;
     void apply_trace(::MatvecArgs& a, const char* site);
+    // measurement only: when set, token_step launches nothing but this site's kernels (one per layer, back to back)
+    const char* only_site_ = nullptr;
+    int site_launches_ = 0;
+    bool site_on(const char* site) {
+        if (only_site_ && strcmp(only_site_, site) != 0) return false;
+        ++site_launches_;
+        return true;
+    }
 
    private:
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
