@@ -9,7 +9,7 @@
 #include <thread>
 
 #include "gguf_reader.h"
-#include "kernels_v5.h"
+#include "kernels_v6.h"
 
 namespace ctamd {
 
@@ -405,6 +405,41 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false>), g5, b5, s, a); \
             else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false>), g5, b5, s, a);
             const int units_per_wg = ((a.n_pairs + (int)g5.x - 1) / (int)g5.x) * (a.gateup ? 2 : 1);
+            static const int gen6 = env_int("CT_AMD_GEN6", 1);
+            if (gen6 && (a.K <= 4096 || (a.K <= 12288 && !a.gateup))) {
+                // generation 6: same data flow, LDS-counter synchronisation (kernels_v6.h); dynamic LDS above 64 KB needs
+                // the per-function opt-in once
+#define V6L(MK, SS, TT, NB, TAV, TBV, GUV) do { \
+                    auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, TBV, GUV>; \
+                    constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
+                    static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
+                    (void)once; \
+                    CT_LAUNCH_DYN(kfn, g5, b5, smem, s, a); } while (0)
+#define V6(MK, SS, TT, NB) \
+                if (a.gateup && ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, 0, true); \
+                else if (a.gateup && ta == GT_Q5_K) V6L(MK, SS, TT, NB, GT_Q5_K, 0, true); \
+                else if (a.gateup) V6L(MK, SS, TT, NB, GT_Q6_K, 0, true); \
+                else if (ta == GT_Q4_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q4_K, 0, false); \
+                else if (ta == GT_Q5_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q5_K, 0, false); \
+                else if (ta == GT_Q6_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q6_K, 0, false); \
+                else if (ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false); \
+                else V6L(MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false);
+                static const int nbuf = env_int("CT_AMD_NBUF", 4);
+                if (a.K <= 4096) {
+                    if (units_per_wg <= 2) { V6(4096, 1, 2, 3) }
+                    else if (nbuf == 3) { V6(4096, 1, 4, 3) }
+                    else { V6(4096, 1, 4, 4) }
+                } else {
+                    if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);
+                    else if (ta == GT_Q5_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q5_K, 0, false);
+                    else if (ta == GT_Q6_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q6_K, 0, false);
+                    else if (ta == GT_Q4_K) V6L(12288, 3, 2, 3, GT_Q4_K, GT_Q6_K, false);
+                    else V6L(12288, 3, 2, 3, GT_Q5_K, GT_Q6_K, false);
+                }
+#undef V6
+#undef V6L
+                return true;
+            }
             static const int mixed_t = env_int("CT_AMD_MIXED_T", 4);
             if (a.K <= 4096) { if (units_per_wg <= 2 || (tb != 0 && mixed_t == 2)) { V5(4096, 1, 2, 2) } else { V5(4096, 1, 4, 2) } } else { V5(12288, 3, 2, 1) }
 #undef V5

@@ -10,6 +10,11 @@
 #else
 #include <hip/hip_runtime.h>
 #define CT_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+// dynamic LDS (more than the 64 KB a static __shared__ declaration may take): size in bytes at launch, CT_DYN_SMEM in the kernel
+#define CT_LAUNCH_DYN(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define CT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define CT_SMEM_OPTIN(fn, bytes) \
+    (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) == hipSuccess)
 #endif
 
 #define DEV __device__ __forceinline__

@@ -54,6 +54,18 @@ void fiber_entry() {
 
 void syncthreads() { arrive(g_block); }
 
+static unsigned long long g_spins = 0;
+void spin_yield() {
+    if (++g_spins > 2000000000ull) { fprintf(stderr, "emu: spin-wait never satisfied\n"); abort(); }
+    yield_to_sched();
+}
+static std::vector<unsigned char> g_dyn;
+void dyn_smem_reserve(size_t n) {
+    if (n > 160 * 1024) { fprintf(stderr, "emu: %zu bytes of LDS requested (160 KB per CU)\n", n); abort(); }
+    if (g_dyn.size() < n + 64) g_dyn.resize(n + 64);
+}
+unsigned char* dyn_smem() { return (unsigned char*)(((uintptr_t)g_dyn.data() + 63) & ~(uintptr_t)63); }
+
 uint64_t wave_exchange(uint64_t v, int src_lane) {
     Fiber& f = g_fibers[g_cur];
     Wave& w = g_waves[f.lin / 64];
@@ -116,6 +128,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                     f.ctx.uc_link = nullptr;
                     makecontext(&f.ctx, (void (*)())fiber_entry, 0);
                 }
+                g_spins = 0;
                 int live = T;
                 while (live > 0) {
                     bool progressed = false;

@@ -33,6 +33,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void syncthreads();
 uint64_t wave_exchange(uint64_t v, int src_lane);
 uint64_t wave_ballot(int pred);
+void spin_yield();                 // a polling loop hands the CPU to the other fibers of the block
+void dyn_smem_reserve(size_t n);   // dynamic LDS of the next launch (zero-filled per workgroup is NOT guaranteed, as on hardware)
+unsigned char* dyn_smem();
 }  // namespace emu
 
 static inline void __syncthreads() { emu::syncthreads(); }
@@ -87,6 +90,10 @@ template <class P> static inline hipError_t hipMalloc(P** p, size_t n) { return 
 template <class P> static inline hipError_t hipHostMalloc(P** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
 
 #define CT_LAUNCH(kernel, grid, block, stream, ...) emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+#define CT_LAUNCH_DYN(kernel, grid, block, smem, stream, ...) \
+    do { emu::dyn_smem_reserve(smem); emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }); } while (0)
+#define CT_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
+#define CT_SMEM_OPTIN(fn, bytes) ((void)(fn), (bytes) <= 160 * 1024)
 
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };

@@ -1,3 +1,2 @@
 cd /root/repo
-export CTAMD_BENCH_MODEL=/tmp/l7b.gguf
-timeout 600 python bench.py --no-cpu-baseline
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
