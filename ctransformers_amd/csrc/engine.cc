@@ -406,7 +406,9 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false>), g5, b5, s, a);
             const int units_per_wg = ((a.n_pairs + (int)g5.x - 1) / (int)g5.x) * (a.gateup ? 2 : 1);
             static const int gen6 = env_int("CT_AMD_GEN6", 1);
-            if (gen6 && (a.K <= 4096 || (a.K <= 12288 && !a.gateup))) {
+            // launches with a single round per workgroup (wo: two units) gain nothing from the lagged chain duty and pay
+            // for the counters: they stay on generation 5
+            if (gen6 && !(a.K <= 4096 && units_per_wg <= 2) && (a.K <= 4096 || (a.K <= 12288 && !a.gateup))) {
                 // generation 6: same data flow, LDS-counter synchronisation (kernels_v6.h); dynamic LDS above 64 KB needs
                 // the per-function opt-in once
 #define V6L(MK, SS, TT, NB, TAV, TBV, GUV) do { \
@@ -426,8 +428,7 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
                 else V6L(MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false);
                 static const int nbuf = env_int("CT_AMD_NBUF", 4);
                 if (a.K <= 4096) {
-                    if (units_per_wg <= 2) { V6(4096, 1, 2, 3) }
-                    else if (nbuf == 3) { V6(4096, 1, 4, 3) }
+                    if (nbuf == 3) { V6(4096, 1, 4, 3) }
                     else { V6(4096, 1, 4, 4) }
                 } else {
                     if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);

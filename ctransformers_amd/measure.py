@@ -4,7 +4,7 @@ import ctypes
 
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 MATVEC_SITES = ("qkv", "wo", "gate_up", "lm_head")  # the K=4096 instantiation of the dominant kernel
-KERNEL = "matvec_v5_kernel<4096,1,T,2,TA,TB> (QKV, Wo, gate+up, lm_head launch sites; `down` is the <12288,3,2,1> instantiation)"
+KERNEL = "matvec_v6_kernel<4096,1,T,NBUF,TA,TB,GU> (QKV, Wo, gate+up, lm_head launch sites; `down` is the <12288,3,2,3,...> instantiation)"
 
 
 class LaunchStat(ctypes.Structure):
@@ -26,7 +26,7 @@ def pmc_traffic():
     `rocprofv3 --pmc FETCH_SIZE` run as the guide prescribes: it cannot share a pass with the timing run)."""
     import json
     import os
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_v5_pmc_traffic.json")
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_v6_pmc_traffic.json")
     try:
         return int(json.load(open(p))["dominant_kernel"]["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):

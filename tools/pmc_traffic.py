@@ -7,7 +7,7 @@ import json
 import sys
 from collections import defaultdict
 
-DOMINANT = ("matvec_v5_kernel<4096",)  # the K=4096 instantiations = qkv / wo / gate_up / lm_head launch sites
+DOMINANT = ("matvec_v6_kernel<4096", "matvec_v5_kernel<4096")  # the K=4096 instantiations = qkv / wo / gate_up / lm_head launch sites
 
 
 def load(path):
@@ -35,7 +35,7 @@ def main():
             tot_b += fb * len(v)
             tot_n += len(v)
     if tot_n:
-        out["dominant_kernel"] = {"match": DOMINANT[0], "dispatches": int(tot_n), "traffic_bytes_per_launch": round(tot_b / tot_n)}
+        out["dominant_kernel"] = {"match": "|".join(DOMINANT), "dispatches": int(tot_n), "traffic_bytes_per_launch": round(tot_b / tot_n)}
     print(json.dumps(out, indent=1))
 
 
