@@ -10,6 +10,7 @@
 
 #include "gguf_reader.h"
 #include "kernels_v6.h"
+#include "kernels_q32.h"
 
 namespace ctamd {
 
@@ -128,6 +129,38 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
                             memcpy(rp + 16 + r * 16, blk + 192, 16);
                             memcpy(rp + 144 + r * 64, blk + 128, 64);
                             memcpy(rp + 656 + r * 128, blk, 128);
+                        }
+                    }
+                }
+        });
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, st.size() + 64, err)) return false;
+        HIP_OK(hipMemcpy(d, st.data(), st.size(), hipMemcpyHostToDevice));
+        m.p[0] = d;
+        return true;
+    }
+    if (exact_ && (t->type == GT_Q8_0 || t->type == GT_Q4_0)) {
+        if (m.K % 128) { err = "tensor " + t->name + ": Q8_0/Q4_0 rows must be a multiple of 128 elements"; return false; }
+        m.layout = LAYOUT_G4;
+        const bool q8 = t->type == GT_Q8_0;
+        const int n_tiles = (M + 7) / 8, ng = nb / 4, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512;
+        std::vector<uint8_t> st((size_t)n_tiles * ng * rec, 0);
+        const uint8_t* src = t->data;
+        parallel_rows(n_tiles, [&](int t0, int t1) {
+            for (int tl = t0; tl < t1; ++tl)
+                for (int g = 0; g < ng; ++g) {
+                    uint8_t* rp = &st[((size_t)tl * ng + g) * rec];
+                    for (int r = 0; r < 8; ++r) {
+                        const int row = tl * 8 + r;
+                        if (row >= M) continue;
+                        for (int i = 0; i < 4; ++i) {
+                            const uint8_t* blk = src + ((size_t)row * nb + (size_t)g * 4 + i) * bb;
+                            memcpy(rp + dbase + r * 8 + i * 2, blk, 2);
+                            if (q8) {
+                                for (int l = 0; l < 8; ++l) memcpy(rp + (r * 8 + l) * 16 + i * 4, blk + 2 + 4 * l, 4);
+                            } else {
+                                for (int l = 0; l < 4; ++l) memcpy(rp + (r * 4 + l) * 16 + i * 4, blk + 2 + 4 * l, 4);
+                            }
                         }
                     }
                 }
@@ -371,6 +404,21 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         item0 += (a.job[j].w.M + 7) / 8;
     }
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
+    if (a.job[0].w.layout == LAYOUT_G4) {
+        const int ty = a.job[0].w.type;
+        for (int j = 1; j < a.njobs; ++j)
+            if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
+        if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
+        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16))), b(1024);
+        if (ty == GT_Q8_0) {
+            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, b, s, a);
+            else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, b, s, a);
+        } else {
+            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, b, s, a);
+            else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, b, s, a);
+        }
+        return true;
+    }
     if (a.job[0].w.layout == LAYOUT_TILE8S) {
         // generation 4: one 1024-thread workgroup per CU, two tiles per barrier round
         const int n_cu = chip_cus();

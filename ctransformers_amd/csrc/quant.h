@@ -51,7 +51,9 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 
 // LAYOUT_TILE8S = tile8 with the 12-byte 6-bit scale/min field of Q4_K/Q5_K headers re-encoded (losslessly, same size) as
 // four 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
-enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1, LAYOUT_TILE8S = 2 };
+// LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
+// four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
+enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1, LAYOUT_TILE8S = 2, LAYOUT_G4 = 3 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).

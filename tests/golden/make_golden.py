@@ -1,7 +1,7 @@
 """Regenerates the committed golden vectors from the REAL reference build (oracle/_ref, built from /root/reference by
 oracle/Makefile).  Run in the build container:  python tests/golden/make_golden.py
 Outputs (small, committed):
-  tiny-q4km.gguf / tiny-q5km.gguf   synthetic llama-tiny models (the files themselves, so fixtures do not depend on numpy RNG)
+  tiny-q4km / -q5km / -q80 / -q40 .gguf   synthetic llama-tiny models (the files themselves, so fixtures do not depend on numpy RNG)
   tiny-*.npz                        reference logits / embeddings / greedy tokens / sampled tokens for those models
   ops.npz                           op-level vectors: Q8_K/Q8_0 activation quantization, the five weight dot products,
                                     rope, rms_norm*w, scale+softmax, fp16 mat-mul, silu*mul
@@ -91,7 +91,10 @@ def ops_golden():
 
 
 if __name__ == "__main__":
-    model_golden("tiny-q4km", "Q4_K_M", 3)
-    model_golden("tiny-q5km", "Q5_K_M", 4)
-    ops_golden()
+    only = sys.argv[1:]   # e.g. `make_golden.py tiny-q80 tiny-q40` regenerates just those
+    for name, ftype, seed in (("tiny-q4km", "Q4_K_M", 3), ("tiny-q5km", "Q5_K_M", 4), ("tiny-q80", "Q8_0", 5), ("tiny-q40", "Q4_0", 6)):
+        if not only or name in only:
+            model_golden(name, ftype, seed)
+    if not only or "ops" in only:
+        ops_golden()
     print("golden vectors written to", HERE)

@@ -20,7 +20,7 @@ def open_hip(path, **kw):
     return LLM(path, config=Config(**cfg))  # default lib = the HIP build; raises if missing / no GPU
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40"])
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_golden_logits_bit_identical(name, graph, monkeypatch):
     monkeypatch.setenv("CT_AMD_GRAPH", graph)
@@ -65,6 +65,9 @@ def test_abi_semantics_on_gpu():
     ("llama-small", "Q4_K_M", 20, 60),   # MHA 8/8, head_dim 64, K = 512 / 1280 (odd block counts)
     ("llama-tiny", "Q5_K_M", 5, 80),     # GQA 4/2, runs past 64 positions (fp16 dot leftovers + full 32-steps)
     ("llama-7b-2l", "Q4_K_M", 33, 12),   # two layers at the real 7B shapes incl. the 32000x4096 Q6_K head
+    ("llama-small", "Q8_0", 20, 40),     # config 3: 32-element blocks, Q8_0 activations (kernels_q32.h)
+    ("llama-small", "Q4_0", 20, 40),     # Q4_0 layers + Q6_K head
+    ("llama-7b-2l", "Q8_0", 33, 8),      # real 7B shapes: K = 4096 / 11008 (86 block groups), 32000-row Q8_0 head
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
     p = str(tmp_path / "m.gguf")
