@@ -409,6 +409,17 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         for (int j = 1; j < a.njobs; ++j)
             if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
         if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
+        static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
+        if (systolic) {   // K split over the waves, accumulators handed from wave to wave (kernels_q32.h)
+            const dim3 gs((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), bs(1024);
+#define Q32S(TY, MG) do { if (a.gateup) CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, true>), gs, bs, s, a); \
+                          else CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, false>), gs, bs, s, a); } while (0)
+            const int per_wave = ((a.K >> 7) + 15) / 16;
+            if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
+            else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
+#undef Q32S
+            return true;
+        }
         const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16))), b(1024);
         if (ty == GT_Q8_0) {
             if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, b, s, a);

@@ -192,3 +192,146 @@ __global__ void __launch_bounds__(1024) matvec_q32_kernel(const MatvecArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Systolic form (default): the K range of every tile is split over the NA <= 16 waves of the workgroup, each wave
+// turns its block groups into (d_b, (float)sumi_b) register pairs — the order-free part, with all of the tile's loads
+// in flight at once — and the row accumulators travel from wave to wave through an LDS mailbox: wave w waits for
+// ctr[slot] == gen*NA + w, continues the reference's fma chain over its own blocks, passes the 64 accumulators on.
+// Waves work on different tiles at the same time (wave 0 is NA-1 tiles ahead of the last wave), so after the first
+// tile's NA hops the workgroup retires one tile per hop time, and the last wave runs hsum + epilogue.
+// wave-per-tile (matvec_q32_kernel above) kept a single wave walking 128 dependent block steps behind a 4-deep
+// prefetch: 18 us for Wo at 7B shapes, latency-bound (Q8_0 and Q4_0 took the same time).
+// ------------------------------------------------------------------------------------------------------------------
+#include "kernels_v6.h"
+
+constexpr int kQ32Slots = 8;
+template <int MAXK> struct SmemQ32S {
+    ActLdsQ32<MAXK> L;
+    float mail[kQ32Slots][64];
+    unsigned ctr[kQ32Slots];
+};
+
+template <int TYPE, int MAXK, int MAXG, bool GU>
+__global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
+    __shared__ SmemQ32S<MAXK> SM;
+    constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+    const int lane = lane_id();
+    const int wv = uniform_int(wave_id());
+    const int ng = a.K >> 7;
+    const int NA = ng < 16 ? ng : 16;                 // waves that own block groups
+    if (threadIdx.x < kQ32Slots) SM.ctr[threadIdx.x] = 0u;   // published by the prologue's barrier
+    const int pos = a.pos ? *a.pos : 0;
+    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if (wv >= NA) return;
+    const int base = ng / NA, rem = ng % NA;
+    const int gcnt = base + (wv < rem ? 1 : 0);
+    const int gbeg = wv * base + (wv < rem ? wv : rem);
+    const int r = lane >> 3, p3 = lane & 7, l = ((p3 & 1) << 2) | (p3 & 2) | (p3 >> 2);   // AVX lane of this position
+    const uint32_t qoff = TYPE == GT_Q8_0 ? (uint32_t)(r * 8 + l) * 16u : (uint32_t)(r * 4 + (l & 3)) * 16u;
+    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)r * 8u;
+    const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
+    // this workgroup's tile sequence: items blockIdx, blockIdx + gridDim, ...; gate/up launches visit (gate t, up t)
+    const int stride = (int)gridDim.x, first = (int)blockIdx.x;
+    const int n_loc = first < a.n_pairs ? (a.n_pairs - first + stride - 1) / stride : 0;
+    const int n_seq = n_loc * (GU ? 2 : 1);
+    auto tile_of = [&](int seq, int& j, int& tile) __attribute__((always_inline)) {
+        const int it = first + (GU ? (seq >> 1) : seq) * stride;
+        j = 0;
+        if (GU) {
+            j = seq & 1;
+        } else {
+            if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
+            if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+        }
+        tile = it - (GU ? 0 : a.job[j].pair0);
+    };
+    u32x4 qv[MAXG];
+    uint64_t dv[MAXG];
+    auto load_tile = [&](int seq) __attribute__((always_inline)) {
+        int j, tile;
+        tile_of(seq, j, tile);
+        const uint8_t* tp = a.job[j].w.p[0] + ((size_t)tile * ng + gbeg) * REC;
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            if (u < gcnt) {
+                qv[u] = ld_stream16(tp + (size_t)u * REC + qoff);
+                dv[u] = *(const uint64_t*)(tp + (size_t)u * REC + doff);
+            }
+        }
+    };
+    if (n_seq > 0) load_tile(0);
+    float gate_res = 0.0f;
+    for (int seq = 0; seq < n_seq; ++seq) {
+        float dd[MAXG][4], ss[MAXG][4];
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            if (u < gcnt) {
+                const int g = gbeg + u;
+                const u32x4 y = *(const u32x4*)&SM.L.q8[(g * 8 + l) * 4];
+                const float4 yd = *(const float4*)&SM.L.yd[g * 4];
+                const float yds[4] = {yd.x, yd.y, yd.z, yd.w};
+                const uint32_t dw[4] = {(uint32_t)(dv[u] & 0xFFFFu), (uint32_t)((dv[u] >> 16) & 0xFFFFu),
+                                        (uint32_t)((dv[u] >> 32) & 0xFFFFu), (uint32_t)(dv[u] >> 48)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int sumi;
+                    if constexpr (TYPE == GT_Q8_0) {
+                        sumi = sdot4((int)qv[u][i], (int)y[i], 0);
+                    } else {
+                        const int nib = (int)((qv[u][i] >> sh) & 0x0F0F0F0Fu);
+                        sumi = sdot4(nib, (int)y[i], 0) - 8 * sdot4(0x01010101, (int)y[i], 0);
+                    }
+                    dd[u][i] = f16_bits_to_f32((uint16_t)dw[i]) * yds[i];
+                    ss[u][i] = (float)sumi;
+                }
+            }
+        }
+        if (seq + 1 < n_seq) load_tile(seq + 1);     // registers of this tile are consumed: request the next one now
+        const int slot = seq % kQ32Slots;
+        const unsigned gen_base = (unsigned)(seq / kQ32Slots) * (unsigned)NA;
+        lds_wait_ge(&SM.ctr[slot], gen_base + (unsigned)wv);   // wave 0: the slot's previous tile was retired
+        float acc = (wv == 0) ? 0.0f : SM.mail[slot][lane];
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            if (u < gcnt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(dd[u][i], ss[u][i], acc);
+            }
+        }
+        if (wv < NA - 1) {
+            SM.mail[slot][lane] = acc;
+            lds_signal(&SM.ctr[slot], lane, 1u);
+            continue;
+        }
+        lds_signal(&SM.ctr[slot], lane, 1u);          // last wave: the slot is free again
+        const float res = hsum8_exact_dpp(acc);
+        int j, tile;
+        tile_of(seq, j, tile);
+        const int row = tile * 8 + r;
+        const bool own = p3 == 0 && row < a.job[j].w.M;
+        if (GU) {
+            if (!(seq & 1)) { gate_res = res; continue; }
+            if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(gate_res)]) * res;
+            continue;
+        }
+        const int epi = a.job[j].epi;
+        if (epi == EPI_ADD) {
+            if (own) a.out[row] = res + a.res[row];
+        } else if (epi == EPI_STORE) {
+            if (own) a.out[row] = res;
+        } else if (epi == EPI_V) {
+            if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else {
+            const float other = lane_xor8(res);
+            const int ip = (row % a.head_dim) >> 1;
+            const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+            const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+            const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+            if (own) {
+                if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+                else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
+            }
+        }
+    }
+}
