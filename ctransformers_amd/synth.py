@@ -390,3 +390,120 @@ def weight_bytes_per_token(path):
         else:
             total += data.size
     return total
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Falcon (reference llm_build_falcon, models/ggml/llama.cpp:2493-2798)
+# ---------------------------------------------------------------------------------------------------------------------
+FALCON_SHAPES = {
+    # n_ff is 4*n_embd in the real models; the "40b" style has the second attention norm (attn_norm_2)
+    "falcon-40b": dict(n_vocab=65024, n_embd=8192, n_head=128, n_head_kv=8, n_layer=60, n_ff=32768, norm2=True),
+    "falcon-7b": dict(n_vocab=65024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=32, n_ff=18176, norm2=False),
+    # parity-test shapes (head_dim 64 like the real models; K-quants need K % 256 == 0)
+    "falcon-tiny": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=2, n_layer=2, n_ff=1024, norm2=True),
+    "falcon-tiny7": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=1, n_layer=2, n_ff=1024, norm2=False),
+    "falcon-small": dict(n_vocab=1024, n_embd=1024, n_head=16, n_head_kv=2, n_layer=3, n_ff=4096, norm2=True),
+}
+
+
+def falcon_tensor_types(ftype, n_layer):
+    """name -> ggml type of the 2-D tensors of a falcon GGUF (reference llama.cpp:4785-4850, arch == FALCON rules)."""
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0}[ftype]
+    t = {"token_embd.weight": base, "output.weight": G.Q8_0}   # :4787-4788: falcon output is always Q8_0
+    for i in range(n_layer):
+        qkv, down = base, base
+        if ftype == "Q4_K_M":
+            qkv = G.Q5_K                                                          # :4845
+            down = G.Q6_K if i < 2 else (G.Q5_K if use_more_bits(i, n_layer) else G.Q4_K)   # :4822-4824
+        elif ftype == "Q5_K_M":
+            qkv = G.Q6_K                                                          # :4846
+            down = G.Q6_K if use_more_bits(i, n_layer) else base                   # :4830
+        t["blk.%d.attn_qkv.weight" % i] = qkv
+        t["blk.%d.attn_output.weight" % i] = base
+        t["blk.%d.ffn_up.weight" % i] = base
+        t["blk.%d.ffn_down.weight" % i] = down
+    return t
+
+
+def make_bpe_vocab(n_vocab):
+    """A byte-level BPE vocabulary for the reference's `llm_tokenizer_bpe` (llama.cpp:3228-3388): that tokenizer looks
+    symbols up as RAW strings (no GPT-2 byte->unicode remap in this version) and falls back to single-byte tokens, and
+    the loader tokenizes "\n" to find the linefeed id (:1751) — so all 256 single-byte strings are tokens.  Token 11 is
+    <|endoftext|> like Falcon's (bos = eos = 11 are hard-coded, :1719-1720).  Then synthetic two-letter merges."""
+    toks = [bytes([b]) for b in range(256)]
+    toks[11] = b"<|endoftext|>"
+    merges = []
+    i = 0
+    while len(toks) < n_vocab:
+        a, b = chr(ord("a") + (i % 26)), chr(ord("a") + ((i // 26) % 26))
+        if i < 676:
+            piece = a + b
+            merges.append(a + " " + b)
+        else:
+            piece = " " + a + b + str(i)
+        toks.append(piece.encode("ascii"))
+        i += 1
+    return toks[:n_vocab], merges
+
+
+def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ctx_train=2048, pooled=None, norm_eps=1e-5,
+                      overrides=None):
+    """Write a synthetic falcon-architecture GGUF v2 file.  Returns the hparams dict."""
+    hp = dict(FALCON_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
+    if overrides:
+        hp.update(overrides)
+    n_vocab, n_embd, n_head, n_head_kv = hp["n_vocab"], hp["n_embd"], hp["n_head"], hp["n_head_kv"]
+    n_layer, n_ff = hp["n_layer"], hp["n_ff"]
+    head_dim = n_embd // n_head
+    if pooled is None:
+        pooled = n_embd >= 2048
+    src = _WeightSource(seed, pooled)
+    types = falcon_tensor_types(ftype, n_layer)
+    w = G.GGUFWriter(path)
+    w.add_str("general.architecture", "falcon")
+    w.add_str("general.name", "synthetic-%s-%s" % (shape if isinstance(shape, str) else "custom", ftype))
+    w.add_u32("falcon.context_length", n_ctx_train)
+    w.add_u32("falcon.embedding_length", n_embd)
+    w.add_u32("falcon.block_count", n_layer)
+    w.add_u32("falcon.feed_forward_length", n_ff)
+    w.add_u32("falcon.attention.head_count", n_head)
+    w.add_u32("falcon.attention.head_count_kv", n_head_kv)
+    w.add_f32("falcon.attention.layer_norm_epsilon", norm_eps)
+    toks, merges = make_bpe_vocab(n_vocab)
+    w.add_str("tokenizer.ggml.model", "gpt2")
+    w.add_arr("tokenizer.ggml.tokens", G.T_STR, toks)
+    w.add_arr("tokenizer.ggml.scores", G.T_F32, [0.0] * n_vocab)
+    w.add_arr("tokenizer.ggml.token_type", G.T_I32, [1] * n_vocab)
+    w.add_arr("tokenizer.ggml.merges", G.T_STR, [m.encode("ascii") for m in merges])
+    w.add_u32("tokenizer.ggml.bos_token_id", 11)
+    w.add_u32("tokenizer.ggml.eos_token_id", 11)
+
+    def mat(name, rows, K, sigma):
+        t = types[name]
+        w.add_tensor(name, (K, rows), t, lambda: src.matrix(rows, K, t, sigma))
+
+    def vec(name, n, bias=False):
+        if bias:
+            w.add_tensor(name, (n,), G.F32, lambda: (src.norm(n) - np.float32(1.0)).astype(np.float32).view(np.uint8))
+        else:
+            w.add_tensor(name, (n,), G.F32, lambda: src.norm(n).view(np.uint8))
+
+    s_e, s_f = 1.0 / np.sqrt(n_embd), 1.0 / np.sqrt(n_ff)
+    mat("token_embd.weight", n_vocab, n_embd, 1.0)
+    vec("output_norm.weight", n_embd)
+    vec("output_norm.bias", n_embd, bias=True)
+    mat("output.weight", n_vocab, n_embd, s_e)
+    for i in range(n_layer):
+        p = "blk.%d." % i
+        vec(p + "attn_norm.weight", n_embd)
+        vec(p + "attn_norm.bias", n_embd, bias=True)
+        if hp.get("norm2"):
+            vec(p + "attn_norm_2.weight", n_embd)
+            vec(p + "attn_norm_2.bias", n_embd, bias=True)
+        mat(p + "attn_qkv.weight", (n_head + 2 * n_head_kv) * head_dim, n_embd, s_e)
+        mat(p + "attn_output.weight", n_embd, n_embd, s_e)
+        mat(p + "ffn_up.weight", n_ff, n_embd, s_e)
+        mat(p + "ffn_down.weight", n_embd, n_ff, s_f)
+    w.write()
+    hp.update(dict(head_dim=head_dim, ftype=ftype, norm_eps=norm_eps))
+    return hp

@@ -181,3 +181,81 @@ def rope(x, pos, freq_base=10000.0, freq_scale=1.0):
     L.mir_rope.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_float]
     L.mir_rope(_p(y), y.shape[0], y.shape[1], int(pos), float(freq_base), float(freq_scale))
     return y
+
+
+class _Falcon(Structure):
+    _fields_ = [("n_vocab", c_int), ("n_embd", c_int), ("n_head", c_int), ("n_head_kv", c_int), ("n_layer", c_int),
+                ("n_ff", c_int), ("n_ctx", c_int), ("norm_eps", c_float), ("rope_freq_base", c_float),
+                ("rope_freq_scale", c_float), ("tok_embd", c_void_p), ("tok_embd_type", c_int),
+                ("output_norm", c_void_p), ("output_norm_b", c_void_p), ("output", c_void_p), ("output_type", c_int),
+                ("attn_norm", c_void_p), ("attn_norm_b", c_void_p), ("attn_norm_2", c_void_p), ("attn_norm_2_b", c_void_p),
+                ("wqkv", c_void_p), ("wo", c_void_p), ("w_up", c_void_p), ("w_down", c_void_p),
+                ("t_wqkv", c_void_p), ("t_wo", c_void_p), ("t_up", c_void_p), ("t_down", c_void_p),
+                ("kcache", c_void_p), ("vcache", c_void_p)]
+
+
+class MirrorFalcon:
+    """The C restatement of llm_build_falcon driven over a GGUF file (same eval contract as MirrorLlama)."""
+
+    def __init__(self, path, context_length=512):
+        self.f = G.GGUFFile(path)
+        kv = self.f.kv
+        a = "falcon."
+        self.n_embd = int(kv[a + "embedding_length"])
+        self.n_head = int(kv[a + "attention.head_count"])
+        self.n_head_kv = int(kv.get(a + "attention.head_count_kv", self.n_head))
+        self.n_layer = int(kv[a + "block_count"])
+        self.n_ff = int(kv[a + "feed_forward_length"])
+        self.n_vocab = len(kv["tokenizer.ggml.tokens"])
+        self.n_ctx = context_length
+        self._keep = []
+        m = _Falcon()
+        m.n_vocab, m.n_embd, m.n_head, m.n_head_kv = self.n_vocab, self.n_embd, self.n_head, self.n_head_kv
+        m.n_layer, m.n_ff, m.n_ctx = self.n_layer, self.n_ff, self.n_ctx
+        m.norm_eps = float(kv[a + "attention.layer_norm_epsilon"])
+        m.rope_freq_base = float(kv.get(a + "rope.freq_base", 10000.0))
+        m.rope_freq_scale = 1.0
+
+        def tensor(name, optional=False):
+            if optional and name not in self.f.tensors:
+                return None, 0
+            shape, t, data = self.f.tensors[name]
+            arr = np.ascontiguousarray(data)
+            self._keep.append(arr)
+            return arr.ctypes.data, t
+
+        m.tok_embd, m.tok_embd_type = tensor("token_embd.weight")
+        m.output_norm, _ = tensor("output_norm.weight")
+        m.output_norm_b, _ = tensor("output_norm.bias")
+        m.output, m.output_type = tensor("output.weight")
+
+        def per_layer(fmt, optional=False):
+            ptrs = (c_void_p * self.n_layer)()
+            types = (c_int * self.n_layer)()
+            for i in range(self.n_layer):
+                ptrs[i], types[i] = tensor(fmt % i, optional)
+            self._keep += [ptrs, types]
+            return ctypes.cast(ptrs, c_void_p), ctypes.cast(types, c_void_p)
+
+        m.attn_norm, _ = per_layer("blk.%d.attn_norm.weight")
+        m.attn_norm_b, _ = per_layer("blk.%d.attn_norm.bias")
+        m.attn_norm_2, _ = per_layer("blk.%d.attn_norm_2.weight", True)
+        m.attn_norm_2_b, _ = per_layer("blk.%d.attn_norm_2.bias", True)
+        m.wqkv, m.t_wqkv = per_layer("blk.%d.attn_qkv.weight")
+        m.wo, m.t_wo = per_layer("blk.%d.attn_output.weight")
+        m.w_up, m.t_up = per_layer("blk.%d.ffn_up.weight")
+        m.w_down, m.t_down = per_layer("blk.%d.ffn_down.weight")
+        g = self.n_embd // self.n_head * self.n_head_kv
+        self.kc = np.zeros(self.n_layer * self.n_ctx * g, dtype=np.uint16)
+        self.vc = np.zeros(self.n_layer * self.n_ctx * g, dtype=np.uint16)
+        m.kcache, m.vcache = self.kc.ctypes.data, self.vc.ctypes.data
+        self.m = m
+        self.logits = np.zeros(self.n_vocab, dtype=np.float32)
+        self.embeddings = np.zeros(self.n_embd, dtype=np.float32)
+        lib().mir_falcon_eval.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+        lib().mir_falcon_eval.restype = c_int
+
+    def eval(self, tokens, n_past):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        lib().mir_falcon_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits), _p(self.embeddings))
+        return self.logits

@@ -126,7 +126,8 @@ class GgmlOps:
         L.ggml_new_tensor_3d.argtypes = [vp, c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
         for f in (L.ggml_new_tensor_1d, L.ggml_new_tensor_2d, L.ggml_new_tensor_3d, L.ggml_get_data, L.ggml_new_graph,
                   L.ggml_rms_norm, L.ggml_soft_max, L.ggml_scale, L.ggml_mul_mat, L.ggml_rope_custom_inplace,
-                  L.ggml_new_f32, L.ggml_mul, L.ggml_add, L.ggml_silu, L.ggml_cpy, L.ggml_diag_mask_inf):
+                  L.ggml_new_f32, L.ggml_mul, L.ggml_add, L.ggml_silu, L.ggml_cpy, L.ggml_diag_mask_inf, L.ggml_gelu,
+                  L.ggml_norm):
             f.restype = vp
         L.ggml_get_data.argtypes = [vp]
         L.ggml_new_graph.argtypes = [vp]
@@ -138,6 +139,8 @@ class GgmlOps:
         L.ggml_add.argtypes = [vp, vp, vp]
         L.ggml_cpy.argtypes = [vp, vp, vp]
         L.ggml_silu.argtypes = [vp, vp]
+        L.ggml_gelu.argtypes = [vp, vp]
+        L.ggml_norm.argtypes = [vp, vp, c_float]
         L.ggml_new_f32.argtypes = [vp, c_float]
         L.ggml_rope_custom_inplace.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_float, c_float]
         L.ggml_build_forward_expand.argtypes = [vp, vp]
@@ -192,6 +195,18 @@ class GgmlOps:
         ta = self._tensor(ctx, np.ascontiguousarray(a_f16).view(np.uint16), 1)
         tb = self._tensor(ctx, b_f32.astype(np.float32))
         return self._run(ctx, self.L.ggml_mul_mat(ctx, ta, tb), (b_f32.shape[0], a_f16.shape[0]))
+
+    def gelu(self, x):
+        ctx = self._ctx()
+        return self._run(ctx, self.L.ggml_gelu(ctx, self._tensor(ctx, x.astype(np.float32))), x.shape)
+
+    def norm_mul_add(self, x, w, b, eps):
+        """LayerNorm as the falcon graph builds it: ggml_add(ggml_mul(ggml_norm(x), w), b)  (llama.cpp:2611-2614)."""
+        ctx = self._ctx()
+        t = self.L.ggml_add(ctx, self.L.ggml_mul(ctx, self.L.ggml_norm(ctx, self._tensor(ctx, x.astype(np.float32)), eps),
+                                                  self._tensor(ctx, w.astype(np.float32))),
+                            self._tensor(ctx, b.astype(np.float32)))
+        return self._run(ctx, t, x.shape)
 
     def silu_mul(self, g, u):
         ctx = self._ctx()
