@@ -245,7 +245,8 @@ bool Engine::build_tables(std::string& err) {
         const float f = f16_bits_to_f32((uint16_t)i);
         e[i] = f32_to_f16_bits(expf(f));
         s[i] = f32_to_f16_bits(f / (1.0f + expf(-f)));
-        g[i] = f32_to_f16_bits(0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f))));
+        // GELU table: the reference build contracts `1 + A*x*x` into one fma and nothing else (oracle/mirror.c:init_gelu_table)
+        g[i] = f32_to_f16_bits((0.5f * f) * (1.0f + tanhf((0.79788456080286535587989211986876f * f) * fmaf(0.044715f * f, f, 1.0f))));
     }
     if (!dev_alloc(dev_allocs_, &exp_tab_, 65536, err) || !dev_alloc(dev_allocs_, &silu_tab_, 65536, err) ||
         !dev_alloc(dev_allocs_, &gelu_tab_, 65536, err))
@@ -291,7 +292,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     GgufFile f;
     if (!f.open(path)) { err = f.error(); return false; }
     if (!f.get_str("general.architecture", hp_.arch)) { err = "general.architecture missing"; return false; }
-    if (hp_.arch != "llama") { err = "architecture '" + hp_.arch + "' is not supported yet (llama only)"; return false; }
+    if (hp_.arch != "llama" && hp_.arch != "falcon") { err = "architecture '" + hp_.arch + "' is not supported yet (llama, falcon)"; return false; }
     const std::string a = hp_.arch + ".";
     uint32_t u;
     auto need = [&](const char* key, int& out) {
@@ -307,7 +308,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (f.get_u32(a + "attention.head_count_kv", u)) hp_.n_head_kv = (int)u;
     hp_.n_rot = hp_.n_embd / hp_.n_head;
     if (f.get_u32(a + "rope.dimension_count", u)) hp_.n_rot = (int)u;
-    if (!f.get_f32(a + "attention.layer_norm_rms_epsilon", hp_.rms_eps)) { err = "missing rms epsilon"; return false; }
+    if (hp_.falcon()) {
+        if (!f.get_f32(a + "attention.layer_norm_epsilon", hp_.rms_eps)) { err = "missing layer_norm epsilon"; return false; }
+    } else if (!f.get_f32(a + "attention.layer_norm_rms_epsilon", hp_.rms_eps)) { err = "missing rms epsilon"; return false; }
     f.get_f32(a + "rope.freq_base", hp_.rope_freq_base);
     float rs = 1.0f;
     if (f.get_f32(a + "rope.scale_linear", rs) && rs != 0.0f) hp_.rope_freq_scale = 1.0f / rs;
@@ -343,6 +346,27 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         tok_embd_.raw = d;
     }
     layers_.resize(hp_.n_layer);
+    if (hp_.falcon()) {
+        if (l0_ != 0 || l1_ != hp_.n_layer) { err = "pipeline stages are implemented for the llama architecture only"; return false; }
+        for (int i = 0; i < hp_.n_layer; ++i) {
+            const std::string p = "blk." + std::to_string(i) + ".";
+            Layer& L = layers_[i];
+            if (!upload_f32(f.tensor(p + "attn_norm.weight"), &L.attn_norm, E, err)) return false;
+            if (!upload_f32(f.tensor(p + "attn_norm.bias"), &L.attn_norm_b, E, err)) return false;
+            if (f.tensor(p + "attn_norm_2.weight")) {   // Falcon-40B style: separate norm for the attention input
+                if (!upload_f32(f.tensor(p + "attn_norm_2.weight"), &L.attn_norm2, E, err)) return false;
+                if (!upload_f32(f.tensor(p + "attn_norm_2.bias"), &L.attn_norm2_b, E, err)) return false;
+            }
+            if (!mat(p + "attn_qkv.weight", L.wqkv, E + 2 * G, E) || !mat(p + "attn_output.weight", L.wo, E, E) ||
+                !mat(p + "ffn_up.weight", L.w_up, F, E) || !mat(p + "ffn_down.weight", L.w_down, E, F))
+                return false;
+        }
+        if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
+        if (!upload_f32(f.tensor("output_norm.bias"), &output_norm_b_, E, err)) return false;
+        if (!mat("output.weight", output_, V, E)) return false;
+        if (!dev_alloc(dev_allocs_, &qkv_tmp_, (size_t)(E + 2 * G), err) || !dev_alloc(dev_allocs_, &attn_proj_, (size_t)E, err))
+            return false;
+    } else {
     for (int i = l0_; i < l1_; ++i) {
         const std::string p = "blk." + std::to_string(i) + ".";
         Layer& L = layers_[i];
@@ -358,6 +382,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (l1_ == hp_.n_layer) {
         if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
         if (!mat("output.weight", output_, V, E)) return false;
+    }
     }
     if (l0_ > 0 || l1_ < hp_.n_layer)
         if (!dev_alloc(dev_allocs_, &xio_, (size_t)n_ctx_ * E, err)) return false;
@@ -603,6 +628,7 @@ bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
 }
 
 bool Engine::token_step(bool want_logits, std::string& err) {
+    if (hp_.falcon()) return token_step_falcon(want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -751,6 +777,120 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     }
     if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     if (dump_dir_) ++dump_seq_;
+    return true;
+}
+
+// llm_build_falcon (llama.cpp:2493-2798), one token: per layer
+//   LayerNorm(attn_norm_2 or attn_norm) -> Q8_K -> fused Wqkv -> [neox RoPE, fp16 Q, KV append] -> attention -> Wo
+//   LayerNorm(attn_norm) -> Q8_K -> W_up -> GELU table -> Q8_K -> W_down -> (ffn + attn_out) + x
+bool Engine::token_step_falcon(bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    if (site_on("embed")) {
+        CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+                  (const int*)d_tokens_, (const int*)d_state_, x_);
+    }
+    MatvecArgs base = MatvecArgs();
+    base.rope_cs = rope_cs_;
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = G;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    base.dbg = env_int("CT_AMD_DBG", 0);
+    base.dbg_sink = scores_;
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * G;
+        {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated)
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_;
+            a.norm_w = L.attn_norm2 ? L.attn_norm2 : L.attn_norm;
+            a.norm_b = L.attn_norm2 ? L.attn_norm2_b : L.attn_norm_b;
+            a.out = qkv_tmp_;
+            set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            apply_trace(a, "qkv");
+            if (site_on("qkv")) {
+                prof_begin("qkv", "matvec", (double)L.wqkv.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
+        }
+        if (site_on("rope_store")) {
+            prof_begin("rope_store", "falcon_rope_store_kernel", 0.0);
+            CT_LAUNCH(falcon_rope_store_kernel, dim3((unsigned)(hp_.n_head + 2 * hp_.n_head_kv)), dim3((unsigned)(hd / 2)), stream_,
+                      (const float*)qkv_tmp_, q_f16_, kc, vc, (const float*)rope_cs_, d_pos, hp_.n_head, hp_.n_head_kv, hd, n_ctx_,
+                      v_stride_);
+            prof_end();
+        }
+        {
+            AttnArgsX ax = AttnArgsX();
+            ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
+            ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
+            ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = 1.0f / sqrtf((float)E / (float)hp_.n_head);
+            if (site_on("attn_fused")) {
+                prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+                const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
+                if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
+                else if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
+                else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
+                else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
+                prof_end();
+            }
+        }
+        {   // Q8_K(attn) -> Wo  (kept apart: the residual is added after the MLP)
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = attn_proj_;
+            set_jobs(a, {{&L.wo, EPI_STORE}});
+            apply_trace(a, "wo");
+            if (site_on("wo")) {
+                prof_begin("wo", "matvec", (double)L.wo.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
+        }
+        {   // LayerNorm(attn_norm) -> Q8_K -> W_up -> GELU   (the MLP reads the attention norm: parallel block)
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b; a.out = h_;
+            set_jobs(a, {{&L.w_up, EPI_GELU}});
+            apply_trace(a, "ffn_up");
+            if (site_on("ffn_up")) {
+                prof_begin("ffn_up", "matvec", (double)L.w_up.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
+        }
+        {   // Q8_K(h) -> W_down -> (ffn + attn_out) + x
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = attn_proj_; a.res2 = x_;
+            set_jobs(a, {{&L.w_down, EPI_ADD2}});
+            apply_trace(a, "down");
+            if (site_on("down")) {
+                prof_begin("down", "matvec", (double)L.w_down.bytes);
+                if (!run_matvec(a, err)) return false;
+                prof_end();
+            }
+        }
+    }
+    if (want_logits) {
+        if (!only_site_)
+            CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_,
+                      (const float*)output_norm_b_, d_emb_, E, hp_.rms_eps);
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        apply_trace(a, "lm_head");
+        if (site_on("lm_head")) {
+            prof_begin("lm_head", "matvec", (double)output_.bytes);
+            if (!run_matvec(a, err)) return false;
+            prof_end();
+        }
+    }
+    if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     return true;
 }
 

@@ -18,7 +18,8 @@ namespace ctamd {
 struct HParams {
     std::string arch;
     int n_vocab = 0, n_embd = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_ff = 0, n_rot = 0, n_ctx_train = 0;
-    float rms_eps = 1e-5f, rope_freq_base = 10000.0f, rope_freq_scale = 1.0f;
+    float rms_eps = 1e-5f, rope_freq_base = 10000.0f, rope_freq_scale = 1.0f;   // rms_eps doubles as falcon's LayerNorm eps
+    bool falcon() const { return arch == "falcon"; }
     int head_dim() const { return n_embd / n_head; }
     int n_embd_gqa() const { return head_dim() * n_head_kv; }
 };
@@ -27,6 +28,11 @@ struct Layer {
     float* attn_norm = nullptr;
     float* ffn_norm = nullptr;
     DevMat wq, wk, wv, wo, w_gate, w_up, w_down;
+    // falcon (llm_build_falcon, llama.cpp:2493-2798): LayerNorm biases, optional second norm (40B), fused QKV
+    float* attn_norm_b = nullptr;
+    float* attn_norm2 = nullptr;
+    float* attn_norm2_b = nullptr;
+    DevMat wqkv;
 };
 
 class Engine {
@@ -81,6 +87,7 @@ class Engine {
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
+    bool token_step_falcon(bool want_logits, std::string& err);
     bool run_matvec(::MatvecArgs& a, std::string& err);
     bool ensure_graphs(std::string& err);
     void free_all();
@@ -95,6 +102,8 @@ class Engine {
     float* xio_ = nullptr;  // [n_ctx][n_embd] residual-stream rows handed between pipeline stages (partial stages only)
     DevMat tok_embd_, output_;
     float* output_norm_ = nullptr;
+    float* output_norm_b_ = nullptr;
+    float *qkv_tmp_ = nullptr, *attn_proj_ = nullptr;   // falcon scratch: un-rotated fused QKV rows, Wo output
     std::vector<Layer> layers_;
     size_t weight_bytes_ = 0;
 

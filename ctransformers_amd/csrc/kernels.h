@@ -37,8 +37,10 @@ DEV int nearest_int_magic(float fval) {
     return (i & 0x007fffff) - 0x00400000;
 }
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_ROPE_Q = 2, EPI_ROPE_K = 3, EPI_V = 4, EPI_SILU_MUL = 5 };
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // LAYERNORM: ggml_norm, *w, +b (falcon, llama.cpp:2611-2614)
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_ROPE_Q = 2, EPI_ROPE_K = 3, EPI_V = 4, EPI_SILU_MUL = 5,
+       EPI_GELU = 6,     // out = gelu_table[fp16(y)]                       (falcon ffn_up, ggml.c:3568-3575)
+       EPI_ADD2 = 7 };   // out = (y + res) + res2                          (falcon: ffn + attn_out + inpL, llama.cpp:2763-2764)
 
 struct MatJob {
     DevMat w;
@@ -63,11 +65,14 @@ struct MatvecArgs {
     int K;              // input length
     int pro;            // PRO_*
     const float* x;     // input activation f32[K]
-    const float* norm_w;  // RMSNorm weight f32[K] (PRO_RMSNORM)
+    const float* norm_w;  // norm weight f32[K] (PRO_RMSNORM / PRO_LAYERNORM)
+    const float* norm_b;  // norm bias f32[K] (PRO_LAYERNORM)
     float eps;
     // epilogue operands
     float* out;             // EPI_STORE / EPI_ADD / EPI_SILU_MUL destination
-    const float* res;       // EPI_ADD residual
+    const float* res;       // EPI_ADD / EPI_ADD2 residual
+    const float* res2;      // EPI_ADD2 second residual
+    const uint16_t* gelu_tab;  // 65536-entry fp16->fp16 GELU table (EPI_GELU)
     uint16_t* q_f16;        // EPI_ROPE_Q destination (fp16 query, n_head*head_dim)
     uint16_t* kcache;       // this layer's K cache  [n_head_kv][n_ctx][head_dim] fp16 (kcache_off)
     uint16_t* vcache;       // this layer's V cache  [n_embd_gqa][n_ctx] fp16 (transposed, as the reference keeps it)
@@ -577,6 +582,62 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 // Device-side cursor {step, pos}: lets N token steps (eager launches or hipGraph replays) be queued back to back with
 // no host round trip — every kernel reads the position from memory, this one advances it.
 // state = {step, pos, n_total}; n_total (= n_past + N of the chunk) stays fixed for the whole chunk.
+// Falcon: the fused QKV mat-mul leaves f32 rows [Q heads | K heads | V heads]; rotate Q and K in NEOX mode (pairs
+// (i, i + head_dim/2), reference ggml.c:12543-12561; the reference build evaluates out[i] = fma(x0, cos, -(x1*sin)),
+// out[i + n/2] = fma(x0, sin, x1*cos) — oracle/mirror.c:mir_rope_neox) and store fp16 Q / K cache / V cache.
+// grid = n_head + 2*n_head_kv (one head each), head_dim/2 threads.
+__global__ void falcon_rope_store_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ q_f16, uint16_t* __restrict__ kcache,
+                                         uint16_t* __restrict__ vcache, const float* __restrict__ rope_cs, const int* __restrict__ pos_p,
+                                         int n_head, int n_head_kv, int head_dim, int n_ctx, int v_stride) {
+    const int hh = (int)blockIdx.x, i = (int)threadIdx.x, half = head_dim >> 1, pos = *pos_p;
+    if (i >= half) return;
+    const float* src = qkv + (size_t)hh * head_dim;
+    if (hh >= n_head + n_head_kv) {   // V head: plain f32 -> f16 into the transposed cache
+        const int row0 = (hh - n_head - n_head_kv) * head_dim;
+        vcache[(size_t)(row0 + i) * v_stride + pos] = f32_to_f16_bits(src[i]);
+        vcache[(size_t)(row0 + i + half) * v_stride + pos] = f32_to_f16_bits(src[i + half]);
+        return;
+    }
+    const float cs = rope_cs[((size_t)pos * half + i) * 2 + 0], sn = rope_cs[((size_t)pos * half + i) * 2 + 1];
+    const float x0 = src[i], x1 = src[i + half];
+    const float o0 = fmaf(x0, cs, -(x1 * sn)), o1 = fmaf(x0, sn, x1 * cs);
+    if (hh < n_head) {
+        q_f16[(size_t)hh * head_dim + i] = f32_to_f16_bits(o0);
+        q_f16[(size_t)hh * head_dim + i + half] = f32_to_f16_bits(o1);
+    } else {
+        const int row0 = (hh - n_head) * head_dim;
+        kcache[kcache_off(pos, row0 + i, head_dim, n_ctx)] = f32_to_f16_bits(o0);
+        kcache[kcache_off(pos, row0 + i + half, head_dim, n_ctx)] = f32_to_f16_bits(o1);
+    }
+}
+
+// LayerNorm of the final hidden state (falcon embeddings output): same arithmetic as the PRO_LAYERNORM prologue.
+template <int NT>
+__global__ void __launch_bounds__(NT) layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, int n, float eps) {
+    __shared__ double red[NT / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < n; i += NT) s += (double)x[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < NT / 64; ++k) tot += red[k];
+    const float mean = (float)(tot / (double)n);
+    __syncthreads();
+    double s2 = 0.0;
+    for (int i = tid; i < n; i += NT) { const float v = x[i] - mean; s2 += (double)(v * v); }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[wv] = s2;
+    __syncthreads();
+    double tot2 = 0.0;
+    for (int k = 0; k < NT / 64; ++k) tot2 += red[k];
+    const float variance = (float)(tot2 / (double)n);
+    const float scale = 1.0f / sqrtf(variance + eps);
+    for (int i = tid; i < n; i += NT) y[i] = (((x[i] - mean) * scale) * w[i]) + b[i];
+}
+
 // Pipeline-stage hand-off: row `step` of the [n_ctx][E] stage buffer <-> the working residual stream.
 // to_rows == 0: dst[i] = src[step*E + i] (stage input); to_rows == 1: dst[step*E + i] = src[i] (stage output).
 __global__ void stage_row_kernel(const float* src, float* dst, int E, const int* state, int to_rows) {

@@ -641,7 +641,7 @@ DEV void block_to_chain(int type, const uint8_t* rp, int b, const ActLdsX<MAXK>&
 // prologue_q8k_exact (reference k_quants.c:1191-1226 with the fused fma; RMSNorm ggml.c:10700-10716).
 template <int NT, int MAXK>
 DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
-                              float eps) {
+                              float eps, const float* __restrict__ nbias = nullptr) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, sub = tid & 15, grp = tid >> 4;
     constexpr int NW = NT / 64, NG = NT / 16;
@@ -686,6 +686,49 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
             const float mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + eps);
         }
+    } else if (pro == PRO_LAYERNORM) {
+        // ggml_compute_forward_norm_f32 (ggml.c:10605-10654): double sum -> f32 mean; v = x - mean; double sum of v*v ->
+        // f32 variance; scale = 1/sqrtf(variance + eps).  v replaces x in the registers.
+        double s1 = 0.0;
+        if (wave_live) {
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                if (grp + rd * NG < nblk) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s1 += (double)v[rd][k].x; s1 += (double)v[rd][k].y; s1 += (double)v[rd][k].z; s1 += (double)v[rd][k].w;
+                    }
+                }
+            }
+            s1 = wave_sum_fast(s1);
+        }
+        if (lane == 0) L.red[wv] = wave_live ? s1 : 0.0;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        __syncthreads();   // L.red is reused for the second moment
+        double s2 = 0.0;
+        if (wave_live) {
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                if (grp + rd * NG < nblk) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[rd][k].x -= mean; v[rd][k].y -= mean; v[rd][k].z -= mean; v[rd][k].w -= mean;
+                        s2 += (double)(v[rd][k].x * v[rd][k].x); s2 += (double)(v[rd][k].y * v[rd][k].y);
+                        s2 += (double)(v[rd][k].z * v[rd][k].z); s2 += (double)(v[rd][k].w * v[rd][k].w);
+                    }
+                }
+            }
+            s2 = wave_sum_fast(s2);
+        }
+        if (lane == 0) L.red[wv] = wave_live ? s2 : 0.0;
+        __syncthreads();
+        double tot2 = 0.0;
+        for (int w = 0; w < NW; ++w) tot2 += L.red[w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
     }
     if (wave_live) {
 #pragma unroll
@@ -696,12 +739,16 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
-                if (live && pro == PRO_RMSNORM) {
+                if (live && pro != PRO_PLAIN) {
                     const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
                     q.x = (q.x * scale) * w4.x;
                     q.y = (q.y * scale) * w4.y;
                     q.z = (q.z * scale) * w4.z;
                     q.w = (q.w * scale) * w4.w;
+                    if (pro == PRO_LAYERNORM) {
+                        const float4 b4 = *(const float4*)(nbias + b * 256 + sub * 16 + k * 4);
+                        q.x += b4.x; q.y += b4.y; q.z += b4.z; q.w += b4.w;
+                    }
                 }
                 t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
             }

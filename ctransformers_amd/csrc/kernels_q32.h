@@ -28,7 +28,8 @@ constexpr int kRecQ8_0 = 1088, kRecQ4_0 = 576;
 
 // (RMSNorm ->) Q8_0 into LDS.  1024 threads: 8 lanes per 32-block (lane l holds elements 4l..4l+3), 128 blocks per pass.
 template <int MAXK>
-DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps) {
+DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps,
+                       const float* __restrict__ nbias = nullptr) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, l = tid & 7;
     const int nblk = K >> 5;
     constexpr int PASSES = (MAXK / 32 + 127) / 128;
@@ -58,18 +59,52 @@ DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const fl
         for (int w = 0; w < 16; ++w) tot += L.red[w];
         const float mean = (float)(tot / (double)K);
         scale = 1.0f / sqrtf(mean + eps);
+    } else if (pro == PRO_LAYERNORM) {   // ggml.c:10605-10654, see prologue_q8k_exact16
+        double s1 = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            if ((tid >> 3) + ps * 128 < nblk) { s1 += (double)v[ps].x; s1 += (double)v[ps].y; s1 += (double)v[ps].z; s1 += (double)v[ps].w; }
+        s1 = wave_sum_fast(s1);
+        if (lane == 0) L.red[wv] = s1;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        __syncthreads();
+        double s2 = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if ((tid >> 3) + ps * 128 < nblk) {
+                v[ps].x -= mean; v[ps].y -= mean; v[ps].z -= mean; v[ps].w -= mean;
+                s2 += (double)(v[ps].x * v[ps].x); s2 += (double)(v[ps].y * v[ps].y);
+                s2 += (double)(v[ps].z * v[ps].z); s2 += (double)(v[ps].w * v[ps].w);
+            }
+        }
+        s2 = wave_sum_fast(s2);
+        if (lane == 0) L.red[wv] = s2;
+        __syncthreads();
+        double tot2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot2 += L.red[w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
     }
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int b = (tid >> 3) + ps * 128;
         const bool live = b < nblk;
         float4 t = v[ps];
-        if (live && pro == PRO_RMSNORM) {
+        if (live && pro != PRO_PLAIN) {
             const float4 w4 = *(const float4*)(nw + b * 32 + l * 4);
             t.x = (t.x * scale) * w4.x;
             t.y = (t.y * scale) * w4.y;
             t.z = (t.z * scale) * w4.z;
             t.w = (t.w * scale) * w4.w;
+            if (pro == PRO_LAYERNORM) {
+                const float4 b4 = *(const float4*)(nbias + b * 32 + l * 4);
+                t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+            }
         }
         float amax = fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w)));
         amax = fmaxf(amax, lane_xor1(amax));
@@ -153,7 +188,7 @@ __global__ void __launch_bounds__(1024) matvec_q32_kernel(const MatvecArgs a) {
     constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
     const int ng = a.K >> 7;
     const int pos = a.pos ? *a.pos : 0;
-    prologue_q8_0<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    prologue_q8_0<MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     const int r = lane >> 3, l = lane & 7;
     const int stride = (int)gridDim.x * 16;
     for (int it = (int)blockIdx.x * 16 + wv; it < a.n_pairs; it += stride) {
@@ -179,6 +214,10 @@ __global__ void __launch_bounds__(1024) matvec_q32_kernel(const MatvecArgs a) {
             if (own) a.out[row] = res;
         } else if (epi == EPI_V) {
             if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else if (epi == EPI_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+        } else if (epi == EPI_ADD2) {
+            if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;
@@ -222,7 +261,7 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
     const int NA = ng < 16 ? ng : 16;                 // waves that own block groups
     if (threadIdx.x < kQ32Slots) SM.ctr[threadIdx.x] = 0u;   // published by the prologue's barrier
     const int pos = a.pos ? *a.pos : 0;
-    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     if (wv >= NA) return;
     const int base = ng / NA, rem = ng % NA;
     const int gcnt = base + (wv < rem ? 1 : 0);
@@ -322,6 +361,10 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
             if (own) a.out[row] = res;
         } else if (epi == EPI_V) {
             if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else if (epi == EPI_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+        } else if (epi == EPI_ADD2) {
+            if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;

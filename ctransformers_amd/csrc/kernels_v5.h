@@ -290,7 +290,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     const int n_loc = first < n_items ? (n_items - first + stride - 1) / stride : 0;
     const int n_units = n_loc * upi;
     if (n_units == 0) {
-        if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+        if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
         return;
     }
     const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
@@ -330,7 +330,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (WITH_PROLOGUE ? 0 : 6);
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     if (trace) tr[2] = clock64_dev();
     const int n_rounds = (n_units + T - 1) / T;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
@@ -339,7 +339,7 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
         float res_in = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (wv == ((round_seq * T + t) & (NW - 1)) && cur[t].valid && !GU && a.job[cur[t].j].epi == EPI_ADD) {
+            if (wv == ((round_seq * T + t) & (NW - 1)) && cur[t].valid && !GU && (a.job[cur[t].j].epi == EPI_ADD || a.job[cur[t].j].epi == EPI_ADD2)) {
                 const int row = cur[t].tile * 8 + G.r;
                 if (row < cur[t].M) res_in = a.res[row];
             }
@@ -378,6 +378,10 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
                     if (own) a.out[row] = res;
                 } else if (epi == EPI_V) {
                     if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+                } else if (epi == EPI_GELU) {
+                    if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+                } else if (epi == EPI_ADD2) {
+                    if (own) a.out[row] = (res + res_in) + a.res2[row];
                 } else {
                     const float other = lane_xor8(res);
                     const int ip = (row % a.head_dim) >> 1;
@@ -477,7 +481,7 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
         float res_in = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !false && a.job[g.cur[t].j].epi == EPI_ADD) {
+            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !false && (a.job[g.cur[t].j].epi == EPI_ADD || a.job[g.cur[t].j].epi == EPI_ADD2)) {
                 const int row = g.cur[t].tile * 8 + G.r;
                 if (row < a.job[g.cur[t].j].w.M) res_in = a.res[row];
             }
@@ -517,6 +521,10 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
                     if (own) a.out[row] = res;
                 } else if (epi == EPI_V) {
                     if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+                } else if (epi == EPI_GELU) {
+                    if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+                } else if (epi == EPI_ADD2) {
+                    if (own) a.out[row] = (res + res_in) + a.res2[row];
                 } else {
                     const float other = lane_xor8(res);
                     const int ip = (row % a.head_dim) >> 1;
@@ -561,7 +569,7 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     group_begin<TA, S, T>(a, 0, a.n_groupA, ga, wv, G);
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     if (trace) tr[2] = clock64_dev();
     if constexpr (TB != 0) {
         // group B (the Q6_K matrix of a mixed launch) is the small one: two units per round keep its preloaded

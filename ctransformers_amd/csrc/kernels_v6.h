@@ -126,6 +126,10 @@ DEV void v6_duty(const MatvecArgs& a, SmemV6<MAXK, TCB, NBUF>& SM, const UnitV6 
                     if (own) a.out[row] = res;
                 } else if (epi == EPI_V) {
                     if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+                } else if (epi == EPI_GELU) {
+                    if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+                } else if (epi == EPI_ADD2) {
+                    if (own) a.out[row] = (res + res_in) + a.res2[row];
                 } else {
                     const float other = lane_xor8(res);
                     const int ip = (row % a.head_dim) >> 1;
@@ -165,7 +169,7 @@ DEV void v6_rounds(const MatvecArgs& a, GroupV6<TYPE, S, T, GU>& g, SmemV6<MAXK,
         if (!GU) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                if (wv == ((rs * T + t) & 15) && g.cur[t].valid && a.job[g.cur[t].j].epi == EPI_ADD) {
+                if (wv == ((rs * T + t) & 15) && g.cur[t].valid && (a.job[g.cur[t].j].epi == EPI_ADD || a.job[g.cur[t].j].epi == EPI_ADD2)) {
                     const int row = g.cur[t].tile * 8 + G.r;
                     if (row < a.job[g.cur[t].j].w.M) res_in = a.res[row];
                 }
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(1024) matvec_v6_kernel(const MatvecArgs a) {
     GroupV6<TA, S, T, GU> ga;
     v6_begin<TA, S, T, GU>(a, 0, a.n_groupA, ga, wv, G);
     if (trace) tr[1] = clock64_dev();
-    prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     if (trace) tr[2] = clock64_dev();
     if constexpr (TB != 0) {
         constexpr int T2 = T > 2 ? 2 : T;   // the Q6_K group of a mixed launch is the small one

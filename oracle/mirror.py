@@ -183,6 +183,28 @@ def rope(x, pos, freq_base=10000.0, freq_scale=1.0):
     return y
 
 
+def norm_mul_add(x, w, b, eps):
+    x, w, b = (np.ascontiguousarray(v, dtype=np.float32) for v in (x, w, b))
+    y = np.zeros_like(x)
+    lib().mir_norm_mul_add.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float]
+    lib().mir_norm_mul_add(_p(x), _p(w), _p(b), _p(y), x.size, float(eps))
+    return y
+
+
+def rope_neox(x, pos, freq_base=10000.0, freq_scale=1.0):
+    """x: [n_head, head_dim] f32 -> rotated copy (neox mode)."""
+    y = np.ascontiguousarray(x, dtype=np.float32).copy()
+    lib().mir_rope_neox.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_float]
+    lib().mir_rope_neox(_p(y), y.shape[0], y.shape[1], int(pos), float(freq_base), float(freq_scale))
+    return y
+
+
+def gelu(x):
+    lib().mir_gelu.restype = c_float
+    lib().mir_gelu.argtypes = [c_float]
+    return np.array([lib().mir_gelu(float(v)) for v in np.asarray(x, dtype=np.float32).ravel()], dtype=np.float32).reshape(np.shape(x))
+
+
 class _Falcon(Structure):
     _fields_ = [("n_vocab", c_int), ("n_embd", c_int), ("n_head", c_int), ("n_head_kv", c_int), ("n_layer", c_int),
                 ("n_ff", c_int), ("n_ctx", c_int), ("norm_eps", c_float), ("rope_freq_base", c_float),

@@ -18,9 +18,12 @@ from ctransformers_amd import gguf as G, synth  # noqa: E402
 from oracle import ref  # noqa: E402
 
 
-def model_golden(name, ftype, seed):
+def model_golden(name, ftype, seed, shape="llama-tiny"):
     path = os.path.join(HERE, name + ".gguf")
-    hp = synth.write_llama_gguf(path, "llama-tiny", ftype, seed=seed)
+    if shape.startswith("falcon"):
+        hp = synth.write_falcon_gguf(path, shape, ftype, seed=seed)
+    else:
+        hp = synth.write_llama_gguf(path, shape, ftype, seed=seed)
     cfg = dict(context_length=96, batch_size=8, threads=4)
     r = ref.open_llm(path, **cfg)
     prompt = synth.prompt_tokens(11, hp["n_vocab"])
@@ -90,11 +93,33 @@ def ops_golden():
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
 
 
+def falcon_ops_golden():
+    """Op-level vectors for the falcon-only ops: LayerNorm*w+b, neox RoPE, GELU through the fp16 table."""
+    rng = np.random.default_rng(4040)
+    ops = ref.GgmlOps()
+    out = {}
+    x = (rng.standard_normal(768) * 2.5 + 0.3).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(768)).astype(np.float32)
+    b = (0.2 * rng.standard_normal(768)).astype(np.float32)
+    out["ln_x"], out["ln_w"], out["ln_b"], out["ln_y"] = x, w, b, ops.norm_mul_add(x, w, b, 1e-5)
+    h = rng.standard_normal((3, 6, 64)).astype(np.float32)
+    out["neox_x"], out["neox_pos"] = h, np.array([0, 17, 301], dtype=np.int32)
+    out["neox_y"] = np.stack([ops.rope(h[i][None], int(p), mode=2)[0] for i, p in enumerate(out["neox_pos"])])
+    g = np.concatenate([(rng.standard_normal(1500) * 3).astype(np.float32), np.array([0.0, -0.0, 1e-8, 65504.0, -65504.0, 1e6], np.float32)])
+    out["gelu_x"], out["gelu_y"] = g, ops.gelu(g)
+    np.savez_compressed(os.path.join(HERE, "falcon_ops.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]   # e.g. `make_golden.py tiny-q80 tiny-q40` regenerates just those
-    for name, ftype, seed in (("tiny-q4km", "Q4_K_M", 3), ("tiny-q5km", "Q5_K_M", 4), ("tiny-q80", "Q8_0", 5), ("tiny-q40", "Q4_0", 6)):
+    for name, ftype, seed, shape in (("tiny-q4km", "Q4_K_M", 3, "llama-tiny"), ("tiny-q5km", "Q5_K_M", 4, "llama-tiny"),
+                                     ("tiny-q80", "Q8_0", 5, "llama-tiny"), ("tiny-q40", "Q4_0", 6, "llama-tiny"),
+                                     ("falcon-tiny-q4km", "Q4_K_M", 7, "falcon-tiny"),      # 40B style: two norms, GQA 4/2
+                                     ("falcon-tiny7-q4km", "Q4_K_M", 8, "falcon-tiny7")):   # 7B style: one norm, MQA 4/1
         if not only or name in only:
-            model_golden(name, ftype, seed)
+            model_golden(name, ftype, seed, shape)
     if not only or "ops" in only:
         ops_golden()
+    if not only or "falcon_ops" in only:
+        falcon_ops_golden()
     print("golden vectors written to", HERE)

@@ -16,11 +16,12 @@ def open_emu(emu_lib, name, **kw):
     return LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(**cfg), lib=emu_lib)
 
 
-@pytest.mark.parametrize("name,steps", [("tiny-q4km", 10), ("tiny-q5km", 4), ("tiny-q80", 4), ("tiny-q40", 4)])
+@pytest.mark.parametrize("name,steps", [("tiny-q4km", 10), ("tiny-q5km", 4), ("tiny-q80", 4), ("tiny-q40", 4),
+                                        ("falcon-tiny-q4km", 4), ("falcon-tiny7-q4km", 3)])
 def test_logits_bit_identical_to_reference(emu_lib, name, steps):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_emu(emu_lib, name)
-    assert m.model_type == "llama" and m.vocab_size == 512 and m.context_length == 96
+    assert m.model_type == ("falcon" if name.startswith("falcon") else "llama") and m.vocab_size == 512 and m.context_length == 96
     assert len(m.logits) == 0  # nothing evaluated yet
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])

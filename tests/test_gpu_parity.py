@@ -20,7 +20,7 @@ def open_hip(path, **kw):
     return LLM(path, config=Config(**cfg))  # default lib = the HIP build; raises if missing / no GPU
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40"])
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40", "falcon-tiny-q4km", "falcon-tiny7-q4km"])
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_golden_logits_bit_identical(name, graph, monkeypatch):
     monkeypatch.setenv("CT_AMD_GRAPH", graph)
@@ -68,10 +68,12 @@ def test_abi_semantics_on_gpu():
     ("llama-small", "Q8_0", 20, 40),     # config 3: 32-element blocks, Q8_0 activations (kernels_q32.h)
     ("llama-small", "Q4_0", 20, 40),     # Q4_0 layers + Q6_K head
     ("llama-7b-2l", "Q8_0", 33, 8),      # real 7B shapes: K = 4096 / 11008 (86 block groups), 32000-row Q8_0 head
+    ("falcon-small", "Q4_K_M", 40, 30),  # config 4 graph: LayerNorm x2, fused QKV (Q5_K), neox RoPE, GQA 16/2, GELU, Q8_0 head
+    ("falcon-tiny7", "Q8_0", 20, 50),    # 7B-style block (one norm, MQA) on the 32-element-block kernels
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
     p = str(tmp_path / "m.gguf")
-    hp = synth.write_llama_gguf(p, shape, ftype, seed=21)
+    hp = (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p, shape, ftype, seed=21)
     ctx = n_prompt + n_decode + 8
     r = ref.open_llm(p, context_length=ctx, batch_size=64, threads=8)
     m = open_hip(p, context_length=ctx, batch_size=64)

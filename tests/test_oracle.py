@@ -40,10 +40,20 @@ def test_rope_and_rmsnorm_bit_exact(mirror):
     assert np.array_equal(mirror.rms_norm_mul(OPS["norm_x"], OPS["norm_w"], 1e-5), OPS["norm_y"])
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_falcon_ops_bit_exact(mirror):
+    """LayerNorm*w+b, neox RoPE (the contraction form the reference build uses) and GELU through the fp16 table."""
+    f = np.load(os.path.join(GOLDEN, "falcon_ops.npz"))
+    assert np.array_equal(mirror.norm_mul_add(f["ln_x"], f["ln_w"], f["ln_b"], 1e-5), f["ln_y"])
+    for i, p in enumerate(f["neox_pos"]):
+        assert np.array_equal(mirror.rope_neox(f["neox_x"][i], int(p)), f["neox_y"][i])
+    assert np.array_equal(mirror.gelu(f["gelu_x"]), f["gelu_y"])
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40", "falcon-tiny-q4km", "falcon-tiny7-q4km"])
 def test_whole_model_bit_exact(mirror, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    m = mirror.MirrorLlama(os.path.join(GOLDEN, name + ".gguf"), 96)
+    cls = mirror.MirrorFalcon if name.startswith("falcon") else mirror.MirrorLlama
+    m = cls(os.path.join(GOLDEN, name + ".gguf"), 96)
     logits = m.eval(g["prompt"], 0)
     assert np.array_equal(logits, g["logits"][0])
     assert np.array_equal(m.embeddings, g["embeddings"][0])

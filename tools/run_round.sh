@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 40 tools/experiments/overlap_probe 2000
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
