@@ -34,7 +34,7 @@ template <int MAXK> struct ActLdsX {
 // Reference k_quants.c:1191-1226 with `iscale*x[j] + 12582912.f` fused into one fma as the reference build does.
 template <int NT, int MAXK>
 DEV void prologue_q8k_exact(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
-                            float eps) {
+                            float eps, const float* __restrict__ nbias = nullptr) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / 64;
@@ -64,18 +64,50 @@ DEV void prologue_q8k_exact(ActLdsX<MAXK>& L, const float* __restrict__ x, const
         for (int w = 0; w < NW; ++w) tot += L.red[w];
         const float mean = (float)(tot / (double)K);
         scale = 1.0f / sqrtf(mean + eps);
+    } else if (pro == PRO_LAYERNORM) {   // ggml.c:10605-10654 (see prologue_q8k_exact16)
+        double s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i)
+            if (wv + i * NW < nblk) { s1 += (double)v[i].x; s1 += (double)v[i].y; s1 += (double)v[i].z; s1 += (double)v[i].w; }
+        s1 = wave_sum(s1);
+        if (lane == 0) L.red[wv] = s1;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += L.red[w];
+        const float mean = (float)(tot / (double)K);
+        __syncthreads();
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (wv + i * NW < nblk) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                s2 += (double)(v[i].x * v[i].x); s2 += (double)(v[i].y * v[i].y);
+                s2 += (double)(v[i].z * v[i].z); s2 += (double)(v[i].w * v[i].w);
+            }
+        }
+        s2 = wave_sum(s2);
+        if (lane == 0) L.red[wv] = s2;
+        __syncthreads();
+        double tot2 = 0.0;
+        for (int w = 0; w < NW; ++w) tot2 += L.red[w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
     }
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
         const int b = wv + i * NW;
         if (b < nblk) {  // wave-uniform
             float4 t = v[i];
-            if (pro == PRO_RMSNORM) {
+            if (pro != PRO_PLAIN) {
                 const float4 w4 = *(const float4*)(nw + b * 256 + lane * 4);
                 t.x = (t.x * scale) * w4.x;
                 t.y = (t.y * scale) * w4.y;
                 t.z = (t.z * scale) * w4.z;
                 t.w = (t.w * scale) * w4.w;
+                if (pro == PRO_LAYERNORM) {
+                    const float4 b4 = *(const float4*)(nbias + b * 256 + lane * 4);
+                    t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+                }
             }
             const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
             const float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
@@ -254,7 +286,7 @@ template <int NT, int MAXK, int UB>
 __global__ void __launch_bounds__(NT) matvec_exact_kernel(const MatvecArgs a) {
     __shared__ ActLdsX<MAXK> L;
     const int lane = lane_id();
-    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
     constexpr int NW = NT / 64;
     const int gw = (int)blockIdx.x * NW + wave_id();
     const int W = (int)gridDim.x * NW;
@@ -282,6 +314,10 @@ __global__ void __launch_bounds__(NT) matvec_exact_kernel(const MatvecArgs a) {
             if (g == 0 && row < jb.w.M) a.out[row] = res + a.res[row];
         } else if (epi == EPI_V) {
             if (g == 0 && row < jb.w.M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else if (epi == EPI_GELU) {
+            if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+        } else if (epi == EPI_ADD2) {
+            if (g == 0 && row < jb.w.M) a.out[row] = (res + a.res[row]) + a.res2[row];
         } else {  // RoPE on the interleaved pair (row&~1, row|1): partner row lives in the neighbouring lane group
             const float other = __shfl_xor(res, 8);
             const int ip = (row % a.head_dim) >> 1;
@@ -1069,6 +1105,10 @@ __global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
             if (own) a.out[row] = res + a.res[row];
         } else if (epi == EPI_V) {
             if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else if (epi == EPI_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+        } else if (epi == EPI_ADD2) {
+            if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;

@@ -237,6 +237,8 @@ LLAMA_SHAPES = {
     "llama-small": dict(n_vocab=1024, n_embd=512, n_head=8, n_head_kv=8, n_layer=3, n_ff=1280),
     # two real-width 7B layers (per-layer kernels at their true shapes, cheap on the CPU side)
     "llama-7b-2l": dict(n_vocab=32000, n_embd=4096, n_head=32, n_head_kv=32, n_layer=2, n_ff=11008),
+    # two layers at the real Llama-2-70B widths (GQA 64/8, K = 8192 / 28672)
+    "llama-70b-2l": dict(n_vocab=32000, n_embd=8192, n_head=64, n_head_kv=8, n_layer=2, n_ff=28672),
 }
 
 
@@ -403,6 +405,8 @@ FALCON_SHAPES = {
     "falcon-tiny": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=2, n_layer=2, n_ff=1024, norm2=True),
     "falcon-tiny7": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=1, n_layer=2, n_ff=1024, norm2=False),
     "falcon-small": dict(n_vocab=1024, n_embd=1024, n_head=16, n_head_kv=2, n_layer=3, n_ff=4096, norm2=True),
+    # two layers at the real Falcon-40B widths (K = 8192 / 32768, 65024 x 8192 Q8_0 head)
+    "falcon-40b-2l": dict(n_vocab=65024, n_embd=8192, n_head=128, n_head_kv=8, n_layer=2, n_ff=32768, norm2=True),
 }
 
 

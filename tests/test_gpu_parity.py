@@ -70,6 +70,8 @@ def test_abi_semantics_on_gpu():
     ("llama-7b-2l", "Q8_0", 33, 8),      # real 7B shapes: K = 4096 / 11008 (86 block groups), 32000-row Q8_0 head
     ("falcon-small", "Q4_K_M", 40, 30),  # config 4 graph: LayerNorm x2, fused QKV (Q5_K), neox RoPE, GQA 16/2, GELU, Q8_0 head
     ("falcon-tiny7", "Q8_0", 20, 50),    # 7B-style block (one norm, MQA) on the 32-element-block kernels
+    ("falcon-40b-2l", "Q4_K_M", 9, 4),   # config 4 widths: K = 8192 (12288 instantiation) and K = 32768 (wide-K path), Q8_0 head
+    ("llama-70b-2l", "Q5_K_M", 9, 4),    # config 5 widths: GQA 64/8, K = 8192 / 28672, Q5_K + Q6_K
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
     p = str(tmp_path / "m.gguf")

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "40b or 70b" 2>&1 | tail -8
