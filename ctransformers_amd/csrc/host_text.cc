@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <map>
 #include <queue>
+#include <regex>
 
 #include "gguf_reader.h"
 
@@ -42,6 +43,18 @@ bool Vocab::load(const GgufFile& f, std::string& err) {
     if (f.get_u32("tokenizer.ggml.bos_token_id", v)) bos_id = (int)v;
     if (f.get_u32("tokenizer.ggml.eos_token_id", v)) eos_id = (int)v;
     if (f.get_u32("tokenizer.ggml.unknown_token_id", v)) unk_id = (int)v;
+    if (type == VOCAB_BPE) {   // merges -> ranks (reference llama.cpp:1691-1716: split at the first space after position 1)
+        const GgufValue* mg = f.find("tokenizer.ggml.merges");
+        if (!mg || mg->type != GV_ARR || mg->elem_type != GV_STR) { err = "cannot find tokenizer merges in model file"; return false; }
+        bpe_rank.reserve(mg->strs.size() * 2);
+        for (size_t i = 0; i < mg->strs.size(); ++i) {
+            const std::string& word = mg->strs[i];
+            std::string first, second;
+            const size_t pos = word.find(' ', 1);
+            if (pos != std::string::npos) { first = word.substr(0, pos); second = word.substr(pos + 1); }
+            bpe_rank.emplace(first + '\x01' + second, (int)i);
+        }
+    }
     return true;
 }
 
@@ -137,6 +150,87 @@ class SpmRun {
 };
 }  // namespace
 
+namespace {
+// Byte-level BPE as the reference runs it (llm_tokenizer_bpe, llama.cpp:3228-3388): GPT-2 pre-split with the same
+// std::regex pattern, symbols = UTF-8 characters, merge the adjacent pair of lowest rank first (ties: leftmost), ranks
+// looked up with ' ' -> U+0120 and '\n' -> U+010A substituted (find_bpe_rank :962-974), then whole-symbol vocabulary
+// lookup with per-byte fallback.
+class BpeRun {
+   public:
+    explicit BpeRun(const Vocab& v) : v_(v) {}
+    void run(const std::string& text, std::vector<int>& out) {
+        static const std::regex re(R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
+        std::string rest = text;
+        std::smatch m;
+        std::vector<std::string> words;
+        while (std::regex_search(rest, m, re)) {
+            for (auto x : m) words.push_back(x);
+            rest = m.suffix();
+        }
+        for (const std::string& word : words) {
+            struct S { int prev, next; size_t off, n; };
+            std::vector<S> sym;
+            size_t off = 0;
+            int idx = 0;
+            while (off < word.size()) {
+                const size_t n = std::min(word.size() - off, utf8_len(word[off]));
+                sym.push_back(S{idx - 1, off + n == word.size() ? -1 : idx + 1, off, n});
+                off += n;
+                ++idx;
+            }
+            struct B { int left, right, rank; std::string text; };
+            auto worse = [](const B& l, const B& r) { return l.rank > r.rank || (l.rank == r.rank && l.left > r.left); };
+            std::priority_queue<B, std::vector<B>, decltype(worse)> q(worse);
+            auto piece = [&](int i) { return word.substr(sym[i].off, sym[i].n); };
+            auto push = [&](int l, int r) {
+                if (l == -1 || r == -1) return;
+                const std::string lt = piece(l), rt = piece(r);
+                const int rank = rank_of(lt, rt);
+                if (rank < 0) return;
+                q.push(B{l, r, rank, lt + rt});
+            };
+            for (size_t i = 1; i < sym.size(); ++i) push((int)i - 1, (int)i);
+            while (!q.empty()) {
+                const B b = q.top();
+                q.pop();
+                S& L = sym[b.left];
+                S& R = sym[b.right];
+                if (L.n == 0 || R.n == 0) continue;
+                if (piece(b.left) + piece(b.right) != b.text) continue;   // outdated bigram
+                L.n += R.n;
+                R.n = 0;
+                L.next = R.next;
+                if (R.next >= 0) sym[R.next].prev = b.left;
+                push(L.prev, b.left);
+                push(b.left, L.next);
+            }
+            for (size_t i = 0; i < sym.size(); ++i) {
+                if (sym[i].n == 0) continue;
+                const std::string str = word.substr(sym[i].off, sym[i].n);
+                auto it = v_.to_id.find(str);
+                if (it != v_.to_id.end()) { out.push_back(it->second); continue; }
+                for (char c : str) {
+                    auto bt = v_.to_id.find(std::string(1, c));
+                    if (bt != v_.to_id.end()) out.push_back(bt->second);
+                    else fprintf(stderr, "ERROR: byte not found in vocab: '%c'\n", c);
+                }
+            }
+        }
+    }
+
+   private:
+    int rank_of(std::string l, std::string r) const {
+        replace_all(l, " ", "\xc4\xa0");
+        replace_all(l, "\n", "\xc4\x8a");
+        replace_all(r, " ", "\xc4\xa0");
+        replace_all(r, "\n", "\xc4\x8a");
+        auto it = v_.bpe_rank.find(l + '\x01' + r);
+        return it == v_.bpe_rank.end() ? -1 : it->second;
+    }
+    const Vocab& v_;
+};
+}  // namespace
+
 std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
     std::vector<int> out;
     if (add_bos && bos_id != -1) out.push_back(bos_id);
@@ -147,13 +241,8 @@ std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
         SpmRun run(*this);
         run.run(t, out);
     } else {
-        // BPE (Falcon) tokenizer is a §8(f) "next" row; until then fall back to byte-level lookup so ids are valid.
-        for (size_t off = 0; off < raw.size();) {
-            const size_t len = std::min(utf8_len(raw[off]), raw.size() - off);
-            auto it = to_id.find(raw.substr(off, len));
-            if (it != to_id.end()) out.push_back(it->second);
-            off += len;
-        }
+        BpeRun run(*this);
+        run.run(raw, out);
     }
     return out;
 }

@@ -23,6 +23,7 @@ struct Vocab {
     std::vector<float> score;
     std::vector<int> ttype;
     std::unordered_map<std::string, int> to_id;
+    std::unordered_map<std::string, int> bpe_rank;   // "left\x01right" -> merge rank (BPE vocabularies)
     int bos_id = 1, eos_id = 2, unk_id = 0;
 
     bool load(const GgufFile& f, std::string& err);

@@ -82,3 +82,15 @@ def test_sampler_chain_matches_reference(emu_lib):
         got = m.sample(top_k=int(k), top_p=float(p), temperature=float(temp), repetition_penalty=float(pen),
                        last_n_tokens=64, seed=int(seed))
         assert got == int(expect)
+
+
+def test_bpe_tokenizer_matches_reference(emu_lib):
+    """Falcon's byte-level BPE (reference llm_tokenizer_bpe, llama.cpp:3228-3388): ids produced by the reference build for
+    these strings are committed in tests/golden/falcon_bpe.json (generated with oracle/_ref on the falcon-tiny vocabulary)."""
+    import json
+    exp = json.load(open(os.path.join(GOLDEN, "falcon_bpe.json")))
+    m = open_emu(emu_lib, "falcon-tiny-q4km")
+    for text, ids in exp.items():
+        assert m.tokenize(text) == ids, repr(text)
+    assert m.tokenize("") == [] and m.eos_token_id == 11 and m.bos_token_id == 11
+    assert m.detokenize(m.tokenize("ab cd\n")) == "ab cd\n"
