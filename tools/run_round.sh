@@ -1,2 +1,3 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "40b or 70b" 2>&1 | tail -8
+timeout 800 python tools/big_models.py llama-2-70b 2>&1 | tail -2
+rm -f /tmp/llama-2-70b_Q5_K_M.gguf
