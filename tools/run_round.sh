@@ -1,3 +1,3 @@
 cd /root/repo
-timeout 800 python tools/big_models.py llama-2-70b 2>&1 | tail -2
-rm -f /tmp/llama-2-70b_Q5_K_M.gguf
+python __graft_entry__.py smoke 2>&1 | tail -2
+mv oracle/_ref oracle/_ref_hidden; python __graft_entry__.py smoke 2>&1 | tail -2; mv oracle/_ref_hidden oracle/_ref
