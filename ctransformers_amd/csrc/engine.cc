@@ -347,8 +347,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     }
     layers_.resize(hp_.n_layer);
     if (hp_.falcon()) {
-        if (l0_ != 0 || l1_ != hp_.n_layer) { err = "pipeline stages are implemented for the llama architecture only"; return false; }
-        for (int i = 0; i < hp_.n_layer; ++i) {
+        for (int i = l0_; i < l1_; ++i) {
             const std::string p = "blk." + std::to_string(i) + ".";
             Layer& L = layers_[i];
             if (!upload_f32(f.tensor(p + "attn_norm.weight"), &L.attn_norm, E, err)) return false;
@@ -361,9 +360,11 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
                 !mat(p + "ffn_up.weight", L.w_up, F, E) || !mat(p + "ffn_down.weight", L.w_down, E, F))
                 return false;
         }
-        if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
-        if (!upload_f32(f.tensor("output_norm.bias"), &output_norm_b_, E, err)) return false;
-        if (!mat("output.weight", output_, V, E)) return false;
+        if (l1_ == hp_.n_layer) {
+            if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
+            if (!upload_f32(f.tensor("output_norm.bias"), &output_norm_b_, E, err)) return false;
+            if (!mat("output.weight", output_, V, E)) return false;
+        }
         if (!dev_alloc(dev_allocs_, &qkv_tmp_, (size_t)(E + 2 * G), err) || !dev_alloc(dev_allocs_, &attn_proj_, (size_t)E, err))
             return false;
     } else {
@@ -786,9 +787,14 @@ bool Engine::token_step(bool want_logits, std::string& err) {
 bool Engine::token_step_falcon(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
-    if (site_on("embed")) {
-        CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
-                  (const int*)d_tokens_, (const int*)d_state_, x_);
+    if (l0_ == 0) {
+        if (site_on("embed")) {
+            CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+                      (const int*)d_tokens_, (const int*)d_state_, x_);
+        }
+    } else {  // inner pipeline stage: this token's residual-stream row was handed over by the previous stage
+        CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)xio_, x_, E,
+                  (const int*)d_state_, 0);
     }
     MatvecArgs base = MatvecArgs();
     base.rope_cs = rope_cs_;
@@ -802,10 +808,10 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
     base.eps = hp_.rms_eps;
     base.dbg = env_int("CT_AMD_DBG", 0);
     base.dbg_sink = scores_;
-    for (int il = 0; il < hp_.n_layer; ++il) {
+    for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
-        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * G;
-        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * G;
+        uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated)
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_LAYERNORM; a.x = x_;
@@ -876,7 +882,10 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
             }
         }
     }
-    if (want_logits) {
+    if (l1_ < hp_.n_layer) {  // hand this token's residual-stream row to the next stage
+        CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)x_, xio_, E,
+                  (const int*)d_state_, 1);
+    } else if (want_logits) {
         if (!only_site_)
             CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_,
                       (const float*)output_norm_b_, d_emb_, E, hp_.rms_eps);

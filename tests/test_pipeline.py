@@ -57,6 +57,22 @@ def test_stage_chain_equals_whole_model(emu_lib, mirror):
     assert not lib.ctransformers_llm_batch_eval(s1._h, (ctypes.c_int * 1)(1), 1, 0, 8, 1)
 
 
+def test_falcon_stage_chain(emu_lib, mirror):
+    """The falcon graph through two stages (40B-style block: two norms, GQA) == the reference goldens."""
+    path = os.path.join(GOLDEN, "falcon-tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "falcon-tiny-q4km.npz"))
+    lib = ctypes.CDLL(emu_lib)
+    s0 = pipeline.HipStage(path, 0, 1, context_length=96, device="cpu", lib=lib)
+    s1 = pipeline.HipStage(path, 1, 2, context_length=96, device="cpu", lib=lib)
+    prompt = [int(t) for t in g["prompt"]]
+    logits = s1.forward([0] * len(prompt), 0, s0.forward(prompt, 0))
+    assert np.array_equal(logits.numpy(), g["logits"][0])
+    t = int(g["greedy"][0])
+    logits = s1.forward([0], len(prompt), s0.forward([t], len(prompt)))
+    assert np.array_equal(logits.numpy(), g["logits"][1])
+    assert pipeline.model_dims(path)["arch"] == "falcon"
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
