@@ -11,6 +11,7 @@
 #include "gguf_reader.h"
 #include "kernels_v6.h"
 #include "kernels_q32.h"
+#include "kernels_ks.h"
 
 namespace ctamd {
 
@@ -88,7 +89,7 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     const int nb = m.nb, M = m.M;
     if (exact_ && is_kquant(t->type)) {
         // tile8 layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row.
-        const bool v4 = design_ == 4 && m.K <= 12288;
+        const bool v4 = design_ == 4 && m.K <= 32768;   // K <= 12288: generations 5/6; wider: the systolic kernel (kernels_ks.h)
         m.layout = v4 ? LAYOUT_TILE8S : LAYOUT_TILE8;
         const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
         std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
@@ -456,6 +457,20 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
         }
         return true;
     }
+    if (a.job[0].w.layout == LAYOUT_TILE8S && a.K > 12288) {   // wide rows: systolic K split, one type, plain epilogues
+        const int ty = a.job[0].w.type;
+        bool ok = !a.gateup && a.K <= 32768;
+        for (int j = 0; j < a.njobs; ++j) {
+            const int e = a.job[j].epi;
+            ok = ok && a.job[j].w.type == ty && (e == EPI_STORE || e == EPI_ADD || e == EPI_ADD2 || e == EPI_GELU);
+        }
+        if (!ok) { err = "wide-K mat-vec (K=" + std::to_string(a.K) + "): unsupported launch shape"; return false; }
+        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), b(1024);
+        if (ty == GT_Q4_K) CT_LAUNCH((matvec_ks_kernel<GT_Q4_K, 32768, 8>), g, b, s, a);
+        else if (ty == GT_Q5_K) CT_LAUNCH((matvec_ks_kernel<GT_Q5_K, 32768, 8>), g, b, s, a);
+        else CT_LAUNCH((matvec_ks_kernel<GT_Q6_K, 32768, 8>), g, b, s, a);
+        return true;
+    }
     if (a.job[0].w.layout == LAYOUT_TILE8S) {
         // generation 4: one 1024-thread workgroup per CU, two tiles per barrier round
         const int n_cu = chip_cus();
@@ -493,7 +508,7 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             static const int gen6 = env_int("CT_AMD_GEN6", 1);
             // launches with a single round per workgroup (wo: two units) gain nothing from the lagged chain duty and pay
             // for the counters: they stay on generation 5
-            if (gen6 && !(a.K <= 4096 && units_per_wg <= 2) && (a.K <= 4096 || (a.K <= 12288 && !a.gateup))) {
+            if (gen6 && !(a.K <= 4096 && units_per_wg <= 2) && (a.K <= 8192 || (a.K <= 12288 && !a.gateup))) {
                 // generation 6: same data flow, LDS-counter synchronisation (kernels_v6.h); dynamic LDS above 64 KB needs
                 // the per-function opt-in once
 #define V6L(MK, SS, TT, NB, TAV, TBV, GUV) do { \
@@ -515,6 +530,8 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
                 if (a.K <= 4096) {
                     if (nbuf == 3) { V6(4096, 1, 4, 3) }
                     else { V6(4096, 1, 4, 4) }
+                } else if (a.K <= 8192) {   // n_embd of Llama-2-70B / Falcon-40B: 32 blocks, two per wave
+                    V6(8192, 2, 2, 4)
                 } else {
                     if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);
                     else if (ta == GT_Q5_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q5_K, 0, false);

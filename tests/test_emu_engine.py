@@ -94,3 +94,17 @@ def test_bpe_tokenizer_matches_reference(emu_lib):
         assert m.tokenize(text) == ids, repr(text)
     assert m.tokenize("") == [] and m.eos_token_id == 11 and m.bos_token_id == 11
     assert m.detokenize(m.tokenize("ab cd\n")) == "ab cd\n"
+
+
+def test_wide_k_systolic_kernel(emu_lib, mirror, tmp_path):
+    """ffn_down with K > 12288 (70B / Falcon-40B class rows) runs on the systolic K-split kernel (kernels_ks.h): here a
+    Q6_K matrix (layer 0 is a use_more_bits layer) with 52 blocks over 16 waves (uneven split), checked against the
+    oracle.  (Q4_K / Q5_K at K = 28672 / 32768 are covered on hardware: tests/test_gpu_parity.py, 70b-2l / 40b-2l.)"""
+    from ctransformers_amd import synth
+    p = str(tmp_path / "wide.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q5_K_M", seed=31, overrides=dict(n_ff=13312, n_layer=1))
+    m = LLM(p, config=Config(context_length=32, batch_size=8, threads=1), lib=emu_lib)
+    o = mirror.MirrorLlama(p, 32)
+    toks = synth.prompt_tokens(2, hp["n_vocab"])
+    m.eval(toks)
+    assert np.array_equal(m.logits.to_numpy(), o.eval(toks, 0))
