@@ -499,6 +499,9 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
             if (a.gateup && ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, true>), g5, b5, s, a); \
             else if (a.gateup && ta == GT_Q5_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, true>), g5, b5, s, a); \
             else if (a.gateup) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, true>), g5, b5, s, a); \
+            else if (a.pro == PRO_LAYERNORM && ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, false, true>), g5, b5, s, a); \
+            else if (a.pro == PRO_LAYERNORM && ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, false, true>), g5, b5, s, a); \
+            else if (a.pro == PRO_LAYERNORM && ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, false, true>), g5, b5, s, a); \
             else if (ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, false>), g5, b5, s, a); \
             else if (ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, false>), g5, b5, s, a); \
             else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, false>), g5, b5, s, a); \
@@ -517,23 +520,37 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
                     static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
                     (void)once; \
                     CT_LAUNCH_DYN(kfn, g5, b5, smem, s, a); } while (0)
+#define V6LN(MK, SS, TT, NB, TAV) do { \
+                    auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, 0, false, true>; \
+                    constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
+                    static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
+                    (void)once; \
+                    CT_LAUNCH_DYN(kfn, g5, b5, smem, s, a); } while (0)
 #define V6(MK, SS, TT, NB) \
                 if (a.gateup && ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, 0, true); \
                 else if (a.gateup && ta == GT_Q5_K) V6L(MK, SS, TT, NB, GT_Q5_K, 0, true); \
                 else if (a.gateup) V6L(MK, SS, TT, NB, GT_Q6_K, 0, true); \
+                else if (ln && ta == GT_Q4_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q4_K); \
+                else if (ln && ta == GT_Q5_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q5_K); \
+                else if (ln && ta == GT_Q6_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q6_K); \
                 else if (ta == GT_Q4_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q4_K, 0, false); \
                 else if (ta == GT_Q5_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q5_K, 0, false); \
                 else if (ta == GT_Q6_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q6_K, 0, false); \
                 else if (ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false); \
                 else V6L(MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false);
                 static const int nbuf = env_int("CT_AMD_NBUF", 4);
+                const bool ln = a.pro == PRO_LAYERNORM;
+                if (ln && (a.gateup || tb != 0)) { err = "LayerNorm prologue with a gate/up or mixed-type launch"; return false; }
                 if (a.K <= 4096) {
                     if (nbuf == 3) { V6(4096, 1, 4, 3) }
                     else { V6(4096, 1, 4, 4) }
                 } else if (a.K <= 8192) {   // n_embd of Llama-2-70B / Falcon-40B: 32 blocks, two per wave
                     V6(8192, 2, 2, 4)
                 } else {
-                    if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);
+                    if (ln && ta == GT_Q4_K) V6LN(12288, 3, 2, 3, GT_Q4_K);
+                    else if (ln && ta == GT_Q5_K) V6LN(12288, 3, 2, 3, GT_Q5_K);
+                    else if (ln) V6LN(12288, 3, 2, 3, GT_Q6_K);
+                    else if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);
                     else if (ta == GT_Q5_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q5_K, 0, false);
                     else if (ta == GT_Q6_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q6_K, 0, false);
                     else if (ta == GT_Q4_K) V6L(12288, 3, 2, 3, GT_Q4_K, GT_Q6_K, false);
@@ -541,6 +558,7 @@ static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, 
                 }
 #undef V6
 #undef V6L
+#undef V6LN
                 return true;
             }
             static const int mixed_t = env_int("CT_AMD_MIXED_T", 4);

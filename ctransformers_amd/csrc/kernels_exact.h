@@ -675,8 +675,119 @@ DEV void block_to_chain(int type, const uint8_t* rp, int b, const ActLdsX<MAXK>&
 // Prologue, 16 lanes per 256-block: lane `sub` owns 16 consecutive elements, so the per-block reductions are 4 DPP
 // steps inside a row of 16 lanes and all 16 (32) blocks of a round proceed at once.  Same arithmetic as
 // prologue_q8k_exact (reference k_quants.c:1191-1226 with the fused fma; RMSNorm ggml.c:10700-10716).
+// Two copies on purpose: the LayerNorm form (falcon) needs more live registers; keeping it out of the RMSNorm / plain
+// function lets the register allocator treat the two call sites separately (with one merged body every mat-vec
+// instantiation started to spill and the Q6_K K=11008 kernel went from 16 to 27 us).
 template <int NT, int MAXK>
 DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
+                              float eps) {
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, sub = tid & 15, grp = tid >> 4;
+    constexpr int NW = NT / 64, NG = NT / 16;
+    constexpr int ROUNDS = (MAXK / 256 + NG - 1) / NG;
+    const int nblk = K >> 8;
+    // A wave whose four 16-lane rows are all past the last block has nothing to quantize: it must SKIP the arithmetic
+    // (wave-uniform branches), not run it predicated off — the prologue is VALU-issue bound (about 250 wave
+    // instructions), and for K = 4096 only 4 of the 16 waves (one per SIMD) are live.
+    const bool wave_live = uniform_int(wv * 4) < nblk;
+    float4 v[ROUNDS][4];
+    double s = 0.0;
+    if (wave_live) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int b = grp + rd * NG;
+            if (b < nblk) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
+                    if (pro == PRO_RMSNORM) {
+                        s += (double)(v[rd][k].x * v[rd][k].x);
+                        s += (double)(v[rd][k].y * v[rd][k].y);
+                        s += (double)(v[rd][k].z * v[rd][k].z);
+                        s += (double)(v[rd][k].w * v[rd][k].w);
+                    }
+                }
+            }
+        }
+    }
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {
+        if (wave_live) {
+            s = wave_sum_fast(s);
+            if (lane == 0) L.red[wv] = s;
+        } else if (lane == 0) {
+            L.red[wv] = 0.0;
+        }
+        __syncthreads();
+        if (wave_live) {
+            double tot = 0.0;
+            for (int w = 0; w < NW; ++w) tot += L.red[w];
+            const float mean = (float)(tot / (double)K);
+            scale = 1.0f / sqrtf(mean + eps);
+        }
+    }
+    if (wave_live) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int b = grp + rd * NG;
+            const bool live = b < nblk;            // uniform within a 16-lane row, may differ between rows of a wave
+            float t[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
+                if (live && pro == PRO_RMSNORM) {
+                    const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                    q.x = (q.x * scale) * w4.x;
+                    q.y = (q.y * scale) * w4.y;
+                    q.z = (q.z * scale) * w4.z;
+                    q.w = (q.w * scale) * w4.w;
+                }
+                t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
+            }
+            float am = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+            float amax = am;
+            amax = fmaxf(amax, lane_xor1(amax));
+            amax = fmaxf(amax, lane_xor2(amax));
+            amax = fmaxf(amax, lane_xor4(amax));
+            amax = fmaxf(amax, lane_xor8(amax));
+            // first element (lowest index) attaining amax keeps its sign
+            const unsigned long long hit = __ballot(am == amax);
+            const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
+            const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
+            float mine = 0.0f;
+#pragma unroll
+            for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
+            const float maxv = __shfl(mine, first);
+            int packed[4] = {0, 0, 0, 0}, s16 = 0;
+            float d = 0.0f;
+            if (amax != 0.0f) {
+                const float iscale = -128.f / maxv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int q = ((int)f32_to_bits(fmaf(iscale, t[e], 12582912.f)) & 0x007fffff) - 0x00400000;
+                    q = q > 127 ? 127 : q;
+                    packed[e >> 2] |= (q & 0xff) << (8 * (e & 3));
+                    s16 += q;
+                }
+                d = 1.0f / iscale;
+            }
+            const int s32 = s16 + lane_xor1(s16);
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) L.q8[b * 64 + sub * 4 + k] = packed[k];
+                L.bsums[b * 16 + sub] = s16;
+                if ((sub & 1) == 0) L.sb[b * 8 + (sub >> 1)] = s32;
+                if (sub == 0) L.yd[b] = d;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NT, int MAXK>
+DEV void prologue_q8k_exact16_ln(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
                               float eps, const float* __restrict__ nbias = nullptr) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, sub = tid & 15, grp = tid >> 4;

@@ -73,7 +73,7 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, const
     }
 }
 
-template <int TYPE, int MAXK, int MAXB>
+template <int TYPE, int MAXK, int MAXB>   // the wide-K launches (ffn_down) never carry a norm: PLAIN prologue only
 __global__ void __launch_bounds__(1024) matvec_ks_kernel(const MatvecArgs a) {
     static_assert(MAXB % 4 == 0, "blocks are processed four images at a time");
     __shared__ SmemKS<MAXK> SM;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(1024) matvec_ks_kernel(const MatvecArgs a) {
     const int NA = nb < 16 ? nb : 16;
     if (threadIdx.x < kKsSlots) SM.ctr[threadIdx.x] = 0u;
     const int pos = a.pos ? *a.pos : 0;
-    prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
     if (wv >= NA) return;
     const int base = nb / NA, rem = nb % NA;
     const int bcnt = base + (wv < rem ? 1 : 0);

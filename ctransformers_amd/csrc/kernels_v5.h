@@ -280,7 +280,7 @@ struct GroupInfo {           // one type-homogeneous group of jobs of a launch
 };
 
 // One group: every wave of the workgroup walks the group's units in rounds of T.
-template <int TYPE, int MAXK, int S, int T, int NBUF, bool WITH_PROLOGUE, bool GU>
+template <int TYPE, int MAXK, int S, int T, int NBUF, bool WITH_PROLOGUE, bool GU, bool LN>
 DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L,
                    ChainBuf5<MAXK / 256> (&CB)[NBUF][T], int lane, int wv, const LaneGeom& G, int pos, int& round_seq) {
     constexpr int NW = 16, MAXNB = MAXK / 256;
@@ -290,7 +290,10 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     const int n_loc = first < n_items ? (n_items - first + stride - 1) / stride : 0;
     const int n_units = n_loc * upi;
     if (n_units == 0) {
-        if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+        if constexpr (WITH_PROLOGUE) {
+            if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+            else prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+        }
         return;
     }
     const uint32_t rec = (uint32_t)tile8_record_bytes(TYPE);
@@ -330,7 +333,10 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (WITH_PROLOGUE ? 0 : 6);
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    if constexpr (WITH_PROLOGUE) prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    if constexpr (WITH_PROLOGUE) {
+        if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+        else prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
+    }
     if (trace) tr[2] = clock64_dev();
     const int n_rounds = (n_units + T - 1) / T;
     for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
@@ -546,7 +552,7 @@ DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MA
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: single group).  a.n_groupA = number of items in group A.
-template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU>
+template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU, bool LN = false>
 __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
@@ -561,7 +567,7 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     const int pos = a.pos ? *a.pos : 0;
     int round_seq = 0;
     if constexpr (TB == 0) {   // single type: the plain loop (the compiler schedules it better than the group-state form)
-        run_group<TA, MAXK, S, T, NBUF, true, GU>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
+        run_group<TA, MAXK, S, T, NBUF, true, GU, LN>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
         if (trace) tr[6] = clock64_dev();
         return;
     }
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     group_begin<TA, S, T>(a, 0, a.n_groupA, ga, wv, G);
     if (trace) tr[1] = clock64_dev();
     // the first weight loads are in flight while the activation vector is normalised / quantized
-    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);   // mixed-type launches: llama only
     if (trace) tr[2] = clock64_dev();
     if constexpr (TB != 0) {
         // group B (the Q6_K matrix of a mixed launch) is the small one: two units per round keep its preloaded

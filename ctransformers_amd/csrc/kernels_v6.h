@@ -202,7 +202,7 @@ DEV void v6_rounds(const MatvecArgs& a, GroupV6<TYPE, S, T, GU>& g, SmemV6<MAXK,
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: one group).  Dynamic LDS: sizeof(SmemV6<MAXK, T, NBUF>).
-template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU>
+template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU, bool LN = false>
 __global__ void __launch_bounds__(1024) matvec_v6_kernel(const MatvecArgs a) {
     static_assert(NBUF >= 2, "the lagged chain duty needs at least two slots (three to gain anything)");
     CT_DYN_SMEM(smem_raw);
@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(1024) matvec_v6_kernel(const MatvecArgs a) {
     GroupV6<TA, S, T, GU> ga;
     v6_begin<TA, S, T, GU>(a, 0, a.n_groupA, ga, wv, G);
     if (trace) tr[1] = clock64_dev();
-    prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    // LN (falcon's LayerNorm prologue) is a template parameter: merged into one body it cost every instantiation registers
+    if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    else prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
     if (trace) tr[2] = clock64_dev();
     if constexpr (TB != 0) {
         constexpr int T2 = T > 2 ? 2 : T;   // the Q6_K group of a mixed launch is the small one
