@@ -171,3 +171,43 @@ class GGUFFile:
             self.pos += n * dt.itemsize
             return arr
         return self._unpack(_SCALAR_FMT[vtype])[0]
+
+
+class LegacyGgmlFile:
+    """Reader of the pre-GGUF GGML container of the reference's legacy model loaders (here: gpt2, models/llms/gpt2.cc:61-381):
+    magic 0x67676d6c, 6 x i32 hparams (n_vocab, n_ctx, n_embd, n_head, n_layer, ftype), vocab (i32 count, then u32 len +
+    bytes each), tensors until EOF: i32 n_dims, i32 name_len, i32 type, dims, name, data (unaligned)."""
+
+    def __init__(self, path):
+        import struct
+        raw = np.memmap(path, dtype=np.uint8, mode="r")
+        off = 0
+
+        def rd(fmt):
+            nonlocal off
+            v = struct.unpack_from("<" + fmt, raw, off)
+            off += struct.calcsize("<" + fmt)
+            return v
+
+        (magic,) = rd("I")
+        if magic != 0x67676d6c:
+            raise ValueError("not a legacy GGML file")
+        n_vocab, n_ctx, n_embd, n_head, n_layer, ftype = rd("6i")
+        self.hparams = dict(n_vocab=n_vocab, n_ctx=n_ctx, n_embd=n_embd, n_head=n_head, n_layer=n_layer, ftype=ftype % 1000)
+        (nv,) = rd("i")
+        self.vocab = []
+        for _ in range(nv):
+            (ln,) = rd("I")
+            self.vocab.append(bytes(raw[off:off + ln]))
+            off += ln
+        self.tensors = {}
+        while off < raw.size:
+            n_dims, name_len, ttype = rd("3i")
+            dims = rd("%di" % n_dims)
+            name = bytes(raw[off:off + name_len]).decode("ascii")
+            off += name_len
+            n_el = int(np.prod(dims))
+            be, bb = TYPE_BLOCK[ttype]
+            nbytes = n_el // be * bb
+            self.tensors[name] = (tuple(dims), ttype, raw[off:off + nbytes])
+            off += nbytes

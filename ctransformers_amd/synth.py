@@ -511,3 +511,80 @@ def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ct
     w.write()
     hp.update(dict(head_dim=head_dim, ftype=ftype, norm_eps=norm_eps))
     return hp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPT-2, legacy (pre-GGUF) GGML file as read by the reference's gpt2_model_load (models/llms/gpt2.cc:61-381)
+# ---------------------------------------------------------------------------------------------------------------------
+GPT2_SHAPES = {
+    "gpt2-117m": dict(n_vocab=50257, n_ctx=1024, n_embd=768, n_head=12, n_layer=12),
+    "gpt2-tiny": dict(n_vocab=512, n_ctx=96, n_embd=256, n_head=4, n_layer=2),
+}
+
+
+def make_gpt2_vocab(n_vocab):
+    """Raw-byte pieces: the 256 single bytes, then two-letter and three-letter ASCII pieces (reference gpt_tokenize,
+    models/common.cc, looks pieces up as raw strings after its regex split)."""
+    toks = [bytes([b]) for b in range(256)]
+    i = 0
+    while len(toks) < n_vocab:
+        a, b, c = chr(ord("a") + (i % 26)), chr(ord("a") + ((i // 26) % 26)), chr(ord("a") + ((i // 676) % 26))
+        piece = (a + b) if i < 676 else (" " + a + b + c)
+        toks.append(piece.encode("ascii"))
+        i += 1
+    return toks[:n_vocab]
+
+
+def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm_head=False):
+    """Synthetic GPT-2 in the legacy GGML container (magic 0x67676d6c, 6 x i32 hparams, vocab, tensors; ftype 2 = Q4_0,
+    stored as ftype + 1000*GGML_QNT_VERSION).  Returns the hparams dict."""
+    import struct
+    hp = dict(GPT2_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
+    V, C, E, H, NL = hp["n_vocab"], hp["n_ctx"], hp["n_embd"], hp["n_head"], hp["n_layer"]
+    if pooled is None:
+        pooled = E >= 2048
+    src = _WeightSource(seed, pooled)
+    wtype = {2: G.Q4_0, 7: G.Q8_0}[ftype]
+    rng = np.random.default_rng(seed + 17)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 0x67676d6c))
+        f.write(struct.pack("<6i", V, C, E, H, NL, ftype + 1000 * 2))
+        toks = make_gpt2_vocab(V)
+        f.write(struct.pack("<i", V))
+        for t in toks:
+            f.write(struct.pack("<I", len(t)) + t)
+
+        def put(name, dims, ttype, data):
+            nb = name.encode("ascii")
+            f.write(struct.pack("<3i", len(dims), len(nb), ttype))
+            for d in dims:
+                f.write(struct.pack("<i", int(d)))
+            f.write(nb)
+            f.write(np.ascontiguousarray(data).tobytes())
+
+        def mat(name, rows, K, sigma):
+            put(name, (K, rows), wtype, src.matrix(rows, K, wtype, sigma))
+
+        def gain(name, n):
+            put(name, (n,), G.F32, src.norm(n))
+
+        def bias(name, n, s=0.1):
+            put(name, (n,), G.F32, (rng.standard_normal(n) * s).astype(np.float32))
+
+        s_e, s_f = 1.0 / np.sqrt(E), 1.0 / np.sqrt(4 * E)
+        gain("model/ln_f/g", E)
+        bias("model/ln_f/b", E)
+        mat("model/wte", V, E, 1.0)
+        put("model/wpe", (E, C), G.F32, (rng.standard_normal((C, E)) * 0.3).astype(np.float32))
+        if lm_head:
+            mat("model/lm_head", V, E, s_e)
+        for i in range(NL):
+            p = "model/h%d/" % i
+            gain(p + "ln_1/g", E); bias(p + "ln_1/b", E)
+            gain(p + "ln_2/g", E); bias(p + "ln_2/b", E)
+            mat(p + "attn/c_attn/w", 3 * E, E, s_e); bias(p + "attn/c_attn/b", 3 * E)
+            mat(p + "attn/c_proj/w", E, E, s_e); bias(p + "attn/c_proj/b", E)
+            mat(p + "mlp/c_fc/w", 4 * E, E, s_e); bias(p + "mlp/c_fc/b", 4 * E)
+            mat(p + "mlp/c_proj/w", E, 4 * E, s_f); bias(p + "mlp/c_proj/b", E)
+    hp.update(dict(ftype=ftype))
+    return hp

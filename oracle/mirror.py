@@ -281,3 +281,73 @@ class MirrorFalcon:
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         lib().mir_falcon_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits), _p(self.embeddings))
         return self.logits
+
+
+class _Gpt2(Structure):
+    _fields_ = [("n_vocab", c_int), ("n_ctx", c_int), ("n_embd", c_int), ("n_head", c_int), ("n_layer", c_int),
+                ("wte", c_void_p), ("wte_type", c_int), ("wpe", c_void_p), ("lm_head", c_void_p), ("lm_head_type", c_int),
+                ("ln_f_g", c_void_p), ("ln_f_b", c_void_p),
+                ("ln_1_g", c_void_p), ("ln_1_b", c_void_p), ("ln_2_g", c_void_p), ("ln_2_b", c_void_p),
+                ("c_attn_w", c_void_p), ("c_attn_b", c_void_p), ("c_proj_w", c_void_p), ("c_proj_b", c_void_p),
+                ("fc_w", c_void_p), ("fc_b", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p),
+                ("wtype", c_int), ("memory_k", c_void_p), ("memory_v", c_void_p)]
+
+
+class MirrorGpt2:
+    """The C restatement of gpt2_eval over a legacy GGML file (n_ctx comes from the file, like the reference)."""
+
+    def __init__(self, path):
+        self.f = G.LegacyGgmlFile(path)
+        hp = self.f.hparams
+        self.n_vocab, self.n_ctx, self.n_embd, self.n_layer = hp["n_vocab"], hp["n_ctx"], hp["n_embd"], hp["n_layer"]
+        self._keep = []
+        m = _Gpt2()
+        m.n_vocab, m.n_ctx, m.n_embd, m.n_head, m.n_layer = hp["n_vocab"], hp["n_ctx"], hp["n_embd"], hp["n_head"], hp["n_layer"]
+
+        def tensor(name):
+            shape, t, data = self.f.tensors[name]
+            arr = np.ascontiguousarray(data)
+            self._keep.append(arr)
+            return arr.ctypes.data, t
+
+        m.wte, m.wte_type = tensor("model/wte")
+        m.wpe, _ = tensor("model/wpe")
+        if "model/lm_head" in self.f.tensors:
+            m.lm_head, m.lm_head_type = tensor("model/lm_head")
+        else:
+            m.lm_head, m.lm_head_type = m.wte, m.wte_type
+        m.ln_f_g, _ = tensor("model/ln_f/g")
+        m.ln_f_b, _ = tensor("model/ln_f/b")
+
+        def per_layer(fmt):
+            ptrs = (c_void_p * self.n_layer)()
+            t = 0
+            for i in range(self.n_layer):
+                ptrs[i], t = tensor(fmt % i)
+            self._keep.append(ptrs)
+            return ctypes.cast(ptrs, c_void_p), t
+
+        m.ln_1_g, _ = per_layer("model/h%d/ln_1/g")
+        m.ln_1_b, _ = per_layer("model/h%d/ln_1/b")
+        m.ln_2_g, _ = per_layer("model/h%d/ln_2/g")
+        m.ln_2_b, _ = per_layer("model/h%d/ln_2/b")
+        m.c_attn_w, m.wtype = per_layer("model/h%d/attn/c_attn/w")
+        m.c_attn_b, _ = per_layer("model/h%d/attn/c_attn/b")
+        m.c_proj_w, _ = per_layer("model/h%d/attn/c_proj/w")
+        m.c_proj_b, _ = per_layer("model/h%d/attn/c_proj/b")
+        m.fc_w, _ = per_layer("model/h%d/mlp/c_fc/w")
+        m.fc_b, _ = per_layer("model/h%d/mlp/c_fc/b")
+        m.proj_w, _ = per_layer("model/h%d/mlp/c_proj/w")
+        m.proj_b, _ = per_layer("model/h%d/mlp/c_proj/b")
+        self.mk = np.zeros(self.n_layer * self.n_ctx * self.n_embd, dtype=np.float32)
+        self.mv = np.zeros(self.n_layer * self.n_ctx * self.n_embd, dtype=np.float32)
+        m.memory_k, m.memory_v = self.mk.ctypes.data, self.mv.ctypes.data
+        self.m = m
+        self.logits = np.zeros(self.n_vocab, dtype=np.float32)
+        lib().mir_gpt2_eval.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+        lib().mir_gpt2_eval.restype = c_int
+
+    def eval(self, tokens, n_past):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        lib().mir_gpt2_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits))
+        return self.logits

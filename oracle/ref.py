@@ -104,11 +104,12 @@ def matvec(weight_type, wraw, x, K):
     return np.array([vec_dot(weight_type, wraw[r], a, K) for r in range(M)], dtype=np.float32)
 
 
-def open_llm(path, **cfg):
-    """Whole-model oracle: the reference CPU implementation driven through the same Python host mirror."""
+def open_llm(path, model_type=None, **cfg):
+    """Whole-model oracle: the reference CPU implementation driven through the same Python host mirror.
+    model_type is needed for legacy (pre-GGUF) files, e.g. "gpt2"."""
     from ctransformers_amd.llm import LLM, Config
     lib()  # existence check
-    return LLM(path, config=Config(**cfg), lib=REF_LIB)
+    return LLM(path, model_type, config=Config(**cfg), lib=REF_LIB)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
