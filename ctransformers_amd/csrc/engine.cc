@@ -389,6 +389,13 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (l0_ > 0 || l1_ < hp_.n_layer)
         if (!dev_alloc(dev_allocs_, &xio_, (size_t)n_ctx_ * E, err)) return false;
 
+    if (!alloc_state(err)) return false;
+    HIP_OK(hipDeviceSynchronize());
+    return true;
+}
+
+bool Engine::alloc_state(std::string& err) {
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, V = hp_.n_vocab;
     v_stride_ = (n_ctx_ + 31) / 32 * 32;  // V rows (one per channel) start 16-byte aligned
     const size_t k_elems = (size_t)(l1_ - l0_) * n_ctx_ * G, v_elems = (size_t)(l1_ - l0_) * v_stride_ * G;
     if (!dev_alloc(dev_allocs_, &kcache_, k_elems, err) || !dev_alloc(dev_allocs_, &vcache_, v_elems + 64, err)) return false;
@@ -410,6 +417,93 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     memset(h_logits_, 0, (size_t)V * 4);
     memset(h_emb_, 0, (size_t)E * 4);
     if (!build_tables(err)) return false;
+    return true;
+}
+
+// GPT-2 from the legacy GGML container (reference gpt2_model_load, models/llms/gpt2.cc:61-381).
+bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
+        return false;
+    }
+    if (device < 0 || device >= ndev) { err = "HIP device ordinal out of range"; return false; }
+    device_ = device;
+    HIP_OK(hipSetDevice(device_));
+    exact_ = true;
+    design_ = 4;
+    LegacyGgmlFile f;
+    if (!f.open(path)) { err = f.error(); return false; }
+    hp_.arch = "gpt2";
+    hp_.n_vocab = f.hparams[0];
+    n_ctx_ = f.hparams[1];          // the reference sizes memory_k / memory_v and wpe from the file, not from the config
+    hp_.n_ctx_train = n_ctx_;
+    hp_.n_embd = f.hparams[2];
+    hp_.n_head = hp_.n_head_kv = f.hparams[3];
+    hp_.n_layer = f.hparams[4];
+    hp_.n_ff = 4 * hp_.n_embd;
+    hp_.n_rot = hp_.head_dim();
+    hp_.rms_eps = 1e-5f;            // ggml_norm(ctx, a) wrapper: models/common.h:211-213
+    if (n_ctx_ > kMaxCtx) { err = "context length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
+    if (hp_.n_embd % 128) { err = "gpt2: n_embd must be a multiple of 128 for the 32-block mat-vec kernels"; return false; }
+    vocab_.load_legacy(f.vocab);
+    l0_ = 0;
+    l1_ = hp_.n_layer;
+    HIP_OK(hipStreamCreate(&stream_));
+    const int E = hp_.n_embd, F = hp_.n_ff, V = hp_.n_vocab;
+    auto mat = [&](const std::string& name, DevMat& m, int M, int K) {
+        const GgufTensor* t = f.tensor(name);
+        if (!t) { err = "missing tensor " + name; return false; }
+        if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
+        if (t->type != GT_Q4_0 && t->type != GT_Q8_0) { err = name + ": only Q4_0 / Q8_0 legacy weights are supported"; return false; }
+        if (!upload_matrix(t, m, false, err)) return false;
+        weight_bytes_ += t->nbytes;
+        return true;
+    };
+    auto vec = [&](const std::string& name, float** out, int n) {
+        const GgufTensor* t = f.tensor(name);
+        if (!t || t->type != GT_F32 || t->ne[0] != n) { err = "bad or missing f32 tensor " + name; return false; }
+        return upload_f32(t, out, n, err);
+    };
+    const GgufTensor* wte = f.tensor("model/wte");
+    if (!wte || wte->ne[0] != E || wte->ne[1] != V) { err = "bad model/wte"; return false; }
+    {   // row lookup copy in file layout
+        tok_embd_.type = wte->type; tok_embd_.K = E; tok_embd_.M = V;
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, wte->nbytes, err)) return false;
+        HIP_OK(hipMemcpy(d, wte->data, wte->nbytes, hipMemcpyHostToDevice));
+        tok_embd_.raw = d;
+    }
+    {   // lm_head = its own tensor if the file has one, else the tied wte (gpt2.cc:357-368)
+        const bool own = f.tensor("model/lm_head") != nullptr;
+        if (!mat(own ? "model/lm_head" : "model/wte", output_, V, E)) return false;
+    }
+    {
+        const GgufTensor* t = f.tensor("model/wpe");
+        if (!t || t->type != GT_F32 || t->ne[0] != E || t->ne[1] != n_ctx_) { err = "bad model/wpe"; return false; }
+        if (!dev_alloc(dev_allocs_, &wpe_, (size_t)E * n_ctx_, err)) return false;
+        HIP_OK(hipMemcpy(wpe_, t->data, (size_t)E * n_ctx_ * 4, hipMemcpyHostToDevice));
+    }
+    if (!vec("model/ln_f/g", &output_norm_, E) || !vec("model/ln_f/b", &output_norm_b_, E)) return false;
+    layers_.resize(hp_.n_layer);
+    for (int i = 0; i < hp_.n_layer; ++i) {
+        const std::string p = "model/h" + std::to_string(i) + "/";
+        Layer& L = layers_[i];
+        if (!vec(p + "ln_1/g", &L.attn_norm, E) || !vec(p + "ln_1/b", &L.attn_norm_b, E) ||
+            !vec(p + "ln_2/g", &L.ffn_norm, E) || !vec(p + "ln_2/b", &L.ffn_norm_b, E) ||
+            !mat(p + "attn/c_attn/w", L.wqkv, 3 * E, E) || !vec(p + "attn/c_attn/b", &L.b_qkv, 3 * E) ||
+            !mat(p + "attn/c_proj/w", L.wo, E, E) || !vec(p + "attn/c_proj/b", &L.b_wo, E) ||
+            !mat(p + "mlp/c_fc/w", L.w_up, F, E) || !vec(p + "mlp/c_fc/b", &L.b_up, F) ||
+            !mat(p + "mlp/c_proj/w", L.w_down, E, F) || !vec(p + "mlp/c_proj/b", &L.b_down, E))
+            return false;
+    }
+    if (!dev_alloc(dev_allocs_, &qkv_tmp_, (size_t)3 * E, err) ||
+        !dev_alloc(dev_allocs_, &kmem_, (size_t)hp_.n_layer * n_ctx_ * E, err) ||
+        !dev_alloc(dev_allocs_, &vmem_, (size_t)hp_.n_layer * n_ctx_ * E, err))
+        return false;
+    HIP_OK(hipMemset(kmem_, 0, (size_t)hp_.n_layer * n_ctx_ * E * 4));
+    HIP_OK(hipMemset(vmem_, 0, (size_t)hp_.n_layer * n_ctx_ * E * 4));
+    if (!alloc_state(err)) return false;
     HIP_OK(hipDeviceSynchronize());
     return true;
 }
@@ -665,6 +759,7 @@ bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
 
 bool Engine::token_step(bool want_logits, std::string& err) {
     if (hp_.falcon()) return token_step_falcon(want_logits, err);
+    if (hp_.gpt2()) return token_step_gpt2(want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -935,6 +1030,66 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
         }
     }
     if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    return true;
+}
+
+// gpt2_eval (models/llms/gpt2.cc:391-699), one token: wte + wpe, then per layer
+//   LN(ln_1) -> Q8_0 -> c_attn + b -> [append K,V rows to the F32 cache] -> F32 attention -> c_proj + b -> + x
+//   LN(ln_2) -> Q8_0 -> c_fc + b -> GELU table -> Q8_0 -> c_proj + b -> + x;   final LN -> lm_head (tied wte)
+bool Engine::token_step_gpt2(bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+              (const int*)d_tokens_, (const int*)d_state_, x_, (const float*)wpe_);
+    MatvecArgs base = MatvecArgs();
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = E;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    base.dbg_sink = scores_;
+    const float kq_scale = 1.0f / (float)sqrt((double)((float)E / (float)hp_.n_head));   // gpt2.cc:540
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b;
+            a.out = qkv_tmp_; a.bias = L.b_qkv;
+            set_jobs(a, {{&L.wqkv, EPI_BIAS_STORE}});
+            if (!run_matvec(a, err)) return false;
+        }
+        CT_LAUNCH(attn_f32_exact_kernel, dim3((unsigned)hp_.n_head), dim3(256), stream_, (const float*)qkv_tmp_,
+                  kmem_ + (size_t)il * n_ctx_ * E, vmem_ + (size_t)il * n_ctx_ * E, attn_out_, (const uint16_t*)exp_tab_, d_pos,
+                  (const int*)(d_state_ + 2), E, hd, kq_scale);
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_; a.bias = L.b_wo;
+            set_jobs(a, {{&L.wo, EPI_BIAS_ADD}});
+            if (!run_matvec(a, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = L.ffn_norm; a.norm_b = L.ffn_norm_b; a.out = h_; a.bias = L.b_up;
+            set_jobs(a, {{&L.w_up, EPI_BIAS_GELU}});
+            if (!run_matvec(a, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_; a.bias = L.b_down;
+            set_jobs(a, {{&L.w_down, EPI_BIAS_ADD}});
+            if (!run_matvec(a, err)) return false;
+        }
+    }
+    if (want_logits) {
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     return true;
 }
 

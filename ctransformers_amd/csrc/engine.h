@@ -20,6 +20,7 @@ struct HParams {
     int n_vocab = 0, n_embd = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_ff = 0, n_rot = 0, n_ctx_train = 0;
     float rms_eps = 1e-5f, rope_freq_base = 10000.0f, rope_freq_scale = 1.0f;   // rms_eps doubles as falcon's LayerNorm eps
     bool falcon() const { return arch == "falcon"; }
+    bool gpt2() const { return arch == "gpt2"; }
     int head_dim() const { return n_embd / n_head; }
     int n_embd_gqa() const { return head_dim() * n_head_kv; }
 };
@@ -33,6 +34,9 @@ struct Layer {
     float* attn_norm2 = nullptr;
     float* attn_norm2_b = nullptr;
     DevMat wqkv;
+    // gpt2 (gpt2.cc:391-699): second norm (ln_2) reuses ffn_norm + ffn_norm_b; row biases of the four mat-muls
+    float* ffn_norm_b = nullptr;
+    float *b_qkv = nullptr, *b_wo = nullptr, *b_up = nullptr, *b_down = nullptr;
 };
 
 class Engine {
@@ -45,6 +49,8 @@ class Engine {
     // begin > 0 has no embedding table, a stage with end < n_layer has no output head.  `device` is the HIP ordinal.
     bool load(const std::string& path, int context_length, int gpu_layers, std::string& err, int layer_begin = -1,
               int layer_end = -1, int device = 0);
+    // Legacy (pre-GGUF) GGML file of the GPT-2 family (reference models/llms/gpt2.cc); n_ctx comes from the file.
+    bool load_gpt2(const std::string& path, std::string& err, int device = 0);
     // Evaluate `n` tokens at absolute positions n_past..n_past+n-1 (KV cache overwrite semantics); logits and the
     // final-norm embedding of the LAST token land in the pinned host buffers.
     bool eval(const int* tokens, int n, int n_past, std::string& err);
@@ -61,7 +67,7 @@ class Engine {
     float* logits() { return h_logits_; }
     int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
     const float* embeddings() const { return h_emb_; }
-    int embeddings_size() const { return have_logits_ ? hp_.n_embd : 0; }
+    int embeddings_size() const { return have_logits_ && !hp_.gpt2() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
 
     // Measurement hook (exported as ctamd_profile_decode): replays the LAST evaluated token `iters` times with eager
@@ -88,6 +94,8 @@ class Engine {
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
     bool token_step_falcon(bool want_logits, std::string& err);
+    bool token_step_gpt2(bool want_logits, std::string& err);
+    bool alloc_state(std::string& err);   // KV cache, scratch, pinned host buffers, tables
     bool run_matvec(::MatvecArgs& a, std::string& err);
     bool ensure_graphs(std::string& err);
     void free_all();
@@ -104,6 +112,8 @@ class Engine {
     float* output_norm_ = nullptr;
     float* output_norm_b_ = nullptr;
     float *qkv_tmp_ = nullptr, *attn_proj_ = nullptr;   // falcon scratch: un-rotated fused QKV rows, Wo output
+    float* wpe_ = nullptr;                              // gpt2 learned position embeddings [n_ctx][n_embd]
+    float *kmem_ = nullptr, *vmem_ = nullptr;           // gpt2 F32 KV cache [n_layer][n_ctx][n_embd] each
     std::vector<Layer> layers_;
     size_t weight_bytes_ = 0;
 

@@ -155,4 +155,60 @@ const GgufTensor* GgufFile::tensor(const std::string& name) const {
     return it == tindex_.end() ? nullptr : &tensors_[it->second];
 }
 
+LegacyGgmlFile::~LegacyGgmlFile() {
+    if (map_) munmap((void*)map_, size_);
+    if (fd_ >= 0) close(fd_);
+}
+
+bool LegacyGgmlFile::open(const std::string& path) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) return fail("cannot open " + path);
+    struct stat st;
+    if (fstat(fd_, &st) != 0) return fail("fstat failed");
+    size_ = (size_t)st.st_size;
+    void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (m == MAP_FAILED) return fail("mmap failed");
+    map_ = (const uint8_t*)m;
+    Cursor c{map_, map_ + size_};
+    if (c.get<uint32_t>() != 0x67676d6cu) return fail("not a legacy GGML file (bad magic)");
+    for (int i = 0; i < 6; ++i) hparams[i] = c.get<int32_t>();
+    hparams[5] %= 1000;   // GGML_QNT_VERSION_FACTOR (gpt2.cc:88-90)
+    const int32_t nv = c.get<int32_t>();
+    if (!c.ok || nv != hparams[0] || nv <= 0) return fail("bad vocabulary size");
+    vocab.reserve((size_t)nv);
+    for (int i = 0; i < nv; ++i) {
+        const uint32_t len = c.get<uint32_t>();
+        if (!c.ok || c.p + len > c.end) return fail("truncated vocabulary");
+        vocab.emplace_back((const char*)c.p, (size_t)len);
+        c.p += len;
+    }
+    while (c.p < c.end) {
+        GgufTensor t;
+        t.n_dims = c.get<int32_t>();
+        const int32_t name_len = c.get<int32_t>();
+        t.type = c.get<int32_t>();
+        if (!c.ok || t.n_dims < 1 || t.n_dims > 4 || name_len < 0) return fail("corrupt tensor header");
+        int64_t n_el = 1;
+        for (int i = 0; i < t.n_dims; ++i) { t.ne[i] = c.get<int32_t>(); n_el *= t.ne[i]; }
+        if (!c.ok || c.p + name_len > c.end) return fail("corrupt tensor name");
+        t.name.assign((const char*)c.p, (size_t)name_len);
+        c.p += name_len;
+        const int be = ggml_block_elems(t.type), bb = ggml_block_bytes(t.type);
+        if (be == 0 || n_el % be) return fail("tensor " + t.name + ": unsupported type " + std::to_string(t.type));
+        t.nbytes = (size_t)(n_el / be) * (size_t)bb;
+        if (c.p + t.nbytes > c.end) return fail("tensor " + t.name + ": truncated data");
+        t.data = c.p;
+        t.offset = (uint64_t)(c.p - map_);
+        c.p += t.nbytes;
+        tindex_[t.name] = tensors_.size();
+        tensors_.push_back(t);
+    }
+    return true;
+}
+
+const GgufTensor* LegacyGgmlFile::tensor(const std::string& name) const {
+    auto it = tindex_.find(name);
+    return it == tindex_.end() ? nullptr : &tensors_[it->second];
+}
+
 }  // namespace ctamd

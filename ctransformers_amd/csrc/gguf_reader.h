@@ -61,4 +61,26 @@ class GgufFile {
     std::map<std::string, size_t> tindex_;
 };
 
+// Pre-GGUF GGML container of the reference's legacy loaders (gpt2: models/llms/gpt2.cc:61-381): magic 0x67676d6c, six i32
+// hparams, vocabulary (i32 count; u32 length + bytes each), then tensors until EOF: i32 n_dims, i32 name_len, i32 type,
+// i32 dims, name, data (no alignment).
+class LegacyGgmlFile {
+   public:
+    ~LegacyGgmlFile();
+    bool open(const std::string& path);
+    const std::string& error() const { return err_; }
+    int32_t hparams[6] = {0, 0, 0, 0, 0, 0};   // n_vocab, n_ctx, n_embd, n_head, n_layer, ftype (quantization version stripped)
+    std::vector<std::string> vocab;
+    const GgufTensor* tensor(const std::string& name) const;
+
+   private:
+    bool fail(const std::string& m) { err_ = m; return false; }
+    std::string err_;
+    int fd_ = -1;
+    const uint8_t* map_ = nullptr;
+    size_t size_ = 0;
+    std::vector<GgufTensor> tensors_;
+    std::map<std::string, size_t> tindex_;
+};
+
 }  // namespace ctamd

@@ -8,6 +8,7 @@
 #include <map>
 #include <queue>
 #include <regex>
+#include <unordered_set>
 
 #include "gguf_reader.h"
 
@@ -56,6 +57,19 @@ bool Vocab::load(const GgufFile& f, std::string& err) {
         }
     }
     return true;
+}
+
+void Vocab::load_legacy(const std::vector<std::string>& pieces) {
+    type = VOCAB_GPT;
+    text = pieces;
+    score.assign(text.size(), 0.0f);
+    ttype.assign(text.size(), TT_NORMAL);
+    to_id.clear();
+    to_id.reserve(text.size() * 2);
+    for (size_t i = 0; i < text.size(); ++i) to_id[text[i]] = (int)i;
+    auto it = to_id.find("<|endoftext|>");
+    eos_id = bos_id = it == to_id.end() ? 0 : it->second;
+    unk_id = -1;
 }
 
 namespace {
@@ -233,6 +247,26 @@ class BpeRun {
 
 std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
     std::vector<int> out;
+    if (type == VOCAB_GPT) {   // gpt_tokenize (models/common.h:66-125; add_bos is ignored, models/llm.h:27-30): GPT-2 regex
+        static const std::regex re(R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
+        std::string rest = raw;    // split, then the LONGEST vocabulary piece at every position of every word
+        std::smatch m;
+        std::vector<std::string> words;
+        while (std::regex_search(rest, m, re)) {
+            for (auto x : m) words.push_back(x);
+            rest = m.suffix();
+        }
+        for (const std::string& word : words) {
+            for (int i = 0; i < (int)word.size();) {
+                for (int j = (int)word.size() - 1; j >= i; --j) {
+                    auto it = to_id.find(word.substr(i, j - i + 1));
+                    if (it != to_id.end()) { out.push_back(it->second); i = j + 1; break; }
+                    if (j == i) { fprintf(stderr, "gpt_tokenize: unknown token '%c'\n", word[i]); ++i; }
+                }
+            }
+        }
+        return out;
+    }
     if (add_bos && bos_id != -1) out.push_back(bos_id);
     if (raw.empty()) return out;
     if (type == VOCAB_SPM) {
@@ -240,7 +274,7 @@ std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
         replace_all(t, " ", "\xe2\x96\x81");
         SpmRun run(*this);
         run.run(t, out);
-    } else {
+    } else if (type == VOCAB_BPE) {
         BpeRun run(*this);
         run.run(raw, out);
     }
@@ -249,6 +283,7 @@ std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
 
 std::string Vocab::piece(int token) const {
     if (token < 0 || token >= size()) return std::string();
+    if (type == VOCAB_GPT) return text[token];
     const int tt = ttype[token];
     if (tt == TT_NORMAL) {
         std::string r = text[token];
@@ -332,6 +367,57 @@ int sample_token(const float* logits, int n_vocab, const int* last_tokens, int n
     for (size_t i = 0; i < size; ++i) probs[i] = c[i].p;
     std::discrete_distribution<> dist(probs.begin(), probs.end());
     return c[dist(rng)].id;
+}
+
+int sample_token_gpt(const float* logits, int n_vocab, const int* last_tokens, int n_last, int top_k, float top_p,
+                     float temperature, float repetition_penalty, int seed) {
+    if (seed < 0) seed = (int)time(nullptr);
+    std::mt19937 rng((unsigned)seed);
+    std::vector<std::pair<double, int>> lid;
+    lid.reserve((size_t)n_vocab);
+    const double temp = temperature;   // `double temp` parameter receives the float
+    const double scale = 1.0 / temp;
+    for (int i = 0; i < n_vocab; ++i) lid.push_back(std::make_pair(logits[i] * scale, i));
+    const std::unordered_set<int> recent(last_tokens, last_tokens + n_last);
+    for (const int token : recent) {
+        if (token < 0 || token >= n_vocab) continue;
+        double& logit = lid[(size_t)token].first;
+        if (logit <= 0) logit *= repetition_penalty;
+        else logit /= repetition_penalty;
+    }
+    if (top_k > n_vocab) top_k = n_vocab;
+    if (top_k < 1) top_k = 1;
+    std::partial_sort(lid.begin(), lid.begin() + top_k, lid.end(),
+                      [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    lid.resize((size_t)top_k);
+    double maxl = -INFINITY;
+    for (const auto& kv : lid) maxl = std::max(maxl, kv.first);
+    std::vector<double> probs;
+    probs.reserve(lid.size());
+    double sum = 0.0;
+    for (const auto& kv : lid) {
+        const double p = exp(kv.first - maxl);
+        probs.push_back(p);
+        sum += p;
+    }
+    for (auto& p : probs) p /= sum;
+    const double tp = top_p;
+    if (tp < 1.0f) {
+        double cumsum = 0.0f;
+        for (int i = 0; i < top_k; i++) {
+            cumsum += probs[(size_t)i];
+            if (cumsum >= tp) {
+                top_k = i + 1;
+                probs.resize((size_t)top_k);
+                lid.resize((size_t)top_k);
+                break;
+            }
+        }
+        cumsum = 1.0 / cumsum;
+        for (size_t i = 0; i < probs.size(); i++) probs[i] *= cumsum;
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return lid[(size_t)dist(rng)].second;
 }
 
 }  // namespace ctamd

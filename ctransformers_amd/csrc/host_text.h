@@ -14,7 +14,7 @@ namespace ctamd {
 
 class GgufFile;
 
-enum VocabType { VOCAB_SPM = 0, VOCAB_BPE = 1 };
+enum VocabType { VOCAB_SPM = 0, VOCAB_BPE = 1, VOCAB_GPT = 2 };   // GPT: legacy models (models/common.h gpt_vocab / gpt_tokenize)
 enum TokenType { TT_UNDEFINED = 0, TT_NORMAL = 1, TT_UNKNOWN = 2, TT_CONTROL = 3, TT_USER = 4, TT_UNUSED = 5, TT_BYTE = 6 };
 
 struct Vocab {
@@ -27,6 +27,8 @@ struct Vocab {
     int bos_id = 1, eos_id = 2, unk_id = 0;
 
     bool load(const GgufFile& f, std::string& err);
+    // legacy GGML files: raw pieces, eos = bos = id of "<|endoftext|>" or 0 (models/llm.h:104-110)
+    void load_legacy(const std::vector<std::string>& pieces);
     int size() const { return (int)text.size(); }
     std::vector<int> tokenize(const std::string& text, bool add_bos) const;
     std::string piece(int token) const;
@@ -35,5 +37,11 @@ struct Vocab {
 // repetition penalty -> top-k -> top-p -> temperature -> multinomial draw with std::mt19937(seed)
 int sample_token(const float* logits, int n_vocab, const int* last_tokens, int n_last, int top_k, float top_p,
                  float temperature, float repetition_penalty, int seed);
+
+// The legacy models' sampler (reference models/common.h:127-205 gpt_sample_top_k_top_p, called from LLM::Sample
+// models/llm.h:74-90): temperature scale, repetition penalty over the SET of recent tokens, partial sort of the top k,
+// double-precision softmax, top-p cut, std::mt19937(seed) + std::discrete_distribution.
+int sample_token_gpt(const float* logits, int n_vocab, const int* last_tokens, int n_last, int top_k, float top_p,
+                     float temperature, float repetition_penalty, int seed);
 
 }  // namespace ctamd

@@ -40,7 +40,10 @@ DEV int nearest_int_magic(float fval) {
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // LAYERNORM: ggml_norm, *w, +b (falcon, llama.cpp:2611-2614)
 enum { EPI_STORE = 0, EPI_ADD = 1, EPI_ROPE_Q = 2, EPI_ROPE_K = 3, EPI_V = 4, EPI_SILU_MUL = 5,
        EPI_GELU = 6,     // out = gelu_table[fp16(y)]                       (falcon ffn_up, ggml.c:3568-3575)
-       EPI_ADD2 = 7 };   // out = (y + res) + res2                          (falcon: ffn + attn_out + inpL, llama.cpp:2763-2764)
+       EPI_ADD2 = 7,     // out = (y + res) + res2                          (falcon: ffn + attn_out + inpL, llama.cpp:2763-2764)
+       EPI_BIAS_STORE = 8,   // out = bias + y                              (gpt2 c_attn, gpt2.cc:470-473)
+       EPI_BIAS_ADD = 9,     // out = (bias + y) + res                      (gpt2 c_proj / mlp proj + residual, gpt2.cc:590-600, :640-646)
+       EPI_BIAS_GELU = 10 }; // out = gelu_table[fp16(bias + y)]            (gpt2 mlp fc, gpt2.cc:625-631)
 
 struct MatJob {
     DevMat w;
@@ -72,6 +75,7 @@ struct MatvecArgs {
     float* out;             // EPI_STORE / EPI_ADD / EPI_SILU_MUL destination
     const float* res;       // EPI_ADD / EPI_ADD2 residual
     const float* res2;      // EPI_ADD2 second residual
+    const float* bias;      // EPI_BIAS_* row bias f32[M]
     const uint16_t* gelu_tab;  // 65536-entry fp16->fp16 GELU table (EPI_GELU)
     uint16_t* q_f16;        // EPI_ROPE_Q destination (fp16 query, n_head*head_dim)
     uint16_t* kcache;       // this layer's K cache  [n_head_kv][n_ctx][head_dim] fp16 (kcache_off)
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(NT) matvec_kq_kernel(const MatvecArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restrict__ raw, int type, int K,
                                                         const int* __restrict__ tokens, const int* __restrict__ state,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const float* __restrict__ wpe = nullptr) {
     const int token = tokens[state[0]];
     const uint8_t* row = raw + (size_t)token * ggml_row_bytes(type, K);
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < K; e += (int)(gridDim.x * blockDim.x)) {
@@ -449,6 +453,7 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
             const int is = l >> 4;
             y = d * (float)sc[is + 2 * grp] * (float)q;
         }
+        if (wpe) y = y + wpe[(size_t)state[1] * K + e];   // gpt2: wte[token] + wpe[pos] (gpt2.cc:441-444)
         out[e] = y;
     }
 }
@@ -636,6 +641,84 @@ __global__ void __launch_bounds__(NT) layernorm_f32_kernel(const float* __restri
     const float variance = (float)(tot2 / (double)n);
     const float scale = 1.0f / sqrtf(variance + eps);
     for (int i = tid; i < n; i += NT) y[i] = (((x[i] - mean) * scale) * w[i]) + b[i];
+}
+
+// GPT-2 attention over the F32 KV cache (reference gpt2.cc:476-585).  Both mat-muls are ggml_vec_dot_f32 (ggml.c:2355-2389,
+// AVX2: 4 accumulators x 8 f32 lanes, 32 elements per step, fma; the f16 dot's reduction tree; leftovers fmaf in float) —
+// restated per thread with the 32 accumulators in registers (this model family is the plumbing config, not a speed
+// target).  grid = n_head, 256 threads.  The workgroup first appends its head's slice of the new K / V rows
+// (qkv = [q | k | v] f32 rows from the c_attn launch) to the cache, which only this workgroup reads.
+DEV float dot_f32_reduce(const float (&s)[4][8]) {
+    float S[8], t0[4];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) S[l] = (s[0][l] + s[2][l]) + (s[1][l] + s[3][l]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t0[m] = S[m] + S[m + 4];
+    return (t0[0] + t0[1]) + (t0[2] + t0[3]);
+}
+__global__ void __launch_bounds__(256) attn_f32_exact_kernel(const float* __restrict__ qkv, float* __restrict__ kmem,
+                                                             float* __restrict__ vmem, float* __restrict__ out,
+                                                             const uint16_t* __restrict__ exp_tab, const int* __restrict__ pos_p,
+                                                             const int* __restrict__ n_total_p, int n_embd, int head_dim,
+                                                             float kq_scale) {
+    __shared__ float prob[kMaxCtx];
+    __shared__ double red[4];
+    __shared__ float redf[4];
+    const int h = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pos = *pos_p, n_kv = pos + 1, n_tot = *n_total_p, E = n_embd, hd = head_dim;
+    for (int i = tid; i < hd; i += 256) {
+        kmem[(size_t)pos * E + h * hd + i] = qkv[E + h * hd + i];
+        vmem[(size_t)pos * E + h * hd + i] = qkv[2 * E + h * hd + i];
+    }
+    __syncthreads();
+    const float* q = qkv + h * hd;
+    float mx = -INFINITY;
+    for (int p = tid; p < n_kv; p += 256) {
+        const float* k = kmem + (size_t)p * E + h * hd;
+        float s[4][8] = {};
+        const int np = hd & ~31;
+        for (int i = 0; i < np; i += 32)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) s[j][l] = fmaf(k[i + 8 * j + l], q[i + 8 * j + l], s[j][l]);
+        float sumf = dot_f32_reduce(s);
+        for (int i = np; i < hd; ++i) sumf = fmaf(k[i], q[i], sumf);
+        const float sc = sumf * kq_scale;
+        prob[p] = sc;
+        mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) redf[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double sum = 0.0;
+    for (int p = tid; p < n_kv; p += 256) {
+        const float e = f16_bits_to_f32(exp_tab[f32_to_f16_bits(prob[p] - mx)]);
+        prob[p] = e;
+        sum += (double)e;   // exact in any order: fp16 values in (0, 1]
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    const float inv = (float)(1.0 / tot);
+    for (int p = tid; p < n_kv; p += 256) prob[p] = prob[p] * inv;   // stays f32: V is F32, so no fp16 conversion of P
+    for (int p = n_kv + tid; p < n_tot; p += 256) prob[p] = 0.0f;     // masked columns of this batch
+    __syncthreads();
+    for (int d = tid; d < hd; d += 256) {
+        const float* v = vmem + h * hd + d;
+        float s[4][8] = {};
+        const int np = n_tot & ~31;
+        for (int i = 0; i < np; i += 32)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) s[j][l] = fmaf(v[(size_t)(i + 8 * j + l) * E], prob[i + 8 * j + l], s[j][l]);
+        float sumf = dot_f32_reduce(s);
+        for (int i = np; i < n_tot; ++i) sumf = fmaf(v[(size_t)i * E], prob[i], sumf);
+        out[h * hd + d] = sumf;
+    }
 }
 
 // Pipeline-stage hand-off: row `step` of the [n_ctx][E] stage buffer <-> the working residual stream.

@@ -218,6 +218,12 @@ __global__ void __launch_bounds__(1024) matvec_q32_kernel(const MatvecArgs a) {
             if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
         } else if (epi == EPI_ADD2) {
             if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
+        } else if (epi == EPI_BIAS_STORE) {
+            if (own) a.out[row] = a.bias[row] + res;
+        } else if (epi == EPI_BIAS_ADD) {
+            if (own) a.out[row] = (a.bias[row] + res) + a.res[row];
+        } else if (epi == EPI_BIAS_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(a.bias[row] + res)]);
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;
@@ -365,6 +371,12 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
             if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
         } else if (epi == EPI_ADD2) {
             if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
+        } else if (epi == EPI_BIAS_STORE) {
+            if (own) a.out[row] = a.bias[row] + res;
+        } else if (epi == EPI_BIAS_ADD) {
+            if (own) a.out[row] = (a.bias[row] + res) + a.res[row];
+        } else if (epi == EPI_BIAS_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(a.bias[row] + res)]);
         } else {
             const float other = lane_xor8(res);
             const int ip = (row % a.head_dim) >> 1;

@@ -574,7 +574,7 @@ def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm
         s_e, s_f = 1.0 / np.sqrt(E), 1.0 / np.sqrt(4 * E)
         gain("model/ln_f/g", E)
         bias("model/ln_f/b", E)
-        mat("model/wte", V, E, 1.0)
+        mat("model/wte", V, E, 0.06)   # small: the tied lm_head then gives a spread-out next-token distribution
         put("model/wpe", (E, C), G.F32, (rng.standard_normal((C, E)) * 0.3).astype(np.float32))
         if lm_head:
             mat("model/lm_head", V, E, s_e)

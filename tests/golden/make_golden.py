@@ -20,16 +20,21 @@ from oracle import ref  # noqa: E402
 
 def model_golden(name, ftype, seed, shape="llama-tiny"):
     path = os.path.join(HERE, name + ".gguf")
-    if shape.startswith("falcon"):
+    mt = None
+    if shape.startswith("gpt2"):
+        path = os.path.join(HERE, name + ".bin")     # legacy GGML container
+        hp = synth.write_gpt2_ggml(path, shape, seed=seed)
+        mt = "gpt2"
+    elif shape.startswith("falcon"):
         hp = synth.write_falcon_gguf(path, shape, ftype, seed=seed)
     else:
         hp = synth.write_llama_gguf(path, shape, ftype, seed=seed)
-    cfg = dict(context_length=96, batch_size=8, threads=4)
+    cfg = dict(context_length=96, batch_size=8, threads=4, model_type=mt)
     r = ref.open_llm(path, **cfg)
     prompt = synth.prompt_tokens(11, hp["n_vocab"])
     r.eval(prompt)
     logits = [r.logits.to_numpy().copy()]
-    emb = [r.embeddings.to_numpy().copy()]
+    emb = [r.embeddings.to_numpy().copy()]   # empty for legacy models
     toks = []
     for _ in range(40):
         t = r.sample(top_k=1, repetition_penalty=1.0)
@@ -45,10 +50,10 @@ def model_golden(name, ftype, seed, shape="llama-tiny"):
     # batch structure: a 45-token prompt as ONE batch vs in chunks of 8 (the reference's default batch_size) — the
     # results differ in the last bits once n_past+N crosses 32 (vec_dot_f16's fma/leftover split), both are golden.
     long_prompt = synth.prompt_tokens(45, hp["n_vocab"])
-    r2 = ref.open_llm(path, context_length=96, batch_size=64, threads=4)
+    r2 = ref.open_llm(path, context_length=96, batch_size=64, threads=4, model_type=mt)
     r2.eval(long_prompt)
     long_one = r2.logits.to_numpy().copy()
-    r3 = ref.open_llm(path, context_length=96, batch_size=8, threads=4)
+    r3 = ref.open_llm(path, context_length=96, batch_size=8, threads=4, model_type=mt)
     r3.eval(long_prompt)
     long_chunked = r3.logits.to_numpy().copy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), prompt=np.array(prompt, dtype=np.int32),
@@ -115,7 +120,8 @@ if __name__ == "__main__":
     for name, ftype, seed, shape in (("tiny-q4km", "Q4_K_M", 3, "llama-tiny"), ("tiny-q5km", "Q5_K_M", 4, "llama-tiny"),
                                      ("tiny-q80", "Q8_0", 5, "llama-tiny"), ("tiny-q40", "Q4_0", 6, "llama-tiny"),
                                      ("falcon-tiny-q4km", "Q4_K_M", 7, "falcon-tiny"),      # 40B style: two norms, GQA 4/2
-                                     ("falcon-tiny7-q4km", "Q4_K_M", 8, "falcon-tiny7")):   # 7B style: one norm, MQA 4/1
+                                     ("falcon-tiny7-q4km", "Q4_K_M", 8, "falcon-tiny7"),    # 7B style: one norm, MQA 4/1
+                                     ("gpt2-tiny-q40", "Q4_0", 9, "gpt2-tiny")):            # config 1 family: legacy GGML, F32 KV
         if not only or name in only:
             model_golden(name, ftype, seed, shape)
     if not only or "ops" in only:

@@ -13,19 +13,24 @@ from ctransformers_amd.llm import LLM, Config
 def open_emu(emu_lib, name, **kw):
     cfg = dict(context_length=96, batch_size=8, threads=1)
     cfg.update(kw)
+    if name.startswith("gpt2"):   # legacy GGML container: model_type is required, as with the reference
+        return LLM(os.path.join(GOLDEN, name + ".bin"), "gpt2", config=Config(**cfg), lib=emu_lib)
     return LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(**cfg), lib=emu_lib)
 
 
 @pytest.mark.parametrize("name,steps", [("tiny-q4km", 4), ("tiny-q5km", 2), ("tiny-q80", 2), ("tiny-q40", 2),
-                                        ("falcon-tiny-q4km", 2), ("falcon-tiny7-q4km", 2)])
+                                        ("falcon-tiny-q4km", 2), ("falcon-tiny7-q4km", 2), ("gpt2-tiny-q40", 2)])
 def test_logits_bit_identical_to_reference(emu_lib, name, steps):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_emu(emu_lib, name)
-    assert m.model_type == ("falcon" if name.startswith("falcon") else "llama") and m.vocab_size == 512 and m.context_length == 96
+    assert m.model_type == name.split("-")[0].replace("tiny", "llama") and m.vocab_size == 512 and m.context_length == 96
     assert len(m.logits) == 0  # nothing evaluated yet
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
-    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    if name.startswith("gpt2"):
+        assert len(m.embeddings) == 0   # legacy models expose no embeddings (reference models/llm.h:73)
+    else:
+        assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
     for i in range(steps):
         t = m.sample(top_k=1, repetition_penalty=1.0)
         assert t == int(g["greedy"][i])
@@ -108,3 +113,18 @@ def test_wide_k_systolic_kernel(emu_lib, mirror, tmp_path):
     toks = synth.prompt_tokens(2, hp["n_vocab"])
     m.eval(toks)
     assert np.array_equal(m.logits.to_numpy(), o.eval(toks, 0))
+
+
+def test_gpt2_tokenizer_and_sampler(emu_lib):
+    """Legacy-model host path (reference models/common.h): regex split + longest-piece tokenizer, raw detokenizer and the
+    double-precision top-k/top-p sampler; expectations generated with the reference build (tests/golden/make_golden.py)."""
+    import json
+    exp = json.load(open(os.path.join(GOLDEN, "gpt2_host.json")))
+    m = open_emu(emu_lib, "gpt2-tiny-q40")
+    for text, ids in exp["tokenize"].items():
+        assert m.tokenize(text) == ids, repr(text)
+    g = np.load(os.path.join(GOLDEN, "gpt2-tiny-q40.npz"))
+    m.eval(list(g["prompt"]))
+    for k, p, temp, pen, seed, tok in exp["samples"]:
+        assert m.sample(top_k=int(k), top_p=p, temperature=temp, repetition_penalty=pen, seed=int(seed)) == int(tok)
+    assert m.eos_token_id == 0 and m.bos_token_id == 0 and m.detokenize([300, 10]) == exp["detok_300_10"]
