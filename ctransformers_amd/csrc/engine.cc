@@ -87,10 +87,11 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     m.nb = m.K / be;
     m.bytes = t->nbytes;
     const int nb = m.nb, M = m.M;
-    if (exact_ && is_kquant(t->type)) {
-        // tile8 layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row.
-        const bool v4 = design_ == 4 && m.K <= 32768;   // K <= 12288: generations 5/6; wider: the systolic kernel (kernels_ks.h)
-        m.layout = v4 ? LAYOUT_TILE8S : LAYOUT_TILE8;
+    if (is_kquant(t->type)) {
+        // tile8S layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row, 6-bit scales re-encoded.
+        if (m.K > 32768) { err = "tensor " + t->name + ": rows longer than 32768 are not supported yet"; return false; }
+        constexpr bool v4 = true;
+        m.layout = LAYOUT_TILE8S;
         const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
         std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
         const uint8_t* src = t->data;
@@ -140,7 +141,7 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         m.p[0] = d;
         return true;
     }
-    if (exact_ && (t->type == GT_Q8_0 || t->type == GT_Q4_0)) {
+    {   // Q8_0 / Q4_0
         if (m.K % 128) { err = "tensor " + t->name + ": Q8_0/Q4_0 rows must be a multiple of 128 elements"; return false; }
         m.layout = LAYOUT_G4;
         const bool q8 = t->type == GT_Q8_0;
@@ -172,62 +173,6 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         m.p[0] = d;
         return true;
     }
-    int psz[4] = {0, 0, 0, 0};  // bytes per block in each plane
-    switch (t->type) {
-        case GT_Q4_K: psz[0] = 128; psz[1] = 16; break;
-        case GT_Q5_K: psz[0] = 128; psz[1] = 16; psz[2] = 32; break;
-        case GT_Q6_K: psz[0] = 128; psz[1] = 16; psz[2] = 64; psz[3] = 2; break;
-        case GT_Q8_0: psz[0] = 32; psz[3] = 2; break;
-        case GT_Q4_0: psz[0] = 16; psz[3] = 2; break;
-    }
-    std::vector<uint8_t> stage[4];
-    for (int k = 0; k < 4; ++k) stage[k].resize((size_t)psz[k] * nb * M);
-    const uint8_t* src = t->data;
-    const int type = t->type;
-    parallel_rows(M, [&](int r0, int r1) {
-        for (size_t i = (size_t)r0 * nb; i < (size_t)r1 * nb; ++i) {
-            const uint8_t* b = src + i * bb;
-            switch (type) {
-                case GT_Q4_K:
-                    memcpy(&stage[1][i * 16], b, 16);
-                    memcpy(&stage[0][i * 128], b + 16, 128);
-                    break;
-                case GT_Q5_K:
-                    memcpy(&stage[1][i * 16], b, 16);
-                    memcpy(&stage[2][i * 32], b + 16, 32);
-                    memcpy(&stage[0][i * 128], b + 48, 128);
-                    break;
-                case GT_Q6_K:
-                    memcpy(&stage[0][i * 128], b, 128);
-                    memcpy(&stage[2][i * 64], b + 128, 64);
-                    memcpy(&stage[1][i * 16], b + 192, 16);
-                    memcpy(&stage[3][i * 2], b + 208, 2);
-                    break;
-                case GT_Q8_0:
-                    memcpy(&stage[3][i * 2], b, 2);
-                    memcpy(&stage[0][i * 32], b + 2, 32);
-                    break;
-                case GT_Q4_0:
-                    memcpy(&stage[3][i * 2], b, 2);
-                    memcpy(&stage[0][i * 16], b + 2, 16);
-                    break;
-            }
-        }
-    });
-    for (int k = 0; k < 4; ++k) {
-        if (!psz[k]) continue;
-        uint8_t* d = nullptr;
-        if (!dev_alloc(dev_allocs_, &d, stage[k].size() + 64, err)) return false;  // +64: tail slack for 16-B loads
-        HIP_OK(hipMemcpy(d, stage[k].data(), stage[k].size(), hipMemcpyHostToDevice));
-        m.p[k] = d;
-    }
-    if (keep_raw) {
-        uint8_t* d = nullptr;
-        if (!dev_alloc(dev_allocs_, &d, t->nbytes, err)) return false;
-        HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
-        m.raw = d;
-    }
-    return true;
 }
 
 bool Engine::upload_f32(const GgufTensor* t, float** out, int n, std::string& err) {
@@ -283,12 +228,6 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     device_ = device;
     HIP_OK(hipSetDevice(device_));
     (void)gpu_layers;  // every layer lives on the GPU(s); the CPU/GPU split of the reference does not exist here
-    pairs_per_wave_ = std::max(1, env_int("CT_AMD_PPW", 2));
-    exact_ = env_int("CT_AMD_EXACT", 1) != 0;
-    design_ = env_int("CT_AMD_DESIGN", 4);
-    fused_attn_ = env_int("CT_AMD_FUSED_ATTN", 1) != 0;
-    items_per_wave_ = std::max(1, env_int("CT_AMD_IPW", 1));
-    max_wgs_ = std::max(1, env_int("CT_AMD_MAXWG", 1024));
 
     GgufFile f;
     if (!f.open(path)) { err = f.error(); return false; }
@@ -430,8 +369,6 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
     if (device < 0 || device >= ndev) { err = "HIP device ordinal out of range"; return false; }
     device_ = device;
     HIP_OK(hipSetDevice(device_));
-    exact_ = true;
-    design_ = 4;
     LegacyGgmlFile f;
     if (!f.open(path)) { err = f.error(); return false; }
     hp_.arch = "gpt2";
@@ -516,188 +453,121 @@ static int chip_cus() {
     return n_cu;
 }
 
-// Bit-exact path: work items are 8-row tiles.
-static bool launch_matvec_exact(MatvecArgs& a, int items_per_wave, int max_wgs, hipStream_t s, std::string& err) {
-    // convert pair bookkeeping (set_jobs) into tile bookkeeping
+// One mat-vec launch.  Work items are 8-row tiles ("units"); the jobs of a launch are concatenated into one item list.
+//   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h)
+//   LAYOUT_TILE8S, K > 12288           -> systolic wide-K K-quant kernel (kernels_ks.h)
+//   LAYOUT_TILE8S, K <= 12288          -> generation 6 (kernels_v6.h); launches with at most two units per workgroup and
+//                                         one weight type stay on generation 5 (one round: the counters buy nothing)
+static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
     int item0 = 0;
-    for (int j = 0; j < a.njobs; ++j) {
+    for (int j = 0; j < a.njobs; ++j) {   // set_jobs counted row pairs; the kernels count tiles
         a.job[j].pair0 = a.gateup ? 0 : item0;
         item0 += (a.job[j].w.M + 7) / 8;
     }
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
-    if (a.job[0].w.layout == LAYOUT_G4) {
-        const int ty = a.job[0].w.type;
+    const int ty = a.job[0].w.type, layout = a.job[0].w.layout;
+    const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
+    if (layout == LAYOUT_G4) {
         for (int j = 1; j < a.njobs; ++j)
             if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
         if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
         static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
-        if (systolic) {   // K split over the waves, accumulators handed from wave to wave (kernels_q32.h)
-            const dim3 gs((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), bs(1024);
-#define Q32S(TY, MG) do { if (a.gateup) CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, true>), gs, bs, s, a); \
-                          else CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, false>), gs, bs, s, a); } while (0)
-            const int per_wave = ((a.K >> 7) + 15) / 16;
-            if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
-            else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
-#undef Q32S
+        if (!systolic) {   // A/B: wave-per-tile form
+            const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16)));
+            if (ty == GT_Q8_0) {
+                if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, block, s, a);
+                else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, block, s, a);
+            } else {
+                if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, block, s, a);
+                else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, block, s, a);
+            }
             return true;
         }
-        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16))), b(1024);
-        if (ty == GT_Q8_0) {
-            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, b, s, a);
-            else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, b, s, a);
-        } else {
-            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, b, s, a);
-            else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, b, s, a);
-        }
+#define Q32S(TY, MG) do { if (a.gateup) CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, true>), grid, block, s, a); \
+                          else CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, false>), grid, block, s, a); } while (0)
+        const int per_wave = ((a.K >> 7) + 15) / 16;
+        if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
+        else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
+#undef Q32S
         return true;
     }
-    if (a.job[0].w.layout == LAYOUT_TILE8S && a.K > 12288) {   // wide rows: systolic K split, one type, plain epilogues
-        const int ty = a.job[0].w.type;
-        bool ok = !a.gateup && a.K <= 32768;
+    if (layout != LAYOUT_TILE8S) { err = "mat-vec: unknown weight layout"; return false; }
+    if (a.K > 12288) {   // wide rows: one type, plain epilogues (ffn_down of the 70B / Falcon-40B class)
+        bool ok = !a.gateup && a.K <= 32768 && a.pro == PRO_PLAIN;
         for (int j = 0; j < a.njobs; ++j) {
             const int e = a.job[j].epi;
             ok = ok && a.job[j].w.type == ty && (e == EPI_STORE || e == EPI_ADD || e == EPI_ADD2 || e == EPI_GELU);
         }
         if (!ok) { err = "wide-K mat-vec (K=" + std::to_string(a.K) + "): unsupported launch shape"; return false; }
-        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), b(1024);
-        if (ty == GT_Q4_K) CT_LAUNCH((matvec_ks_kernel<GT_Q4_K, 32768, 8>), g, b, s, a);
-        else if (ty == GT_Q5_K) CT_LAUNCH((matvec_ks_kernel<GT_Q5_K, 32768, 8>), g, b, s, a);
-        else CT_LAUNCH((matvec_ks_kernel<GT_Q6_K, 32768, 8>), g, b, s, a);
+        if (ty == GT_Q4_K) CT_LAUNCH((matvec_ks_kernel<GT_Q4_K, 32768, 8>), grid, block, s, a);
+        else if (ty == GT_Q5_K) CT_LAUNCH((matvec_ks_kernel<GT_Q5_K, 32768, 8>), grid, block, s, a);
+        else CT_LAUNCH((matvec_ks_kernel<GT_Q6_K, 32768, 8>), grid, block, s, a);
         return true;
     }
-    if (a.job[0].w.layout == LAYOUT_TILE8S) {
-        // generation 4: one 1024-thread workgroup per CU, two tiles per barrier round
-        const int n_cu = chip_cus();
-        static const int cap = env_int("CT_AMD_V4_WGS", 0);
-        const int rounds_total = a.gateup ? a.n_pairs : (a.n_pairs + 1) / 2;
-        const int max_w = cap > 0 ? cap : n_cu;
-        const int per_wg = (rounds_total + max_w - 1) / max_w;
-        const int wgs = std::max(1, (rounds_total + per_wg - 1) / per_wg);
-        // every workgroup must own at least one item: wgs <= n_pairs holds because rounds_total <= n_pairs
-        static const int gen = env_int("CT_AMD_GEN", 5);
-        // generation 5: type-specialised kernels; job groups must be (TA...)(TB...) with TB == Q6_K or absent
-        int ta = a.job[0].w.type, tb = 0, na = 0;
-        bool ok5 = gen == 5;
-        for (int j = 0; j < a.njobs && ok5; ++j) {
-            const int tj = a.job[j].w.type;
-            const int items = a.gateup ? (j == 0 ? a.n_pairs : 0) : (a.job[j].w.M + 7) / 8;
-            if (tj == ta && tb == 0) na += items;
-            else if (tb == 0 && tj == GT_Q6_K) tb = tj;
-            else if (tj != tb) ok5 = false;
-        }
-        if (a.gateup) { na = a.n_pairs; tb = 0; ok5 = ok5 && a.job[0].w.type == a.job[1].w.type; }
-        if (ok5) {
-            a.n_groupA = na;
-            const dim3 g5((unsigned)std::max(1, std::min(max_w, a.n_pairs))), b5(1024);
-#define V5(MK, SS, TT, NB) \
-            if (a.gateup && ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, true>), g5, b5, s, a); \
-            else if (a.gateup && ta == GT_Q5_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, true>), g5, b5, s, a); \
-            else if (a.gateup) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, true>), g5, b5, s, a); \
-            else if (a.pro == PRO_LAYERNORM && ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, false, true>), g5, b5, s, a); \
-            else if (a.pro == PRO_LAYERNORM && ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, false, true>), g5, b5, s, a); \
-            else if (a.pro == PRO_LAYERNORM && ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, false, true>), g5, b5, s, a); \
-            else if (ta == GT_Q4_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, 0, false>), g5, b5, s, a); \
-            else if (ta == GT_Q5_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, 0, false>), g5, b5, s, a); \
-            else if (ta == GT_Q6_K && tb == 0) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q6_K, 0, false>), g5, b5, s, a); \
-            else if (ta == GT_Q4_K) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false>), g5, b5, s, a); \
-            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false>), g5, b5, s, a);
-            const int units_per_wg = ((a.n_pairs + (int)g5.x - 1) / (int)g5.x) * (a.gateup ? 2 : 1);
-            static const int gen6 = env_int("CT_AMD_GEN6", 1);
-            // launches with a single round per workgroup (wo: two units) gain nothing from the lagged chain duty and pay
-            // for the counters: they stay on generation 5
-            if (gen6 && !(a.K <= 4096 && units_per_wg <= 2) && (a.K <= 8192 || (a.K <= 12288 && !a.gateup))) {
-                // generation 6: same data flow, LDS-counter synchronisation (kernels_v6.h); dynamic LDS above 64 KB needs
-                // the per-function opt-in once
-#define V6L(MK, SS, TT, NB, TAV, TBV, GUV) do { \
-                    auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, TBV, GUV>; \
-                    constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
-                    static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
-                    (void)once; \
-                    CT_LAUNCH_DYN(kfn, g5, b5, smem, s, a); } while (0)
-#define V6LN(MK, SS, TT, NB, TAV) do { \
-                    auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, 0, false, true>; \
-                    constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
-                    static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
-                    (void)once; \
-                    CT_LAUNCH_DYN(kfn, g5, b5, smem, s, a); } while (0)
-#define V6(MK, SS, TT, NB) \
-                if (a.gateup && ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, 0, true); \
-                else if (a.gateup && ta == GT_Q5_K) V6L(MK, SS, TT, NB, GT_Q5_K, 0, true); \
-                else if (a.gateup) V6L(MK, SS, TT, NB, GT_Q6_K, 0, true); \
-                else if (ln && ta == GT_Q4_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q4_K); \
-                else if (ln && ta == GT_Q5_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q5_K); \
-                else if (ln && ta == GT_Q6_K && tb == 0) V6LN(MK, SS, TT, NB, GT_Q6_K); \
-                else if (ta == GT_Q4_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q4_K, 0, false); \
-                else if (ta == GT_Q5_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q5_K, 0, false); \
-                else if (ta == GT_Q6_K && tb == 0) V6L(MK, SS, TT, NB, GT_Q6_K, 0, false); \
-                else if (ta == GT_Q4_K) V6L(MK, SS, TT, NB, GT_Q4_K, GT_Q6_K, false); \
-                else V6L(MK, SS, TT, NB, GT_Q5_K, GT_Q6_K, false);
-                static const int nbuf = env_int("CT_AMD_NBUF", 4);
-                const bool ln = a.pro == PRO_LAYERNORM;
-                if (ln && (a.gateup || tb != 0)) { err = "LayerNorm prologue with a gate/up or mixed-type launch"; return false; }
-                if (a.K <= 4096) {
-                    if (nbuf == 3) { V6(4096, 1, 4, 3) }
-                    else { V6(4096, 1, 4, 4) }
-                } else if (a.K <= 8192) {   // n_embd of Llama-2-70B / Falcon-40B: 32 blocks, two per wave
-                    V6(8192, 2, 2, 4)
-                } else {
-                    if (ln && ta == GT_Q4_K) V6LN(12288, 3, 2, 3, GT_Q4_K);
-                    else if (ln && ta == GT_Q5_K) V6LN(12288, 3, 2, 3, GT_Q5_K);
-                    else if (ln) V6LN(12288, 3, 2, 3, GT_Q6_K);
-                    else if (ta == GT_Q4_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q4_K, 0, false);
-                    else if (ta == GT_Q5_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q5_K, 0, false);
-                    else if (ta == GT_Q6_K && tb == 0) V6L(12288, 3, 2, 3, GT_Q6_K, 0, false);
-                    else if (ta == GT_Q4_K) V6L(12288, 3, 2, 3, GT_Q4_K, GT_Q6_K, false);
-                    else V6L(12288, 3, 2, 3, GT_Q5_K, GT_Q6_K, false);
-                }
-#undef V6
-#undef V6L
-#undef V6LN
-                return true;
-            }
-            static const int mixed_t = env_int("CT_AMD_MIXED_T", 4);
-            if (a.K <= 4096) { if (units_per_wg <= 2 || (tb != 0 && mixed_t == 2)) { V5(4096, 1, 2, 2) } else { V5(4096, 1, 4, 2) } } else { V5(12288, 3, 2, 1) }
+    // job groups: (TA ...)(TB ...) with TB == Q6_K or absent — K-quant files only ever mix one base type with Q6_K
+    int ta = ty, tb = 0, na = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const int tj = a.job[j].w.type;
+        if (a.job[j].w.layout != LAYOUT_TILE8S) { err = "mixed weight layouts in one launch"; return false; }
+        const int items = a.gateup ? (j == 0 ? a.n_pairs : 0) : (a.job[j].w.M + 7) / 8;
+        if (tj == ta && tb == 0) na += items;
+        else if (tb == 0 && tj == GT_Q6_K) tb = tj;
+        else if (tj != tb) { err = "unsupported weight-type mix in one launch"; return false; }
+    }
+    if (a.gateup) {
+        if (a.job[0].w.type != a.job[1].w.type) { err = "gate/up weight types differ"; return false; }
+        na = a.n_pairs;
+        tb = 0;
+    }
+    a.n_groupA = na;
+    const bool ln = a.pro == PRO_LAYERNORM;
+    if (ln && (a.gateup || tb != 0)) { err = "LayerNorm prologue with a gate/up or mixed-type launch"; return false; }
+    const int units_per_wg = ((a.n_pairs + (int)grid.x - 1) / (int)grid.x) * (a.gateup ? 2 : 1);
+    static const int gen6 = env_int("CT_AMD_GEN6", 1);   // 0: A/B, generation 5 wherever it can run
+    const bool v5_ok = tb == 0 && (a.K <= 4096 || !a.gateup);
+    if (v5_ok && ((a.K <= 4096 && units_per_wg <= 2) || !gen6)) {
+#define V5L(MK, SS, TT, NB, TAV) do { \
+            if (a.gateup) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, true, false>), grid, block, s, a); \
+            else if (ln) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, false, true>), grid, block, s, a); \
+            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, false, false>), grid, block, s, a); } while (0)
+#define V5(MK, SS, TT, NB) do { if (ta == GT_Q4_K) V5L(MK, SS, TT, NB, GT_Q4_K); else if (ta == GT_Q5_K) V5L(MK, SS, TT, NB, GT_Q5_K); \
+                                 else V5L(MK, SS, TT, NB, GT_Q6_K); } while (0)
+        if (a.K > 4096) V5(12288, 3, 2, 1);
+        else if (units_per_wg <= 2) V5(4096, 1, 2, 2);
+        else V5(4096, 1, 4, 2);
 #undef V5
-            return true;
-        }
-        if (a.K <= 4096) CT_LAUNCH((matvec_v4_kernel<4096, 1, 2>), dim3((unsigned)wgs), dim3(1024), s, a);
-        else CT_LAUNCH((matvec_v4_kernel<12288, 3, 1>), dim3((unsigned)wgs), dim3(1024), s, a);
+#undef V5L
         return true;
     }
-    static const int design = env_int("CT_AMD_DESIGN", 2);
-    if (design == 2 && a.K <= 12288) {
-        // design C: one tile per workgroup step, K split over the waves; persistent grid, balanced items per workgroup
-        const int per_wg = (a.n_pairs + max_wgs - 1) / max_wgs;
-        const int wgs = (a.n_pairs + per_wg - 1) / per_wg;
-        if (a.K <= 4096) CT_LAUNCH((matvec_exact2_kernel<256, 4096, 4>), dim3((unsigned)wgs), dim3(256), s, a);
-        else CT_LAUNCH((matvec_exact2_kernel<512, 12288, 2>), dim3((unsigned)wgs), dim3(512), s, a);
-        return true;
+    if (a.gateup && a.K > 8192) { err = "gate/up launch with K > 8192 not supported yet"; return false; }
+    // generation 6 uses dynamic LDS (up to 146 KB): the per-function opt-in is done once per instantiation
+#define V6L(MK, SS, TT, NB, TAV, TBV, GUV, LNV) do { \
+        auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, TBV, GUV, LNV>; \
+        constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
+        static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
+        (void)once; \
+        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
+#define V6T(MK, SS, TT, NB, TAV) do { \
+        if (a.gateup) V6L(MK, SS, TT, NB, TAV, 0, true, false); \
+        else if (ln) V6L(MK, SS, TT, NB, TAV, 0, false, true); \
+        else if (tb != 0) V6L(MK, SS, TT, NB, TAV, GT_Q6_K, false, false); \
+        else V6L(MK, SS, TT, NB, TAV, 0, false, false); } while (0)
+#define V6(MK, SS, TT, NB) do { if (ta == GT_Q4_K) V6T(MK, SS, TT, NB, GT_Q4_K); else if (ta == GT_Q5_K) V6T(MK, SS, TT, NB, GT_Q5_K); \
+                                 else V6L(MK, SS, TT, NB, GT_Q6_K, 0, false, false); } while (0)
+    if (ta == GT_Q6_K && (a.gateup || ln)) {   // all-Q6_K files: gate/up and LayerNorm launches of a Q6_K base type
+        if (a.K <= 4096) { if (a.gateup) V6L(4096, 1, 4, 4, GT_Q6_K, 0, true, false); else V6L(4096, 1, 4, 4, GT_Q6_K, 0, false, true); }
+        else if (a.K <= 8192) { if (a.gateup) V6L(8192, 2, 2, 4, GT_Q6_K, 0, true, false); else V6L(8192, 2, 2, 4, GT_Q6_K, 0, false, true); }
+        else V6L(12288, 3, 2, 3, GT_Q6_K, 0, false, true);
+    } else if (a.K <= 4096) {
+        V6(4096, 1, 4, 4);
+    } else if (a.K <= 8192) {   // n_embd of Llama-2-70B / Falcon-40B: 32 blocks, two per wave
+        V6(8192, 2, 2, 4);
+    } else {
+        V6(12288, 3, 2, 3);
     }
-    constexpr int NT = 256, NW = NT / 64;
-    const int waves = (a.n_pairs + items_per_wave - 1) / items_per_wave;
-    const int wgs = std::max(1, std::min(max_wgs, (waves + NW - 1) / NW));
-    const dim3 grid((unsigned)wgs), block((unsigned)NT);
-    if (a.K <= 12288) CT_LAUNCH((matvec_exact_kernel<NT, 12288, 4>), grid, block, s, a);
-    else if (a.K <= 32768) CT_LAUNCH((matvec_exact_kernel<NT, 32768, 4>), grid, block, s, a);
-    else { err = "mat-vec with K=" + std::to_string(a.K) + " not supported"; return false; }
-    return true;
-}
-
-static bool launch_matvec(MatvecArgs& a, int pairs_per_wave, int max_wgs, hipStream_t s, std::string& err) {
-    const int type0 = a.job[0].w.type;
-    if (!is_kquant(type0)) { err = "mat-vec kernel for weight type " + std::to_string(type0) + " not implemented yet"; return false; }
-    const int nb = a.job[0].w.nb;
-    const int need_i = (nb * 8 + 63) / 64;
-    constexpr int NT = 256, NW = NT / 64;
-    int waves = (a.n_pairs + pairs_per_wave - 1) / pairs_per_wave;
-    int wgs = std::max(1, std::min(max_wgs, (waves + NW - 1) / NW));
-    const dim3 grid((unsigned)wgs), block((unsigned)NT);
-    if (need_i <= 1) CT_LAUNCH((matvec_kq_kernel<NT, 1, 12288>), grid, block, s, a);
-    else if (need_i <= 2) CT_LAUNCH((matvec_kq_kernel<NT, 2, 12288>), grid, block, s, a);
-    else if (need_i <= 4) CT_LAUNCH((matvec_kq_kernel<NT, 4, 12288>), grid, block, s, a);
-    else if (need_i <= 6 && a.K <= 12288) CT_LAUNCH((matvec_kq_kernel<NT, 6, 12288>), grid, block, s, a);
-    else if (need_i <= 8) CT_LAUNCH((matvec_kq_kernel<NT, 8, 32768>), grid, block, s, a);
-    else { err = "mat-vec with K=" + std::to_string(a.K) + " not supported yet"; return false; }
+#undef V6
+#undef V6T
+#undef V6L
     return true;
 }
 
@@ -749,12 +619,22 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
     }
 }
 
-bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
-    static const int repeat = env_int("CT_AMD_REPEAT", 1);  // measurement only (breaks results): relaunch to see warm-cache timing
-    for (int r = 1; r < repeat; ++r)
-        if (!launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err)) return false;
-    if (a.job[0].w.layout != LAYOUT_PLANES) return launch_matvec_exact(a, items_per_wave_, max_wgs_, stream_, err);
-    return launch_matvec(a, pairs_per_wave_, max_wgs_, stream_, err);
+bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err); }
+
+// One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
+void Engine::launch_attention(uint16_t* kc, uint16_t* vc) {
+    const int hd = hp_.head_dim();
+    AttnArgsX ax = AttnArgsX();
+    ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.out = attn_out_; ax.pos = d_state_ + 1;
+    ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
+    ax.n_embd_gqa = hp_.n_embd_gqa(); ax.n_ctx = n_ctx_; ax.v_stride = v_stride_;
+    ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
+    if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
+    const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
+    if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
+    else if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
+    else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
+    else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
 }
 
 bool Engine::token_step(bool want_logits, std::string& err) {
@@ -784,22 +664,6 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     base.eps = hp_.rms_eps;
     base.dbg = env_int("CT_AMD_DBG", 0);
     base.dbg_sink = scores_;
-    AttnArgs at = AttnArgs();
-    at.q_f16 = q_f16_;
-    at.scores = scores_;
-    at.out = attn_out_;
-    at.pos = d_pos;
-    at.exp_tab = exp_tab_;
-    at.n_head = hp_.n_head;
-    at.n_head_kv = hp_.n_head_kv;
-    at.head_dim = hd;
-    at.n_embd_gqa = G;
-    at.n_ctx = n_ctx_;
-    at.v_stride = v_stride_;
-    at.kq_scale = 1.0f / sqrtf((float)E / (float)hp_.n_head);
-    at.chunk = 64;
-    const int n_chunks = (n_ctx_ + at.chunk - 1) / at.chunk;
-    constexpr int DCH = 16;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
@@ -817,39 +681,12 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             }
             debug_dump("1qkv", il);
         }
-        at.kcache = kc;
-        at.vcache = vc;
-        if (exact_) {
-            AttnArgsX ax = AttnArgsX();
-            ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
-            ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
-            ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = at.kq_scale;
-            if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
-            if (!site_on("attn_fused")) {
-            } else if (fused_attn_) {
-                prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
-                const int nt = env_int("CT_AMD_ATTN_NT", 512);
-                const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
-#define ATT(NTV, HDV) CT_LAUNCH((attn_fused_exact_kernel<NTV, HDV>), ag, dim3(NTV), stream_, ax)
-                if (hd == 128) { if (nt == 256) ATT(256, 128); else if (nt == 1024) ATT(1024, 128); else ATT(512, 128); }
-                else if (hd == 64) ATT(512, 64);
-                else if (hd == 192) ATT(512, 192);
-                else ATT(512, 256);
-#undef ATT
-                prof_end();
-            } else {
-                prof_begin("attn_scores", "attn_scores_exact_kernel", 0.0);
-                CT_LAUNCH(attn_scores_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)((n_ctx_ + 63) / 64)), dim3(256), stream_, ax);
-                prof_end();
-                prof_begin("attn_softmax_pv", "attn_softmax_pv_exact_kernel", 0.0);
-                CT_LAUNCH(attn_softmax_pv_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)(hd / 64)), dim3(256), stream_, ax);
-                prof_end();
-            }
-            debug_dump("2attn", il);
-        } else {
-            CT_LAUNCH((attn_scores_kernel<256>), dim3((unsigned)hp_.n_head, (unsigned)n_chunks), dim3(256), stream_, at);
-            CT_LAUNCH((attn_softmax_pv_kernel<256, DCH>), dim3((unsigned)hp_.n_head, (unsigned)(hd / DCH)), dim3(256), stream_, at);
+        if (site_on("attn_fused")) {
+            prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+            launch_attention(kc, vc);
+            prof_end();
         }
+        debug_dump("2attn", il);
         {   // Q8_K(attn) -> Wo -> + residual
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
@@ -963,20 +800,10 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
                       v_stride_);
             prof_end();
         }
-        {
-            AttnArgsX ax = AttnArgsX();
-            ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.scores = scores_; ax.out = attn_out_; ax.pos = d_pos;
-            ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
-            ax.n_embd_gqa = G; ax.n_ctx = n_ctx_; ax.v_stride = v_stride_; ax.kq_scale = 1.0f / sqrtf((float)E / (float)hp_.n_head);
-            if (site_on("attn_fused")) {
-                prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
-                const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
-                if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
-                else if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
-                else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
-                else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
-                prof_end();
-            }
+        if (site_on("attn_fused")) {
+            prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+            launch_attention(kc, vc);
+            prof_end();
         }
         {   // Q8_K(attn) -> Wo  (kept apart: the residual is added after the MLP)
             MatvecArgs a = base;

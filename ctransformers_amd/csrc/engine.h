@@ -93,6 +93,7 @@ class Engine {
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
+    void launch_attention(uint16_t* kc, uint16_t* vc);
     bool token_step_falcon(bool want_logits, std::string& err);
     bool token_step_gpt2(bool want_logits, std::string& err);
     bool alloc_state(std::string& err);   // KV cache, scratch, pinned host buffers, tables
@@ -138,9 +139,6 @@ class Engine {
     void prof_begin(const char* site, const char* kernel, double bytes);
     void prof_end();
     std::vector<void*> dev_allocs_;
-    int pairs_per_wave_ = 2, max_wgs_ = 2048, items_per_wave_ = 1;
-    bool exact_ = true, fused_attn_ = true;
-    int design_ = 4;
 };
 
 }  // namespace ctamd

@@ -32,308 +32,6 @@ template <int MAXK> struct ActLdsX {
 
 // Prologue: (RMSNorm ->) Q8_K into LDS, values held in registers between the two phases (one global read of x).
 // Reference k_quants.c:1191-1226 with `iscale*x[j] + 12582912.f` fused into one fma as the reference build does.
-template <int NT, int MAXK>
-DEV void prologue_q8k_exact(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
-                            float eps, const float* __restrict__ nbias = nullptr) {
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    constexpr int NW = NT / 64;
-    constexpr int MAXB = (MAXK / 256 + NW - 1) / NW;  // blocks per wave
-    const int nblk = K >> 8;
-    float4 v[MAXB];
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int b = wv + i * NW;
-        if (b < nblk) {
-            v[i] = *(const float4*)(x + b * 256 + lane * 4);
-            if (pro == PRO_RMSNORM) {
-                s += (double)(v[i].x * v[i].x);
-                s += (double)(v[i].y * v[i].y);
-                s += (double)(v[i].z * v[i].z);
-                s += (double)(v[i].w * v[i].w);
-            }
-        }
-    }
-    float scale = 1.0f;
-    if (pro == PRO_RMSNORM) {
-        s = wave_sum(s);
-        if (lane == 0) L.red[wv] = s;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += L.red[w];
-        const float mean = (float)(tot / (double)K);
-        scale = 1.0f / sqrtf(mean + eps);
-    } else if (pro == PRO_LAYERNORM) {   // ggml.c:10605-10654 (see prologue_q8k_exact16)
-        double s1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < MAXB; ++i)
-            if (wv + i * NW < nblk) { s1 += (double)v[i].x; s1 += (double)v[i].y; s1 += (double)v[i].z; s1 += (double)v[i].w; }
-        s1 = wave_sum(s1);
-        if (lane == 0) L.red[wv] = s1;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < NW; ++w) tot += L.red[w];
-        const float mean = (float)(tot / (double)K);
-        __syncthreads();
-        double s2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < MAXB; ++i) {
-            if (wv + i * NW < nblk) {
-                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-                s2 += (double)(v[i].x * v[i].x); s2 += (double)(v[i].y * v[i].y);
-                s2 += (double)(v[i].z * v[i].z); s2 += (double)(v[i].w * v[i].w);
-            }
-        }
-        s2 = wave_sum(s2);
-        if (lane == 0) L.red[wv] = s2;
-        __syncthreads();
-        double tot2 = 0.0;
-        for (int w = 0; w < NW; ++w) tot2 += L.red[w];
-        const float variance = (float)(tot2 / (double)K);
-        scale = 1.0f / sqrtf(variance + eps);
-    }
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int b = wv + i * NW;
-        if (b < nblk) {  // wave-uniform
-            float4 t = v[i];
-            if (pro != PRO_PLAIN) {
-                const float4 w4 = *(const float4*)(nw + b * 256 + lane * 4);
-                t.x = (t.x * scale) * w4.x;
-                t.y = (t.y * scale) * w4.y;
-                t.z = (t.z * scale) * w4.z;
-                t.w = (t.w * scale) * w4.w;
-                if (pro == PRO_LAYERNORM) {
-                    const float4 b4 = *(const float4*)(nbias + b * 256 + lane * 4);
-                    t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
-                }
-            }
-            const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
-            const float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-            const float amax = wave_max(am);
-            const unsigned long long hit = __ballot(am == amax);
-            const int first = __ffsll(hit) - 1;
-            const float mine = (a0 == amax) ? t.x : (a1 == amax) ? t.y : (a2 == amax) ? t.z : t.w;
-            const float maxv = __shfl(mine, first);
-            int packed = 0, s4 = 0;
-            float d = 0.0f;
-            if (amax != 0.0f) {
-                const float iscale = -128.f / maxv;
-                int q0 = ((int)f32_to_bits(fmaf(iscale, t.x, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q1 = ((int)f32_to_bits(fmaf(iscale, t.y, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q2 = ((int)f32_to_bits(fmaf(iscale, t.z, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q3 = ((int)f32_to_bits(fmaf(iscale, t.w, 12582912.f)) & 0x007fffff) - 0x00400000;
-                q0 = q0 > 127 ? 127 : q0;
-                q1 = q1 > 127 ? 127 : q1;
-                q2 = q2 > 127 ? 127 : q2;
-                q3 = q3 > 127 ? 127 : q3;
-                packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
-                s4 = q0 + q1 + q2 + q3;
-                d = 1.0f / iscale;
-            }
-            L.q8[b * 64 + lane] = packed;
-            s4 += __shfl_xor(s4, 1);
-            s4 += __shfl_xor(s4, 2);
-            if ((lane & 3) == 0) L.bsums[b * 16 + (lane >> 2)] = s4;
-            s4 += __shfl_xor(s4, 4);
-            if ((lane & 7) == 0) L.sb[b * 8 + (lane >> 3)] = s4;
-            if (lane == 0) L.yd[b] = d;
-        }
-    }
-    __syncthreads();
-}
-
-// Transpose-reduce over the four lanes {g, g^2, g^4, g^6} (c = g>>1): in: 4 ints per lane, out: lane c holds the
-// 4-lane total of element kk(c) = 2*(c&1) + (c>>1).
-DEV int quad_transpose_reduce(int p0, int p1, int p2, int p3, int c) {
-    const bool odd = (c & 1) != 0;
-    const int send0 = odd ? p0 : p2, send1 = odd ? p1 : p3;
-    const int keep0 = odd ? p2 : p0, keep1 = odd ? p3 : p1;
-    const int q0 = keep0 + __shfl_xor(send0, 2);
-    const int q1 = keep1 + __shfl_xor(send1, 2);
-    const bool up = (c & 2) != 0;
-    const int send = up ? q0 : q1;
-    const int keep = up ? q1 : q0;
-    return keep + __shfl_xor(send, 4);
-}
-
-// hsum_float_8 of the 8 per-lane accumulators of one row, in the reference's association order (k_quants.c:90-97).
-// Lane g holds x[l(g)], l(g) = 4*(g&1) + 2*((g>>1)&1) + (g>>2).
-DEV float hsum8_exact(float acc) {
-    const float t = acc + __shfl_xor(acc, 1);  // x[k] + x[k+4]
-    const float u = t + __shfl_xor(t, 2);      // (r0+r2) or (r1+r3)
-    return u + __shfl_xor(u, 4);               // (r0+r2) + (r1+r3)
-}
-
-struct TileResult { float v; };
-
-// One 8-row tile (this lane: row r = lane>>3, unit g = lane&7) against the LDS-resident activation vector.
-// Returns the finished dot product of row r in every lane of the row's group.
-template <int MAXK, int UB>
-DEV float tile_dot_exact(const DevMat& w, int tile, const ActLdsX<MAXK>& L, int lane) {
-    const int nb = w.nb;
-    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
-    const int rec = tile8_record_bytes(w.type);
-    const uint8_t* base = w.p[0] + (size_t)tile * nb * rec;
-    float acc = 0.0f, accm = 0.0f;
-    if (w.type == GT_Q4_K || w.type == GT_Q5_K) {
-        const bool q5 = w.type == GT_Q5_K;
-        const int qh_off = 128, qs_off = q5 ? 128 + 256 : 128;
-        for (int b0 = 0; b0 < nb; b0 += UB) {
-            u32x4 qs[UB], hd[UB], qh[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int bb = (b0 + u < nb) ? b0 + u : nb - 1;
-                const uint8_t* rp = base + (size_t)bb * rec;
-                hd[u] = ld_stream16(rp + r * 16);
-                qs[u] = ld_stream16(rp + qs_off + r * 128 + g * 16);
-                if (q5) qh[u] = ld_stream16(rp + qh_off + r * 32 + h * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int b = b0 + u;
-                if (b < nb) {  // wave-uniform
-                    const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
-                    const int* ahi = alo + 8;
-                    int sc_lo, sc_hi, m_lo, m_hi;
-                    scale_min_pair(hd[u][1], hd[u][2], hd[u][3], c, sc_lo, sc_hi, m_lo, m_hi);
-                    int part[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        uint32_t lo = qs[u][k] & 0x0F0F0F0Fu;
-                        uint32_t hi = (qs[u][k] >> 4) & 0x0F0F0F0Fu;
-                        if (q5) {
-                            lo |= ((qh[u][k] >> (2 * c)) & 0x01010101u) << 4;
-                            hi |= ((qh[u][k] >> (2 * c + 1)) & 0x01010101u) << 4;
-                        }
-                        part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
-                    }
-                    const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
-                    const float yd = L.yd[b];
-                    const float d = yd * f16_bits_to_f32((uint16_t)(hd[u][0] & 0xFFFF));
-                    const float dmin = -yd * f16_bits_to_f32((uint16_t)(hd[u][0] >> 16));
-                    acc = fmaf(d, (float)sumi, acc);
-                    // min term: this lane's chunk c owns sub-blocks 2c, 2c+1 => prod[c]; only the h == 0 lanes carry it
-                    int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
-                    if (q5) {  // scalar summs: all four prods are added as integers first
-                        prod += __shfl_xor(prod, 2);
-                        prod += __shfl_xor(prod, 4);
-                    }
-                    accm = fmaf(dmin, (float)prod, accm);
-                }
-            }
-        }
-        float tot = hsum8_exact(acc);
-        if (!q5) {
-            const float wsum = accm + __shfl_xor(accm, 4);   // (m0+m2) | (m1+m3)   [t = c, lanes with h == 0]
-            accm = wsum + __shfl_xor(wsum, 2);               // (m0+m2) + (m1+m3)
-        }
-        accm = __shfl(accm, lane & ~7);                      // lane g = 0 of the row (h == 0, c == 0)
-        tot = tot + accm;
-        return tot;
-    }
-    // ---- GT_Q6_K ----
-    {
-        const int n = g >> 2, gg = g & 3, hh = gg & 1, kq = gg >> 1;
-        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
-        for (int b0 = 0; b0 < nb; b0 += UB) {
-            u32x4 ql[UB], qh[UB], sc[UB];
-            uint16_t dd[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int bb = (b0 + u < nb) ? b0 + u : nb - 1;
-                const uint8_t* rp = base + (size_t)bb * rec;
-                dd[u] = *(const uint16_t*)(rp + r * 2);
-                sc[u] = ld_stream16(rp + 16 + r * 16);
-                qh[u] = ld_stream16(rp + 144 + r * 64 + n * 32 + hh * 16);
-                ql[u] = ld_stream16(rp + 656 + r * 128 + g * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int b = b0 + u;
-                if (b < nb) {
-                    const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
-                    const int* ahi = alo + 16;
-                    const uint32_t w_lo = n ? sc[u][2] : sc[u][0];
-                    const uint32_t w_hi = n ? sc[u][3] : sc[u][1];
-                    const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
-                    const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
-                    int part[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t lo = (ql[u][k] & 0x0F0F0F0Fu) | (((qh[u][k] >> s_lo) & 0x03030303u) << 4);
-                        const uint32_t hi = ((ql[u][k] >> 4) & 0x0F0F0F0Fu) | (((qh[u][k] >> s_hi) & 0x03030303u) << 4);
-                        const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
-                        const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
-                        part[k] = sc_lo * dl + sc_hi * dh;
-                    }
-                    const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
-                    const float d = L.yd[b] * f16_bits_to_f32(dd[u]);
-                    acc = fmaf(d, (float)sumi, acc);
-                }
-            }
-        }
-        return hsum8_exact(acc);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Fused launch: prologue -> one 8-row tile per wave step -> epilogue.  Work item = tile index over the concatenated
-// jobs (gate/up mode: item t = gate tile t followed by up tile t).
-// ------------------------------------------------------------------------------------------------------------------
-template <int NT, int MAXK, int UB>
-__global__ void __launch_bounds__(NT) matvec_exact_kernel(const MatvecArgs a) {
-    __shared__ ActLdsX<MAXK> L;
-    const int lane = lane_id();
-    prologue_q8k_exact<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
-    constexpr int NW = NT / 64;
-    const int gw = (int)blockIdx.x * NW + wave_id();
-    const int W = (int)gridDim.x * NW;
-    const int i_begin = (int)(((long long)a.n_pairs * gw) / W);  // n_pairs == number of work items (tiles) here
-    const int i_end = (int)(((long long)a.n_pairs * (gw + 1)) / W);
-    const int pos = a.pos ? *a.pos : 0;
-    const int r = lane >> 3, g = lane & 7;
-    for (int it = i_begin; it < i_end; ++it) {
-        int j = 0;
-        if (!a.gateup) {
-            if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
-            if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
-        }
-        const MatJob& jb = a.job[j];
-        const int tile = it - jb.pair0;
-        const int row = tile * 8 + r;
-        float res = tile_dot_exact<MAXK, UB>(jb.w, tile, L, lane);
-        const int epi = a.gateup ? EPI_SILU_MUL : jb.epi;
-        if (epi == EPI_SILU_MUL) {
-            const float up = tile_dot_exact<MAXK, UB>(a.job[1].w, tile, L, lane);
-            if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
-        } else if (epi == EPI_STORE) {
-            if (g == 0 && row < jb.w.M) a.out[row] = res;
-        } else if (epi == EPI_ADD) {
-            if (g == 0 && row < jb.w.M) a.out[row] = res + a.res[row];
-        } else if (epi == EPI_V) {
-            if (g == 0 && row < jb.w.M) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
-        } else if (epi == EPI_GELU) {
-            if (g == 0 && row < jb.w.M) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
-        } else if (epi == EPI_ADD2) {
-            if (g == 0 && row < jb.w.M) a.out[row] = (res + a.res[row]) + a.res2[row];
-        } else {  // RoPE on the interleaved pair (row&~1, row|1): partner row lives in the neighbouring lane group
-            const float other = __shfl_xor(res, 8);
-            const int ip = (row % a.head_dim) >> 1;
-            const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
-            const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-            // reference build: out0 = fma(x0, cos, -(x1*sin)), out1 = fma(x1, cos, x0*sin)  (how gcc contracts
-            // ggml.c:12536-12537; established against the reference's own rope op, see oracle/mirror.c mir_rope)
-            const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-            if (g == 0 && row < jb.w.M) {
-                if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Bit-exact decode attention.  The reference computes both attention mat-muls with ggml_vec_dot_f16 (ggml.c:2392-2425,
 // AVX: 4 accumulators x 8 f32 lanes, 32 elements per step, fma; reduce macro ggml.c:1964-1982):
@@ -393,85 +91,6 @@ struct AttnArgsX {
     float kq_scale;
     unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
 };
-
-// scores[h][p] = vec_dot_f16(K[p], Q[h]) * kq_scale.   grid (n_head, ceil(n_ctx/64)), 256 threads: quad per position.
-__global__ void __launch_bounds__(256) attn_scores_exact_kernel(const AttnArgsX a) {
-    const int h = (int)blockIdx.x;
-    const int n_kv = *a.pos + 1;
-    const int c0 = (int)blockIdx.y * 64;
-    if (c0 >= n_kv) return;
-    const int tid = (int)threadIdx.x, j = tid & 3;
-    const int p = c0 + (tid >> 2);
-    const bool ok = p < n_kv;
-    const int pp = ok ? p : c0;
-    const int hd = a.head_dim;
-    const int hk = h / (a.n_head / a.n_head_kv);
-    const uint16_t* krow = a.kcache + ((size_t)hk * a.n_ctx + pp) * hd;
-    const uint16_t* qrow = a.q_f16 + (size_t)h * hd;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e0 = 0; e0 < hd; e0 += 32) {
-        float kf[8], qf[8];
-        unpack8_f16(ld16(krow + e0 + 8 * j), kf);
-        unpack8_f16(ld16(qrow + e0 + 8 * j), qf);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
-    }
-    const float res = f16dot_reduce_exact(acc, j);
-    if (ok && j == 0) a.scores[(size_t)h * a.n_ctx + p] = res * a.kq_scale;
-}
-
-// softmax (reference ggml.c:12047-12069) + out[h][d] = vec_dot_f16(V[d], P).   grid (n_head, head_dim/64), 256 threads.
-// Batch structure matters for bit-identity: the reference evaluates a chunk of N tokens as one graph, so every query row
-// of the chunk runs vec_dot_f16 over ALL n_total = n_past + N columns (masked columns hold P = 0): the split between the
-// 32-wide fma part and the scalar double-precision leftovers is taken at n_total & ~31, not at this token's own length.
-// fma(v, 0, acc) == acc, so only the split point has to be reproduced.
-__global__ void __launch_bounds__(256) attn_softmax_pv_exact_kernel(const AttnArgsX a) {
-    __shared__ float prob[kMaxCtx];
-    __shared__ double red[4];
-    __shared__ float redf[4];
-    const int h = (int)blockIdx.x;
-    const int n_kv = *a.pos + 1;
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-    const float* s = a.scores + (size_t)h * a.n_ctx;
-    float mx = -INFINITY;
-    for (int i = tid; i < n_kv; i += 256) mx = fmaxf(mx, s[i]);
-    mx = wave_max(mx);
-    if (lane == 0) redf[wv] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    double sum = 0.0;
-    for (int i = tid; i < n_kv; i += 256) {
-        const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(s[i] - mx)]);
-        prob[i] = e;
-        sum += (double)e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[wv] = sum;
-    __syncthreads();
-    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
-    const float inv = (float)(1.0 / tot);
-    for (int i = tid; i < n_kv; i += 256) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
-    const int n_tot = *a.n_total;
-    const int np = n_tot & ~31;
-    for (int i = n_kv + tid; i < np; i += 256) prob[i] = 0.0f;  // masked columns of this batch
-    __syncthreads();
-    const int j = tid & 3;
-    const int d = (int)blockIdx.y * 64 + (tid >> 2);
-    const int hk = h / (a.n_head / a.n_head_kv);
-    const uint16_t* vrow = a.vcache + ((size_t)hk * a.head_dim + d) * a.v_stride;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < np; i += 32) {
-        float vf[8];
-        unpack8_f16(ld16(vrow + i + 8 * j), vf);
-        const float* pr = &prob[i + 8 * j];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
-    }
-    const float res = f16dot_reduce_exact(acc, j);
-    double sumf = (double)res;
-    for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
-    if (j == 0) a.out[(size_t)h * a.head_dim + d] = (float)sumf;
-}
 
 // Fused form of the two kernels above (one launch per layer instead of two): grid (n_head, head_dim/64), 1024 threads.
 // Every workgroup recomputes the (cheap) score row of its head into LDS — 256 positions per pass, a quad per position —
@@ -592,84 +211,6 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
     if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Design C: the same bit-exact arithmetic with K split across the waves of a workgroup.
-// The integer part of a block (loads, nibble unpack, dot4, transpose-reduce) is order-free, so the NW waves of a
-// workgroup take the blocks b = wave, wave+NW, ... of ONE 8-row tile concurrently and leave per block
-//     S[b][lane] = (float)sumi[l(g)]   D[b][row] = y.d*fp16(x.d)   DM[b][row] = -y.d*fp16(x.dmin)   PM[b][row][t]
-// in LDS; after one barrier a single wave replays the reference's sequential f32 fma chain over b = 0..nb-1 from LDS
-// (nb short dependent steps) and runs the epilogue.  This multiplies the loads in flight per tile by NW and cuts the
-// serial depth per tile from nb block-steps to nb/NW, which is what the small 4096-row matrices (Wo, W_down: 512
-// tiles) need to keep every CU streaming.
-// ------------------------------------------------------------------------------------------------------------------
-template <int MAXNB> struct ChainBuf {
-    float S[MAXNB][64];
-    float D[MAXNB][8];
-    float DM[MAXNB][8];
-    float PM[MAXNB][32];
-};
-
-// Integer work of one block for this lane's row; results go to the chain buffer.
-template <int MAXK, int MAXNB>
-DEV void block_to_chain(int type, const uint8_t* rp, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane,
-                        const u32x4 v0, const u32x4 v1, const u32x4 v2, const uint16_t dd) {
-    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
-    (void)rp;
-    if (type == GT_Q4_K || type == GT_Q5_K) {
-        const bool q5 = type == GT_Q5_K;
-        // v0 = hdr, v1 = qs, v2 = qh (Q5_K)
-        const int* alo = &L.q8[b * 64 + 16 * c + 4 * h];
-        const int* ahi = alo + 8;
-        int sc_lo, sc_hi, m_lo, m_hi;
-        scale_min_pair(v0[1], v0[2], v0[3], c, sc_lo, sc_hi, m_lo, m_hi);
-        int part[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t lo = v1[k] & 0x0F0F0F0Fu;
-            uint32_t hi = (v1[k] >> 4) & 0x0F0F0F0Fu;
-            if (q5) {
-                lo |= ((v2[k] >> (2 * c)) & 0x01010101u) << 4;
-                hi |= ((v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
-            }
-            part[k] = sc_lo * sdot4((int)lo, alo[k], 0) + sc_hi * sdot4((int)hi, ahi[k], 0);
-        }
-        const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
-        C.S[b][lane] = (float)sumi;
-        int prod = (h == 0) ? m_lo * L.sb[b * 8 + 2 * c] + m_hi * L.sb[b * 8 + 2 * c + 1] : 0;
-        if (q5) {
-            prod += __shfl_xor(prod, 2);
-            prod += __shfl_xor(prod, 4);
-        }
-        if (h == 0) C.PM[b][r * 4 + c] = (float)prod;
-        if (g == 0) {
-            const float yd = L.yd[b];
-            C.D[b][r] = yd * f16_bits_to_f32((uint16_t)(v0[0] & 0xFFFF));
-            C.DM[b][r] = -yd * f16_bits_to_f32((uint16_t)(v0[0] >> 16));
-        }
-    } else {  // GT_Q6_K: v0 = sc, v1 = ql, v2 = qh, dd = d
-        const int n = g >> 2, gg = g & 3, kq = gg >> 1;
-        const int s_lo = 2 * kq, s_hi = 4 + 2 * kq;
-        const int* alo = &L.q8[b * 64 + 32 * n + 4 * gg];
-        const int* ahi = alo + 16;
-        const uint32_t w_lo = n ? v0[2] : v0[0];
-        const uint32_t w_hi = n ? v0[3] : v0[1];
-        const int sc_lo = (int)(int8_t)((w_lo >> (8 * gg)) & 0xFF);
-        const int sc_hi = (int)(int8_t)((w_hi >> (8 * gg)) & 0xFF);
-        int part[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = (v1[k] & 0x0F0F0F0Fu) | (((v2[k] >> s_lo) & 0x03030303u) << 4);
-            const uint32_t hi = ((v1[k] >> 4) & 0x0F0F0F0Fu) | (((v2[k] >> s_hi) & 0x03030303u) << 4);
-            const int dl = sdot4((int)lo, alo[k], 0) - 32 * sdot4(0x01010101, alo[k], 0);
-            const int dh = sdot4((int)hi, ahi[k], 0) - 32 * sdot4(0x01010101, ahi[k], 0);
-            part[k] = sc_lo * dl + sc_hi * dh;
-        }
-        const int sumi = quad_transpose_reduce(part[0], part[1], part[2], part[3], c);
-        C.S[b][lane] = (float)sumi;
-        if (g == 0) C.D[b][r] = L.yd[b] * f16_bits_to_f32(dd);
-    }
 }
 
 // Prologue, 16 lanes per 256-block: lane `sub` owns 16 consecutive elements, so the per-block reductions are 4 DPP
@@ -959,14 +500,6 @@ DEV float hsum8_exact_dpp(float acc) {
     return u + lane_xor4(u);
 }
 
-// Register image of one chunk (UB blocks of this wave) of one tile.
-// One block image (this lane's pieces of one K-block of an 8-row tile) in named registers — no arrays, so the
-// compiler keeps the 4-deep load pipeline in VGPRs (an array-of-vectors image was demoted to scratch by hipcc).
-struct BlockRegs {
-    u32x4 v0, v1, v2;
-    uint32_t dd;
-};
-
 // Per-lane constants of the tile geometry (computed once per kernel).
 struct LaneGeom {
     int r, g, c, h;           // row in tile, unit in block, chunk, AVX half
@@ -995,254 +528,3 @@ DEV LaneGeom lane_geom(int lane) {
 }
 
 // rec_base: wave-uniform pointer to the (tile, block) record.
-DEV BlockRegs block_load2(int type, const uint8_t* rec_base, const LaneGeom& G) {
-    BlockRegs R;
-    if (type == GT_Q6_K) {
-        R.dd = *(const uint16_t*)(rec_base + G.off6_d);
-        R.v0 = ld_stream16(rec_base + G.off6_sc);
-        R.v2 = ld_stream16(rec_base + G.off6_qh);
-        R.v1 = ld_stream16(rec_base + G.off6_ql);
-    } else if (type == GT_Q5_K) {
-        R.dd = 0;
-        R.v0 = ld_stream16(rec_base + G.off_hdr);
-        R.v1 = ld_stream16(rec_base + 384 + G.off_qs);
-        R.v2 = ld_stream16(rec_base + G.off_qh5);
-    } else {
-        R.dd = 0;
-        R.v0 = ld_stream16(rec_base + G.off_hdr);
-        R.v1 = ld_stream16(rec_base + G.off_qs + 128);
-        R.v2 = R.v0;
-    }
-    return R;
-}
-
-// Integer work of one block (DPP transposes, 24-bit multiplies), results into the chain buffer.
-template <int MAXK, int MAXNB>
-DEV void block_to_chain3(int type, int b, const ActLdsX<MAXK>& L, ChainBuf<MAXNB>& C, int lane, const LaneGeom& G,
-                         const BlockRegs& R) {
-    const int c = G.c;
-    if (type == GT_Q4_K || type == GT_Q5_K) {
-        const bool q5 = type == GT_Q5_K;
-        const int* alo = &L.q8[b * 64 + G.a45];
-        const int* ahi = alo + 8;
-        // 6-bit scales/mins of sub-blocks 2c, 2c+1 as byte pairs (reference get_scale_min_k4, k_quants.c:306-314)
-        const uint32_t A = R.v0[1] >> G.sh16, B = R.v0[2] >> G.sh16, C3 = R.v0[3] >> G.sh16;
-        const uint32_t scL = A & 0x3F3Fu, mL = B & 0x3F3Fu;
-        const uint32_t scH = (C3 & 0x0F0Fu) | ((A >> 2) & 0x3030u);
-        const uint32_t mH = ((C3 >> 4) & 0x0F0Fu) | ((B >> 2) & 0x3030u);
-        const uint32_t scp = c < 2 ? scL : scH, mp = c < 2 ? mL : mH;
-        const int sc_lo = (int)(scp & 0xFF), sc_hi = (int)(scp >> 8), m_lo = (int)(mp & 0xFF), m_hi = (int)(mp >> 8);
-        int part[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t lo = R.v1[k] & 0x0F0F0F0Fu;
-            uint32_t hi = (R.v1[k] >> 4) & 0x0F0F0F0Fu;
-            if (q5) {
-                lo |= ((R.v2[k] >> (2 * c)) & 0x01010101u) << 4;
-                hi |= ((R.v2[k] >> (2 * c + 1)) & 0x01010101u) << 4;
-            }
-            part[k] = mul24(sc_lo, sdot4((int)lo, alo[k], 0)) + mul24(sc_hi, sdot4((int)hi, ahi[k], 0));
-        }
-        const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
-        C.S[b][lane] = (float)sumi;
-        int prod = mul24(m_lo, L.sb[b * 8 + 2 * c]) + mul24(m_hi, L.sb[b * 8 + 2 * c + 1]);
-        if (G.h != 0) prod = 0;
-        if (q5) {
-            prod += lane_xor2(prod);
-            prod += lane_xor4(prod);
-        }
-        if (G.h == 0) C.PM[b][G.r * 4 + c] = (float)prod;
-        if (G.g == 0) {
-            const float yd = L.yd[b];
-            C.D[b][G.r] = yd * f16_bits_to_f32((uint16_t)(R.v0[0] & 0xFFFF));
-            C.DM[b][G.r] = -yd * f16_bits_to_f32((uint16_t)(R.v0[0] >> 16));
-        }
-    } else {
-        const int n = G.g >> 2;
-        const int* alo = &L.q8[b * 64 + G.a6];
-        const int* ahi = alo + 16;
-        const uint32_t w_lo = n ? R.v0[2] : R.v0[0];
-        const uint32_t w_hi = n ? R.v0[3] : R.v0[1];
-        const int sc_lo = (int)(int8_t)((w_lo >> G.sc_sh6) & 0xFF);
-        const int sc_hi = (int)(int8_t)((w_hi >> G.sc_sh6) & 0xFF);
-        int part[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = (R.v1[k] & 0x0F0F0F0Fu) | (((R.v2[k] >> G.s_lo6) & 0x03030303u) << 4);
-            const uint32_t hi = ((R.v1[k] >> 4) & 0x0F0F0F0Fu) | (((R.v2[k] >> G.s_hi6) & 0x03030303u) << 4);
-            // (q - 32) . a  ==  q . a - 32 * sum(a): fold the -32 into the dot4 chain with a constant operand
-            const int dl = sdot4((int)lo, alo[k], sdot4((int)0xE0E0E0E0u, alo[k], 0));
-            const int dh = sdot4((int)hi, ahi[k], sdot4((int)0xE0E0E0E0u, ahi[k], 0));
-            part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
-        }
-        const int sumi = quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
-        C.S[b][lane] = (float)sumi;
-        if (G.g == 0) C.D[b][G.r] = L.yd[b] * f16_bits_to_f32((uint16_t)R.dd);
-    }
-}
-
-// One wave: the reference's sequential accumulation over all blocks (operands preloaded 16 blocks at a time so the
-// dependent part is a bare fma chain), then its reduction tree.
-template <int MAXNB>
-DEV float chain_reduce2(int type, int nb, const ChainBuf<MAXNB>& C, int lane) {
-    const int r = lane >> 3, g = lane & 7, c = g >> 1, h = g & 1;
-    float acc = 0.0f, accm = 0.0f;
-    const bool mins = type != GT_Q6_K;
-    for (int b0 = 0; b0 < nb; b0 += 16) {
-        float dv[16], sv[16], mv[16], pv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int b = (b0 + u < nb) ? b0 + u : nb - 1;
-            dv[u] = C.D[b][r];
-            sv[u] = C.S[b][lane];
-            mv[u] = mins ? C.DM[b][r] : 0.0f;
-            pv[u] = (mins && h == 0) ? C.PM[b][r * 4 + c] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (b0 + u < nb) {
-                acc = fmaf(dv[u], sv[u], acc);
-                accm = fmaf(mv[u], pv[u], accm);
-            }
-        }
-    }
-    float tot = hsum8_exact_dpp(acc);
-    if (!mins) return tot;
-    if (type == GT_Q4_K) {
-        const float wsum = accm + lane_xor4(accm);
-        accm = wsum + lane_xor2(wsum);
-    }
-    accm = __shfl(accm, lane & ~7);
-    return tot + accm;
-}
-
-// Work cursor of a persistent workgroup: walks items -> units (matrix, tile) -> block steps with adds and compares
-// only (no integer divisions; everything here is wave-uniform and lives in SGPRs).
-struct StepCursor {
-    int item, part, chunk;     // current item, unit inside the item (gate/up), block step inside the unit
-    int j, tile, unit_seq;     // job index, tile index inside the job's matrix, running unit number (chain buffer parity)
-    int type, nb, M;
-    const uint8_t* tile_base;  // first record of the tile
-    uint32_t rec;
-    bool valid;
-};
-DEV void cursor_set_unit(StepCursor& c, const MatvecArgs& a) {
-    int j = 0;
-    if (!a.gateup) {
-        if (a.njobs > 1 && c.item >= a.job[1].pair0) j = 1;
-        if (a.njobs > 2 && c.item >= a.job[2].pair0) j = 2;
-    }
-    c.j = j;
-    const DevMat& w = a.gateup ? a.job[c.part].w : a.job[j].w;
-    c.tile = c.item - (a.gateup ? 0 : a.job[j].pair0);
-    c.type = w.type; c.nb = w.nb; c.M = w.M;
-    c.rec = (uint32_t)tile8_record_bytes(w.type);
-    c.tile_base = w.p[0] + (size_t)c.tile * w.nb * c.rec;
-}
-DEV void cursor_init(StepCursor& c, const MatvecArgs& a, int first_item) {
-    c.item = first_item; c.part = 0; c.chunk = 0; c.unit_seq = 0;
-    c.valid = first_item < a.n_pairs;
-    if (c.valid) cursor_set_unit(c, a);
-}
-DEV void cursor_next(StepCursor& c, const MatvecArgs& a, int cpu, int upi, int stride) {
-    if (!c.valid) return;
-    if (++c.chunk < cpu) return;
-    c.chunk = 0;
-    ++c.unit_seq;
-    if (++c.part >= upi) {
-        c.part = 0;
-        c.item += stride;
-        if (c.item >= a.n_pairs) { c.valid = false; return; }
-    }
-    cursor_set_unit(c, a);
-}
-
-// Fused launch, design C: persistent workgroups; the loads of the next four block steps are in flight while the current
-// one is unpacked; a unit (one 8-row tile of one matrix) ends with a barrier, after which a rotating wave replays the
-// f32 chain from LDS and runs the epilogue while the others continue with the next unit.
-template <int NT, int MAXK, int UB>
-__global__ void __launch_bounds__(NT) matvec_exact2_kernel(const MatvecArgs a) {
-    constexpr int NW = NT / 64;
-    constexpr int MAXNB = MAXK / 256;
-    __shared__ ActLdsX<MAXK> L;
-    __shared__ ChainBuf<MAXNB> CB[2];
-    const int lane = lane_id();
-    const int wv = uniform_int(wave_id());
-    const LaneGeom G = lane_geom(lane);
-    const int nb0 = a.job[0].w.nb;                      // all jobs of a launch share K
-    const int cpu = (nb0 + NW - 1) / NW;                // block steps per unit for every wave (tail blocks masked)
-    const int upi = a.gateup ? 2 : 1;
-    const int stride = (int)gridDim.x;
-
-    StepCursor lc, cc;                                  // load cursor (4 steps ahead) and compute cursor
-    cursor_init(lc, a, (int)blockIdx.x);
-    cursor_init(cc, a, (int)blockIdx.x);
-    auto load_step = [&]() __attribute__((always_inline)) -> BlockRegs {
-        BlockRegs R;
-        if (lc.valid) {
-            int b = wv + lc.chunk * NW;
-            b = b < lc.nb ? b : lc.nb - 1;
-            R = block_load2(lc.type, lc.tile_base + (size_t)b * lc.rec, G);
-        } else {
-            R.v0 = R.v1 = R.v2 = u32x4{0, 0, 0, 0};
-            R.dd = 0;
-        }
-        cursor_next(lc, a, cpu, upi, stride);
-        return R;
-    };
-
-    BlockRegs R0 = load_step(), R1 = load_step(), R2 = load_step(), R3 = load_step();
-    prologue_q8k_exact16<NT, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);
-    const int pos = a.pos ? *a.pos : 0;
-    float res_gate = 0.0f;
-
-    auto finish_unit = [&]() __attribute__((always_inline)) {  // every wave, after the last block step of a unit
-        __syncthreads();
-        const int item_seq = a.gateup ? (cc.unit_seq >> 1) : cc.unit_seq;
-        const int cw = item_seq & (NW - 1);
-        if (wv != cw) return;
-        const float res = chain_reduce2<MAXNB>(cc.type, cc.nb, CB[cc.unit_seq & 1], lane);
-        const int row = cc.tile * 8 + G.r;
-        const bool own = G.g == 0 && row < cc.M;
-        if (a.gateup) {
-            if (cc.part == 0) { res_gate = res; return; }
-            if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res_gate)]) * res;
-            return;
-        }
-        const int epi = a.job[cc.j].epi;
-        if (epi == EPI_STORE) {
-            if (own) a.out[row] = res;
-        } else if (epi == EPI_ADD) {
-            if (own) a.out[row] = res + a.res[row];
-        } else if (epi == EPI_V) {
-            if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
-        } else if (epi == EPI_GELU) {
-            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
-        } else if (epi == EPI_ADD2) {
-            if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
-        } else {
-            const float other = lane_xor8(res);
-            const int ip = (row % a.head_dim) >> 1;
-            const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
-            const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-            const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-            if (own) {
-                if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
-            }
-        }
-    };
-    auto compute_step = [&](const BlockRegs& R) __attribute__((always_inline)) {
-        if (!cc.valid) return;
-        const int b = wv + cc.chunk * NW;
-        if (b < cc.nb) block_to_chain3<MAXK, MAXNB>(cc.type, b, L, CB[cc.unit_seq & 1], lane, G, R);
-        if (cc.chunk == cpu - 1) finish_unit();
-        cursor_next(cc, a, cpu, upi, stride);
-    };
-    while (cc.valid) {
-        compute_step(R0); R0 = load_step();
-        compute_step(R1); R1 = load_step();
-        compute_step(R2); R2 = load_step();
-        compute_step(R3); R3 = load_step();
-    }
-}

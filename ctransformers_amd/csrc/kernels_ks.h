@@ -84,7 +84,6 @@ __global__ void __launch_bounds__(1024) matvec_ks_kernel(const MatvecArgs a) {
     const int nb = a.K >> 8;
     const int NA = nb < 16 ? nb : 16;
     if (threadIdx.x < kKsSlots) SM.ctr[threadIdx.x] = 0u;
-    const int pos = a.pos ? *a.pos : 0;
     prologue_q8k_exact16<1024, MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps);
     if (wv >= NA) return;
     const int base = nb / NA, rem = nb % NA;

@@ -1,102 +1,20 @@
-// Mat-vec, generation 5: generation 4's organisation (one 1024-thread workgroup per CU, K split over 16 waves, chain
-// replay from LDS, re-encoded scale field) with the weight TYPE a compile-time parameter.  The round-1 ablation
-// (CT_AMD_DBG) showed the generic kernel streaming at 4-7 TB/s when it only loads, but spending 2-3x that time in a
-// maze of per-block type/validity branches; here a launch is split on the host into at most two type-homogeneous job
-// groups (TA then TB — K-quant files only ever mix one base type with Q6_K) and each group runs a branch-free loop:
-//   round = T tiles; per wave T*S block steps (tail blocks are clamped: recomputing the last block writes identical
-//   values, so no predication), one barrier, then T waves replay one f32 chain each (rotating) while the rest start
+// Mat-vec, generation 5 (and the arithmetic building blocks shared with generation 6, kernels_v6.h, and the wide-K kernel,
+// kernels_ks.h): one 1024-thread workgroup per CU, the K-blocks of an 8-row tile split over the 16 waves, weight TYPE a
+// compile-time parameter.
+//   round = T tiles; per wave T*S block steps -> chain storage in LDS (tail blocks are clamped: recomputing the last
+//   block writes identical values), one barrier, then T waves replay one f32 chain each (rotating) while the rest start
 //   the next round from the other half of the chain storage.
+// Today it serves the launches with at most two tiles per workgroup (one round: Wo); everything else runs generation 6.
 #pragma once
-#include "kernels_v4.h"
+#include "kernels_exact.h"
 
-// Prologue for 1024-thread workgroups: one wave per 256-block (lane = 4 consecutive elements), so every wave of the
-// workgroup takes part and a thread touches 4 values instead of 16.  Arithmetic identical to prologue_q8k_exact16.
-template <int MAXK>
-DEV void prologue_q8k_wave(ActLdsX<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro,
-                           float eps, int lane, int wv) {
-    constexpr int NW = 16;
-    constexpr int MAXB = (MAXK / 256 + NW - 1) / NW;
-    const int nblk = K >> 8;
-    float4 v[MAXB];
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int b = wv + i * NW;
-        if (b < nblk) {
-            v[i] = *(const float4*)(x + b * 256 + lane * 4);
-            if (pro == PRO_RMSNORM) {
-                s += (double)(v[i].x * v[i].x);
-                s += (double)(v[i].y * v[i].y);
-                s += (double)(v[i].z * v[i].z);
-                s += (double)(v[i].w * v[i].w);
-            }
-        }
-    }
-    float scale = 1.0f;
-    if (pro == PRO_RMSNORM) {
-        s = wave_sum_fast(s);
-        if (lane == 0) L.red[wv] = s;
-        __syncthreads();
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) tot += L.red[w];
-        const float mean = (float)(tot / (double)K);
-        scale = 1.0f / sqrtf(mean + eps);
-    }
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int b = wv + i * NW;
-        if (b < nblk) {  // wave-uniform
-            float4 t = v[i];
-            if (pro == PRO_RMSNORM) {
-                const float4 w4 = *(const float4*)(nw + b * 256 + lane * 4);
-                t.x = (t.x * scale) * w4.x;
-                t.y = (t.y * scale) * w4.y;
-                t.z = (t.z * scale) * w4.z;
-                t.w = (t.w * scale) * w4.w;
-            }
-            const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
-            const float am = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-            float amax = am;
-            amax = fmaxf(amax, lane_xor1(amax));
-            amax = fmaxf(amax, lane_xor2(amax));
-            amax = fmaxf(amax, lane_xor4(amax));
-            amax = fmaxf(amax, lane_xor8(amax));
-            amax = fmaxf(amax, lane_xor16(amax));
-            amax = fmaxf(amax, lane_xor32(amax));
-            const unsigned long long hit = __ballot(am == amax);
-            const int first = __ffsll(hit) - 1;
-            const float mine = (a0 == amax) ? t.x : (a1 == amax) ? t.y : (a2 == amax) ? t.z : t.w;
-            const float maxv = __shfl(mine, first);
-            int packed = 0, s4 = 0;
-            float d = 0.0f;
-            if (amax != 0.0f) {
-                const float iscale = -128.f / maxv;
-                int q0 = ((int)f32_to_bits(fmaf(iscale, t.x, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q1 = ((int)f32_to_bits(fmaf(iscale, t.y, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q2 = ((int)f32_to_bits(fmaf(iscale, t.z, 12582912.f)) & 0x007fffff) - 0x00400000;
-                int q3 = ((int)f32_to_bits(fmaf(iscale, t.w, 12582912.f)) & 0x007fffff) - 0x00400000;
-                q0 = q0 > 127 ? 127 : q0;
-                q1 = q1 > 127 ? 127 : q1;
-                q2 = q2 > 127 ? 127 : q2;
-                q3 = q3 > 127 ? 127 : q3;
-                packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
-                s4 = q0 + q1 + q2 + q3;
-                d = 1.0f / iscale;
-            }
-            L.q8[b * 64 + lane] = packed;
-            s4 += lane_xor1(s4);
-            s4 += lane_xor2(s4);
-            if ((lane & 3) == 0) L.bsums[b * 16 + (lane >> 2)] = s4;
-            s4 += lane_xor4(s4);
-            if ((lane & 7) == 0) L.sb[b * 8 + (lane >> 3)] = s4;
-            if (lane == 0) L.yd[b] = d;
-        }
-    }
-    __syncthreads();
-}
+struct UnitInfo {            // one 8-row tile of a launch, wave-uniform
+    int valid, type, nb, M, tile, j;
+    const uint8_t* base;     // first record of the tile
+    uint32_t rec;
+};
 
-// Chain storage of generation 5: like ChainBuf4, but the block scales arrive already multiplied out
+// Chain storage of generation 5: per (block, lane) `(float)sumi[l]`, per (block, row) the block scales already multiplied out
 // (D = y.d * fp16(x.d), DM = -y.d * fp16(x.dmin)): those products are order-free, so the block step that holds the
 // header does them and the replay — the serial part of a round — is left with LDS fetches and the fma chain only.
 template <int MAXNB> struct ChainBuf5 {
@@ -408,156 +326,13 @@ DEV void run_group(const MatvecArgs& a, int item0, int n_items, ActLdsX<MAXK>& L
     }
 }
 
-// One type-homogeneous group of a launch, as seen by one workgroup: its units (local items k = 0.. with
-// item = item0 + blockIdx + k*gridDim, times 2 for gate/up pairs), the units of the current round and their block
-// images in registers.
-struct UnitRef {            // wave-uniform; kept small so that T of them stay in SGPRs
-    const uint8_t* base;    // first record of the tile
-    int tile, j;            // tile index inside its matrix, job index
-    bool valid;
-};
-template <int TYPE, int S, int T> struct GroupState {
-    int item0, first, stride, n_units;
-    UnitRef cur[T];
-    BlkImg<TYPE> R[T][S];
-};
-
-template <int TYPE, int S, int T>
-DEV void group_unit_of(const MatvecArgs& a, const GroupState<TYPE, S, T>& g, int u, UnitRef& U) {   // u clamps to the last unit
-    const int uu = u < g.n_units ? u : g.n_units - 1;
-    const int k = false ? (uu >> 1) : uu;
-    const int part = false ? (uu & 1) : 0;
-    const int it = g.item0 + g.first + k * g.stride;
-    int j = 0;
-    if (!false) {
-        if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
-        if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
-    }
-    const DevMat& w = false ? a.job[part].w : a.job[j].w;
-    constexpr uint32_t rec = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
-    U.valid = u < g.n_units;
-    U.j = false ? part : j;
-    U.tile = it - (false ? 0 : a.job[j].pair0);
-    U.base = w.p[0] + (size_t)U.tile * (uint32_t)(a.K >> 8) * rec;
-}
-
-template <int TYPE, int S>
-DEV BlkImg<TYPE> group_load_img(const UnitRef& U, int nb, int i, int wv, const LaneGeom& G) {
-    constexpr uint32_t rec = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
-    int b = wv + i * 16;
-    b = b < nb ? b : nb - 1;
-    return img_load<TYPE>(U.base + (size_t)b * rec, G);
-}
-
-// Sets the group up and issues the loads of its first round.
-template <int TYPE, int S, int T>
-DEV void group_begin(const MatvecArgs& a, int item0, int n_items, GroupState<TYPE, S, T>& g, int wv, const LaneGeom& G) {
-    g.item0 = item0;
-    g.stride = (int)gridDim.x;
-    g.first = (int)blockIdx.x;
-    const int n_loc = g.first < n_items ? (n_items - g.first + g.stride - 1) / g.stride : 0;
-    g.n_units = n_loc * (false ? 2 : 1);
-    if (g.n_units == 0) return;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        group_unit_of<TYPE, S, T>(a, g, t, g.cur[t]);
-        if (g.cur[t].valid) {
-#pragma unroll
-            for (int i = 0; i < S; ++i) g.R[t][i] = group_load_img<TYPE, S>(g.cur[t], a.K >> 8, i, wv, G);
-        }
-    }
-}
-
-// Every wave of the workgroup walks the group's units in rounds of T.  `hook` runs once, in the last round after this
-// wave's block math and before the barrier: the kernel uses it to issue the NEXT group's first loads, so the weight
-// stream does not stop while this group's last chains are replayed.
-template <int TYPE, int MAXK, int S, int T, int TCB, int NBUF, bool GROUP_B, class Hook>
-DEV void group_rounds(const MatvecArgs& a, GroupState<TYPE, S, T>& g, ActLdsX<MAXK>& L, ChainBuf5<MAXK / 256> (&CB)[NBUF][TCB],
-                      int lane, int wv, const LaneGeom& G, int pos, int& round_seq, Hook hook) {
-    constexpr int NW = 16, MAXNB = MAXK / 256;
-    const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
-    unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv + (GROUP_B ? 6 : 0);
-    const int n_rounds = (g.n_units + T - 1) / T;
-    if (n_rounds == 0) { hook(); return; }
-    UnitRef nxt[T];
-    const int nb = a.K >> 8;
-    for (int rd = 0; rd < n_rounds; ++rd, ++round_seq) {
-        const int par = round_seq % NBUF;
-        // the wave that will replay unit t's chain starts the dependent residual load now
-        float res_in = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (wv == ((round_seq * T + t) & (NW - 1)) && g.cur[t].valid && !false && (a.job[g.cur[t].j].epi == EPI_ADD || a.job[g.cur[t].j].epi == EPI_ADD2)) {
-                const int row = g.cur[t].tile * 8 + G.r;
-                if (row < a.job[g.cur[t].j].w.M) res_in = a.res[row];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            group_unit_of<TYPE, S, T>(a, g, (rd + 1) * T + t, nxt[t]);
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                int b = wv + i * NW;
-                b = b < nb ? b : nb - 1;
-                if (g.cur[t].valid) img_to_chain<TYPE, MAXK, MAXNB>(g.R[t][i], b, L, CB[par][t], lane, G);   // tail rounds: skip
-                if (nxt[t].valid) g.R[t][i] = group_load_img<TYPE, S>(nxt[t], nb, i, wv, G);                     // the padding units
-            }
-        }
-        if (rd == n_rounds - 1) hook();
-        if (trace && rd == 0) tr[3] = clock64_dev();
-        __syncthreads();
-        if (trace && rd == 0) tr[4] = clock64_dev();
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (wv != ((round_seq * T + t) & (NW - 1)) || !g.cur[t].valid) continue;
-            if (false && (t & 1)) continue;                       // the gate wave also replays the up chain
-            const UnitRef& U = g.cur[t];
-            const int row = U.tile * 8 + G.r;
-            const bool own = G.g == 0 && row < a.job[U.j].w.M;
-            if (false) {
-                float res, up;
-                chain_typed2<TYPE, MAXK, MAXNB>(nb, L, CB[par][t], CB[par][t + 1 < T ? t + 1 : t], lane, G, res, up);
-                if (own) a.out[row] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
-            } else {
-                const float res = chain_typed<TYPE, MAXK, MAXNB>(nb, L, CB[par][t], lane, G);
-                const int epi = a.job[U.j].epi;
-                if (epi == EPI_ADD) {
-                    if (own) a.out[row] = res + res_in;
-                } else if (epi == EPI_STORE) {
-                    if (own) a.out[row] = res;
-                } else if (epi == EPI_V) {
-                    if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
-                } else if (epi == EPI_GELU) {
-                    if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
-                } else if (epi == EPI_ADD2) {
-                    if (own) a.out[row] = (res + res_in) + a.res2[row];
-                } else {
-                    const float other = lane_xor8(res);
-                    const int ip = (row % a.head_dim) >> 1;
-                    const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
-                    const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-                    const float o = (G.r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-                    if (own) {
-                        if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
-                        else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
-                    }
-                }
-            }
-        }
-        if (trace && rd == 0) tr[5] = clock64_dev();
-        if (NBUF == 1) __syncthreads();
-#pragma unroll
-        for (int t = 0; t < T; ++t) g.cur[t] = nxt[t];
-    }
-}
-
-// TA / TB: weight types of the two job groups (TB == 0: single group).  a.n_groupA = number of items in group A.
-template <int MAXK, int S, int T, int NBUF, int TA, int TB, bool GU, bool LN = false>
+// TA: weight type of the launch (one type; mixed-type launches run on generation 6).  GU: gate/up pairs.  LN: LayerNorm
+// prologue (falcon / gpt2) — a template parameter because merged into one body it cost every instantiation registers.
+template <int MAXK, int S, int T, int NBUF, int TA, bool GU, bool LN>
 __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     constexpr int MAXNB = MAXK / 256;
     __shared__ ActLdsX<MAXK> L;
     __shared__ ChainBuf5<MAXNB> CB[NBUF][T];
-    if (a.dbg & 16) return;
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
@@ -566,29 +341,6 @@ __global__ void __launch_bounds__(1024) matvec_v5_kernel(const MatvecArgs a) {
     if (trace) tr[0] = clock64_dev();
     const int pos = a.pos ? *a.pos : 0;
     int round_seq = 0;
-    if constexpr (TB == 0) {   // single type: the plain loop (the compiler schedules it better than the group-state form)
-        run_group<TA, MAXK, S, T, NBUF, true, GU, LN>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
-        if (trace) tr[6] = clock64_dev();
-        return;
-    }
-    GroupState<TA, S, T> ga;
-    group_begin<TA, S, T>(a, 0, a.n_groupA, ga, wv, G);
-    if (trace) tr[1] = clock64_dev();
-    // the first weight loads are in flight while the activation vector is normalised / quantized
-    prologue_q8k_exact16<1024, MAXK>(L, a.x, a.norm_w, a.K, a.pro, a.eps);   // mixed-type launches: llama only
-    if (trace) tr[2] = clock64_dev();
-    if constexpr (TB != 0) {
-        // group B (the Q6_K matrix of a mixed launch) is the small one: two units per round keep its preloaded
-        // images within the 128-VGPR budget of a 1024-thread workgroup
-        constexpr int T2 = T > 2 ? 2 : T;
-        GroupState<TB, S, T2> gb;
-        group_rounds<TA, MAXK, S, T, T, NBUF, false>(a, ga, L, CB, lane, wv, G, pos, round_seq, [&]() __attribute__((always_inline)) {
-            group_begin<TB, S, T2>(a, a.n_groupA, a.n_pairs - a.n_groupA, gb, wv, G);
-            if (trace) tr[7] = clock64_dev();
-        });
-        group_rounds<TB, MAXK, S, T2, T, NBUF, true>(a, gb, L, CB, lane, wv, G, pos, round_seq, []() {});
-    } else {
-        group_rounds<TA, MAXK, S, T, T, NBUF, false>(a, ga, L, CB, lane, wv, G, pos, round_seq, []() {});
-    }
+    run_group<TA, MAXK, S, T, NBUF, true, GU, LN>(a, 0, a.n_groupA, L, CB, lane, wv, G, pos, round_seq);
     if (trace) tr[6] = clock64_dev();
 }
