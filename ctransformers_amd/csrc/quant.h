@@ -1,4 +1,5 @@
-// GGML block formats as stored in model files, and the GPU-side "plane" layout they are repacked into at load time.
+// GGML block formats as stored in model files, and the GPU-side layouts they are repacked into at load time
+// (engine.cc:upload_matrix; values and total bytes unchanged, so the roofline byte count is the file's).
 //
 // File layouts (reference models/ggml/ggml.c:888-925 Q4_0/Q8_0; models/ggml/k_quants.h:76-126 Q4_K/Q5_K/Q6_K):
 //   Q4_0  18 B / 32 w : f16 d | 16 B nibbles (lo nibble = w[j], hi nibble = w[j+16])
@@ -6,23 +7,15 @@
 //   Q4_K 144 B / 256 w: f16 d | f16 dmin | 12 B 6-bit scales+mins | 128 B nibbles
 //   Q5_K 176 B / 256 w: f16 d | f16 dmin | 12 B scales | 32 B high bits | 128 B nibbles
 //   Q6_K 210 B / 256 w: 128 B low nibbles | 64 B high 2-bits | 16 x int8 scales | f16 d
+// (a Q6_K row of K=11008 is 9030 B in the file: rows are only 2-byte aligned — the repack is what makes 16-byte loads legal)
 //
-// Repacked planes (one-time, values unchanged): the byte streams a wavefront reads with 16-byte loads are made
-// contiguous per row and 16-byte aligned (a Q6_K row of K=11008 is 9030 B in the file: rows are only 2-byte aligned):
-//   Q4_K: p0 = qs[M][nb*128]  p1 = hdr[M][nb*16] (d,dmin,scales = the first 16 file bytes)
-//   Q5_K: p0 = qs[M][nb*128]  p1 = hdr[M][nb*16]  p2 = qh[M][nb*32]
-//   Q6_K: p0 = ql[M][nb*128]  p1 = sc[M][nb*16]   p2 = qh[M][nb*64]  p3 = d[M][nb] (f16)
-//   Q8_0: p0 = qs[M][K]                                              p3 = d[M][K/32] (f16)
-//   Q4_0: p0 = qs[M][K/2]                                            p3 = d[M][K/32] (f16)
-// Total bytes are identical to the file (no padding inside planes), so the roofline byte count is unchanged.
-//
-// "tile8" layout (LAYOUT_TILE8, used by the bit-exact mat-vec): 8 consecutive rows form a tile; for every K-block b
-// the 8 rows' blocks are stored together as one record, fields grouped so that a wavefront (8 lanes per row) reads
-// each field with one fully-coalesced 16-byte-per-lane load, and a tile is one contiguous stream of nb records:
+// LAYOUT_TILE8S (K-quants): 8 consecutive rows form a tile; for every K-block b the 8 rows' blocks are stored together as
+// one record, fields grouped so that a wavefront (8 lanes per row) reads each field with one fully-coalesced
+// 16-byte-per-lane load, and a tile is one contiguous stream of nb records:
 //   Q4_K record 1152 B: hdr[8][16] | qs[8][128]
 //   Q5_K record 1408 B: hdr[8][16] | qh[8][32] | qs[8][128]
 //   Q6_K record 1680 B: d[8] f16 (16 B) | sc[8][16] | qh[8][64] | ql[8][128]
-// Record sizes are 8 x the file block size: bytes unchanged.  Rows beyond M in the last tile are zero blocks.
+// Record sizes are 8 x the file block size.  Rows beyond M in the last tile are zero blocks.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -49,11 +42,11 @@ CT_HD static inline int ggml_block_bytes(int t) {
 CT_HD static inline size_t ggml_row_bytes(int t, int64_t k) { return (size_t)(k / ggml_block_elems(t)) * ggml_block_bytes(t); }
 CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K || t == GT_Q6_K; }
 
-// LAYOUT_TILE8S = tile8 with the 12-byte 6-bit scale/min field of Q4_K/Q5_K headers re-encoded (losslessly, same size) as
-// four 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
+// In LAYOUT_TILE8S the 12-byte 6-bit scale/min field of Q4_K/Q5_K headers is re-encoded (losslessly, same size) as four
+// 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
-enum { LAYOUT_PLANES = 0, LAYOUT_TILE8 = 1, LAYOUT_TILE8S = 2, LAYOUT_G4 = 3 };
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
@@ -63,6 +56,6 @@ struct DevMat {
     int nb = 0;                 // blocks per row (K/256 for K-quants, K/32 for Q4_0/Q8_0)
     const uint8_t* p[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
-    int layout = 0;                // LAYOUT_PLANES / LAYOUT_TILE8 (tile8 data lives in p[0])
+    int layout = 0;                // LAYOUT_TILE8S / LAYOUT_G4 (records live in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };
