@@ -78,7 +78,7 @@ def main():
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or os.environ.get("CTAMD_FORCE_PIPELINE") == "1":   # the env switch lets a 1-GPU box run the N > 1 code path with world_size 1
         from ctransformers_amd import pipeline
         return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
 
