@@ -27,6 +27,18 @@ def test_hip_library_exports_every_header_symbol(hip_lib):
         assert hasattr(lib, s), s
 
 
+def test_hip_library_exports_every_extension_symbol(hip_lib):
+    """include/ctransformers_amd_ext.h: measurement hooks and the pipeline-stage entry points."""
+    text = open(os.path.join(ROOT, "include", "ctransformers_amd_ext.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = re.findall(r"\b(ctamd_\w+)\s*\(", text)
+    assert {"ctamd_profile_decode", "ctamd_weight_bytes", "ctamd_trace_site", "ctamd_stage_create", "ctamd_stage_eval",
+            "ctamd_n_layer", "ctamd_n_embd"} <= set(syms)
+    lib = ctypes.CDLL(hip_lib)
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
 def test_config_struct_matches_header_layout():
     # struct ctransformers_config { int; int; bool; bool; } -> 12 bytes on x86-64, passed by value
     assert ctypes.sizeof(ConfigStruct) == 12
@@ -38,6 +50,9 @@ def test_create_fails_loudly_without_gpu(hip_lib, capfd):
     path = os.path.join(ROOT, "tests", "golden", "tiny-q4km.gguf")
     with pytest.raises(RuntimeError):
         LLM(path, config=Config(context_length=64), lib=hip_lib)
+    assert "no CPU fallback" in capfd.readouterr().err
+    with pytest.raises(RuntimeError):   # legacy GGML (gpt2) path: same loud failure
+        LLM(os.path.join(ROOT, "tests", "golden", "gpt2-tiny-q40.bin"), "gpt2", config=Config(context_length=64), lib=hip_lib)
     assert "no CPU fallback" in capfd.readouterr().err
 
 
