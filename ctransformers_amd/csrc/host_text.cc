@@ -320,6 +320,28 @@ void softmax_sorted(std::vector<Cand>& c, size_t& size, bool& sorted) {
 
 int sample_token(const float* logits, int n_vocab, const int* last_tokens, int n_last, int top_k, float top_p,
                  float temperature, float repetition_penalty, int seed) {
+    if (top_k == 1 && n_vocab > 0) {
+        // Greedy fast path, same result as the chain below: after the penalty, partial_sort with k = 1 keeps the first
+        // strict maximum in index order, and top-p / temperature / the draw over one candidate cannot change it.
+        static thread_local std::vector<float> tmp;
+        const float* lg = logits;
+        if (n_last > 0 && repetition_penalty != 1.0f) {
+            tmp.assign(logits, logits + n_vocab);
+            std::vector<int> seen(last_tokens, last_tokens + n_last);
+            std::sort(seen.begin(), seen.end());
+            seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+            for (const int t : seen) {
+                if (t < 0 || t >= n_vocab) continue;
+                if (tmp[(size_t)t] <= 0) tmp[(size_t)t] *= repetition_penalty;
+                else tmp[(size_t)t] /= repetition_penalty;
+            }
+            lg = tmp.data();
+        }
+        int best = 0;
+        for (int i = 1; i < n_vocab; ++i)
+            if (lg[i] > lg[best]) best = i;
+        return best;
+    }
     if (seed < 0) seed = (int)time(nullptr);
     std::mt19937 rng;
     rng.seed(seed);

@@ -128,3 +128,24 @@ def test_gpt2_tokenizer_and_sampler(emu_lib):
     for k, p, temp, pen, seed, tok in exp["samples"]:
         assert m.sample(top_k=int(k), top_p=p, temperature=temp, repetition_penalty=pen, seed=int(seed)) == int(tok)
     assert m.eos_token_id == 0 and m.bos_token_id == 0 and m.detokenize([300, 10]) == exp["detok_300_10"]
+
+
+def test_greedy_fast_path_equals_reference_chain(emu_lib, ref):
+    """sample(top_k=1) takes an argmax fast path; it must pick what the reference's chain picks, including exact ties
+    (partial_sort keeps the first strict maximum) and repetition penalties.  Needs the reference build (skips without)."""
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = open_emu(emu_lib, "tiny-q4km")
+    r = ref.open_llm(os.path.join(GOLDEN, "tiny-q4km.gguf"), context_length=96, batch_size=8, threads=1)
+    p = list(g["prompt"])
+    m.eval(p)
+    r.eval(p)
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        noise = rng.standard_normal(512).astype(np.float32)
+        if trial % 3 == 0:
+            noise = np.round(noise)   # many exact ties
+        for i in range(512):
+            m.logits[i] = float(noise[i])   # in-place mutation through the ABI's logits buffer
+            r.logits[i] = float(noise[i])
+        for pen in (1.0, 1.3, 0.7):
+            assert m.sample(top_k=1, repetition_penalty=pen, last_n_tokens=8) == r.sample(top_k=1, repetition_penalty=pen, last_n_tokens=8)
