@@ -34,8 +34,7 @@ Engine::~Engine() { free_all(); }
 void Engine::free_all() {
     for (void* p : dev_allocs_) (void)hipFree(p);
     dev_allocs_.clear();
-    if (h_logits_) (void)hipHostFree(h_logits_);
-    if (h_emb_) (void)hipHostFree(h_emb_);
+    if (h_logits_) (void)hipHostFree(h_logits_);   // h_emb_ lives in the same pinned block
     if (h_scalars_) (void)hipHostFree(h_scalars_);
     h_logits_ = h_emb_ = nullptr;
     h_scalars_ = nullptr;
@@ -343,11 +342,13 @@ bool Engine::alloc_state(std::string& err) {
     if (!dev_alloc(dev_allocs_, &x_, (size_t)E, err) || !dev_alloc(dev_allocs_, &attn_out_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
-        !dev_alloc(dev_allocs_, &d_logits_, (size_t)V, err) || !dev_alloc(dev_allocs_, &d_emb_, (size_t)E, err) ||
-        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_tokens_, (size_t)n_ctx_, err) || !dev_alloc(dev_allocs_, &d_state_, 4, err))
+        !dev_alloc(dev_allocs_, &d_logits_, (size_t)V + E, err) ||   // [logits | final-norm embedding]: one D2H copy per eval
+        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_state_, (size_t)n_ctx_ + 4, err))   // [cursor(4) | tokens]: one H2D copy
         return false;
-    HIP_OK(hipHostMalloc(&h_logits_, (size_t)V * 4));
-    HIP_OK(hipHostMalloc(&h_emb_, (size_t)E * 4));
+    d_emb_ = d_logits_ + V;
+    d_tokens_ = d_state_ + 4;
+    HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
+    h_emb_ = h_logits_ + V;
     HIP_OK(hipHostMalloc(&h_scalars_, ((size_t)n_ctx_ + 16) * 4));
     use_graph_ = env_int("CT_AMD_GRAPH", 1) != 0;
     dump_dir_ = getenv("CT_AMD_DUMP");
@@ -964,8 +965,8 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
     h_scalars_[0] = 0;           // step
     h_scalars_[1] = n_past;      // position of the first token of this chunk
     h_scalars_[2] = n_past + n;  // n_total: the reference runs this chunk as ONE batch (see attn_softmax_pv_exact_kernel)
-    HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], (size_t)n * 4, hipMemcpyHostToDevice, stream_));
-    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 12, hipMemcpyHostToDevice, stream_));
+    h_scalars_[3] = 0;
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
 #ifndef CT_EMU
     if (use_graph_) {
         if (!ensure_graphs(err)) return false;
@@ -977,8 +978,7 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
             if (!token_step(i == n - 1, err)) return false;
     }
     if (l1_ == hp_.n_layer) {
-        HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)hp_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(h_emb_, d_emb_, (size_t)hp_.n_embd * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost, stream_));
     } else {
         HIP_OK(hipMemcpyAsync(x_out_dev, xio_, xbytes, hipMemcpyDeviceToDevice, stream_));
     }

@@ -338,8 +338,11 @@ int sample_token(const float* logits, int n_vocab, const int* last_tokens, int n
             lg = tmp.data();
         }
         int best = 0;
-        for (int i = 1; i < n_vocab; ++i)
-            if (lg[i] > lg[best]) best = i;
+        float bv = lg[0];
+        for (int i = 1; i < n_vocab; ++i) {
+            const float v = lg[i];
+            if (v > bv) { bv = v; best = i; }
+        }
         return best;
     }
     if (seed < 0) seed = (int)time(nullptr);
