@@ -24,8 +24,12 @@ def main():
     else:
         stage = pipeline.HipStage(model, l0, l1, context_length=96, device="cpu", lib=ctypes.CDLL(emu))
         pipe = pipeline.Pipeline(stage, rank, world, device)
-    g = np.load(os.path.splitext(model)[0] + ".npz")
-    prompt = [int(t) for t in g["long_prompt"]]
+    npz = os.path.splitext(model)[0] + ".npz"
+    if os.path.exists(npz):
+        prompt = [int(t) for t in np.load(npz)["long_prompt"]]
+    else:   # ad-hoc model: a fixed pseudo-random prompt
+        from ctransformers_amd import synth
+        prompt = synth.prompt_tokens(13, dims["n_vocab"])
     pre = pipe.prefill(prompt, 0, micro_batch=micro)
     logits, toks, pos = pre, [], len(prompt)
     for _ in range(n_new):

@@ -112,3 +112,35 @@ def test_gloo_pipeline_world2(emu_lib, tmp_path, mirror):
         pos += 1
     assert recs[1]["tokens"] == want
     assert np.array_equal(np.load(tmp_path / "logits.npy"), lg)
+
+
+def test_gloo_pipeline_world3_middle_rank(emu_lib, tmp_path, mirror):
+    """Three ranks: the middle rank only receives, runs its layers and sends on (no token ids, no sampling).  A 3-layer
+    model, one layer per rank; tokens and final logits equal the oracle's."""
+    from ctransformers_amd import synth
+    path = str(tmp_path / "three.gguf")
+    synth.write_llama_gguf(path, "llama-tiny", "Q4_K_M", seed=41, overrides=dict(n_layer=3))
+    port = _free_port()
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pipeline_worker.py"), path, emu_lib,
+                                       str(tmp_path), "8", "2"], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [r["layers"] for r in recs] == [[0, 1], [1, 2], [2, 3]]
+    assert recs[0]["tokens"] == recs[2]["tokens"] and len(recs[0]["tokens"]) == 2
+    orc = mirror.MirrorLlama(path, 96)
+    prompt = synth.prompt_tokens(13, 512)
+    for s in range(0, len(prompt), 8):
+        lg = orc.eval(prompt[s:s + 8], s)
+    want, pos = [], len(prompt)
+    for _ in range(2):
+        t = int(np.argmax(lg))
+        want.append(t)
+        lg = orc.eval([t], pos)
+        pos += 1
+    assert recs[2]["tokens"] == want
+    assert np.array_equal(np.load(tmp_path / "logits.npy"), lg)
