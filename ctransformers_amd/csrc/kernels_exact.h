@@ -170,10 +170,16 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
     if (trace) tr[3] = clock64_dev();
     double sum = 0.0;
-    for (int i = tid; i < n_kv; i += NT) {
-        const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]);
-        prob[i] = e;
-        sum += (double)e;
+    constexpr int SB = 4;   // exp-table lookups of 4 elements per thread in flight together
+    for (int i0 = 0; i0 < n_kv; i0 += NT * SB) {
+        uint16_t e16[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { const int i = i0 + u * NT + tid; e16[u] = i < n_kv ? a.exp_tab[f32_to_f16_bits(prob[i] - mx)] : (uint16_t)0; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * NT + tid;
+            if (i < n_kv) { const float e = f16_bits_to_f32(e16[u]); prob[i] = e; sum += (double)e; }
+        }
     }
     sum = wave_sum(sum);
     if (lane == 0) red[wv] = sum;

@@ -191,3 +191,21 @@ def test_pipeline_two_processes_one_gpu(tmp_path):
     recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
     assert np.array_equal(np.load(tmp_path / "prefill_logits.npy"), g["long_chunked"])
     assert recs[0]["tokens"] == recs[1]["tokens"] and len(recs[0]["tokens"]) == 3
+
+
+def test_long_context(ref, tmp_path):
+    """A 630-token prompt (chunks of 64) and decode beyond it: several passes of the attention kernel's position loops,
+    logits bit-identical to the reference build."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-small", "Q4_K_M", seed=33)
+    r = ref.open_llm(p, context_length=768, batch_size=64, threads=8)
+    m = open_hip(p, context_length=768, batch_size=64)
+    toks = synth.prompt_tokens(630, hp["n_vocab"])
+    r.eval(toks)
+    m.eval(toks)
+    for i in range(24):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "position %d" % (630 + i)
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
