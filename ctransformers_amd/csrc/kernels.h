@@ -80,7 +80,7 @@ struct MatvecArgs {
     int n_ctx, head_dim, n_embd_gqa, v_stride;
     const uint16_t* silu_tab;  // 65536-entry fp16->fp16 table (reference ggml.c:4328-4332)
     float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
-    int dbg;                   // measurement only (CT_AMD_DBG): 1 skip prologue, 2 skip block math, 4 skip chain+epilogue, 8 skip weight loads, 16 return at once
+    int dbg;                   // measurement only (CT_AMD_DBG / ctamd_trace_site): bit 32 = write in-kernel s_memtime stamps to dbg_sink
 };
 
 // ------------------------------------------------------------------------------------------------------------------
