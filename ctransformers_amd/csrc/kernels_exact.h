@@ -52,30 +52,19 @@ DEV void unpack8_f16(const u32x4 v, float* f) {
 }
 
 // in: acc[8] = s_j[0..7] of quad lane j; out (all 4 lanes): res of the reference's reduce.
+// Two DPP quad exchanges per accumulator give every lane S[l] = (s_0[l] + s_2[l]) + (s_1[l] + s_3[l]) (the operands of each
+// addition are the reference's, in commuted order in half of the lanes); the rest of the tree is in-lane.  23 VALU
+// operations and no LDS traffic — the bpermute/select form this replaces cost more than the dot product itself.
 DEV float f16dot_reduce_exact(const float* acc, int j) {
-    // step A (partner j^2): keep l in {0,1,4,5} (j<2) or {2,3,6,7} (j>=2)
-    const bool hiA = (j & 2) != 0;
-    float kA[4], sA[4];
+    (void)j;
+    float S[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int l_lo = (t & 1) + 4 * (t >> 1);        // 0,1,4,5
-        const int l_hi = l_lo + 2;                      // 2,3,6,7
-        kA[t] = hiA ? acc[l_hi] : acc[l_lo];
-        sA[t] = hiA ? acc[l_lo] : acc[l_hi];
+    for (int l = 0; l < 8; ++l) {
+        const float x = acc[l] + lane_xor2(acc[l]);
+        S[l] = x + lane_xor1(x);
     }
-    float a[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = kA[t] + __shfl_xor(sA[t], 2);   // s_j[l] + s_{j^2}[l], l = base(t) (+2 if j>=2)
-    // a[] now holds l = {0,1,4,5} (+2 when j>=2).  step B (partner j^1): even j keeps t = {0,2} (l', l'+4 with l' even
-    // offset 0), odd j keeps t = {1,3}.
-    const bool odd = (j & 1) != 0;
-    const float k0 = odd ? a[1] : a[0], k1 = odd ? a[3] : a[2];
-    const float s0 = odd ? a[0] : a[1], s1 = odd ? a[2] : a[3];
-    const float S_lo = k0 + __shfl_xor(s0, 1);   // S[l'],   l' = j
-    const float S_hi = k1 + __shfl_xor(s1, 1);   // S[l'+4]
-    const float t0 = S_lo + S_hi;                // t0[j]
-    const float t1 = t0 + __shfl_xor(t0, 1);     // t0[0]+t0[1]  |  t0[2]+t0[3]
-    return t1 + __shfl_xor(t1, 2);
+    const float t0 = S[0] + S[4], t1 = S[1] + S[5], t2 = S[2] + S[6], t3 = S[3] + S[7];
+    return (t0 + t1) + (t2 + t3);
 }
 
 struct AttnArgsX {
@@ -124,9 +113,9 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     // The V rows do not depend on the probabilities: their first VB chunks are requested now, so that their latency
     // overlaps the score and softmax phases instead of following them.
     u32x4 vv[VB];
-    u32x4 qv[NC];
+    float qf[NC][8];   // this lane's slices of the query, converted once
 #pragma unroll
-    for (int c = 0; c < NC; ++c) qv[c] = ld16(qrow + 32 * c + 8 * j);
+    for (int c = 0; c < NC; ++c) unpack8_f16(ld16(qrow + 32 * c + 8 * j), qf[c]);
     float mx = -INFINITY;
     for (int base = 0; base < n_kv; base += NQ * PB) {
         u32x4 kv[PB][NC];
@@ -148,11 +137,10 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float kf[8], qf[8];
+                float kf[8];
                 unpack8_f16(kv[u][c], kf);
-                unpack8_f16(qv[c], qf);
 #pragma unroll
-                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[c][l], acc[l]);
             }
             const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
             if (p < n_kv) {

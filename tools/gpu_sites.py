@@ -10,7 +10,7 @@ from ctransformers_amd.llm import LLM, Config
 p = "/tmp/l7b.gguf"
 if not os.path.exists(p):
     synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
-m = LLM(p, config=Config(context_length=512, batch_size=512), lib=os.environ.get("SITES_LIB") or None)
+m = LLM(p, config=Config(context_length=int(os.environ.get("SITES_CTX", "512")), batch_size=512), lib=os.environ.get("SITES_LIB") or None)
 NP = int(os.environ.get("SITES_PROMPT", "64"))
 m.eval(synth.prompt_tokens(NP, 32000))
 tok = m.sample(top_k=1, repetition_penalty=1.0)

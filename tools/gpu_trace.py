@@ -7,7 +7,7 @@ from ctransformers_amd.llm import LLM, Config
 p = "/tmp/l7b.gguf"
 if not os.path.exists(p):
     synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
-m = LLM(p, config=Config(context_length=512, batch_size=512))
+m = LLM(p, config=Config(context_length=int(os.environ.get("SITES_CTX", "512")), batch_size=512))
 m.eval(synth.prompt_tokens(int(os.environ.get("SITES_PROMPT", "64")), 32000))
 lib = m._lib
 lib.ctamd_trace_site.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
