@@ -156,6 +156,7 @@ int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, in
 
 int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine.hparams().n_layer; }
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine.hparams().n_embd; }
+long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine.chunk_tokens(); }
 
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {

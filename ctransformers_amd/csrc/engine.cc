@@ -12,6 +12,7 @@
 #include "kernels_v6.h"
 #include "kernels_q32.h"
 #include "kernels_ks.h"
+#include "kernels_pf.h"
 
 namespace ctamd {
 
@@ -347,6 +348,20 @@ bool Engine::alloc_state(std::string& err) {
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
+    pf_ok_ = !hp_.falcon() && !hp_.gpt2() && E <= 12288 && F <= 12288 && env_int("CT_AMD_PF", 1) != 0;
+    for (int i = l0_; i < l1_ && pf_ok_; ++i) {
+        const Layer& L = layers_[i];
+        for (const DevMat* m : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down})
+            pf_ok_ = pf_ok_ && m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K);
+    }
+    if (pf_ok_) {
+        pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
+        const size_t aw = (size_t)pf_act_words(std::max(E, F));
+        if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
+            !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
+            !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
+            return false;
+    }
     HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
     h_emb_ = h_logits_ + V;
     HIP_OK(hipHostMalloc(&h_scalars_, ((size_t)n_ctx_ + 16) * 4));
@@ -623,20 +638,132 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
 bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err); }
 
 // One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
-void Engine::launch_attention(uint16_t* kc, uint16_t* vc) {
+void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     const int hd = hp_.head_dim();
     AttnArgsX ax = AttnArgsX();
-    ax.q_f16 = q_f16_; ax.kcache = kc; ax.vcache = vc; ax.out = attn_out_; ax.pos = d_state_ + 1;
+    ax.q_f16 = nt ? q_f16_b_ : q_f16_; ax.kcache = kc; ax.vcache = vc; ax.out = nt ? attn_out_b_ : attn_out_; ax.pos = d_state_ + 1;
+    ax.q_stride = hp_.n_embd; ax.out_stride = hp_.n_embd;
     ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
     ax.n_embd_gqa = hp_.n_embd_gqa(); ax.n_ctx = n_ctx_; ax.v_stride = v_stride_;
     ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
     if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
-    const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64));
+    const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
     if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
     else if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
     else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
     else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
 }
+
+// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernel.
+bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
+                       std::string& err) {
+    int item0 = 0;
+    for (int j = 0; j < m.njobs; ++j) {
+        m.job[j].pair0 = m.gateup ? 0 : item0;
+        item0 += (m.job[j].w.M + 7) / 8;
+    }
+    m.n_pairs = m.gateup ? (m.job[0].w.M + 7) / 8 : item0;
+    const int aw = pf_act_words(m.K);
+    if (!site_on(site)) return true;
+    prof_begin(site, "matvec_pf", bytes);
+    if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
+    else CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
+    PfArgs a;
+    a.m = m;
+    a.acts = acts_; a.act_words = aw; a.n_tok = nt;
+    a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
+    const int groups = (nt + kPfTokens - 1) / kPfTokens;
+    // every CU gets a workgroup; a launch with few tiles then has one or two busy waves per SIMD instead of idle CUs
+    const int gx = std::max(1, std::min(chip_cus() / groups, m.n_pairs));
+    const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
+    const size_t smem = (size_t)kPfTokens * aw * 4;
+    if (m.gateup) {
+        auto kfn = matvec_pf_kernel<kPfTokens, true>;
+        static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
+        (void)once;
+        CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+    } else {
+        auto kfn = matvec_pf_kernel<kPfTokens, false>;
+        static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
+        (void)once;
+        CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+    }
+    prof_end();
+    (void)err;
+    return true;
+}
+
+// llm_build_llama (llama.cpp:2162-2491) for nt tokens of one batch_eval chunk at once: the same launches as token_step,
+// each over rows [c0, c0 + nt) of the chunk (kernels_pf.h).  The cursor in d_state_ is at token c0 on entry.
+bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    if (l0_ == 0) {
+        CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256), (unsigned)nt), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+                  (const int*)d_tokens_, (const int*)d_state_, xb_);
+    } else {
+        HIP_OK(hipMemcpyAsync(xb_, xio_ + (size_t)c0 * E, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
+    }
+    MatvecArgs base = MatvecArgs();
+    base.rope_cs = rope_cs_;
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = G;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.eps = hp_.rms_eps;
+    for (int il = l0_; il < l1_; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_RMSNORM; a.norm_w = L.attn_norm;
+            a.q_f16 = q_f16_b_; a.kcache = kc; a.vcache = vc;
+            set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});
+            if (!pf_matvec(a, xb_, E, nt, 0, 0, "qkv", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes), err)) return false;
+        }
+        if (site_on("attn_fused")) {
+            prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+            launch_attention(kc, vc, nt);
+            prof_end();
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
+            set_jobs(a, {{&L.wo, EPI_ADD}});
+            if (!pf_matvec(a, attn_out_b_, E, nt, E, E, "wo", (double)L.wo.bytes, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_RMSNORM; a.norm_w = L.ffn_norm; a.out = hb_;
+            a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
+            a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
+            a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            if (!pf_matvec(a, xb_, E, nt, F, 0, "gate_up", (double)(L.w_gate.bytes + L.w_up.bytes), err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
+            set_jobs(a, {{&L.w_down, EPI_ADD}});
+            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+        }
+    }
+    if (l1_ < hp_.n_layer) {
+        HIP_OK(hipMemcpyAsync(xio_ + (size_t)c0 * E, xb_, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
+    } else if (want_logits) {   // the chunk's last token only (llama.cpp:2955-2959 keeps the last column)
+        const float* xl = xb_ + (size_t)(nt - 1) * E;
+        CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_RMSNORM; a.x = xl; a.norm_w = output_norm_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
+    return true;
+}
+
 
 bool Engine::token_step(bool want_logits, std::string& err) {
     if (hp_.falcon()) return token_step_falcon(want_logits, err);
@@ -967,14 +1094,23 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
     h_scalars_[2] = n_past + n;  // n_total: the reference runs this chunk as ONE batch (see attn_softmax_pv_exact_kernel)
     h_scalars_[3] = 0;
     HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
+    int done = 0;
+    if (pf_ok_ && n >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights
+        while (n - done >= pf_min_) {
+            const int nt = std::min(kPfChunk, n - done);
+            if (!chunk_step(done, nt, done + nt == n, err)) return false;
+            done += nt;
+            chunk_tokens_ += nt;
+        }
+    }
 #ifndef CT_EMU
     if (use_graph_) {
-        if (!ensure_graphs(err)) return false;
-        for (int i = 0; i < n; ++i) HIP_OK(hipGraphLaunch(i == n - 1 ? graph_step_head_ : graph_step_, stream_));
+        if (done < n && !ensure_graphs(err)) return false;
+        for (int i = done; i < n; ++i) HIP_OK(hipGraphLaunch(i == n - 1 ? graph_step_head_ : graph_step_, stream_));
     } else
 #endif
     {
-        for (int i = 0; i < n; ++i)
+        for (int i = done; i < n; ++i)
             if (!token_step(i == n - 1, err)) return false;
     }
     if (l1_ == hp_.n_layer) {

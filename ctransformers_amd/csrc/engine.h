@@ -69,6 +69,7 @@ class Engine {
     const float* embeddings() const { return h_emb_; }
     int embeddings_size() const { return have_logits_ && !hp_.gpt2() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
+    long long chunk_tokens() const { return chunk_tokens_; }
 
     // Measurement hook (exported as ctamd_profile_decode): replays the LAST evaluated token `iters` times with eager
     // launches bracketed by HIP events on the engine's stream; one entry per launch site, times summed over iters.
@@ -93,7 +94,9 @@ class Engine {
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
-    void launch_attention(uint16_t* kc, uint16_t* vc);
+    bool chunk_step(int c0, int nt, bool want_logits, std::string& err);   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
+    bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
+    void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     bool token_step_falcon(bool want_logits, std::string& err);
     bool token_step_gpt2(bool want_logits, std::string& err);
     bool alloc_state(std::string& err);   // KV cache, scratch, pinned host buffers, tables
@@ -123,6 +126,13 @@ class Engine {
     uint16_t* vcache_ = nullptr;
     float *x_ = nullptr, *attn_out_ = nullptr, *h_ = nullptr, *scores_ = nullptr, *d_logits_ = nullptr, *d_emb_ = nullptr;
     uint16_t* q_f16_ = nullptr;
+    // prompt-chunk scratch (rows of kPfChunk tokens): residual stream, attention output, FFN hidden, fp16 queries, Q8_K images
+    float *xb_ = nullptr, *attn_out_b_ = nullptr, *hb_ = nullptr;
+    uint16_t* q_f16_b_ = nullptr;
+    int* acts_ = nullptr;
+    bool pf_ok_ = false;    // llama architecture, every layer matrix a K-quant in the tile layout, K <= 12288
+    int pf_min_ = 2;        // chunks shorter than this run token by token
+    long long chunk_tokens_ = 0;
     float* rope_cs_ = nullptr;
     uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;
     int *d_tokens_ = nullptr, *d_state_ = nullptr;  // token ids of the current chunk; {step, pos} cursor

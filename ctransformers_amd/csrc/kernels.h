@@ -89,8 +89,9 @@ struct MatvecArgs {
 __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restrict__ raw, int type, int K,
                                                         const int* __restrict__ tokens, const int* __restrict__ state,
                                                         float* __restrict__ out, const float* __restrict__ wpe = nullptr) {
-    const int token = tokens[state[0]];
+    const int token = tokens[state[0] + (int)blockIdx.y];   // blockIdx.y: token inside a prompt chunk (kernels_pf.h), else 0
     const uint8_t* row = raw + (size_t)token * ggml_row_bytes(type, K);
+    out += (size_t)blockIdx.y * K;
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < K; e += (int)(gridDim.x * blockDim.x)) {
         float y;
         if (type == GT_F32) {

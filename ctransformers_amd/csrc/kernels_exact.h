@@ -79,6 +79,7 @@ struct AttnArgsX {
     int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
     float kq_scale;
     unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
+    int q_stride, out_stride;    // prompt chunks (kernels_pf.h): token blockIdx.z has position *pos + z, query row z, output row z
 };
 
 // Fused form of the two kernels above (one launch per layer instead of two): grid (n_head, head_dim/64), 1024 threads.
@@ -99,13 +100,14 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     const bool trace = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0;
     unsigned long long* tr = a.trace + 16 * (threadIdx.x >> 6);
     if (trace) tr[0] = clock64_dev();
-    const int n_kv = *a.pos + 1;
+    const int tok = (int)blockIdx.z;
+    const int n_kv = *a.pos + tok + 1;
     const int n_tot = *a.n_total;
     const int np = n_tot & ~31;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3;
     const int hk = h / (a.n_head / a.n_head_kv);
     if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
-    const uint16_t* qrow = a.q_f16 + (size_t)h * HD;
+    const uint16_t* qrow = a.q_f16 + (size_t)tok * a.q_stride + (size_t)h * HD;
     const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
     const bool pv_thread = tid < 256;           // 64 channels x 4 lanes run the V*P part
     const int d = (int)blockIdx.y * 64 + ((tid & 255) >> 2);
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     double sumf = (double)res;
     if (trace) tr[5] = clock64_dev();
     for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
-    if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
+    if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
 }
 

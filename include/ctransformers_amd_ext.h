@@ -35,6 +35,9 @@ int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, in
                      void* x_out_dev);
 int ctamd_n_layer(ctransformers_llm* llm);
 int ctamd_n_embd(ctransformers_llm* llm);
+/* Tokens this handle has evaluated through the prompt-chunk kernels (kernels_pf.h) rather than token by token; lets a
+   test assert which path produced the logits it compared. */
+long long ctamd_chunk_tokens(ctransformers_llm* llm);
 #ifdef __cplusplus
 }
 #endif

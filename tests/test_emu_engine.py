@@ -18,6 +18,14 @@ def open_emu(emu_lib, name, **kw):
     return LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(**cfg), lib=emu_lib)
 
 
+def chunk_tokens(m):
+    """Tokens the handle evaluated through the prompt-chunk kernels (include/ctransformers_amd_ext.h)."""
+    import ctypes
+    f = m._lib.ctamd_chunk_tokens
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
 @pytest.mark.parametrize("name,steps", [("tiny-q4km", 4), ("tiny-q5km", 2), ("tiny-q80", 2), ("tiny-q40", 2),
                                         ("falcon-tiny-q4km", 2), ("falcon-tiny7-q4km", 2), ("gpt2-tiny-q40", 2)])
 def test_logits_bit_identical_to_reference(emu_lib, name, steps):
@@ -27,6 +35,8 @@ def test_logits_bit_identical_to_reference(emu_lib, name, steps):
     assert len(m.logits) == 0  # nothing evaluated yet
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    # llama K-quant files take the prompt-chunk kernels (chunks of 8 + 3 tokens here); the rest run token by token
+    assert chunk_tokens(m) == (len(g["prompt"]) if name in ("tiny-q4km", "tiny-q5km") else 0)
     if name.startswith("gpt2"):
         assert len(m.embeddings) == 0   # legacy models expose no embeddings (reference models/llm.h:73)
     else:
@@ -45,6 +55,27 @@ def test_batch_structure(emu_lib):
     m = open_emu(emu_lib, "tiny-q4km", batch_size=64)
     m.eval(list(g["long_prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["long_one"])
+    assert chunk_tokens(m) == 45   # 32 + 13 tokens through the chunk kernels
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
+    """The chunk kernels (kernels_pf.h) against the decode kernels on the same batches: ragged chunk lengths (a full
+    32-token pass plus 1, a short tail, 2 tokens), a non-zero n_past, and embeddings as well as logits."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    toks = list(g["long_prompt"])
+    out = {}
+    for pf in ("1", "0"):
+        monkeypatch.setenv("CT_AMD_PF", pf)
+        m = open_emu(emu_lib, name, batch_size=64)
+        res = []
+        for lo, hi in ((0, 33), (33, 35), (35, 45)):
+            m.eval(toks[lo:hi])
+            res.append((m.logits.to_numpy().copy(), m.embeddings.to_numpy().copy()))
+        out[pf] = (res, chunk_tokens(m))
+    assert out["1"][1] == 32 + 2 + 10 and out["0"][1] == 0   # 33 = one 32-token pass + one token on the decode path
+    for (la, ea), (lb, eb) in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(la, lb) and np.array_equal(ea, eb)
 
 
 def test_abi_semantics(emu_lib):
