@@ -88,7 +88,12 @@ def main():
     load_s = time.perf_counter() - t0
     n_vocab = llm.vocab_size
     prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
-    # prefill (timed separately; reported, not the headline value)
+    # prefill (timed separately; reported, not the headline value): once cold (first use of every kernel: code-object load,
+    # LDS opt-ins, graph capture), then the same prompt again from position 0 — the steady-state number
+    t0 = time.perf_counter()
+    llm.eval(prompt)
+    prefill_cold_s = time.perf_counter() - t0
+    llm._context = []
     t0 = time.perf_counter()
     llm.eval(prompt)
     prefill_s = time.perf_counter() - t0
@@ -115,7 +120,7 @@ def main():
                data="synthetic",
                config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on 1xMI355X, 128-tok prefill + 256-tok greedy decode, ctx 512",
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism="1 GPU"),
-               prefill_tok_s=round(N_PROMPT / prefill_s, 1), load_s=round(load_s, 2),
+               prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
                token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4)),
                roofline=roof)
     if not a.no_cpu_baseline:

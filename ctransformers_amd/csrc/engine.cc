@@ -12,7 +12,7 @@
 #include "kernels_v6.h"
 #include "kernels_q32.h"
 #include "kernels_ks.h"
-#include "kernels_pf.h"
+#include "kernels_pfm.h"
 
 namespace ctamd {
 
@@ -43,6 +43,8 @@ void Engine::free_all() {
     if (graph_step_) (void)hipGraphExecDestroy(graph_step_);
     if (graph_step_head_) (void)hipGraphExecDestroy(graph_step_head_);
     graph_step_ = graph_step_head_ = nullptr;
+    for (auto& kv : chunk_graphs_) (void)hipGraphExecDestroy(kv.second);
+    chunk_graphs_.clear();
 #endif
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
@@ -356,6 +358,7 @@ bool Engine::alloc_state(std::string& err) {
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
+        pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
         const size_t aw = (size_t)pf_act_words(std::max(E, F));
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
@@ -648,45 +651,82 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
     if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
+    if (nt > 0 && (hd == 128 || hd == 64)) {
+        // prompt chunk: n_head x nt workgroups, each latency-bound — 256-thread workgroups let three of them share a CU
+        // (the arithmetic does not depend on the workgroup size: scores, softmax and V*P are per position / per channel)
+        if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<256, 128>), ag, dim3(256), stream_, ax);
+        else CT_LAUNCH((attn_fused_exact_kernel<256, 64>), ag, dim3(256), stream_, ax);
+        return;
+    }
     if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
     else if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
     else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
     else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
 }
 
-// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernel.
+// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernels — the
+// Q4_K jobs of the site on the matrix cores (kernels_pfm.h), jobs of the other K-quant types on the dot4 form (kernels_pf.h).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
                        std::string& err) {
-    int item0 = 0;
-    for (int j = 0; j < m.njobs; ++j) {
-        m.job[j].pair0 = m.gateup ? 0 : item0;
-        item0 += (m.job[j].w.M + 7) / 8;
-    }
-    m.n_pairs = m.gateup ? (m.job[0].w.M + 7) / 8 : item0;
     const int aw = pf_act_words(m.K);
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
     if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
     else CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
-    PfArgs a;
-    a.m = m;
-    a.acts = acts_; a.act_words = aw; a.n_tok = nt;
-    a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
-    const int groups = (nt + kPfTokens - 1) / kPfTokens;
-    // every CU gets a workgroup; a launch with few tiles then has one or two busy waves per SIMD instead of idle CUs
-    const int gx = std::max(1, std::min(chip_cus() / groups, m.n_pairs));
-    const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
-    const size_t smem = (size_t)kPfTokens * aw * 4;
-    if (m.gateup) {
-        auto kfn = matvec_pf_kernel<kPfTokens, true>;
-        static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
-        (void)once;
-        CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
-    } else {
-        auto kfn = matvec_pf_kernel<kPfTokens, false>;
-        static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
-        (void)once;
-        CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+    static const int use_mfma = env_int("CT_AMD_PF_MFMA", 1);
+    static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: Q4_K jobs -> MFMA kernel; pass 1: the rest -> dot4 kernel
+        const bool mfma = pass == 0;
+        if (mfma && !use_mfma) continue;
+        PfArgs a;
+        a.m = m;
+        a.acts = acts_; a.act_words = aw; a.n_tok = nt;
+        a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
+        const int rows_per_item = mfma ? 16 : 8;
+        int nj = 0, item0 = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            const bool q4 = m.job[j].w.type == GT_Q4_K && use_mfma;
+            if (q4 != mfma) continue;
+            a.m.job[nj] = m.job[j];
+            a.m.job[nj].pair0 = m.gateup ? 0 : item0;
+            item0 += (m.job[j].w.M + rows_per_item - 1) / rows_per_item;
+            ++nj;
+        }
+        if (nj == 0) continue;
+        a.m.njobs = nj;
+        a.m.n_pairs = m.gateup ? (m.job[0].w.M + rows_per_item - 1) / rows_per_item : item0;
+        if (mfma) {
+            const bool t16 = (size_t)16 * aw * 4 <= 160 * 1024;
+            const int tok = t16 ? 16 : 8, groups = (nt + tok - 1) / tok;
+            const int gx = std::max(1, std::min(gx_mul * chip_cus() / groups, a.m.n_pairs));
+            const dim3 grid((unsigned)gx, (unsigned)groups), block(512);
+            const size_t smem = (size_t)tok * aw * 4;
+#define PFM(TOKV, GUV) do { \
+                auto kfn = matvec_pfm_kernel<TOKV, GUV>; \
+                static bool once = [&] { return CT_SMEM_OPTIN(kfn, 160 * 1024); }(); \
+                (void)once; \
+                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
+            if (t16) { if (m.gateup) PFM(16, true); else PFM(16, false); }
+            else { if (m.gateup) PFM(8, true); else PFM(8, false); }
+#undef PFM
+        } else {
+            const int groups = (nt + kPfTokens - 1) / kPfTokens;
+            // every CU gets a workgroup; a launch with few tiles then has one or two busy waves per SIMD instead of idle CUs
+            const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
+            const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
+            const size_t smem = (size_t)kPfTokens * aw * 4;
+            if (m.gateup) {
+                auto kfn = matvec_pf_kernel<kPfTokens, true>;
+                static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
+                (void)once;
+                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+            } else {
+                auto kfn = matvec_pf_kernel<kPfTokens, false>;
+                static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
+                (void)once;
+                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+            }
+        }
     }
     prof_end();
     (void)err;
@@ -764,6 +804,35 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
     return true;
 }
 
+
+// A whole-model handle launches nothing in chunk_step that depends on c0 (the cursor lives in d_state_), so the ~300 launches
+// of a chunk shape seen before are replayed from a graph: the first use of a shape runs eagerly (it also performs the
+// one-time dynamic-LDS opt-ins), the second captures.
+bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
+#ifndef CT_EMU
+    if (use_graph_ && l0_ == 0 && l1_ == hp_.n_layer && !prof_ && !only_site_) {
+        const int key = 2 * nt + (want_logits ? 1 : 0);
+        auto it = chunk_graphs_.find(key);
+        if (it == chunk_graphs_.end() && chunk_seen_[key]++ >= 1) {
+            hipGraph_t g = nullptr;
+            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+            const bool ok = chunk_step(c0, nt, want_logits, err);
+            const hipError_t e = hipStreamEndCapture(stream_, &g);
+            if (!ok) return false;
+            if (e != hipSuccess) { err = std::string("hipStreamEndCapture (chunk) failed: ") + hipGetErrorString(e); return false; }
+            hipGraphExec_t ex = nullptr;
+            HIP_OK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIP_OK(hipGraphDestroy(g));
+            it = chunk_graphs_.emplace(key, ex).first;
+        }
+        if (it != chunk_graphs_.end()) {
+            HIP_OK(hipGraphLaunch(it->second, stream_));
+            return true;
+        }
+    }
+#endif
+    return chunk_step(c0, nt, want_logits, err);
+}
 
 bool Engine::token_step(bool want_logits, std::string& err) {
     if (hp_.falcon()) return token_step_falcon(want_logits, err);
@@ -1097,8 +1166,8 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
     int done = 0;
     if (pf_ok_ && n >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights
         while (n - done >= pf_min_) {
-            const int nt = std::min(kPfChunk, n - done);
-            if (!chunk_step(done, nt, done + nt == n, err)) return false;
+            const int nt = std::min(pf_chunk_, n - done);
+            if (!run_chunk(done, nt, done + nt == n, err)) return false;
             done += nt;
             chunk_tokens_ += nt;
         }

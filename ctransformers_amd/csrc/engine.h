@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -94,7 +95,8 @@ class Engine {
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
-    bool chunk_step(int c0, int nt, bool want_logits, std::string& err);   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
+    bool chunk_step(int c0, int nt, bool want_logits, std::string& err);
+    bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     bool token_step_falcon(bool want_logits, std::string& err);
@@ -132,6 +134,7 @@ class Engine {
     int* acts_ = nullptr;
     bool pf_ok_ = false;    // llama architecture, every layer matrix a K-quant in the tile layout, K <= 12288
     int pf_min_ = 2;        // chunks shorter than this run token by token
+    int pf_chunk_ = 64;     // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
     long long chunk_tokens_ = 0;
     float* rope_cs_ = nullptr;
     uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;
@@ -141,6 +144,8 @@ class Engine {
     bool use_graph_ = false;
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
+    std::map<int, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by 2 * n_tokens + want_logits; captured on second use
+    std::map<int, int> chunk_seen_;
 #endif
     bool have_logits_ = false;
     int last_token_ = -1, last_pos_ = -1;

@@ -85,6 +85,42 @@ DEV u32x4 ld_stream16(const void* p) { return __builtin_nontemporal_load((const 
 DEV u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 #endif
 
+// ---- int8 matrix core: D[16][16] += A[16][32] * B[32][16] (v_mfma_i32_16x16x32_i8) ---------------------------------------
+// Operand layout (checked on hardware by tools/experiments/mfma_i8_layout.cpp): lane i gives A[i & 15][8q .. 8q+7] and
+// B[8q .. 8q+7][i & 15] (q = i >> 4) as eight int8 in one 64-bit operand, and holds D[4q + j][i & 15] in register j.
+#ifdef CT_EMU
+struct i32x4 {
+    int v[4];
+    int operator[](int i) const { return v[i]; }
+    int& operator[](int i) { return v[i]; }
+};
+static inline i32x4 mfma_i8_16x16x32(uint64_t a, uint64_t b, i32x4 c) {
+    const int lane = (int)(threadIdx.x & 63), q = lane >> 4, n = lane & 15;
+    uint64_t bk[4];
+    for (int kc = 0; kc < 4; ++kc) bk[kc] = emu_shfl_any(b, n + 16 * kc);
+    for (int j = 0; j < 4; ++j) {
+        for (int kc = 0; kc < 4; ++kc) {
+            const uint64_t am = emu_shfl_any(a, 4 * q + j + 16 * kc);
+            for (int e = 0; e < 8; ++e) c[j] += (int)(int8_t)(am >> (8 * e)) * (int)(int8_t)(bk[kc] >> (8 * e));
+        }
+    }
+    return c;
+}
+// two u16 lanes of `a` times the two u16 lanes of `s` (low 16 bits each): v_pk_mul_lo_u16
+static inline uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
+    return (((a & 0xFFFFu) * (s & 0xFFFFu)) & 0xFFFFu) | (((a >> 16) * (s >> 16)) << 16);
+}
+#else
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+DEV i32x4 mfma_i8_16x16x32(uint64_t a, uint64_t b, i32x4 c) {
+    return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+DEV uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, s));
+}
+#endif
+
 // ---- cross-lane moves without the LDS crossbar where the ISA allows it ----------------------------------------------
 // __shfl_xor always lowers to ds_bpermute_b32 (address VGPR + LDS pipe, ~100 cycles dependent latency).  Butterflies
 // inside a row of 16 lanes can use DPP modifiers instead: quad_perm for xor 1/2, row_half_mirror o quad_perm(3,2,1,0)

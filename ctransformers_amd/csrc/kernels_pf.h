@@ -20,7 +20,7 @@
 #include "kernels_v6.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
-constexpr int kPfChunk = 32;    // tokens per launch (grid.y = 4 token groups)
+constexpr int kPfChunk = 64;    // tokens per launch (grid.y = 8 token groups here, 4 of 16 on the matrix-core path)
 
 struct PfArgs {
     MatvecArgs m;        // jobs and epilogue operands; x / norm_w / pro are the quantize kernel's business
@@ -183,9 +183,16 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
     const int t0 = (int)blockIdx.y * TB;
     const int nt = a.n_tok - t0 < TB ? a.n_tok - t0 : TB;
     {   // this token group's images, contiguous in global memory
+        // all TB images (the scratch buffer always holds kPfChunk; images past n_tok are stale and never stored from)
         const u32x4* src = (const u32x4*)(a.acts + (size_t)t0 * a.act_words);
-        const int n16 = nt * (a.act_words >> 2);
-        for (int i = tid; i < n16; i += 1024) ((u32x4*)lds)[i] = ld16(src + i);
+        const int n16 = TB * (a.act_words >> 2);
+        for (int i0 = 0; i0 < n16; i0 += 4 * 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024 + tid; v[u] = ld16(src + (i < n16 ? i : n16 - 1)); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024 + tid; ((u32x4*)lds)[i < n16 ? i : n16 - 1] = v[u]; }
+        }
     }
     __syncthreads();
     const int pos0 = (m.pos ? *m.pos : 0) + t0;

@@ -1,0 +1,206 @@
+// Prompt chunks, Q4_K weights on the int8 matrix cores — still bit-identical to the reference CPU build.
+//
+// What has to be reproduced per (row, token) and 256-block is the reference's eight int32 lane sums
+//     sumi[l] = sum_{s<8} sc_s * sum_{e<4} q_s[4l+e] * a_s[4l+e]                  (k_quants.c:2651-2720; kernels_exact.h)
+// followed by ONE f32 fma per lane and block.  The integer part is a matrix product with K = 32 per AVX lane l
+// (k = (s, e)), except that the 6-bit sub-block scale sits between the 4-bit weight and the product.  Splitting the
+// scale as sc = 8*hi3 + lo3 makes both halves fit the matrix core's int8 operands (q * 7 <= 105):
+//     sumi[l] = 8 * sum_k a_k * (q_k * hi3_s(k)) + sum_k a_k * (q_k * lo3_s(k))
+// i.e. two v_mfma_i32_16x16x32_i8 per l, exact in int32, the second accumulating onto the first one's result << 3.
+// The scaled weight bytes come from ONE packed 16-bit multiply per dword (a byte times 7 cannot carry into its neighbour).
+// The f32 side — acc[l] = fma(y.d * fp16(x.d), (float)sumi[l], acc[l]), the four min-term accumulators, hsum_float_8 —
+// is the decode kernels', now entirely in-lane (no cross-lane reduction is left: the matrix core did the sums).
+//
+// Shapes: a wave owns 16 weight rows (two 8-row tiles of the TILE8S layout) x 16 tokens.  The MFMA is issued
+// transposed, D[token][row] = A[token][k] * B[k][row], so that a lane's results are four tokens of ITS row (lane & 15):
+// everything per-row (d, dmin, scales, mins) is already in the lane that loaded the row's header.
+//   weights   lane (row r16 = lane & 15, q = lane >> 4) loads the row's header (16 B) and the 32 bytes of nibble units
+//             2q, 2q+1: dword l = elements 4l..4l+3 of sub-blocks 2q (low nibbles) and 2q+1 (high nibbles)
+//   tokens    lane (token n = lane & 15, q) reads words [16q, 16q+16) of the token's block: word l / 8+l = the same
+//             elements of sub-blocks 2q / 2q+1; operand k-order {sub-block 2q, sub-block 2q+1} on both sides
+//   results   lane (r16, q), register j: token 4q + j
+// Per block and wave (256 (row, token) pairs): 16 MFMA + ~250 VALU, against 8 x ~55 VALU for 64 pairs in kernels_pf.h.
+#pragma once
+#include "kernels_pf.h"
+
+// All blocks of one 16-row item.  TOK (16 or 8) = token images in LDS; with 8 the upper half of the token axis repeats
+// the lower (K > 8192 does not leave room for 16 images) and is dropped at the store.
+template <int TOK>
+DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+                      int K, int lane, float (&res)[4]) {
+    constexpr uint32_t REC = 1152;
+    const int r16 = lane & 15, q = lane >> 4;
+    int tile = 2 * item + (r16 >> 3);
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const uint8_t* base = w0 + (size_t)tile * nb * REC + (r16 & 7) * 16;
+    const uint32_t qoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const int nq = K >> 2, nbk = K >> 8;
+    const int* imgA = lds + ((lane & 15) & (TOK - 1)) * act_words + 16 * q;
+    const int* imgT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + ((4 * q + j) & (TOK - 1)) * act_words + nq;
+    float acc[4][8], accm[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[j][l] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accm[j][t] = 0.0f;
+    }
+    // Two weight records in flight per lane, as a ring indexed by the unrolled loop position: the slot is refilled with
+    // block b+2 right after its registers are read.  (Written as "load block b+1 at the top of iteration b" hipcc turns the
+    // loop into "load block b, wait, use it": the memory latency of every block lands on the critical path.)
+    constexpr int PF = 2;
+    u32x4 rh[PF], ra[PF], rb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const uint8_t* p = base + (size_t)(u < nb ? u : nb - 1) * REC;
+        rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+    }
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int b = b0 + u;
+        const u32x4 H = rh[u], QA = ra[u], QB = rb[u];
+        {
+            const uint8_t* p = base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC;
+            rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+        }
+        if (b >= nb) continue;
+        // the four 24-bit scale groups {sc[2c], sc[2c+1], m[2c], m[2c+1]} x 6 bit of this row (engine.cc:upload_matrix)
+        const uint32_t x0 = H[1], x1 = alignbit32(H[2], H[1], 24), x2 = alignbit32(H[3], H[2], 16), x3 = H[3] >> 8;
+        const uint32_t xq = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+        const uint32_t sc_lo = xq & 63u, sc_hi = bfe32(xq, 6, 6);
+        const uint32_t s_l3 = (sc_lo & 7u) * 0x00010001u, s_h3 = (sc_lo >> 3) * 0x00010001u;
+        const uint32_t t_l3 = (sc_hi & 7u) * 0x00010001u, t_h3 = (sc_hi >> 3) * 0x00010001u;
+        const float dw = f16_bits_to_f32((uint16_t)(H[0] & 0xFFFF));
+        const float dmw = f16_bits_to_f32((uint16_t)(H[0] >> 16));
+        float D[4], DM[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float yd = bits_to_f32((uint32_t)imgT[j][b]);
+            D[j] = yd * dw;
+            DM[j] = -yd * dmw;
+        }
+        const u32x4 a0 = *(const u32x4*)(imgA + b * 64), a1 = *(const u32x4*)(imgA + b * 64 + 4);
+        const u32x4 a2 = *(const u32x4*)(imgA + b * 64 + 8), a3 = *(const u32x4*)(imgA + b * 64 + 12);
+        u32x4 s0[4], s1[4];   // q8s[0..7] of this lane's four tokens: requested together, consumed after the matrix work
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int* sb = imgT[j] + nbk + b * 8;
+            s0[j] = *(const u32x4*)sb;
+            s1[j] = *(const u32x4*)(sb + 4);
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const uint32_t qs = l < 4 ? QA[l & 3] : QB[l & 3];
+            const uint32_t wlo = qs & 0x0F0F0F0Fu, whi = (qs >> 4) & 0x0F0F0F0Fu;
+            const uint32_t alo = l < 4 ? a0[l & 3] : a1[l & 3], ahi = l < 4 ? a2[l & 3] : a3[l & 3];
+            const uint64_t A = (uint64_t)alo | ((uint64_t)ahi << 32);
+            const uint64_t Bh = (uint64_t)pk_mul_u16(wlo, s_h3) | ((uint64_t)pk_mul_u16(whi, t_h3) << 32);
+            const uint64_t Bl = (uint64_t)pk_mul_u16(wlo, s_l3) | ((uint64_t)pk_mul_u16(whi, t_l3) << 32);
+            i32x4 c = {0, 0, 0, 0};
+            c = mfma_i8_16x16x32(A, Bh, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 3);
+            c = mfma_i8_16x16x32(A, Bl, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+        }
+        // min term: prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1], acc_m[t] = fma(-y.d * dmin, (float)prod[t], acc_m[t])
+        const int m0 = (int)bfe32(x0, 12, 6), m1 = (int)bfe32(x0, 18, 6), m2 = (int)bfe32(x1, 12, 6), m3 = (int)bfe32(x1, 18, 6);
+        const int m4 = (int)bfe32(x2, 12, 6), m5 = (int)bfe32(x2, 18, 6), m6 = (int)bfe32(x3, 12, 6), m7 = (int)bfe32(x3, 18, 6);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accm[j][0] = fmaf(DM[j], (float)(mul24(m0, (int)s0[j][0]) + mul24(m1, (int)s0[j][1])), accm[j][0]);
+            accm[j][1] = fmaf(DM[j], (float)(mul24(m2, (int)s0[j][2]) + mul24(m3, (int)s0[j][3])), accm[j][1]);
+            accm[j][2] = fmaf(DM[j], (float)(mul24(m4, (int)s1[j][0]) + mul24(m5, (int)s1[j][1])), accm[j][2]);
+            accm[j][3] = fmaf(DM[j], (float)(mul24(m6, (int)s1[j][2]) + mul24(m7, (int)s1[j][3])), accm[j][3]);
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // hsum_float_8 (k_quants.c:90-97) and the Q4_K min-term tree, in-lane
+        const float tot = ((acc[j][0] + acc[j][4]) + (acc[j][2] + acc[j][6])) + ((acc[j][1] + acc[j][5]) + (acc[j][3] + acc[j][7]));
+        const float am = (accm[j][0] + accm[j][2]) + (accm[j][1] + accm[j][3]);
+        res[j] = tot + am;
+    }
+}
+
+// Launch over the Q4_K jobs of a site (the caller sends the other types through matvec_pf_kernel): items are 16-row
+// pairs of tiles, job after job; 512 threads, wave w takes items w * gridDim.x + blockIdx.x + k * 8 * gridDim.x.
+template <int TOK, bool GU>
+__global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
+    CT_DYN_SMEM(smem_raw);
+    int* lds = reinterpret_cast<int*>(smem_raw);
+    const MatvecArgs& m = a.m;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const int wv = uniform_int(wave_id());
+    const int t0 = (int)blockIdx.y * TOK;
+    const int nt = a.n_tok - t0 < TOK ? a.n_tok - t0 : TOK;
+    {
+        // All TOK images of the group are copied (the scratch buffer always holds kPfChunk of them; images past n_tok are stale
+        // and their results are dropped at the store): no predicates, eight loads in flight per thread, tail indices clamped.
+        const u32x4* src = (const u32x4*)(a.acts + (size_t)t0 * a.act_words);
+        const int n16 = TOK * (a.act_words >> 2);
+        for (int i0 = 0; i0 < n16; i0 += 8 * 512) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; v[u] = ld16(src + (i < n16 ? i : n16 - 1)); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; ((u32x4*)lds)[i < n16 ? i : n16 - 1] = v[u]; }
+        }
+    }
+    __syncthreads();
+    const int pos0 = (m.pos ? *m.pos : 0) + t0;
+    const int GX = (int)gridDim.x, nb = m.K >> 8;
+    const int r16 = lane & 15, q = lane >> 4;
+    for (int item = wv * GX + (int)blockIdx.x; item < m.n_pairs; item += 8 * GX) {
+        if constexpr (GU) {
+            const int n_tiles = (m.job[0].w.M + 7) / 8;
+            float gate[4], up[4];
+            pfm_item_q4k<TOK>(m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
+            pfm_item_q4k<TOK>(m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
+            const int row = item * 16 + r16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * q + j;
+                if (t < nt && row < m.job[0].w.M)
+                    m.out[(size_t)(t0 + t) * a.ld_out + row] = f16_bits_to_f32(m.silu_tab[f32_to_f16_bits(gate[j])]) * up[j];
+            }
+        } else {
+            int jb = 0;
+            if (m.njobs > 1 && item >= m.job[1].pair0) jb = 1;
+            if (m.njobs > 2 && item >= m.job[2].pair0) jb = 2;
+            const int it = item - m.job[jb].pair0;
+            float res[4];
+            pfm_item_q4k<TOK>(m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
+            const int row = it * 16 + r16;
+            const bool row_ok = row < m.job[jb].w.M;
+            const int epi = m.job[jb].epi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * q + j;
+                const bool own = row_ok && t < nt;
+                const int tok = t0 + t, pos = pos0 + t;
+                if (epi == EPI_ADD) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = res[j] + m.res[(size_t)tok * a.ld_res + row];
+                } else if (epi == EPI_STORE) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = res[j];
+                } else if (epi == EPI_V) {
+                    if (own) m.vcache[(size_t)row * m.v_stride + pos] = f32_to_f16_bits(res[j]);
+                } else {   // RoPE, normal mode (ggml.c:12522-12539): rows 2i, 2i+1 are neighbouring lanes
+                    const float other = lane_xor1(res[j]);
+                    if (own) {
+                        const int ip = (row % m.head_dim) >> 1;
+                        const float cs = m.rope_cs[((size_t)pos * (m.head_dim >> 1) + ip) * 2 + 0];
+                        const float sn = m.rope_cs[((size_t)pos * (m.head_dim >> 1) + ip) * 2 + 1];
+                        const float o = (row & 1) ? fmaf(res[j], cs, other * sn) : fmaf(res[j], cs, -(other * sn));
+                        if (epi == EPI_ROPE_Q) m.q_f16[(size_t)tok * a.ld_q + row] = f32_to_f16_bits(o);
+                        else m.kcache[kcache_off(pos, row, m.head_dim, m.n_ctx)] = f32_to_f16_bits(o);
+                    }
+                }
+            }
+        }
+    }
+}

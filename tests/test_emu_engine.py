@@ -65,6 +65,7 @@ def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     toks = list(g["long_prompt"])
     out = {}
+    monkeypatch.setenv("CT_AMD_PF_CHUNK", "32")
     for pf in ("1", "0"):
         monkeypatch.setenv("CT_AMD_PF", pf)
         m = open_emu(emu_lib, name, batch_size=64)

@@ -1,6 +1,6 @@
 """Per-site durations of the prompt-chunk launches from a rocprofv3 kernel trace (CT_AMD_GRAPH=0 run of decode_loop.py).
-The chunk path launches, per layer: quantize, matvec_pf(qkv), attention, quantize, matvec_pf(wo), quantize,
-matvec_pf<GU>(gate_up), quantize, matvec_pf(down) — the non-GU launches are told apart by their position in that cycle.
+The chunk path launches, per layer: quantize, matvec_pf[m](qkv) (one launch per kernel kind), attention, quantize, matvec_pf[m](wo), quantize,
+matvec_pf[m]<GU>(gate_up), quantize, matvec_pf[m](down) — a mat-vec launch belongs to the site of the quantize launch before it.
 usage: pf_sites.py <rocprof_out_dir>"""
 import csv, glob, os, sys
 from collections import defaultdict
@@ -12,14 +12,11 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in rows:
         n, dur = r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         z = int(r.get("Grid_Size_Z", r.get("Grid_Size_z", 1)) or 1)
-        if "matvec_pf_kernel" in n:
-            if "true" in n.split("matvec_pf_kernel")[1][:12] or "Lb1" in n:
-                agg["pf gate_up"].append(dur)
-            else:
-                agg["pf " + ("qkv", "wo", "down")[k % 3]].append(dur)
-                k += 1
+        if "matvec_pf_kernel" in n or "matvec_pfm_kernel" in n:   # belongs to the site of the preceding quantize launch
+            agg[("mfma " if "pfm" in n else "dot4 ") + ("qkv", "wo", "gate_up", "down")[(k - 1) % 4]].append(dur)
         elif "pf_quantize" in n:
             agg["pf quantize"].append(dur)
+            k += 1
         elif "attn_fused" in n:
             agg["attention (chunk)" if z > 1 else "attention (token)"].append(dur)
         else:
