@@ -358,6 +358,7 @@ bool Engine::alloc_state(std::string& err) {
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
+        pfm_force_t8_ = env_int("CT_AMD_PFM_T8", 0) != 0;   // tests: the 8-token matrix-core form at any K
         pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
         const size_t aw = (size_t)pf_act_words(std::max(E, F));
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
@@ -696,7 +697,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         a.m.njobs = nj;
         a.m.n_pairs = m.gateup ? (m.job[0].w.M + rows_per_item - 1) / rows_per_item : item0;
         if (mfma) {
-            const bool t16 = (size_t)16 * aw * 4 <= 160 * 1024;
+            const bool t16 = (size_t)16 * aw * 4 <= 160 * 1024 && !pfm_force_t8_;
             const int tok = t16 ? 16 : 8, groups = (nt + tok - 1) / tok;
             const int gx = std::max(1, std::min(gx_mul * chip_cus() / groups, a.m.n_pairs));
             const dim3 grid((unsigned)gx, (unsigned)groups), block(512);

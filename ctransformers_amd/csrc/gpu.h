@@ -106,6 +106,23 @@ static inline i32x4 mfma_i8_16x16x32(uint64_t a, uint64_t b, i32x4 c) {
     }
     return c;
 }
+// 16x16x64 (gfx950): 16 bytes per lane and operand.  Only the pairing matters to the callers: byte e of lane (n, q)'s A
+// meets byte e of lane (m, q)'s B, D[n][m] sums all 64 products and keeps the 16x16 result map (also hardware-checked).
+static inline i32x4 mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
+    const int lane = (int)(threadIdx.x & 63), q = lane >> 4, n = lane & 15;
+    const uint64_t a01 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a23 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    const uint64_t b01 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b23 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    uint64_t bk[4][2];
+    for (int kc = 0; kc < 4; ++kc) { bk[kc][0] = emu_shfl_any(b01, n + 16 * kc); bk[kc][1] = emu_shfl_any(b23, n + 16 * kc); }
+    for (int j = 0; j < 4; ++j) {
+        for (int kc = 0; kc < 4; ++kc) {
+            const uint64_t am[2] = {emu_shfl_any(a01, 4 * q + j + 16 * kc), emu_shfl_any(a23, 4 * q + j + 16 * kc)};
+            for (int w = 0; w < 2; ++w)
+                for (int e = 0; e < 8; ++e) c[j] += (int)(int8_t)(am[w] >> (8 * e)) * (int)(int8_t)(bk[kc][w] >> (8 * e));
+        }
+    }
+    return c;
+}
 // two u16 lanes of `a` times the two u16 lanes of `s` (low 16 bits each): v_pk_mul_lo_u16
 static inline uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
     return (((a & 0xFFFFu) * (s & 0xFFFFu)) & 0xFFFFu) | (((a >> 16) * (s >> 16)) << 16);
@@ -114,6 +131,9 @@ static inline uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 DEV i32x4 mfma_i8_16x16x32(uint64_t a, uint64_t b, i32x4 c) {
     return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+}
+DEV i32x4 mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
 }
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 DEV uint32_t pk_mul_u16(uint32_t a, uint32_t s) {

@@ -127,6 +127,111 @@ DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
     }
 }
 
+// The same for K > 8192, where LDS holds 8 token images only.  Running the 16-token form on 8 tokens would compute every
+// result twice; instead the 16 token slots of the matrix product become (token, half of the AVX lanes): slot n < 8 is
+// token n with lanes l' = 0..3, slot n >= 8 is token n - 8 with lanes l' + 4.  One v_mfma_i32_16x16x64_i8 carries both
+// K sets — k = (half, sub-block, e) — and a slot's A operand is zero in the other half's bytes, so
+//     D[(token, half)][row] = sumi[l' + 4 * half]      for l' = 0..3: 8 MFMA per block, 16 accumulators per lane.
+// The min term splits the same way (half 0: acc_m[0..1], half 1: acc_m[2..3]); the two halves of a (row, token) sit in
+// lanes 32 apart and meet once per item for the final hsum_float_8 tree.
+DEV void pfm_item_q4k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+                         int K, int lane, float (&res)[4]) {
+    constexpr uint32_t REC = 1152;
+    const int r16 = lane & 15, q = lane >> 4, half = q >> 1;
+    int tile = 2 * item + (r16 >> 3);
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const uint8_t* base = w0 + (size_t)tile * nb * REC + (r16 & 7) * 16;
+    const uint32_t qoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const int nq = K >> 2, nbk = K >> 8;
+    const bool a_hi_half = (lane & 8) != 0;   // A side: slot n = lane & 15 -> token n & 7, half n >> 3
+    const int* imgA = lds + (lane & 7) * act_words + 16 * q + (a_hi_half ? 4 : 0);
+    const int* imgT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + (4 * (q & 1) + j) * act_words + nq;
+    float acc[4][4], accm[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[j][l] = 0.0f;
+        accm[j][0] = accm[j][1] = 0.0f;
+    }
+    constexpr int PF = 2;
+    u32x4 rh[PF], ra[PF], rb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const uint8_t* p = base + (size_t)(u < nb ? u : nb - 1) * REC;
+        rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+    }
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int b = b0 + u;
+        const u32x4 H = rh[u], QA = ra[u], QB = rb[u];
+        {
+            const uint8_t* p = base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC;
+            rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+        }
+        if (b >= nb) continue;
+        const uint32_t x0 = H[1], x1 = alignbit32(H[2], H[1], 24), x2 = alignbit32(H[3], H[2], 16), x3 = H[3] >> 8;
+        const uint32_t xq = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+        const uint32_t sc_lo = xq & 63u, sc_hi = bfe32(xq, 6, 6);
+        const uint32_t s_l3 = (sc_lo & 7u) * 0x00010001u, s_h3 = (sc_lo >> 3) * 0x00010001u;
+        const uint32_t t_l3 = (sc_hi & 7u) * 0x00010001u, t_h3 = (sc_hi >> 3) * 0x00010001u;
+        const float dw = f16_bits_to_f32((uint16_t)(H[0] & 0xFFFF));
+        const float dmw = f16_bits_to_f32((uint16_t)(H[0] >> 16));
+        float D[4], DM[4];
+        u32x4 sbv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float yd = bits_to_f32((uint32_t)imgT[j][b]);
+            D[j] = yd * dw;
+            DM[j] = -yd * dmw;
+            sbv[j] = *(const u32x4*)(imgT[j] + nbk + b * 8 + 4 * half);   // q8s[4 * half .. + 3]
+        }
+        const u32x4 alo = *(const u32x4*)(imgA + b * 64), ahi = *(const u32x4*)(imgA + b * 64 + 8);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const uint32_t w0lo = QA[l] & 0x0F0F0F0Fu, w0hi = (QA[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l
+            const uint32_t w1lo = QB[l] & 0x0F0F0F0Fu, w1hi = (QB[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l + 4
+            const uint32_t al = alo[l], ah = ahi[l];
+            const u32x4 A = a_hi_half ? u32x4{0u, 0u, al, ah} : u32x4{al, ah, 0u, 0u};
+            const u32x4 Bh = u32x4{pk_mul_u16(w0lo, s_h3), pk_mul_u16(w0hi, t_h3), pk_mul_u16(w1lo, s_h3), pk_mul_u16(w1hi, t_h3)};
+            const u32x4 Bl = u32x4{pk_mul_u16(w0lo, s_l3), pk_mul_u16(w0hi, t_l3), pk_mul_u16(w1lo, s_l3), pk_mul_u16(w1hi, t_l3)};
+            i32x4 c = {0, 0, 0, 0};
+            c = mfma_i8_16x16x64(A, Bh, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 3);
+            c = mfma_i8_16x16x64(A, Bl, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+        }
+        const uint32_t xa = half ? x2 : x0, xb = half ? x3 : x1;   // scale groups 2 * half, 2 * half + 1
+        const int ma0 = (int)bfe32(xa, 12, 6), ma1 = (int)bfe32(xa, 18, 6), mb0 = (int)bfe32(xb, 12, 6), mb1 = (int)bfe32(xb, 18, 6);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accm[j][0] = fmaf(DM[j], (float)(mul24(ma0, (int)sbv[j][0]) + mul24(ma1, (int)sbv[j][1])), accm[j][0]);
+            accm[j][1] = fmaf(DM[j], (float)(mul24(mb0, (int)sbv[j][2]) + mul24(mb1, (int)sbv[j][3])), accm[j][1]);
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // x_l + x_{l+4}: one operand is this lane's, the other the partner half's (fp addition commutes bit for bit)
+        const float p0 = acc[j][0] + lane_xor32(acc[j][0]), p1 = acc[j][1] + lane_xor32(acc[j][1]);
+        const float p2 = acc[j][2] + lane_xor32(acc[j][2]), p3 = acc[j][3] + lane_xor32(acc[j][3]);
+        const float tot = (p0 + p2) + (p1 + p3);
+        const float am = (accm[j][0] + lane_xor32(accm[j][0])) + (accm[j][1] + lane_xor32(accm[j][1]));   // (m0 + m2) + (m1 + m3)
+        res[j] = tot + am;
+    }
+}
+
+template <int TOK>
+DEV void pfm_item(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words, int K,
+                  int lane, float (&res)[4]) {
+    if constexpr (TOK == 16) pfm_item_q4k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+    else pfm_item_q4k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+}
+
 // Launch over the Q4_K jobs of a site (the caller sends the other types through matvec_pf_kernel): items are 16-row
 // pairs of tiles, job after job; 512 threads, wave w takes items w * gridDim.x + blockIdx.x + k * 8 * gridDim.x.
 template <int TOK, bool GU>
@@ -159,8 +264,8 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
         if constexpr (GU) {
             const int n_tiles = (m.job[0].w.M + 7) / 8;
             float gate[4], up[4];
-            pfm_item_q4k<TOK>(m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
-            pfm_item_q4k<TOK>(m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
+            pfm_item<TOK>(m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
+            pfm_item<TOK>(m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
             const int row = item * 16 + r16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -174,7 +279,7 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
             if (m.njobs > 2 && item >= m.job[2].pair0) jb = 2;
             const int it = item - m.job[jb].pair0;
             float res[4];
-            pfm_item_q4k<TOK>(m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
+            pfm_item<TOK>(m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
             const int row = it * 16 + r16;
             const bool row_ok = row < m.job[jb].w.M;
             const int epi = m.job[jb].epi;

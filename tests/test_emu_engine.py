@@ -58,6 +58,17 @@ def test_batch_structure(emu_lib):
     assert chunk_tokens(m) == 45   # 32 + 13 tokens through the chunk kernels
 
 
+def test_prompt_chunk_eight_token_matrix_core_form(emu_lib, monkeypatch):
+    """kernels_pfm.h's K > 8192 form (8 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token slots),
+    forced on the tiny model: golden logits of the reference for a one-batch 45-token prompt."""
+    monkeypatch.setenv("CT_AMD_PFM_T8", "1")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = open_emu(emu_lib, "tiny-q4km", batch_size=64)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_one"])
+    assert chunk_tokens(m) == 45
+
+
 @pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
 def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
     """The chunk kernels (kernels_pf.h) against the decode kernels on the same batches: ragged chunk lengths (a full
