@@ -676,7 +676,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     else CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
     static const int use_mfma = env_int("CT_AMD_PF_MFMA", 1);
     static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
-    for (int pass = 0; pass < 2; ++pass) {   // pass 0: Q4_K jobs -> MFMA kernel; pass 1: the rest -> dot4 kernel
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: Q4_K and Q6_K jobs -> MFMA kernel; pass 1: the rest (Q5_K) -> dot4 kernel
         const bool mfma = pass == 0;
         if (mfma && !use_mfma) continue;
         PfArgs a;
@@ -686,7 +686,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         const int rows_per_item = mfma ? 16 : 8;
         int nj = 0, item0 = 0;
         for (int j = 0; j < m.njobs; ++j) {
-            const bool q4 = m.job[j].w.type == GT_Q4_K && use_mfma;
+            const bool q4 = (m.job[j].w.type == GT_Q4_K || m.job[j].w.type == GT_Q6_K) && use_mfma;
             if (q4 != mfma) continue;
             a.m.job[nj] = m.job[j];
             a.m.job[nj].pair0 = m.gateup ? 0 : item0;

@@ -225,14 +225,202 @@ DEV void pfm_item_q4k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
     }
 }
 
-template <int TOK>
-DEV void pfm_item(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words, int K,
-                  int lane, float (&res)[4]) {
-    if constexpr (TOK == 16) pfm_item_q4k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
-    else pfm_item_q4k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+// ---- Q6_K --------------------------------------------------------------------------------------------------------------
+// Reference (k_quants.c:3800-3872): sumi[l] = sum over the eight 32-element vectors v of
+//     scales[2v + (l >> 2)] * sum_{e<4} (q6_v[4l+e] - 32) * a_v[4l+e],        scales int8, q6 in [0, 63]
+// — the Q4_K shape with a signed 8-bit scale on a signed 6-bit weight.  With u = scale + 128 = u0 + 4 u1 + 16 u2 + 64 u3
+// (2-bit digits) every operand byte (q6 - 32) * u_i lies in [-96, 93], and
+//     sumi[l] = P0 + 4 P1 + 16 P2 + 64 P3 + 128 Pn,   P_i = sum a * (q6 - 32) * u_i,   Pn = sum a * (32 - q6)
+// is five chained MFMAs (shift the accumulator between them).  A signed byte product without a packed byte multiplier:
+// q6 * u_i by the packed 16-bit multiply (<= 189, no carry), plus (128 - 32 u_i) per byte (still < 256), xor 0x80.
+struct Q6Scale {            // one 16-element scale, prepared for four weight dwords: multiplier and byte offset per digit
+    uint32_t cu[4], off[4];
+};
+DEV Q6Scale q6_scale(uint32_t sc_byte) {
+    const uint32_t u = sc_byte ^ 0x80u;
+    Q6Scale S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        S.cu[i] = ((u >> (2 * i)) & 3u) * 0x00010001u;
+        S.off[i] = 0x80808080u - pk_mul_u16(0x20202020u, S.cu[i]);
+    }
+    return S;
+}
+DEV uint32_t q6_piece(uint32_t q6, const Q6Scale& S, int i) { return (pk_mul_u16(q6, S.cu[i]) + S.off[i]) ^ 0x80808080u; }
+DEV uint32_t q6_neg(uint32_t q6) { return (0xA0A0A0A0u - q6) ^ 0x80808080u; }   // bytes 32 - q6
+
+struct Q6Rec { u32x4 sc, ql0, ql1, qh0, qh1; uint32_t d; };
+// lane (row r16 & 7 of its tile, q): scales of the row, the 32 bytes of ql units 2q, 2q+1 and of qh units (q >> 1, 0..1)
+DEV Q6Rec q6_load(const uint8_t* rec, int r, int q) {
+    Q6Rec R;
+    R.d = *(const uint16_t*)(rec + r * 2);
+    R.sc = ld_stream16(rec + 16 + r * 16);
+    R.qh0 = ld_stream16(rec + 144 + r * 64 + (q >> 1) * 32);
+    R.qh1 = ld_stream16(rec + 144 + r * 64 + (q >> 1) * 32 + 16);
+    R.ql0 = ld_stream16(rec + 656 + r * 128 + q * 32);
+    R.ql1 = ld_stream16(rec + 656 + r * 128 + q * 32 + 16);
+    return R;
+}
+// the two 6-bit weight dwords of AVX lane l: vector 4n + kq (low nibbles) and vector 4n + 2 + kq (high nibbles)
+DEV void q6_unpack(const Q6Rec& R, int l, int kq, uint32_t& lo6, uint32_t& hi6) {
+    const uint32_t qlw = l < 4 ? R.ql0[l & 3] : R.ql1[l & 3], qhw = l < 4 ? R.qh0[l & 3] : R.qh1[l & 3];
+    lo6 = (qlw & 0x0F0F0F0Fu) | (((qhw >> (2 * kq)) & 0x03030303u) << 4);
+    hi6 = ((qlw >> 4) & 0x0F0F0F0Fu) | (((qhw >> (4 + 2 * kq)) & 0x03030303u) << 4);
 }
 
-// Launch over the Q4_K jobs of a site (the caller sends the other types through matvec_pf_kernel): items are 16-row
+template <int TOK>
+DEV void pfm_item_q6k(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+                      int K, int lane, float (&res)[4]) {
+    constexpr uint32_t REC = 1680;
+    const int r16 = lane & 15, q = lane >> 4, n = q >> 1, kq = q & 1;
+    int tile = 2 * item + (r16 >> 3);
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const uint8_t* base = w0 + (size_t)tile * nb * REC;
+    const int nq = K >> 2;
+    const int* imgA = lds + ((lane & 15) & (TOK - 1)) * act_words + 32 * n + 8 * kq;   // words l / 16 + l of the block
+    const int* imgT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + ((4 * q + j) & (TOK - 1)) * act_words + nq;
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[j][l] = 0.0f;
+    }
+    constexpr int PF = 2;
+    Q6Rec ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) ring[u] = q6_load(base + (size_t)(u < nb ? u : nb - 1) * REC, r16 & 7, q);
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int b = b0 + u;
+        const Q6Rec R = ring[u];
+        ring[u] = q6_load(base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC, r16 & 7, q);
+        if (b >= nb) continue;
+        const float dw = f16_bits_to_f32((uint16_t)(R.d & 0xFFFF));
+        float D[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[j] = bits_to_f32((uint32_t)imgT[j][b]) * dw;
+        const uint32_t w_lo = n ? R.sc[2] : R.sc[0], w_hi = n ? R.sc[3] : R.sc[1];   // scales 8n.., 8n+4..
+        const u32x4 a0 = *(const u32x4*)(imgA + b * 64), a1 = *(const u32x4*)(imgA + b * 64 + 4);
+        const u32x4 a2 = *(const u32x4*)(imgA + b * 64 + 16), a3 = *(const u32x4*)(imgA + b * 64 + 20);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Q6Scale SL = q6_scale((w_lo >> (8 * (2 * kq + h))) & 0xFFu), SH = q6_scale((w_hi >> (8 * (2 * kq + h))) & 0xFFu);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int l = 4 * h + k;
+                uint32_t lo6, hi6;
+                q6_unpack(R, l, kq, lo6, hi6);
+                const uint64_t A = (uint64_t)(h ? a1[k] : a0[k]) | ((uint64_t)(h ? a3[k] : a2[k]) << 32);
+                i32x4 c = {0, 0, 0, 0};
+                c = mfma_i8_16x16x32(A, (uint64_t)q6_neg(lo6) | ((uint64_t)q6_neg(hi6) << 32), c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 1);
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                    c = mfma_i8_16x16x32(A, (uint64_t)q6_piece(lo6, SL, i) | ((uint64_t)q6_piece(hi6, SH, i) << 32), c);
+                    if (i > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 2);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+            }
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        res[j] = ((acc[j][0] + acc[j][4]) + (acc[j][2] + acc[j][6])) + ((acc[j][1] + acc[j][5]) + (acc[j][3] + acc[j][7]));
+}
+
+// K > 8192 form (see pfm_item_q4k_t8): token slots = (token, AVX-lane half), one 16x16x64 MFMA carries lanes l' and l' + 4.
+DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+                         int K, int lane, float (&res)[4]) {
+    constexpr uint32_t REC = 1680;
+    const int r16 = lane & 15, q = lane >> 4, n = q >> 1, kq = q & 1;
+    int tile = 2 * item + (r16 >> 3);
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const uint8_t* base = w0 + (size_t)tile * nb * REC;
+    const int nq = K >> 2;
+    const bool a_hi_half = (lane & 8) != 0;
+    const int* imgA = lds + (lane & 7) * act_words + 32 * n + 8 * kq + (a_hi_half ? 4 : 0);
+    const int* imgT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + (4 * (q & 1) + j) * act_words + nq;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[j][l] = 0.0f;
+    }
+    constexpr int PF = 2;
+    Q6Rec ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) ring[u] = q6_load(base + (size_t)(u < nb ? u : nb - 1) * REC, r16 & 7, q);
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int b = b0 + u;
+        const Q6Rec R = ring[u];
+        ring[u] = q6_load(base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC, r16 & 7, q);
+        if (b >= nb) continue;
+        const float dw = f16_bits_to_f32((uint16_t)(R.d & 0xFFFF));
+        float D[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[j] = bits_to_f32((uint32_t)imgT[j][b]) * dw;
+        const uint32_t w_lo = n ? R.sc[2] : R.sc[0], w_hi = n ? R.sc[3] : R.sc[1];
+        const Q6Scale SL0 = q6_scale((w_lo >> (16 * kq)) & 0xFFu), SH0 = q6_scale((w_hi >> (16 * kq)) & 0xFFu);           // lanes 0..3
+        const Q6Scale SL1 = q6_scale((w_lo >> (16 * kq + 8)) & 0xFFu), SH1 = q6_scale((w_hi >> (16 * kq + 8)) & 0xFFu);   // lanes 4..7
+        const u32x4 alo = *(const u32x4*)(imgA + b * 64), ahi = *(const u32x4*)(imgA + b * 64 + 16);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            uint32_t lo0, hi0, lo1, hi1;
+            q6_unpack(R, l, kq, lo0, hi0);
+            q6_unpack(R, l + 4, kq, lo1, hi1);
+            const uint32_t al = alo[l], ah = ahi[l];
+            const u32x4 A = a_hi_half ? u32x4{0u, 0u, al, ah} : u32x4{al, ah, 0u, 0u};
+            i32x4 c = {0, 0, 0, 0};
+            c = mfma_i8_16x16x64(A, u32x4{q6_neg(lo0), q6_neg(hi0), q6_neg(lo1), q6_neg(hi1)}, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 1);
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                c = mfma_i8_16x16x64(A, u32x4{q6_piece(lo0, SL0, i), q6_piece(hi0, SH0, i), q6_piece(lo1, SL1, i), q6_piece(hi1, SH1, i)}, c);
+                if (i > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 2);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+        }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float p0 = acc[j][0] + lane_xor32(acc[j][0]), p1 = acc[j][1] + lane_xor32(acc[j][1]);
+        const float p2 = acc[j][2] + lane_xor32(acc[j][2]), p3 = acc[j][3] + lane_xor32(acc[j][3]);
+        res[j] = (p0 + p2) + (p1 + p3);
+    }
+}
+
+template <int TOK>
+DEV void pfm_item(int type, const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+                  int K, int lane, float (&res)[4]) {
+    if (type == GT_Q4_K) {
+        if constexpr (TOK == 16) pfm_item_q4k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+        else pfm_item_q4k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+    } else {
+        if constexpr (TOK == 16) pfm_item_q6k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+        else pfm_item_q6k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+    }
+}
+
+// Launch over the Q4_K and Q6_K jobs of a site (the caller sends Q5_K through matvec_pf_kernel): items are 16-row
 // pairs of tiles, job after job; 512 threads, wave w takes items w * gridDim.x + blockIdx.x + k * 8 * gridDim.x.
 template <int TOK, bool GU>
 __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
@@ -264,8 +452,8 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
         if constexpr (GU) {
             const int n_tiles = (m.job[0].w.M + 7) / 8;
             float gate[4], up[4];
-            pfm_item<TOK>(m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
-            pfm_item<TOK>(m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
+            pfm_item<TOK>(m.job[0].w.type, m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
+            pfm_item<TOK>(m.job[1].w.type, m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
             const int row = item * 16 + r16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -279,7 +467,7 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
             if (m.njobs > 2 && item >= m.job[2].pair0) jb = 2;
             const int it = item - m.job[jb].pair0;
             float res[4];
-            pfm_item<TOK>(m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
+            pfm_item<TOK>(m.job[jb].w.type, m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
             const int row = it * 16 + r16;
             const bool row_ok = row < m.job[jb].w.M;
             const int epi = m.job[jb].epi;

@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/pf6; rm -rf $O; mkdir -p $O
+O=gpurun_out/pf7; rm -rf $O; mkdir -p $O
 export CTAMD_BENCH_MODEL=/tmp/l7b.gguf
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "golden and (q4km or q5km) and not falcon or batch_structure or (bit_identical_to_reference and (llama-small-Q4_K_M or llama-tiny or llama-7b-2l-Q4_K_M)) or full_7b" > $O/pytest.log 2>&1
 tail -5 $O/pytest.log
