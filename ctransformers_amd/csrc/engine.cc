@@ -350,7 +350,9 @@ bool Engine::alloc_state(std::string& err) {
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
-    pf_ok_ = !hp_.falcon() && !hp_.gpt2() && E <= 12288 && F <= 12288 && env_int("CT_AMD_PF", 1) != 0;
+    // prompt chunks (kernels_pf.h): llama graph, K-quant tile layout, n_embd <= 12288; an ffn_down wider than 12288 (70B class)
+    // stays on the wide-K decode kernel, token by token inside the chunk
+    pf_ok_ = !hp_.falcon() && !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
     for (int i = l0_; i < l1_ && pf_ok_; ++i) {
         const Layer& L = layers_[i];
         for (const DevMat* m : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down})
@@ -360,7 +362,7 @@ bool Engine::alloc_state(std::string& err) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
         pfm_force_t8_ = env_int("CT_AMD_PFM_T8", 0) != 0;   // tests: the 8-token matrix-core form at any K
         pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
-        const size_t aw = (size_t)pf_act_words(std::max(E, F));
+        const size_t aw = (size_t)pf_act_words(F <= 12288 ? std::max(E, F) : E);
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
@@ -665,8 +667,8 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
 }
 
-// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernels — the
-// Q4_K jobs of the site on the matrix cores (kernels_pfm.h), jobs of the other K-quant types on the dot4 form (kernels_pf.h).
+// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernel(s) on the
+// matrix cores (kernels_pfm.h; the dot4 form of kernels_pf.h is kept for A/B runs).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
                        std::string& err) {
     const int aw = pf_act_words(m.K);
@@ -676,18 +678,16 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     else CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
     static const int use_mfma = env_int("CT_AMD_PF_MFMA", 1);
     static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
-    for (int pass = 0; pass < 2; ++pass) {   // pass 0: Q4_K and Q6_K jobs -> MFMA kernel; pass 1: the rest (Q5_K) -> dot4 kernel
-        const bool mfma = pass == 0;
-        if (mfma && !use_mfma) continue;
+    // one launch per weight type present in the site's jobs (matrix-core kernel; CT_AMD_PF_MFMA=0: the dot4 kernel, A/B)
+    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
         PfArgs a;
         a.m = m;
         a.acts = acts_; a.act_words = aw; a.n_tok = nt;
         a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
-        const int rows_per_item = mfma ? 16 : 8;
+        const int rows_per_item = use_mfma ? 16 : 8;
         int nj = 0, item0 = 0;
         for (int j = 0; j < m.njobs; ++j) {
-            const bool q4 = (m.job[j].w.type == GT_Q4_K || m.job[j].w.type == GT_Q6_K) && use_mfma;
-            if (q4 != mfma) continue;
+            if (m.job[j].w.type != ty) continue;
             a.m.job[nj] = m.job[j];
             a.m.job[nj].pair0 = m.gateup ? 0 : item0;
             item0 += (m.job[j].w.M + rows_per_item - 1) / rows_per_item;
@@ -696,19 +696,21 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         if (nj == 0) continue;
         a.m.njobs = nj;
         a.m.n_pairs = m.gateup ? (m.job[0].w.M + rows_per_item - 1) / rows_per_item : item0;
-        if (mfma) {
+        if (use_mfma) {
             const bool t16 = (size_t)16 * aw * 4 <= 160 * 1024 && !pfm_force_t8_;
             const int tok = t16 ? 16 : 8, groups = (nt + tok - 1) / tok;
             const int gx = std::max(1, std::min(gx_mul * chip_cus() / groups, a.m.n_pairs));
             const dim3 grid((unsigned)gx, (unsigned)groups), block(512);
             const size_t smem = (size_t)tok * aw * 4;
-#define PFM(TOKV, GUV) do { \
-                auto kfn = matvec_pfm_kernel<TOKV, GUV>; \
+#define PFM(TYV, TOKV, GUV) do { \
+                auto kfn = matvec_pfm_kernel<TYV, TOKV, GUV>; \
                 static bool once = [&] { return CT_SMEM_OPTIN(kfn, 160 * 1024); }(); \
                 (void)once; \
                 CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
-            if (t16) { if (m.gateup) PFM(16, true); else PFM(16, false); }
-            else { if (m.gateup) PFM(8, true); else PFM(8, false); }
+#define PFM_T(TYV) do { if (t16) { if (m.gateup) PFM(TYV, 16, true); else PFM(TYV, 16, false); } \
+                        else { if (m.gateup) PFM(TYV, 8, true); else PFM(TYV, 8, false); } } while (0)
+            if (ty == GT_Q4_K) PFM_T(GT_Q4_K); else if (ty == GT_Q5_K) PFM_T(GT_Q5_K); else PFM_T(GT_Q6_K);
+#undef PFM_T
 #undef PFM
         } else {
             const int groups = (nt + kPfTokens - 1) / kPfTokens;
@@ -788,7 +790,15 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
-            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+            if (F <= 12288) {
+                if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+            } else {   // wide rows: 8 Q8_K images of this length do not fit LDS — the decode kernel, one token at a time
+                for (int t = 0; t < nt; ++t) {
+                    MatvecArgs at = a;
+                    at.x = hb_ + (size_t)t * F; at.out = xb_ + (size_t)t * E; at.res = xb_ + (size_t)t * E;
+                    if (site_on("down") && !run_matvec(at, err)) return false;
+                }
+            }
         }
     }
     if (l1_ < hp_.n_layer) {

@@ -25,15 +25,20 @@
 
 // All blocks of one 16-row item.  TOK (16 or 8) = token images in LDS; with 8 the upper half of the token axis repeats
 // the lower (K > 8192 does not leave room for 16 images) and is dropped at the store.
-template <int TOK>
-DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+// Q5_K (TYPE == GT_Q5_K) differs in three places: the fifth bit comes from the row's 32 qh bytes (bit 2q / 2q+1 of byte e =
+// sub-block 2q / 2q+1), q5 * 7 would not fit int8 so the scale goes in three 2-bit digits (q5 * 3 <= 93, three MFMAs per
+// l), and the min term is one scalar: summs = fma(-y.d * dmin, (float)(prod[0] + .. + prod[3]), summs) (k_quants.c:3183-3262).
+template <int TYPE, int TOK>
+DEV void pfm_item_q45(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                       int K, int lane, float (&res)[4]) {
-    constexpr uint32_t REC = 1152;
+    constexpr bool Q5 = TYPE == GT_Q5_K;
+    constexpr uint32_t REC = Q5 ? 1408 : 1152, QS0 = Q5 ? 384 : 128;
     const int r16 = lane & 15, q = lane >> 4;
     int tile = 2 * item + (r16 >> 3);
     tile = tile < n_tiles ? tile : n_tiles - 1;
     const uint8_t* base = w0 + (size_t)tile * nb * REC + (r16 & 7) * 16;
-    const uint32_t qoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const uint32_t qoff = QS0 - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const uint32_t hoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 32u;   // Q5_K: the row's qh bytes
     const int nq = K >> 2, nbk = K >> 8;
     const int* imgA = lds + ((lane & 15) & (TOK - 1)) * act_words + 16 * q;
     const int* imgT[4];
@@ -51,28 +56,38 @@ DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
     // block b+2 right after its registers are read.  (Written as "load block b+1 at the top of iteration b" hipcc turns the
     // loop into "load block b, wait, use it": the memory latency of every block lands on the critical path.)
     constexpr int PF = 2;
-    u32x4 rh[PF], ra[PF], rb[PF];
+    u32x4 rh[PF], ra[PF], rb[PF], rq0[PF], rq1[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const uint8_t* p = base + (size_t)(u < nb ? u : nb - 1) * REC;
         rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+        if constexpr (Q5) { rq0[u] = ld_stream16(p + hoff); rq1[u] = ld_stream16(p + hoff + 16); }
     }
     for (int b0 = 0; b0 < nb; b0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int b = b0 + u;
         const u32x4 H = rh[u], QA = ra[u], QB = rb[u];
+        u32x4 QH0 = H, QH1 = H;
+        if constexpr (Q5) { QH0 = rq0[u]; QH1 = rq1[u]; }
         {
             const uint8_t* p = base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC;
             rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+            if constexpr (Q5) { rq0[u] = ld_stream16(p + hoff); rq1[u] = ld_stream16(p + hoff + 16); }
         }
         if (b >= nb) continue;
         // the four 24-bit scale groups {sc[2c], sc[2c+1], m[2c], m[2c+1]} x 6 bit of this row (engine.cc:upload_matrix)
         const uint32_t x0 = H[1], x1 = alignbit32(H[2], H[1], 24), x2 = alignbit32(H[3], H[2], 16), x3 = H[3] >> 8;
         const uint32_t xq = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
         const uint32_t sc_lo = xq & 63u, sc_hi = bfe32(xq, 6, 6);
-        const uint32_t s_l3 = (sc_lo & 7u) * 0x00010001u, s_h3 = (sc_lo >> 3) * 0x00010001u;
-        const uint32_t t_l3 = (sc_hi & 7u) * 0x00010001u, t_h3 = (sc_hi >> 3) * 0x00010001u;
+        // scale digits, low to high: Q4_K 3 + 3 bits, Q5_K 2 + 2 + 2 bits
+        constexpr int ND = Q5 ? 3 : 2, DB = Q5 ? 2 : 3;
+        uint32_t sd[ND], td[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            sd[i] = ((sc_lo >> (DB * i)) & ((1u << DB) - 1u)) * 0x00010001u;
+            td[i] = ((sc_hi >> (DB * i)) & ((1u << DB) - 1u)) * 0x00010001u;
+        }
         const float dw = f16_bits_to_f32((uint16_t)(H[0] & 0xFFFF));
         const float dmw = f16_bits_to_f32((uint16_t)(H[0] >> 16));
         float D[4], DM[4];
@@ -94,35 +109,49 @@ DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
             const uint32_t qs = l < 4 ? QA[l & 3] : QB[l & 3];
-            const uint32_t wlo = qs & 0x0F0F0F0Fu, whi = (qs >> 4) & 0x0F0F0F0Fu;
+            uint32_t wlo = qs & 0x0F0F0F0Fu, whi = (qs >> 4) & 0x0F0F0F0Fu;
+            if constexpr (Q5) {
+                const uint32_t qh = l < 4 ? QH0[l & 3] : QH1[l & 3];
+                wlo |= ((qh >> (2 * q)) & 0x01010101u) << 4;
+                whi |= ((qh >> (2 * q + 1)) & 0x01010101u) << 4;
+            }
             const uint32_t alo = l < 4 ? a0[l & 3] : a1[l & 3], ahi = l < 4 ? a2[l & 3] : a3[l & 3];
             const uint64_t A = (uint64_t)alo | ((uint64_t)ahi << 32);
-            const uint64_t Bh = (uint64_t)pk_mul_u16(wlo, s_h3) | ((uint64_t)pk_mul_u16(whi, t_h3) << 32);
-            const uint64_t Bl = (uint64_t)pk_mul_u16(wlo, s_l3) | ((uint64_t)pk_mul_u16(whi, t_l3) << 32);
             i32x4 c = {0, 0, 0, 0};
-            c = mfma_i8_16x16x32(A, Bh, c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 3);
-            c = mfma_i8_16x16x32(A, Bl, c);
+            for (int i = ND - 1; i >= 0; --i) {
+                c = mfma_i8_16x16x32(A, (uint64_t)pk_mul_u16(wlo, sd[i]) | ((uint64_t)pk_mul_u16(whi, td[i]) << 32), c);
+                if (i > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
         }
-        // min term: prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1], acc_m[t] = fma(-y.d * dmin, (float)prod[t], acc_m[t])
+        // min term: prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1];  Q4_K: acc_m[t] = fma(-y.d * dmin, (float)prod[t], acc_m[t]),
+        // Q5_K: summs = fma(-y.d * dmin, (float)(prod[0] + prod[1] + prod[2] + prod[3]), summs)
         const int m0 = (int)bfe32(x0, 12, 6), m1 = (int)bfe32(x0, 18, 6), m2 = (int)bfe32(x1, 12, 6), m3 = (int)bfe32(x1, 18, 6);
         const int m4 = (int)bfe32(x2, 12, 6), m5 = (int)bfe32(x2, 18, 6), m6 = (int)bfe32(x3, 12, 6), m7 = (int)bfe32(x3, 18, 6);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            accm[j][0] = fmaf(DM[j], (float)(mul24(m0, (int)s0[j][0]) + mul24(m1, (int)s0[j][1])), accm[j][0]);
-            accm[j][1] = fmaf(DM[j], (float)(mul24(m2, (int)s0[j][2]) + mul24(m3, (int)s0[j][3])), accm[j][1]);
-            accm[j][2] = fmaf(DM[j], (float)(mul24(m4, (int)s1[j][0]) + mul24(m5, (int)s1[j][1])), accm[j][2]);
-            accm[j][3] = fmaf(DM[j], (float)(mul24(m6, (int)s1[j][2]) + mul24(m7, (int)s1[j][3])), accm[j][3]);
+            const int p0 = mul24(m0, (int)s0[j][0]) + mul24(m1, (int)s0[j][1]), p1 = mul24(m2, (int)s0[j][2]) + mul24(m3, (int)s0[j][3]);
+            const int p2 = mul24(m4, (int)s1[j][0]) + mul24(m5, (int)s1[j][1]), p3 = mul24(m6, (int)s1[j][2]) + mul24(m7, (int)s1[j][3]);
+            if constexpr (Q5) {
+                accm[j][0] = fmaf(DM[j], (float)((p0 + p1) + (p2 + p3)), accm[j][0]);
+            } else {
+                accm[j][0] = fmaf(DM[j], (float)p0, accm[j][0]);
+                accm[j][1] = fmaf(DM[j], (float)p1, accm[j][1]);
+                accm[j][2] = fmaf(DM[j], (float)p2, accm[j][2]);
+                accm[j][3] = fmaf(DM[j], (float)p3, accm[j][3]);
+            }
         }
     }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // hsum_float_8 (k_quants.c:90-97) and the Q4_K min-term tree, in-lane
+    for (int j = 0; j < 4; ++j) {   // hsum_float_8 (k_quants.c:90-97) and the min-term tree, in-lane
         const float tot = ((acc[j][0] + acc[j][4]) + (acc[j][2] + acc[j][6])) + ((acc[j][1] + acc[j][5]) + (acc[j][3] + acc[j][7]));
-        const float am = (accm[j][0] + accm[j][2]) + (accm[j][1] + accm[j][3]);
+        const float am = Q5 ? accm[j][0] : (accm[j][0] + accm[j][2]) + (accm[j][1] + accm[j][3]);
         res[j] = tot + am;
     }
 }
@@ -134,14 +163,17 @@ DEV void pfm_item_q4k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
 //     D[(token, half)][row] = sumi[l' + 4 * half]      for l' = 0..3: 8 MFMA per block, 16 accumulators per lane.
 // The min term splits the same way (half 0: acc_m[0..1], half 1: acc_m[2..3]); the two halves of a (row, token) sit in
 // lanes 32 apart and meet once per item for the final hsum_float_8 tree.
-DEV void pfm_item_q4k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+template <int TYPE>
+DEV void pfm_item_q45_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                          int K, int lane, float (&res)[4]) {
-    constexpr uint32_t REC = 1152;
+    constexpr bool Q5 = TYPE == GT_Q5_K;
+    constexpr uint32_t REC = Q5 ? 1408 : 1152, QS0 = Q5 ? 384 : 128;
     const int r16 = lane & 15, q = lane >> 4, half = q >> 1;
     int tile = 2 * item + (r16 >> 3);
     tile = tile < n_tiles ? tile : n_tiles - 1;
     const uint8_t* base = w0 + (size_t)tile * nb * REC + (r16 & 7) * 16;
-    const uint32_t qoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const uint32_t qoff = QS0 - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
+    const uint32_t hoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 32u;
     const int nq = K >> 2, nbk = K >> 8;
     const bool a_hi_half = (lane & 8) != 0;   // A side: slot n = lane & 15 -> token n & 7, half n >> 3
     const int* imgA = lds + (lane & 7) * act_words + 16 * q + (a_hi_half ? 4 : 0);
@@ -156,61 +188,85 @@ DEV void pfm_item_q4k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
         accm[j][0] = accm[j][1] = 0.0f;
     }
     constexpr int PF = 2;
-    u32x4 rh[PF], ra[PF], rb[PF];
+    u32x4 rh[PF], ra[PF], rb[PF], rq0[PF], rq1[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const uint8_t* p = base + (size_t)(u < nb ? u : nb - 1) * REC;
         rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+        if constexpr (Q5) { rq0[u] = ld_stream16(p + hoff); rq1[u] = ld_stream16(p + hoff + 16); }
     }
     for (int b0 = 0; b0 < nb; b0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int b = b0 + u;
         const u32x4 H = rh[u], QA = ra[u], QB = rb[u];
+        u32x4 QH0 = H, QH1 = H;
+        if constexpr (Q5) { QH0 = rq0[u]; QH1 = rq1[u]; }
         {
             const uint8_t* p = base + (size_t)(b + PF < nb ? b + PF : nb - 1) * REC;
             rh[u] = ld_stream16(p); ra[u] = ld_stream16(p + qoff); rb[u] = ld_stream16(p + qoff + 16);
+            if constexpr (Q5) { rq0[u] = ld_stream16(p + hoff); rq1[u] = ld_stream16(p + hoff + 16); }
         }
         if (b >= nb) continue;
         const uint32_t x0 = H[1], x1 = alignbit32(H[2], H[1], 24), x2 = alignbit32(H[3], H[2], 16), x3 = H[3] >> 8;
         const uint32_t xq = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
         const uint32_t sc_lo = xq & 63u, sc_hi = bfe32(xq, 6, 6);
-        const uint32_t s_l3 = (sc_lo & 7u) * 0x00010001u, s_h3 = (sc_lo >> 3) * 0x00010001u;
-        const uint32_t t_l3 = (sc_hi & 7u) * 0x00010001u, t_h3 = (sc_hi >> 3) * 0x00010001u;
+        constexpr int ND = Q5 ? 3 : 2, DB = Q5 ? 2 : 3;
+        uint32_t sd[ND], td[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            sd[i] = ((sc_lo >> (DB * i)) & ((1u << DB) - 1u)) * 0x00010001u;
+            td[i] = ((sc_hi >> (DB * i)) & ((1u << DB) - 1u)) * 0x00010001u;
+        }
         const float dw = f16_bits_to_f32((uint16_t)(H[0] & 0xFFFF));
         const float dmw = f16_bits_to_f32((uint16_t)(H[0] >> 16));
         float D[4], DM[4];
-        u32x4 sbv[4];
+        u32x4 sbv[4], sbo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float yd = bits_to_f32((uint32_t)imgT[j][b]);
             D[j] = yd * dw;
             DM[j] = -yd * dmw;
             sbv[j] = *(const u32x4*)(imgT[j] + nbk + b * 8 + 4 * half);   // q8s[4 * half .. + 3]
+            if constexpr (Q5) sbo[j] = *(const u32x4*)(imgT[j] + nbk + b * 8 + 4 * (1 - half));   // the other four: Q5_K sums all eight
         }
         const u32x4 alo = *(const u32x4*)(imgA + b * 64), ahi = *(const u32x4*)(imgA + b * 64 + 8);
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const uint32_t w0lo = QA[l] & 0x0F0F0F0Fu, w0hi = (QA[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l
-            const uint32_t w1lo = QB[l] & 0x0F0F0F0Fu, w1hi = (QB[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l + 4
+            uint32_t w0lo = QA[l] & 0x0F0F0F0Fu, w0hi = (QA[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l
+            uint32_t w1lo = QB[l] & 0x0F0F0F0Fu, w1hi = (QB[l] >> 4) & 0x0F0F0F0Fu;   // AVX lane l + 4
+            if constexpr (Q5) {
+                w0lo |= ((QH0[l] >> (2 * q)) & 0x01010101u) << 4; w0hi |= ((QH0[l] >> (2 * q + 1)) & 0x01010101u) << 4;
+                w1lo |= ((QH1[l] >> (2 * q)) & 0x01010101u) << 4; w1hi |= ((QH1[l] >> (2 * q + 1)) & 0x01010101u) << 4;
+            }
             const uint32_t al = alo[l], ah = ahi[l];
             const u32x4 A = a_hi_half ? u32x4{0u, 0u, al, ah} : u32x4{al, ah, 0u, 0u};
-            const u32x4 Bh = u32x4{pk_mul_u16(w0lo, s_h3), pk_mul_u16(w0hi, t_h3), pk_mul_u16(w1lo, s_h3), pk_mul_u16(w1hi, t_h3)};
-            const u32x4 Bl = u32x4{pk_mul_u16(w0lo, s_l3), pk_mul_u16(w0hi, t_l3), pk_mul_u16(w1lo, s_l3), pk_mul_u16(w1hi, t_l3)};
             i32x4 c = {0, 0, 0, 0};
-            c = mfma_i8_16x16x64(A, Bh, c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << 3);
-            c = mfma_i8_16x16x64(A, Bl, c);
+            for (int i = ND - 1; i >= 0; --i) {
+                c = mfma_i8_16x16x64(A, u32x4{pk_mul_u16(w0lo, sd[i]), pk_mul_u16(w0hi, td[i]), pk_mul_u16(w1lo, sd[i]), pk_mul_u16(w1hi, td[i])}, c);
+                if (i > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
         }
         const uint32_t xa = half ? x2 : x0, xb = half ? x3 : x1;   // scale groups 2 * half, 2 * half + 1
         const int ma0 = (int)bfe32(xa, 12, 6), ma1 = (int)bfe32(xa, 18, 6), mb0 = (int)bfe32(xb, 12, 6), mb1 = (int)bfe32(xb, 18, 6);
+        const uint32_t xc = half ? x0 : x2, xd = half ? x1 : x3;   // Q5_K: the other half's groups
+        const int mc0 = (int)bfe32(xc, 12, 6), mc1 = (int)bfe32(xc, 18, 6), md0 = (int)bfe32(xd, 12, 6), md1 = (int)bfe32(xd, 18, 6);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            accm[j][0] = fmaf(DM[j], (float)(mul24(ma0, (int)sbv[j][0]) + mul24(ma1, (int)sbv[j][1])), accm[j][0]);
-            accm[j][1] = fmaf(DM[j], (float)(mul24(mb0, (int)sbv[j][2]) + mul24(mb1, (int)sbv[j][3])), accm[j][1]);
+            const int pa = mul24(ma0, (int)sbv[j][0]) + mul24(ma1, (int)sbv[j][1]), pb = mul24(mb0, (int)sbv[j][2]) + mul24(mb1, (int)sbv[j][3]);
+            if constexpr (Q5) {   // one scalar term: both halves of the lane pair compute the whole sum (integers: any order)
+                const int pc = mul24(mc0, (int)sbo[j][0]) + mul24(mc1, (int)sbo[j][1]), pd = mul24(md0, (int)sbo[j][2]) + mul24(md1, (int)sbo[j][3]);
+                accm[j][0] = fmaf(DM[j], (float)((pa + pb) + (pc + pd)), accm[j][0]);
+            } else {
+                accm[j][0] = fmaf(DM[j], (float)pa, accm[j][0]);
+                accm[j][1] = fmaf(DM[j], (float)pb, accm[j][1]);
+            }
         }
     }
     }
@@ -220,7 +276,7 @@ DEV void pfm_item_q4k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
         const float p0 = acc[j][0] + lane_xor32(acc[j][0]), p1 = acc[j][1] + lane_xor32(acc[j][1]);
         const float p2 = acc[j][2] + lane_xor32(acc[j][2]), p3 = acc[j][3] + lane_xor32(acc[j][3]);
         const float tot = (p0 + p2) + (p1 + p3);
-        const float am = (accm[j][0] + lane_xor32(accm[j][0])) + (accm[j][1] + lane_xor32(accm[j][1]));   // (m0 + m2) + (m1 + m3)
+        const float am = Q5 ? accm[j][0] : (accm[j][0] + lane_xor32(accm[j][0])) + (accm[j][1] + lane_xor32(accm[j][1]));   // Q4_K: (m0 + m2) + (m1 + m3)
         res[j] = tot + am;
     }
 }
@@ -337,7 +393,7 @@ DEV void pfm_item_q6k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
         res[j] = ((acc[j][0] + acc[j][4]) + (acc[j][2] + acc[j][6])) + ((acc[j][1] + acc[j][5]) + (acc[j][3] + acc[j][7]));
 }
 
-// K > 8192 form (see pfm_item_q4k_t8): token slots = (token, AVX-lane half), one 16x16x64 MFMA carries lanes l' and l' + 4.
+// K > 8192 form (see pfm_item_q45_t8): token slots = (token, AVX-lane half), one 16x16x64 MFMA carries lanes l' and l' + 4.
 DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                          int K, int lane, float (&res)[4]) {
     constexpr uint32_t REC = 1680;
@@ -408,21 +464,22 @@ DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
     }
 }
 
-template <int TOK>
-DEV void pfm_item(int type, const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
+template <int TYPE, int TOK>
+DEV void pfm_item(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                   int K, int lane, float (&res)[4]) {
-    if (type == GT_Q4_K) {
-        if constexpr (TOK == 16) pfm_item_q4k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
-        else pfm_item_q4k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
-    } else {
+    if constexpr (TYPE == GT_Q6_K) {
         if constexpr (TOK == 16) pfm_item_q6k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
         else pfm_item_q6k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+    } else {
+        if constexpr (TOK == 16) pfm_item_q45<TYPE, 16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+        else pfm_item_q45_t8<TYPE>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
     }
 }
 
-// Launch over the Q4_K and Q6_K jobs of a site (the caller sends Q5_K through matvec_pf_kernel): items are 16-row
+// Launch over the jobs of a site that have weight type TYPE (one launch per type: a kernel holding all three forms needs
+// more than 256 VGPRs, and uniform items balance better — a Q6_K item costs about twice a Q4_K item): items are 16-row
 // pairs of tiles, job after job; 512 threads, wave w takes items w * gridDim.x + blockIdx.x + k * 8 * gridDim.x.
-template <int TOK, bool GU>
+template <int TYPE, int TOK, bool GU>
 __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
     CT_DYN_SMEM(smem_raw);
     int* lds = reinterpret_cast<int*>(smem_raw);
@@ -452,8 +509,8 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
         if constexpr (GU) {
             const int n_tiles = (m.job[0].w.M + 7) / 8;
             float gate[4], up[4];
-            pfm_item<TOK>(m.job[0].w.type, m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
-            pfm_item<TOK>(m.job[1].w.type, m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
+            pfm_item<TYPE, TOK>(m.job[0].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, gate);
+            pfm_item<TYPE, TOK>(m.job[1].w.p[0], item, n_tiles, nb, lds, a.act_words, m.K, lane, up);
             const int row = item * 16 + r16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -467,7 +524,7 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
             if (m.njobs > 2 && item >= m.job[2].pair0) jb = 2;
             const int it = item - m.job[jb].pair0;
             float res[4];
-            pfm_item<TOK>(m.job[jb].w.type, m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
+            pfm_item<TYPE, TOK>(m.job[jb].w.p[0], it, (m.job[jb].w.M + 7) / 8, nb, lds, a.act_words, m.K, lane, res);
             const int row = it * 16 + r16;
             const bool row_ok = row < m.job[jb].w.M;
             const int epi = m.job[jb].epi;

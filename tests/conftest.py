@@ -21,6 +21,20 @@ def has_gpu():
     return os.path.exists("/dev/kfd")
 
 
+def pytest_sessionstart(session):
+    """On a GPU box, bring up torch's HIP runtime before the library's: torch ships its own copy of the runtime, and
+    initialising it after another runtime instance of the process has created and destroyed contexts fails with
+    "No HIP GPUs are available" (seen when a pipeline test — the only user of torch device tensors — ran after a plain
+    C-ABI test with only this one test file collected).  The pipeline launcher itself always starts with torch."""
+    if has_gpu():
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:   # noqa: BLE001 — a box without a usable torch runs the C-ABI tests only
+            pass
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """CPU emulation of the HIP kernels (tests/emu) — kernel-logic checks without a GPU."""

@@ -58,12 +58,13 @@ def test_batch_structure(emu_lib):
     assert chunk_tokens(m) == 45   # 32 + 13 tokens through the chunk kernels
 
 
-def test_prompt_chunk_eight_token_matrix_core_form(emu_lib, monkeypatch):
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_prompt_chunk_eight_token_matrix_core_form(emu_lib, monkeypatch, name):
     """kernels_pfm.h's K > 8192 form (8 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token slots),
     forced on the tiny model: golden logits of the reference for a one-batch 45-token prompt."""
     monkeypatch.setenv("CT_AMD_PFM_T8", "1")
-    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
-    m = open_emu(emu_lib, "tiny-q4km", batch_size=64)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_emu(emu_lib, name, batch_size=64)
     m.eval(list(g["long_prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["long_one"])
     assert chunk_tokens(m) == 45
