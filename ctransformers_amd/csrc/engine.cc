@@ -350,8 +350,7 @@ bool Engine::alloc_state(std::string& err) {
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
-    // prompt chunks (kernels_pf.h): llama graph, K-quant tile layout, n_embd <= 12288; an ffn_down wider than 12288 (70B class)
-    // stays on the wide-K decode kernel, token by token inside the chunk
+    // prompt chunks (kernels_pf.h, kernels_pfm.h): llama graph, K-quant tile layout, n_embd <= 12288, n_ff <= 32768
     pf_ok_ = !hp_.falcon() && !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
     for (int i = l0_; i < l1_ && pf_ok_; ++i) {
         const Layer& L = layers_[i];
@@ -360,9 +359,10 @@ bool Engine::alloc_state(std::string& err) {
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
-        pfm_force_t8_ = env_int("CT_AMD_PFM_T8", 0) != 0;   // tests: the 8-token matrix-core form at any K
+        use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
+        pfm_force_tok_ = env_int("CT_AMD_PFM_TOK", 0);   // tests: 8 or 4 forces that matrix-core form at any K
         pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
-        const size_t aw = (size_t)pf_act_words(F <= 12288 ? std::max(E, F) : E);
+        const size_t aw = (size_t)pf_act_words(std::max(E, F));
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
@@ -675,8 +675,9 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
     if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
-    else CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
-    static const int use_mfma = env_int("CT_AMD_PF_MFMA", 1);
+    else if (m.K <= 12288) CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
+    else CT_LAUNCH((pf_quantize_kernel<32768>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
+    const int use_mfma = use_mfma_ ? 1 : 0;
     static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
     // one launch per weight type present in the site's jobs (matrix-core kernel; CT_AMD_PF_MFMA=0: the dot4 kernel, A/B)
     for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
@@ -697,8 +698,10 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         a.m.njobs = nj;
         a.m.n_pairs = m.gateup ? (m.job[0].w.M + rows_per_item - 1) / rows_per_item : item0;
         if (use_mfma) {
-            const bool t16 = (size_t)16 * aw * 4 <= 160 * 1024 && !pfm_force_t8_;
-            const int tok = t16 ? 16 : 8, groups = (nt + tok - 1) / tok;
+            // token images per workgroup: 16 where they fit LDS (and the chunk has more than 8 tokens), else 8, else 4
+            int tok = ((size_t)16 * aw * 4 <= 160 * 1024 && nt > 8) ? 16 : ((size_t)8 * aw * 4 <= 160 * 1024 ? 8 : 4);
+            if (pfm_force_tok_ == 8 || pfm_force_tok_ == 4) tok = std::min(tok, pfm_force_tok_);
+            const int groups = (nt + tok - 1) / tok;
             const int gx = std::max(1, std::min(gx_mul * chip_cus() / groups, a.m.n_pairs));
             const dim3 grid((unsigned)gx, (unsigned)groups), block(512);
             const size_t smem = (size_t)tok * aw * 4;
@@ -707,8 +710,9 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
                 static bool once = [&] { return CT_SMEM_OPTIN(kfn, 160 * 1024); }(); \
                 (void)once; \
                 CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
-#define PFM_T(TYV) do { if (t16) { if (m.gateup) PFM(TYV, 16, true); else PFM(TYV, 16, false); } \
-                        else { if (m.gateup) PFM(TYV, 8, true); else PFM(TYV, 8, false); } } while (0)
+#define PFM_T(TYV) do { if (tok == 16) { if (m.gateup) PFM(TYV, 16, true); else PFM(TYV, 16, false); } \
+                        else if (tok == 8) { if (m.gateup) PFM(TYV, 8, true); else PFM(TYV, 8, false); } \
+                        else { if (m.gateup) PFM(TYV, 4, true); else PFM(TYV, 4, false); } } while (0)
             if (ty == GT_Q4_K) PFM_T(GT_Q4_K); else if (ty == GT_Q5_K) PFM_T(GT_Q5_K); else PFM_T(GT_Q6_K);
 #undef PFM_T
 #undef PFM
@@ -790,9 +794,9 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
-            if (F <= 12288) {
+            if (F <= 12288 || use_mfma_) {
                 if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
-            } else {   // wide rows: 8 Q8_K images of this length do not fit LDS — the decode kernel, one token at a time
+            } else {   // dot4 A/B form: 8 Q8_K images of this length do not fit LDS — the decode kernel, one token at a time
                 for (int t = 0; t < nt; ++t) {
                     MatvecArgs at = a;
                     at.x = hb_ + (size_t)t * F; at.out = xb_ + (size_t)t * E; at.res = xb_ + (size_t)t * E;

@@ -136,7 +136,8 @@ class Engine {
     int pf_min_ = 2;        // chunks shorter than this run token by token
     int pf_chunk_ = 64;     // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
     long long chunk_tokens_ = 0;
-    bool pfm_force_t8_ = false;
+    bool use_mfma_ = true;
+    int pfm_force_tok_ = 0;
     float* rope_cs_ = nullptr;
     uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;
     int *d_tokens_ = nullptr, *d_state_ = nullptr;  // token ids of the current chunk; {step, pos} cursor

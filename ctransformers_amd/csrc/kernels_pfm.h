@@ -156,6 +156,12 @@ DEV void pfm_item_q45(const uint8_t* __restrict__ w0, int item, int n_tiles, int
     }
 }
 
+// the lane holding the other AVX-lane half of the same (row, token) in the 8- / 4-token forms below
+template <int NT, class T> DEV T pf_partner(T v) {
+    if constexpr (NT == 8) return lane_xor32(v);
+    else return lane_xor16(v);
+}
+
 // The same for K > 8192, where LDS holds 8 token images only.  Running the 16-token form on 8 tokens would compute every
 // result twice; instead the 16 token slots of the matrix product become (token, half of the AVX lanes): slot n < 8 is
 // token n with lanes l' = 0..3, slot n >= 8 is token n - 8 with lanes l' + 4.  One v_mfma_i32_16x16x64_i8 carries both
@@ -163,23 +169,25 @@ DEV void pfm_item_q45(const uint8_t* __restrict__ w0, int item, int n_tiles, int
 //     D[(token, half)][row] = sumi[l' + 4 * half]      for l' = 0..3: 8 MFMA per block, 16 accumulators per lane.
 // The min term splits the same way (half 0: acc_m[0..1], half 1: acc_m[2..3]); the two halves of a (row, token) sit in
 // lanes 32 apart and meet once per item for the final hsum_float_8 tree.
-template <int TYPE>
+// NT = 8 token images (8192 < K <= 12288), or 4 (K up to 32768: the 70B-class ffn_down) — then only slots 0..7 are distinct
+// (token = slot & 3, half = bit 2 of the slot), the partner half sits 16 lanes away and lanes 32..63 repeat lanes 0..31.
+template <int TYPE, int NT>
 DEV void pfm_item_q45_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                          int K, int lane, float (&res)[4]) {
     constexpr bool Q5 = TYPE == GT_Q5_K;
     constexpr uint32_t REC = Q5 ? 1408 : 1152, QS0 = Q5 ? 384 : 128;
-    const int r16 = lane & 15, q = lane >> 4, half = q >> 1;
+    const int r16 = lane & 15, q = lane >> 4, half = NT == 8 ? q >> 1 : q & 1;
     int tile = 2 * item + (r16 >> 3);
     tile = tile < n_tiles ? tile : n_tiles - 1;
     const uint8_t* base = w0 + (size_t)tile * nb * REC + (r16 & 7) * 16;
     const uint32_t qoff = QS0 - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 128u + (uint32_t)q * 32u;
     const uint32_t hoff = 128u - (uint32_t)(r16 & 7) * 16u + (uint32_t)(r16 & 7) * 32u;
     const int nq = K >> 2, nbk = K >> 8;
-    const bool a_hi_half = (lane & 8) != 0;   // A side: slot n = lane & 15 -> token n & 7, half n >> 3
-    const int* imgA = lds + (lane & 7) * act_words + 16 * q + (a_hi_half ? 4 : 0);
+    const bool a_hi_half = (lane & NT) != 0;   // A side: slot n = lane & 15 -> token n & (NT - 1), half = the next bit
+    const int* imgA = lds + (lane & (NT - 1)) * act_words + 16 * q + (a_hi_half ? 4 : 0);
     const int* imgT[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) imgT[j] = lds + (4 * (q & 1) + j) * act_words + nq;
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + (NT == 8 ? 4 * (q & 1) + j : j) * act_words + nq;
     float acc[4][4], accm[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -273,10 +281,10 @@ DEV void pfm_item_q45_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // x_l + x_{l+4}: one operand is this lane's, the other the partner half's (fp addition commutes bit for bit)
-        const float p0 = acc[j][0] + lane_xor32(acc[j][0]), p1 = acc[j][1] + lane_xor32(acc[j][1]);
-        const float p2 = acc[j][2] + lane_xor32(acc[j][2]), p3 = acc[j][3] + lane_xor32(acc[j][3]);
+        const float p0 = acc[j][0] + pf_partner<NT>(acc[j][0]), p1 = acc[j][1] + pf_partner<NT>(acc[j][1]);
+        const float p2 = acc[j][2] + pf_partner<NT>(acc[j][2]), p3 = acc[j][3] + pf_partner<NT>(acc[j][3]);
         const float tot = (p0 + p2) + (p1 + p3);
-        const float am = Q5 ? accm[j][0] : (accm[j][0] + lane_xor32(accm[j][0])) + (accm[j][1] + lane_xor32(accm[j][1]));   // Q4_K: (m0 + m2) + (m1 + m3)
+        const float am = Q5 ? accm[j][0] : (accm[j][0] + pf_partner<NT>(accm[j][0])) + (accm[j][1] + pf_partner<NT>(accm[j][1]));   // Q4_K: (m0 + m2) + (m1 + m3)
         res[j] = tot + am;
     }
 }
@@ -394,6 +402,7 @@ DEV void pfm_item_q6k(const uint8_t* __restrict__ w0, int item, int n_tiles, int
 }
 
 // K > 8192 form (see pfm_item_q45_t8): token slots = (token, AVX-lane half), one 16x16x64 MFMA carries lanes l' and l' + 4.
+template <int NT>
 DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb, const int* __restrict__ lds, int act_words,
                          int K, int lane, float (&res)[4]) {
     constexpr uint32_t REC = 1680;
@@ -402,11 +411,11 @@ DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
     tile = tile < n_tiles ? tile : n_tiles - 1;
     const uint8_t* base = w0 + (size_t)tile * nb * REC;
     const int nq = K >> 2;
-    const bool a_hi_half = (lane & 8) != 0;
-    const int* imgA = lds + (lane & 7) * act_words + 32 * n + 8 * kq + (a_hi_half ? 4 : 0);
+    const bool a_hi_half = (lane & NT) != 0;
+    const int* imgA = lds + (lane & (NT - 1)) * act_words + 32 * n + 8 * kq + (a_hi_half ? 4 : 0);
     const int* imgT[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) imgT[j] = lds + (4 * (q & 1) + j) * act_words + nq;
+    for (int j = 0; j < 4; ++j) imgT[j] = lds + (NT == 8 ? 4 * (q & 1) + j : j) * act_words + nq;
     float acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -458,8 +467,8 @@ DEV void pfm_item_q6k_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float p0 = acc[j][0] + lane_xor32(acc[j][0]), p1 = acc[j][1] + lane_xor32(acc[j][1]);
-        const float p2 = acc[j][2] + lane_xor32(acc[j][2]), p3 = acc[j][3] + lane_xor32(acc[j][3]);
+        const float p0 = acc[j][0] + pf_partner<NT>(acc[j][0]), p1 = acc[j][1] + pf_partner<NT>(acc[j][1]);
+        const float p2 = acc[j][2] + pf_partner<NT>(acc[j][2]), p3 = acc[j][3] + pf_partner<NT>(acc[j][3]);
         res[j] = (p0 + p2) + (p1 + p3);
     }
 }
@@ -469,10 +478,10 @@ DEV void pfm_item(const uint8_t* __restrict__ w0, int item, int n_tiles, int nb,
                   int K, int lane, float (&res)[4]) {
     if constexpr (TYPE == GT_Q6_K) {
         if constexpr (TOK == 16) pfm_item_q6k<16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
-        else pfm_item_q6k_t8(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+        else pfm_item_q6k_t8<TOK>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
     } else {
         if constexpr (TOK == 16) pfm_item_q45<TYPE, 16>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
-        else pfm_item_q45_t8<TYPE>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
+        else pfm_item_q45_t8<TYPE, TOK>(w0, item, n_tiles, nb, lds, act_words, K, lane, res);
     }
 }
 
@@ -514,7 +523,7 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
             const int row = item * 16 + r16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int t = 4 * q + j;
+                const int t = TOK == 4 ? (q == 0 ? j : TOK) : 4 * q + j;   // 4-token form: lanes 0..15 hold the results
                 if (t < nt && row < m.job[0].w.M)
                     m.out[(size_t)(t0 + t) * a.ld_out + row] = f16_bits_to_f32(m.silu_tab[f32_to_f16_bits(gate[j])]) * up[j];
             }
@@ -530,7 +539,7 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
             const int epi = m.job[jb].epi;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int t = 4 * q + j;
+                const int t = TOK == 4 ? (q == 0 ? j : TOK) : 4 * q + j;
                 const bool own = row_ok && t < nt;
                 const int tok = t0 + t, pos = pos0 + t;
                 if (epi == EPI_ADD) {

@@ -58,11 +58,11 @@ def test_batch_structure(emu_lib):
     assert chunk_tokens(m) == 45   # 32 + 13 tokens through the chunk kernels
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
-def test_prompt_chunk_eight_token_matrix_core_form(emu_lib, monkeypatch, name):
-    """kernels_pfm.h's K > 8192 form (8 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token slots),
-    forced on the tiny model: golden logits of the reference for a one-batch 45-token prompt."""
-    monkeypatch.setenv("CT_AMD_PFM_T8", "1")
+@pytest.mark.parametrize("name,tok", [("tiny-q4km", 8), ("tiny-q5km", 4)])   # the other two combinations: tests/test_gpu_parity.py
+def test_prompt_chunk_half_slot_matrix_core_forms(emu_lib, monkeypatch, name, tok):
+    """kernels_pfm.h's wide-K forms (8 or 4 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token
+    slots), forced on the tiny models: golden logits of the reference for a one-batch 45-token prompt."""
+    monkeypatch.setenv("CT_AMD_PFM_TOK", str(tok))
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_emu(emu_lib, name, batch_size=64)
     m.eval(list(g["long_prompt"]))
@@ -70,7 +70,7 @@ def test_prompt_chunk_eight_token_matrix_core_form(emu_lib, monkeypatch, name):
     assert chunk_tokens(m) == 45
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+@pytest.mark.parametrize("name", ["tiny-q4km"])   # tiny-q5km: tests/test_gpu_parity.py
 def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
     """The chunk kernels (kernels_pf.h) against the decode kernels on the same batches: ragged chunk lengths (a full
     32-token pass plus 1, a short tail, 2 tokens), a non-zero n_past, and embeddings as well as logits."""

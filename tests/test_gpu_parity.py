@@ -209,3 +209,49 @@ def test_long_context(ref, tmp_path):
         t = int(a.argmax())
         r.eval([t])
         m.eval([t])
+
+
+def chunk_tokens(m):
+    """Tokens the handle evaluated through the prompt-chunk kernels (include/ctransformers_amd_ext.h)."""
+    import ctypes
+    f = m._lib.ctamd_chunk_tokens
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
+@pytest.mark.parametrize("name,tok", [("tiny-q4km", 0), ("tiny-q5km", 0), ("tiny-q4km", 8), ("tiny-q5km", 8), ("tiny-q4km", 4),
+                                      ("tiny-q5km", 4)])
+def test_prompt_chunk_matrix_core_forms(name, tok, monkeypatch):
+    """kernels_pfm.h: the 16-token form (tok = 0: what these widths select) and the 8- / 4-token half-slot forms forced on the
+    tiny models (Q4_K + Q6_K and Q5_K + Q6_K files) against the reference's golden one-batch logits."""
+    if tok:
+        monkeypatch.setenv("CT_AMD_PFM_TOK", str(tok))
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_hip(os.path.join(GOLDEN, name + ".gguf"), batch_size=64)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_one"])
+    assert chunk_tokens(m) == 45
+
+
+@pytest.mark.parametrize("shape,ftype", [("llama-7b-2l", "Q4_K_M"), ("llama-70b-2l", "Q5_K_M")])
+def test_prompt_chunks_equal_token_by_token_and_reference(ref, tmp_path, monkeypatch, shape, ftype):
+    """Real layer widths (K = 4096 / 11008 and K = 8192 / 28672: all three token forms), ragged chunking — 64 + 6 tokens, then
+    2, then 1 — three ways: chunk kernels, the decode kernels token by token (CT_AMD_PF=0), the reference CPU build."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, shape, ftype, seed=5)
+    toks = synth.prompt_tokens(73, hp["n_vocab"])
+    cuts = ((0, 70), (70, 72), (72, 73))
+    r = ref.open_llm(p, context_length=96, batch_size=64, threads=16)
+    want = []
+    for lo, hi in cuts:
+        r.eval(toks[lo:hi])
+        want.append((r.logits.to_numpy().copy(), r.embeddings.to_numpy().copy()))
+    del r
+    for pf, expect_chunked in (("1", 64 + 6 + 2), ("0", 0)):
+        monkeypatch.setenv("CT_AMD_PF", pf)
+        m = open_hip(p, context_length=96, batch_size=64)
+        for (lo, hi), (wl, we) in zip(cuts, want):
+            m.eval(toks[lo:hi])
+            assert np.array_equal(m.logits.to_numpy(), wl) and np.array_equal(m.embeddings.to_numpy(), we), (pf, lo)
+        assert chunk_tokens(m) == expect_chunked
+        del m

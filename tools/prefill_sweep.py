@@ -1,0 +1,23 @@
+"""Prompt throughput of the HIP library against the ABI's batch_size (the reference's default is 8): tokens/s of a 256-token
+prompt evaluated in chunks of that size, second pass (warm).  usage: prefill_sweep.py <model.gguf> [batch sizes...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ctransformers_amd import synth  # noqa: E402
+from ctransformers_amd.llm import LLM, Config  # noqa: E402
+
+path = sys.argv[1]
+if not os.path.exists(path):
+    synth.write_llama_gguf(path, "llama-2-7b", "Q4_K_M", seed=1234)
+sizes = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16, 32, 64, 128]
+N = 256
+for bs in sizes:
+    m = LLM(path, config=Config(context_length=512, batch_size=bs, gpu_layers=1000))
+    toks = synth.prompt_tokens(N, m.vocab_size)
+    m.eval(toks)
+    m._context = []
+    t0 = time.perf_counter()
+    m.eval(toks)
+    dt = time.perf_counter() - t0
+    print("batch_size %4d: %8.1f tok/s  (%.2f ms per chunk)" % (bs, N / dt, dt / ((N + bs - 1) // bs) * 1e3), flush=True)
+    del m
