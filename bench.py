@@ -13,6 +13,7 @@ Extra objects on the JSON line:
   roofline      dominant kernel (the K=4096 weight mat-vec launch: QKV / Wo / gate+up / lm_head sites) —
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
+  prefill       the 128-token prompt through the prompt-chunk kernels (second, warm pass; the cold first pass beside it)
 """
 import argparse
 import json
@@ -123,6 +124,13 @@ def main():
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
                token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4)),
                roofline=roof)
+    # prompt chunks: 2 ops per weight of the 2-D matrices per token, against the dense int8 MFMA
+    # floor of the guide; the bound is VALU issue (the exact f32 chain step per block, AVX lane, row and token), not MFMA
+    pf_flop = 2 * 6.607e9 if SHAPE == "llama-2-7b" else None
+    out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=64,
+                          kernel="matvec_pfm_kernel<TYPE,TOK,GU> (int8 MFMA, exact), one hipGraph per chunk shape",
+                          int8_tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_peak_tops=3944,
+                          bound="valu")
     if not a.no_cpu_baseline:
         del llm
         out["cpu_baseline"] = cpu_baseline(n_vocab)

@@ -351,21 +351,26 @@ bool Engine::alloc_state(std::string& err) {
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
     // prompt chunks (kernels_pf.h, kernels_pfm.h): llama graph, K-quant tile layout, n_embd <= 12288, n_ff <= 32768
-    pf_ok_ = !hp_.falcon() && !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
+    use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
+    pf_ok_ = !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
     for (int i = l0_; i < l1_ && pf_ok_; ++i) {
         const Layer& L = layers_[i];
-        for (const DevMat* m : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down})
+        const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
+        const std::initializer_list<const DevMat*> falcon_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};
+        for (const DevMat* m : hp_.falcon() ? falcon_mats : llama_mats)
             pf_ok_ = pf_ok_ && m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K);
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
-        use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
         pfm_force_tok_ = env_int("CT_AMD_PFM_TOK", 0);   // tests: 8 or 4 forces that matrix-core form at any K
         pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
         const size_t aw = (size_t)pf_act_words(std::max(E, F));
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
+            return false;
+        if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
+                             !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))
             return false;
     }
     HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
@@ -674,9 +679,13 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     const int aw = pf_act_words(m.K);
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
-    if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
-    else if (m.K <= 12288) CT_LAUNCH((pf_quantize_kernel<12288>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
-    else CT_LAUNCH((pf_quantize_kernel<32768>), dim3((unsigned)nt), dim3(1024), stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw);
+    const dim3 qg((unsigned)nt), qb(1024);
+    if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
+        if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
+        else CT_LAUNCH((pf_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
+    } else if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
+    else if (m.K <= 12288) CT_LAUNCH((pf_quantize_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
+    else CT_LAUNCH((pf_quantize_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
     const int use_mfma = use_mfma_ ? 1 : 0;
     static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
     // one launch per weight type present in the site's jobs (matrix-core kernel; CT_AMD_PF_MFMA=0: the dot4 kernel, A/B)
@@ -743,6 +752,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 // llm_build_llama (llama.cpp:2162-2491) for nt tokens of one batch_eval chunk at once: the same launches as token_step,
 // each over rows [c0, c0 + nt) of the chunk (kernels_pf.h).  The cursor in d_state_ is at token c0 on entry.
 bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
+    if (hp_.falcon()) return chunk_step_falcon(c0, nt, want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -819,6 +829,78 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
     return true;
 }
 
+
+// llm_build_falcon (llama.cpp:2493-2798) for the nt tokens of a chunk: token_step_falcon's launches over rows of the chunk.
+bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    if (l0_ == 0) {
+        CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256), (unsigned)nt), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+                  (const int*)d_tokens_, (const int*)d_state_, xb_);
+    } else {
+        HIP_OK(hipMemcpyAsync(xb_, xio_ + (size_t)c0 * E, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
+    }
+    MatvecArgs base = MatvecArgs();
+    base.rope_cs = rope_cs_;
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = G;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    for (int il = l0_; il < l1_; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
+        uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
+        {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated), one row of E + 2G per token
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM;
+            a.norm_w = L.attn_norm2 ? L.attn_norm2 : L.attn_norm;
+            a.norm_b = L.attn_norm2 ? L.attn_norm2_b : L.attn_norm_b;
+            a.out = qkv_tmp_b_;
+            set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            if (!pf_matvec(a, xb_, E, nt, E + 2 * G, 0, "qkv", (double)L.wqkv.bytes, err)) return false;
+        }
+        if (site_on("rope_store"))
+            CT_LAUNCH(falcon_rope_store_kernel, dim3((unsigned)(hp_.n_head + 2 * hp_.n_head_kv), (unsigned)nt), dim3((unsigned)(hd / 2)), stream_,
+                      (const float*)qkv_tmp_b_, q_f16_b_, kc, vc, (const float*)rope_cs_, d_pos, hp_.n_head, hp_.n_head_kv, hd, n_ctx_,
+                      v_stride_);
+        if (site_on("attn_fused")) launch_attention(kc, vc, nt);
+        {   // Wo, kept apart: the residual is added after the MLP
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.out = attn_proj_b_;
+            set_jobs(a, {{&L.wo, EPI_STORE}});
+            if (!pf_matvec(a, attn_out_b_, E, nt, E, 0, "wo", (double)L.wo.bytes, err)) return false;
+        }
+        {   // LayerNorm(attn_norm) -> Q8_K -> W_up -> GELU (parallel block: the MLP reads the attention norm)
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b; a.out = hb_;
+            set_jobs(a, {{&L.w_up, EPI_GELU}});
+            if (!pf_matvec(a, xb_, E, nt, F, 0, "ffn_up", (double)L.w_up.bytes, err)) return false;
+        }
+        {   // W_down -> (ffn + attn_out) + x
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = attn_proj_b_; a.res2 = xb_;
+            set_jobs(a, {{&L.w_down, EPI_ADD2}});
+            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+        }
+    }
+    if (l1_ < hp_.n_layer) {
+        HIP_OK(hipMemcpyAsync(xio_ + (size_t)c0 * E, xb_, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
+    } else if (want_logits) {
+        const float* xl = xb_ + (size_t)(nt - 1) * E;
+        CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, (const float*)output_norm_b_,
+                  d_emb_, E, hp_.rms_eps);
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = xl; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
+    return true;
+}
 
 // A whole-model handle launches nothing in chunk_step that depends on c0 (the cursor lives in d_state_), so the ~300 launches
 // of a chunk shape seen before are replayed from a graph: the first use of a shape runs eagerly (it also performs the

@@ -96,6 +96,7 @@ class Engine {
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
     bool chunk_step(int c0, int nt, bool want_logits, std::string& err);
+    bool chunk_step_falcon(int c0, int nt, bool want_logits, std::string& err);
     bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
@@ -132,6 +133,7 @@ class Engine {
     float *xb_ = nullptr, *attn_out_b_ = nullptr, *hb_ = nullptr;
     uint16_t* q_f16_b_ = nullptr;
     int* acts_ = nullptr;
+    float *qkv_tmp_b_ = nullptr, *attn_proj_b_ = nullptr;   // falcon chunks: fused QKV rows, Wo output
     bool pf_ok_ = false;    // llama architecture, every layer matrix a K-quant in the tile layout, K <= 12288
     int pf_min_ = 2;        // chunks shorter than this run token by token
     int pf_chunk_ = 64;     // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)

@@ -179,9 +179,11 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 __global__ void falcon_rope_store_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ q_f16, uint16_t* __restrict__ kcache,
                                          uint16_t* __restrict__ vcache, const float* __restrict__ rope_cs, const int* __restrict__ pos_p,
                                          int n_head, int n_head_kv, int head_dim, int n_ctx, int v_stride) {
-    const int hh = (int)blockIdx.x, i = (int)threadIdx.x, half = head_dim >> 1, pos = *pos_p;
+    // blockIdx.y: token inside a prompt chunk (rows of n_head + 2 n_head_kv heads in qkv, n_head heads in q_f16), else 0
+    const int hh = (int)blockIdx.x, i = (int)threadIdx.x, half = head_dim >> 1, tok = (int)blockIdx.y, pos = *pos_p + tok;
     if (i >= half) return;
-    const float* src = qkv + (size_t)hh * head_dim;
+    const float* src = qkv + ((size_t)tok * (n_head + 2 * n_head_kv) + hh) * head_dim;
+    q_f16 += (size_t)tok * n_head * head_dim;
     if (hh >= n_head + n_head_kv) {   // V head: plain f32 -> f16 into the transposed cache
         const int row0 = (hh - n_head - n_head_kv) * head_dim;
         vcache[(size_t)(row0 + i) * v_stride + pos] = f32_to_f16_bits(src[i]);

@@ -32,12 +32,14 @@ struct PfArgs {
 
 constexpr int pf_act_words(int K) { return ((K >> 2) + (K >> 8) + (K >> 5) + 3) & ~3; }
 
-template <int MAXK>
+template <int MAXK, bool LN = false>
 __global__ void __launch_bounds__(1024) pf_quantize_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
-                                                           int pro, float eps, int* __restrict__ acts, int act_words) {
+                                                           int pro, float eps, int* __restrict__ acts, int act_words,
+                                                           const float* __restrict__ nb_ = nullptr) {
     __shared__ ActLdsX<MAXK> L;
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
-    prologue_q8k_exact16<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
+    if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // falcon: LayerNorm + bias
+    else prologue_q8k_exact16<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
     int* o = acts + (size_t)t * act_words;
     const int nq = K >> 2, nb = K >> 8, ns = K >> 5;
     for (int i = tid; i < nq; i += 1024) o[i] = L.q8[i];

@@ -546,6 +546,10 @@ __global__ void __launch_bounds__(512) matvec_pfm_kernel(const PfArgs a) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[j] + m.res[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_STORE) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[j];
+                } else if (epi == EPI_GELU) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.gelu_tab[f32_to_f16_bits(res[j])]);
+                } else if (epi == EPI_ADD2) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = (res[j] + m.res[(size_t)tok * a.ld_res + row]) + m.res2[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_V) {
                     if (own) m.vcache[(size_t)row * m.v_stride + pos] = f32_to_f16_bits(res[j]);
                 } else {   // RoPE, normal mode (ggml.c:12522-12539): rows 2i, 2i+1 are neighbouring lanes

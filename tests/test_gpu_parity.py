@@ -20,6 +20,14 @@ def open_hip(path, model_type=None, **kw):
     return LLM(path, model_type, config=Config(**cfg))  # default lib = the HIP build; raises if missing / no GPU
 
 
+def chunk_tokens(m):
+    """Tokens the handle evaluated through the prompt-chunk kernels (include/ctransformers_amd_ext.h)."""
+    import ctypes
+    f = m._lib.ctamd_chunk_tokens
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
 @pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40", "falcon-tiny-q4km", "falcon-tiny7-q4km",
                                   "gpt2-tiny-q40"])
 @pytest.mark.parametrize("graph", ["1", "0"])
@@ -32,6 +40,8 @@ def test_golden_logits_bit_identical(name, graph, monkeypatch):
         m = open_hip(os.path.join(GOLDEN, name + ".gguf"))
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    # K-quant llama and falcon files: the prompt went through the chunk kernels (8 + 3 tokens); Q8_0 / Q4_0 / gpt2 token by token
+    assert chunk_tokens(m) == (len(g["prompt"]) if name.endswith(("q4km", "q5km")) else 0)
     if not name.startswith("gpt2"):
         assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
     for i, t in enumerate(g["greedy"]):
@@ -209,14 +219,6 @@ def test_long_context(ref, tmp_path):
         t = int(a.argmax())
         r.eval([t])
         m.eval([t])
-
-
-def chunk_tokens(m):
-    """Tokens the handle evaluated through the prompt-chunk kernels (include/ctransformers_amd_ext.h)."""
-    import ctypes
-    f = m._lib.ctamd_chunk_tokens
-    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
-    return int(f(m._llm))
 
 
 @pytest.mark.parametrize("name,tok", [("tiny-q4km", 0), ("tiny-q5km", 0), ("tiny-q4km", 8), ("tiny-q5km", 8), ("tiny-q4km", 4),

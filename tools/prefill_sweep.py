@@ -1,14 +1,14 @@
 """Prompt throughput of the HIP library against the ABI's batch_size (the reference's default is 8): tokens/s of a 256-token
-prompt evaluated in chunks of that size, second pass (warm).  usage: prefill_sweep.py <model.gguf> [batch sizes...]"""
+prompt evaluated in chunks of that size, second pass (warm).  usage: prefill_sweep.py <model.gguf>[:shape:ftype] [batch sizes...]   (shape/ftype: generate the synthetic file if missing)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ctransformers_amd import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
-path = sys.argv[1]
+path, shape, ftype = (sys.argv[1].split(":") + ["llama-2-7b", "Q4_K_M"])[:3]
 if not os.path.exists(path):
-    synth.write_llama_gguf(path, "llama-2-7b", "Q4_K_M", seed=1234)
+    (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(path, shape, ftype, seed=1234)
 sizes = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16, 32, 64, 128]
 N = 256
 for bs in sizes:
