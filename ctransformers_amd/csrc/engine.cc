@@ -353,12 +353,19 @@ bool Engine::alloc_state(std::string& err) {
     // prompt chunks (kernels_pf.h, kernels_pfm.h): llama graph, K-quant tile layout, n_embd <= 12288, n_ff <= 32768
     use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
     pf_ok_ = !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
-    for (int i = l0_; i < l1_ && pf_ok_; ++i) {
-        const Layer& L = layers_[i];
-        const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
-        const std::initializer_list<const DevMat*> falcon_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};
-        for (const DevMat* m : hp_.falcon() ? falcon_mats : llama_mats)
-            pf_ok_ = pf_ok_ && m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K);
+    {   // every layer matrix a K-quant in the tile layout, or (llama graph) every one Q8_0 / Q4_0 of one type with K <= 12288
+        int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
+        for (int i = l0_; i < l1_; ++i) {
+            const Layer& L = layers_[i];
+            const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
+            const std::initializer_list<const DevMat*> falcon_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};
+            for (const DevMat* m : hp_.falcon() ? falcon_mats : llama_mats) {
+                ++n_all;
+                if (m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K)) ++n_kq;
+                if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
+            }
+        }
+        pf_ok_ = pf_ok_ && (n_kq == n_all || (n_q32 == n_all && !hp_.falcon()));
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
@@ -680,6 +687,37 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
+    if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 images, the dot4 chunk kernel (no matrix-core form)
+        const int aw32 = pf_act_words_q32(m.K);
+        CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32);
+        PfArgs a;
+        a.m = m;
+        a.acts = acts_; a.act_words = aw32; a.n_tok = nt;
+        a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
+        int item0 = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            a.m.job[j].pair0 = m.gateup ? 0 : item0;
+            item0 += (m.job[j].w.M + 7) / 8;
+        }
+        a.m.n_pairs = m.gateup ? (m.job[0].w.M + 7) / 8 : item0;
+        const int groups = (nt + kPfTokens - 1) / kPfTokens;
+        const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
+        const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
+        const size_t smem = (size_t)kPfTokens * aw32 * 4;
+        if (m.gateup) {
+            auto kfn = matvec_pf_kernel<kPfTokens, true, true>;
+            static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4); }();
+            (void)once;
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+        } else {
+            auto kfn = matvec_pf_kernel<kPfTokens, false, true>;
+            static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4); }();
+            (void)once;
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
+        }
+        prof_end();
+        return true;
+    }
     if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
         if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
         else CT_LAUNCH((pf_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);

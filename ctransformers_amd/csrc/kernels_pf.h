@@ -18,6 +18,7 @@
 //   embed / attention    the decode kernels with a token index in blockIdx.y / blockIdx.z
 #pragma once
 #include "kernels_v6.h"
+#include "kernels_q32.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
 constexpr int kPfChunk = 64;    // tokens per launch (grid.y = 8 token groups here, 4 of 16 on the matrix-core path)
@@ -166,15 +167,100 @@ DEV void pf_tile(const uint8_t* __restrict__ base, int nb, const int* __restrict
     }
 }
 
-template <int TB>
+// ---- Q8_0 / Q4_0 weights (LAYOUT_G4, kernels_q32.h): Q8_0 activation images  q8[K/4] ([group][l][i] order) | yd[K/32] -----------
+constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }
+
+template <int MAXK>
+__global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
+                                                               int pro, float eps, int* __restrict__ acts, int act_words) {
+    __shared__ ActLdsQ32<MAXK> L;
+    const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
+    prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
+    int* o = acts + (size_t)t * act_words;
+    const int nq = K >> 2, nb = K >> 5;
+    for (int i = tid; i < nq; i += 1024) o[i] = L.q8[i];
+    for (int i = tid; i < nb; i += 1024) o[nq + i] = (int)f32_to_bits(L.yd[i]);
+}
+
+// q32_tile_dot for the nt tokens in LDS: one fma per 32-block, AVX lane and token (ggml.c:3321 / :2428, AVX2 forms), the
+// weight group fetched (and its nibbles extracted) once for all tokens.  res[t] valid in every lane of the row.
+template <int TYPE, int TB>
+DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __restrict__ lds, int act_words, int K, int nt, int lane,
+                     float (&res)[TB]) {
+    constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+    constexpr int PF = 4;
+    const int r = lane >> 3, p3 = lane & 7, l = ((p3 & 1) << 2) | (p3 & 2) | (p3 >> 2);   // AVX lane = bitrev3(position), see q32_tile_dot
+    const uint32_t qoff = TYPE == GT_Q8_0 ? (uint32_t)(r * 8 + l) * 16u : (uint32_t)(r * 4 + (l & 3)) * 16u;
+    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)r * 8u;
+    const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
+    const int nq = K >> 2;
+    float acc[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
+    u32x4 qv[PF];
+    uint64_t dv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int g = u < ng ? u : ng - 1;
+        qv[u] = ld_stream16(tile + (size_t)g * REC + qoff);
+        dv[u] = *(const uint64_t*)(tile + (size_t)g * REC + doff);
+    }
+    for (int g0 = 0; g0 < ng; g0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int g = g0 + u;
+            const u32x4 q = qv[u];
+            const uint64_t dd = dv[u];
+            {
+                const int gn = (g + PF < ng) ? g + PF : ng - 1;
+                qv[u] = ld_stream16(tile + (size_t)gn * REC + qoff);
+                dv[u] = *(const uint64_t*)(tile + (size_t)gn * REC + doff);
+            }
+            if (g >= ng) continue;
+            int w[4];
+            float dw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = TYPE == GT_Q8_0 ? (int)q[i] : (int)((q[i] >> sh) & 0x0F0F0F0Fu);
+                dw[i] = f16_bits_to_f32((uint16_t)((dd >> (16 * i)) & 0xFFFFu));
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                if (t < nt) {
+                    const int* img = lds + t * act_words;
+                    const u32x4 y = *(const u32x4*)(img + (g * 8 + l) * 4);
+                    const u32x4 yd = *(const u32x4*)(img + nq + g * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int sumi;
+                        if constexpr (TYPE == GT_Q8_0) sumi = sdot4(w[i], (int)y[i], 0);
+                        else sumi = sdot4(w[i], (int)y[i], 0) - 8 * sdot4(0x01010101, (int)y[i], 0);
+                        acc[t] = fmaf(dw[i] * bits_to_f32(yd[i]), (float)sumi, acc[t]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) res[t] = hsum8_exact_dpp(acc[t]);
+}
+
+template <int TB, bool Q32>
 DEV void pf_tile_any(int type, const uint8_t* __restrict__ w0, int tile, int nb, const int* __restrict__ lds, int act_words, int K,
                      int nt, const LaneGeom& G, float (&res)[TB]) {
+    if constexpr (Q32) {
+        const int ng = K >> 7;
+        const int lane = G.r * 8 + G.g;
+        if (type == GT_Q8_0) pf_tile_q32<GT_Q8_0, TB>(w0 + (size_t)tile * ng * kRecQ8_0, ng, lds, act_words, K, nt, lane, res);
+        else pf_tile_q32<GT_Q4_0, TB>(w0 + (size_t)tile * ng * kRecQ4_0, ng, lds, act_words, K, nt, lane, res);
+        return;
+    }
     if (type == GT_Q4_K) pf_tile<GT_Q4_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q4_K>(), nb, lds, act_words, K, nt, G, res);
     else if (type == GT_Q5_K) pf_tile<GT_Q5_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q5_K>(), nb, lds, act_words, K, nt, G, res);
     else pf_tile<GT_Q6_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q6_K>(), nb, lds, act_words, K, nt, G, res);
 }
 
-template <int TB, bool GU>
+template <int TB, bool GU, bool Q32 = false>
 __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
     CT_DYN_SMEM(smem_raw);
     int* lds = reinterpret_cast<int*>(smem_raw);
@@ -203,8 +289,8 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
     for (int item = wv * GX + (int)blockIdx.x; item < m.n_pairs; item += 16 * GX) {
         if constexpr (GU) {
             float gate[TB], up[TB];
-            pf_tile_any<TB>(m.job[0].w.type, m.job[0].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, gate);
-            pf_tile_any<TB>(m.job[1].w.type, m.job[1].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, up);
+            pf_tile_any<TB, Q32>(m.job[0].w.type, m.job[0].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, gate);
+            pf_tile_any<TB, Q32>(m.job[1].w.type, m.job[1].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, up);
             const int row = item * 8 + G.r;
             const bool own = own_lane && row < m.job[0].w.M;
 #pragma unroll
@@ -216,7 +302,7 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
             if (m.njobs > 2 && item >= m.job[2].pair0) j = 2;
             const int tile = item - m.job[j].pair0;
             float res[TB];
-            pf_tile_any<TB>(m.job[j].w.type, m.job[j].w.p[0], tile, nb, lds, a.act_words, m.K, nt, G, res);
+            pf_tile_any<TB, Q32>(m.job[j].w.type, m.job[j].w.p[0], tile, nb, lds, a.act_words, m.K, nt, G, res);
             const int row = tile * 8 + G.r;
             const bool own = own_lane && row < m.job[j].w.M;
             const int epi = m.job[j].epi;
