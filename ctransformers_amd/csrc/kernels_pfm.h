@@ -117,17 +117,26 @@ DEV void pfm_item_q45(const uint8_t* __restrict__ w0, int item, int n_tiles, int
             }
             const uint32_t alo = l < 4 ? a0[l & 3] : a1[l & 3], ahi = l < 4 ? a2[l & 3] : a3[l & 3];
             const uint64_t A = (uint64_t)alo | ((uint64_t)ahi << 32);
-            i32x4 c = {0, 0, 0, 0};
+            if constexpr (ND == 2) {   // Q4_K: two independent MFMAs (they pipeline), combined (hi << 3) + lo
+                const i32x4 zero = {0, 0, 0, 0};
+                i32x4 pd[ND];
 #pragma unroll
-            for (int i = ND - 1; i >= 0; --i) {
-                c = mfma_i8_16x16x32(A, (uint64_t)pk_mul_u16(wlo, sd[i]) | ((uint64_t)pk_mul_u16(whi, td[i]) << 32), c);
-                if (i > 0) {
+                for (int i = 0; i < ND; ++i) pd[i] = mfma_i8_16x16x32(A, (uint64_t)pk_mul_u16(wlo, sd[i]) | ((uint64_t)pk_mul_u16(whi, td[i]) << 32), zero);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)((int)((uint32_t)pd[1][j] << DB) + pd[0][j]), acc[j][l]);
+            } else {                   // Q5_K: chained through the accumulator (three independent results cost too many registers)
+                i32x4 c = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = ND - 1; i >= 0; --i) {
+                    c = mfma_i8_16x16x32(A, (uint64_t)pk_mul_u16(wlo, sd[i]) | ((uint64_t)pk_mul_u16(whi, td[i]) << 32), c);
+                    if (i > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+                for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+            }
         }
         // min term: prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1];  Q4_K: acc_m[t] = fma(-y.d * dmin, (float)prod[t], acc_m[t]),
         // Q5_K: summs = fma(-y.d * dmin, (float)(prod[0] + prod[1] + prod[2] + prod[3]), summs)
@@ -249,17 +258,26 @@ DEV void pfm_item_q45_t8(const uint8_t* __restrict__ w0, int item, int n_tiles, 
             }
             const uint32_t al = alo[l], ah = ahi[l];
             const u32x4 A = a_hi_half ? u32x4{0u, 0u, al, ah} : u32x4{al, ah, 0u, 0u};
-            i32x4 c = {0, 0, 0, 0};
+            if constexpr (ND == 2) {   // Q4_K: two independent MFMAs (they pipeline), combined (hi << 3) + lo
+                const i32x4 zero = {0, 0, 0, 0};
+                i32x4 pd[ND];
 #pragma unroll
-            for (int i = ND - 1; i >= 0; --i) {
-                c = mfma_i8_16x16x64(A, u32x4{pk_mul_u16(w0lo, sd[i]), pk_mul_u16(w0hi, td[i]), pk_mul_u16(w1lo, sd[i]), pk_mul_u16(w1hi, td[i])}, c);
-                if (i > 0) {
+                for (int i = 0; i < ND; ++i) pd[i] = mfma_i8_16x16x64(A, u32x4{pk_mul_u16(w0lo, sd[i]), pk_mul_u16(w0hi, td[i]), pk_mul_u16(w1lo, sd[i]), pk_mul_u16(w1hi, td[i])}, zero);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)((int)((uint32_t)pd[1][j] << DB) + pd[0][j]), acc[j][l]);
+            } else {                   // Q5_K: chained through the accumulator (three independent results cost too many registers)
+                i32x4 c = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = ND - 1; i >= 0; --i) {
+                    c = mfma_i8_16x16x64(A, u32x4{pk_mul_u16(w0lo, sd[i]), pk_mul_u16(w0hi, td[i]), pk_mul_u16(w1lo, sd[i]), pk_mul_u16(w1hi, td[i])}, c);
+                    if (i > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) c[j] = (int)((uint32_t)c[j] << DB);
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+                for (int j = 0; j < 4; ++j) acc[j][l] = fmaf(D[j], (float)c[j], acc[j][l]);
+            }
         }
         const uint32_t xa = half ? x2 : x0, xb = half ? x3 : x1;   // scale groups 2 * half, 2 * half + 1
         const int ma0 = (int)bfe32(xa, 12, 6), ma1 = (int)bfe32(xa, 18, 6), mb0 = (int)bfe32(xb, 12, 6), mb1 = (int)bfe32(xb, 18, 6);

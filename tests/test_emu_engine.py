@@ -61,32 +61,33 @@ def test_batch_structure(emu_lib):
 @pytest.mark.parametrize("name,tok", [("tiny-q4km", 8), ("tiny-q5km", 4)])   # the other two combinations: tests/test_gpu_parity.py
 def test_prompt_chunk_half_slot_matrix_core_forms(emu_lib, monkeypatch, name, tok):
     """kernels_pfm.h's wide-K forms (8 or 4 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token
-    slots), forced on the tiny models: golden logits of the reference for a one-batch 45-token prompt."""
+    slots), forced on the tiny models: golden logits of the reference for the 11-token prompt in chunks of 8 + 3."""
     monkeypatch.setenv("CT_AMD_PFM_TOK", str(tok))
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    m = open_emu(emu_lib, name, batch_size=64)
-    m.eval(list(g["long_prompt"]))
-    assert np.array_equal(m.logits.to_numpy(), g["long_one"])
-    assert chunk_tokens(m) == 45
+    m = open_emu(emu_lib, name)
+    m.eval(list(g["prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    assert chunk_tokens(m) == len(g["prompt"])
 
 
 @pytest.mark.parametrize("name", ["tiny-q4km"])   # tiny-q5km: tests/test_gpu_parity.py
 def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
-    """The chunk kernels (kernels_pf.h) against the decode kernels on the same batches: ragged chunk lengths (a full
-    32-token pass plus 1, a short tail, 2 tokens), a non-zero n_past, and embeddings as well as logits."""
+    """The chunk kernels (kernels_pf.h / kernels_pfm.h) against the decode kernels on the same batches: a full pass of
+    CT_AMD_PF_CHUNK tokens plus one on the decode path, a 2-token chunk at a non-zero n_past; logits and embeddings."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    toks = list(g["long_prompt"])
+    toks = list(g["long_prompt"])[:19]
+    monkeypatch.setenv("CT_AMD_PF_CHUNK", "16")
     out = {}
-    monkeypatch.setenv("CT_AMD_PF_CHUNK", "32")
     for pf in ("1", "0"):
         monkeypatch.setenv("CT_AMD_PF", pf)
         m = open_emu(emu_lib, name, batch_size=64)
         res = []
-        for lo, hi in ((0, 33), (33, 35), (35, 45)):
+        for lo, hi in ((0, 17), (17, 19)):
             m.eval(toks[lo:hi])
             res.append((m.logits.to_numpy().copy(), m.embeddings.to_numpy().copy()))
         out[pf] = (res, chunk_tokens(m))
-    assert out["1"][1] == 32 + 2 + 10 and out["0"][1] == 0   # 33 = one 32-token pass + one token on the decode path
+    assert out["1"][1] == 16 + 2 and out["0"][1] == 0   # 17 = one 16-token pass + one token on the decode path
     for (la, ea), (lb, eb) in zip(out["1"][0], out["0"][0]):
         assert np.array_equal(la, lb) and np.array_equal(ea, eb)
 
