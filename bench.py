@@ -129,7 +129,7 @@ def main():
     # prompt chunks: 2 ops per weight of the 2-D matrices per token, against the dense int8 MFMA
     # floor of the guide; the bound is VALU issue (the exact f32 chain step per block, AVX lane, row and token), not MFMA
     pf_flop = 2 * 6.607e9 if SHAPE == "llama-2-7b" else None
-    out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=64,
+    out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=128,
                           kernel="matvec_pfm_kernel<TYPE,TOK,GU> (int8 MFMA, exact), one hipGraph per chunk shape",
                           int8_tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_peak_tops=3944,
                           bound="valu")

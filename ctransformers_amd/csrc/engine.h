@@ -136,7 +136,7 @@ class Engine {
     float *qkv_tmp_b_ = nullptr, *attn_proj_b_ = nullptr;   // falcon chunks: fused QKV rows, Wo output
     bool pf_ok_ = false;    // llama architecture, every layer matrix a K-quant in the tile layout, K <= 12288
     int pf_min_ = 2;        // chunks shorter than this run token by token
-    int pf_chunk_ = 64;     // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
+    int pf_chunk_ = 128;    // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
     long long chunk_tokens_ = 0;
     bool use_mfma_ = true;
     int pfm_force_tok_ = 0;

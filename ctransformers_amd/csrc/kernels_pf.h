@@ -21,7 +21,8 @@
 #include "kernels_q32.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
-constexpr int kPfChunk = 64;    // tokens per launch (grid.y = 8 token groups here, 4 of 16 on the matrix-core path)
+constexpr int kPfChunk = 128;   // tokens per launch (8 groups of 16 on the matrix-core path: enough (item, group) units to
+                                // keep the imbalance of whole items per wave small — 7B gate/up: 5504 units on 2048 waves)
 
 struct PfArgs {
     MatvecArgs m;        // jobs and epilogue operands; x / norm_w / pro are the quantize kernel's business

@@ -1,5 +1,5 @@
 """Prompt throughput of the HIP library against the ABI's batch_size (the reference's default is 8): tokens/s of a 256-token
-prompt evaluated in chunks of that size, second pass (warm).  usage: prefill_sweep.py <model.gguf>[:shape:ftype] [batch sizes...]   (shape/ftype: generate the synthetic file if missing)"""
+prompt evaluated in chunks of that size, third pass (steady state).  usage: prefill_sweep.py <model.gguf>[:shape:ftype] [batch sizes...]   (shape/ftype: generate the synthetic file if missing)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,8 @@ for bs in sizes:
     m = LLM(path, config=Config(context_length=512, batch_size=bs, gpu_layers=1000))
     toks = synth.prompt_tokens(N, m.vocab_size)
     m.eval(toks)
+    m._context = []
+    m.eval(toks)          # chunk shapes are captured into hipGraphs on their second use
     m._context = []
     t0 = time.perf_counter()
     m.eval(toks)
