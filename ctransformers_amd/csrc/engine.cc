@@ -332,6 +332,26 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
 
     if (!alloc_state(err)) return false;
     HIP_OK(hipDeviceSynchronize());
+    if (!warm_up(err)) return false;
+    return true;
+}
+
+// First use of a kernel pays for loading the code object, the dynamic-LDS opt-ins and (decode) the graph capture: ~7 ms on a
+// first 128-token prompt.  A whole-model handle pays it here, at load time, with a two-token chunk of token 0 and the capture
+// of the token-step graphs.  Nothing of it is observable through the ABI: the logits stay "not evaluated" (size 0), the
+// positions it touched in the KV cache are rewritten by the first real tokens that use them.
+bool Engine::warm_up(std::string& err) {
+#ifndef CT_EMU
+    if (l0_ != 0 || l1_ != hp_.n_layer || dump_dir_ || env_int("CT_AMD_WARMUP", 1) == 0 || n_ctx_ < 4) return true;
+    h_scalars_[0] = 0; h_scalars_[1] = 0; h_scalars_[2] = 2; h_scalars_[3] = 0; h_scalars_[4] = 0; h_scalars_[5] = 0;
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 6 * 4, hipMemcpyHostToDevice, stream_));
+    if (pf_ok_) { if (!chunk_step(0, 2, true, err)) return false; }
+    else { if (!token_step(true, err)) return false; }
+    if (use_graph_ && !ensure_graphs(err)) return false;
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipGetLastError());
+#endif
+    (void)err;
     return true;
 }
 

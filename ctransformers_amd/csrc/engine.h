@@ -102,6 +102,7 @@ class Engine {
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     bool token_step_falcon(bool want_logits, std::string& err);
     bool token_step_gpt2(bool want_logits, std::string& err);
+    bool warm_up(std::string& err);       // first-use costs (code object, LDS opt-ins, graph capture) paid at load
     bool alloc_state(std::string& err);   // KV cache, scratch, pinned host buffers, tables
     bool run_matvec(::MatvecArgs& a, std::string& err);
     bool ensure_graphs(std::string& err);
