@@ -80,6 +80,19 @@ bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int
     const int n_ctx = llm->engine.n_ctx();
     batch_size = std::min(n_ctx, batch_size);
     if (batch_size <= 0) return n_tokens <= 0;
+    // The reference evaluates batch after batch (models/llm.h:40-54).  Where the prompt-chunk kernels apply, the whole request
+    // goes down as one eval: the only thing a batch boundary changes in the arithmetic is the length of the attention-value
+    // dot product, which the attention kernel derives per token from the batch size (kernels_exact.h), so the result is
+    // bit-identical to the batch-by-batch evaluation while the weights are passed over once per 128 tokens instead of
+    // once per batch (the reference's default batch is 8).  Requests that run into the context clamp keep the loop.
+    if (n_tokens > batch_size && n_past >= 0 && n_past + n_tokens <= n_ctx && llm->engine.coalesces_batches()) {
+        std::string err;
+        if (!llm->engine.eval(tokens, n_tokens, n_past, err, batch_size)) {
+            fprintf(stderr, "ctransformers_amd: eval failed: %s\n", err.c_str());
+            return false;
+        }
+        return true;
+    }
     for (int start = 0; start < n_tokens; start += batch_size) {
         const int n = std::min(batch_size, n_tokens - start);
         const int past = std::min(n_ctx - n, n_past);  // reference models/llm.h:126

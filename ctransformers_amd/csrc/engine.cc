@@ -1294,12 +1294,12 @@ bool Engine::ensure_graphs(std::string& err) {
     return true;
 }
 
-bool Engine::eval(const int* tokens, int n, int n_past, std::string& err) {
+bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
     if (l0_ != 0 || l1_ != hp_.n_layer) { err = "this handle is a pipeline stage: use eval_stage"; return false; }
-    return eval_stage(tokens, n, n_past, nullptr, nullptr, err);
+    return eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch);
 }
 
-bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err) {
+bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err, int batch) {
     if (n <= 0) return true;
     if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
     if (l0_ > 0 && !x_in_dev) { err = "stage with layer_begin > 0 needs x_in"; return false; }
@@ -1315,8 +1315,8 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
     if (l0_ > 0) HIP_OK(hipMemcpyAsync(xio_, x_in_dev, xbytes, hipMemcpyDeviceToDevice, stream_));
     h_scalars_[0] = 0;           // step
     h_scalars_[1] = n_past;      // position of the first token of this chunk
-    h_scalars_[2] = n_past + n;  // n_total: the reference runs this chunk as ONE batch (see attn_softmax_pv_exact_kernel)
-    h_scalars_[3] = 0;
+    h_scalars_[2] = n_past + n;  // end of the eval; with [3] the attention kernels derive the reference batch each token belongs to
+    h_scalars_[3] = batch > 0 && batch < n ? batch : 0;   // 0: the reference runs these n tokens as ONE batch
     HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
     int done = 0;
     if (pf_ok_ && n >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights

@@ -54,10 +54,13 @@ class Engine {
     bool load_gpt2(const std::string& path, std::string& err, int device = 0);
     // Evaluate `n` tokens at absolute positions n_past..n_past+n-1 (KV cache overwrite semantics); logits and the
     // final-norm embedding of the LAST token land in the pinned host buffers.
-    bool eval(const int* tokens, int n, int n_past, std::string& err);
+    // batch > 0: evaluate the n tokens exactly as the reference would in batches of `batch` (models/llm.h:40-54), in one go
+    bool eval(const int* tokens, int n, int n_past, std::string& err, int batch = 0);
+    // whether batch_eval may hand a whole multi-batch request to one eval (the chunk kernels then see up to 128 tokens at once)
+    bool coalesces_batches() const { return pf_ok_ && l0_ == 0 && l1_ == hp_.n_layer; }
     // Stage form: x_in_dev / x_out_dev are DEVICE pointers to [n][n_embd] f32 residual-stream rows (the hand-off between
     // pipeline stages).  x_in_dev is required iff layer_begin > 0, x_out_dev iff layer_end < n_layer.
-    bool eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err);
+    bool eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err, int batch = 0);
     int layer_begin() const { return l0_; }
     int layer_end() const { return l1_; }
     bool has_head() const { return l1_ == hp_.n_layer; }

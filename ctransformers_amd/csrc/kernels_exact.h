@@ -102,7 +102,18 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     if (trace) tr[0] = clock64_dev();
     const int tok = (int)blockIdx.z;
     const int n_kv = *a.pos + tok + 1;
-    const int n_tot = *a.n_total;
+    // The length of the value dot product is that of the reference batch this token belongs to (its fma / leftover split
+    // depends on it).  The cursor {step, pos, n_past + n, batch} describes an eval of n tokens the reference would have run in
+    // batches of `batch` (0: one batch): this token is number step + tok of the eval, its batch ends at the next multiple.
+    int n_tot = *a.n_total;
+    {
+        const int bs = a.n_total[1];
+        if (bs > 0) {
+            const int idx = a.pos[-1] + tok, base = *a.pos - a.pos[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = n_tot - base;
+            n_tot = base + (end < n_eval ? end : n_eval);
+        }
+    }
     const int np = n_tot & ~31;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3;
     const int hk = h / (a.n_head / a.n_head_kv);

@@ -58,6 +58,17 @@ def test_batch_structure(emu_lib):
     assert chunk_tokens(m) == 45   # 32 + 13 tokens through the chunk kernels
 
 
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km"])
+def test_batches_coalesced_into_one_pass(emu_lib, name):
+    """batch_eval with the reference's default batch_size 8: the 45-token prompt goes down as ONE eval (chunk kernels over all
+    45 tokens) and still equals the reference's batch-by-batch result — which differs from its one-batch result."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_emu(emu_lib, name, batch_size=8)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
+    assert chunk_tokens(m) == 45
+
+
 @pytest.mark.parametrize("name,tok", [("tiny-q4km", 8), ("tiny-q5km", 4)])   # the other two combinations: tests/test_gpu_parity.py
 def test_prompt_chunk_half_slot_matrix_core_forms(emu_lib, monkeypatch, name, tok):
     """kernels_pfm.h's wide-K forms (8 or 4 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token

@@ -257,3 +257,27 @@ def test_prompt_chunks_equal_token_by_token_and_reference(ref, tmp_path, monkeyp
             assert np.array_equal(m.logits.to_numpy(), wl) and np.array_equal(m.embeddings.to_numpy(), we), (pf, lo)
         assert chunk_tokens(m) == expect_chunked
         del m
+
+
+@pytest.mark.parametrize("shape,ftype,bs", [("llama-7b-2l", "Q4_K_M", 8), ("llama-small", "Q5_K_M", 24), ("falcon-small", "Q4_K_M", 8),
+                                            ("llama-small", "Q8_0", 16)])
+def test_batches_coalesced_equal_reference_batches(ref, tmp_path, shape, ftype, bs):
+    """ctransformers_llm_batch_eval with a small batch_size (the reference's default is 8): the library evaluates the whole
+    request in one pass of the chunk kernels and must reproduce the reference's batch-by-batch logits — a 77-token prompt
+    (ragged last batch), then a second request at n_past = 77, then greedy steps."""
+    p = str(tmp_path / "m.gguf")
+    hp = (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p, shape, ftype, seed=9)
+    toks = synth.prompt_tokens(77 + 19, hp["n_vocab"])
+    r = ref.open_llm(p, context_length=128, batch_size=bs, threads=16)
+    m = open_hip(p, context_length=128, batch_size=bs)
+    for lo, hi in ((0, 77), (77, 96)):
+        r.eval(toks[lo:hi])
+        m.eval(toks[lo:hi])
+        assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy()), lo
+        assert np.array_equal(r.embeddings.to_numpy(), m.embeddings.to_numpy()), lo
+    assert chunk_tokens(m) == 96
+    for i in range(4):
+        t = int(r.logits.to_numpy().argmax())
+        r.eval([t])
+        m.eval([t])
+        assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy()), "step %d" % i
