@@ -281,3 +281,27 @@ def test_batches_coalesced_equal_reference_batches(ref, tmp_path, shape, ftype, 
         r.eval([t])
         m.eval([t])
         assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy()), "step %d" % i
+
+
+def test_batch_coalescing_many_shapes(ref, tmp_path):
+    """Random request shapes against the reference on one pair of handles: request lengths 1..40, batch sizes 1..17 (also
+    larger than the request), running n_past, a rollback to an earlier position in between."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=11)
+    rng = np.random.default_rng(5)
+    r = ref.open_llm(p, context_length=256, batch_size=8, threads=8)
+    m = open_hip(p, context_length=256, batch_size=8)
+    n_done = 0
+    for case in range(14):
+        n = int(rng.integers(1, 41))
+        bs = int(rng.integers(1, 18))
+        if n_done + n > 250 or case == 7:   # roll back: overwrite the KV cache from an earlier position on
+            n_done = int(rng.integers(0, 20))
+            r._context = r._context[:n_done]
+            m._context = m._context[:n_done]
+        toks = [int(t) for t in rng.integers(3, hp["n_vocab"], size=n)]
+        r.eval(toks, batch_size=bs)
+        m.eval(toks, batch_size=bs)
+        n_done += n
+        assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy()), (case, n, bs, n_done)
+        assert np.array_equal(r.embeddings.to_numpy(), m.embeddings.to_numpy()), (case, n, bs, n_done)
