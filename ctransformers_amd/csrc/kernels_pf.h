@@ -1,28 +1,33 @@
-// Prompt chunks: the K-quant mat-vec of kernels_v5.h / kernels_v6.h applied to a chunk of tokens per launch, so that a
-// weight tile is fetched and unpacked once for 8 tokens instead of once per token.
+// Prompt chunks: the mat-vec of the decode kernels applied to a chunk of tokens per launch, so that a weight tile is fetched
+// and unpacked once for 8 tokens instead of once per token.  This file: the shared pieces (activation images, the
+// quantize kernels, launch arguments) and the dot4 form; kernels_pfm.h: the K-quants on the int8 matrix cores, which is
+// what the engine launches for them (the dot4 K-quant form stays selectable for A/B runs, CT_AMD_PF_MFMA=0).
 //
 // The arithmetic per (row, token) is the decode kernels' — the reference's per-block integer sums and its per-block
-// fma `acc[l] = fma(y.d * fp16(x.d), (float)sumi[l], acc[l])` in block order, then hsum_float_8 (kernels_exact.h has
-// the citations) — so a token evaluated inside a chunk produces the same bits as the token evaluated alone.  What
-// changes is where the chain lives.  The decode kernels split the K blocks of a tile over the 16 waves of a workgroup
-// (a CU sees only a handful of tiles per launch) and replay the serial f32 chain from LDS; here a launch has
+// fma `acc[l] = fma(y.d * fp16(x.d), (float)sumi[l], acc[l])` in block order, then hsum_float_8 (kernels_exact.h and
+// kernels_q32.h have the citations) — so a token evaluated inside a chunk produces the same bits as the token evaluated
+// alone.  What changes is where the chain lives.  The decode kernels split the K blocks of a tile over the 16 waves of a
+// workgroup (a CU sees only a handful of tiles per launch) and replay the serial f32 chain from LDS; here a launch has
 // tiles x token-groups units of work, enough for every wave to own (tile, 8 tokens) outright: it walks the tile's
-// blocks in order with the 2 x 8 accumulators in registers and there is no chain storage and no intra-workgroup
+// blocks in order with the accumulators in registers and there is no chain storage and no intra-workgroup
 // synchronisation after the activations are in LDS.
 //
-//   pf_quantize_kernel   one workgroup per token: (RMSNorm ->) Q8_K exactly as the decode prologue does it (it IS the
-//                        decode prologue), written out as a compact image  q8[K/4] | yd[K/256] | sb[K/32]  (words)
-//   matvec_pf_kernel     grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
-//                        w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first,
-//                        then over the SIMDs of a CU); epilogues as in the decode kernels, per token
-//   embed / attention    the decode kernels with a token index in blockIdx.y / blockIdx.z
+//   pf_quantize_kernel      one workgroup per token: (RMSNorm / LayerNorm ->) Q8_K exactly as the decode prologue does it (it
+//                           IS the decode prologue), written out as a compact image  q8[K/4] | yd[K/256] | sb[K/32]  (words)
+//   pf_quantize_q80_kernel  the same for the Q8_0 activations of Q8_0 / Q4_0 weights:  q8[K/4] | yd[K/32]
+//   matvec_pf_kernel        grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
+//                           w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first,
+//                           then over the SIMDs of a CU); epilogues as in the decode kernels, per token.
+//                           Q32 = true: Q8_0 / Q4_0 weights (the form the engine uses for them — their lane sums are
+//                           4-element dots, nothing for a matrix core to contract); Q32 = false: K-quants, dot4 form
+//   embed / attention / falcon RoPE store   the decode kernels with a token index in blockIdx.y / blockIdx.z
 #pragma once
 #include "kernels_v6.h"
 #include "kernels_q32.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
-constexpr int kPfChunk = 128;   // tokens per launch (8 groups of 16 on the matrix-core path: enough (item, group) units to
-                                // keep the imbalance of whole items per wave small — 7B gate/up: 5504 units on 2048 waves)
+constexpr int kPfChunk = 128;   // tokens per chunk_step (8 groups of 16 on the matrix-core path): the per-chunk launches of Wo,
+                                // the quantize kernels and attention are shared by more tokens (64 -> 128: +11 %)
 
 struct PfArgs {
     MatvecArgs m;        // jobs and epilogue operands; x / norm_w / pro are the quantize kernel's business

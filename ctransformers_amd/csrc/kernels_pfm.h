@@ -1,4 +1,5 @@
-// Prompt chunks, Q4_K weights on the int8 matrix cores — still bit-identical to the reference CPU build.
+// Prompt chunks, K-quant weights on the int8 matrix cores — still bit-identical to the reference CPU build.
+// (Q4_K explained here; Q5_K and Q6_K differ in how the scale is split — see pfm_item_q45 and the Q6_K section.)
 //
 // What has to be reproduced per (row, token) and 256-block is the reference's eight int32 lane sums
 //     sumi[l] = sum_{s<8} sc_s * sum_{e<4} q_s[4l+e] * a_s[4l+e]                  (k_quants.c:2651-2720; kernels_exact.h)
@@ -6,7 +7,7 @@
 // (k = (s, e)), except that the 6-bit sub-block scale sits between the 4-bit weight and the product.  Splitting the
 // scale as sc = 8*hi3 + lo3 makes both halves fit the matrix core's int8 operands (q * 7 <= 105):
 //     sumi[l] = 8 * sum_k a_k * (q_k * hi3_s(k)) + sum_k a_k * (q_k * lo3_s(k))
-// i.e. two v_mfma_i32_16x16x32_i8 per l, exact in int32, the second accumulating onto the first one's result << 3.
+// i.e. two v_mfma_i32_16x16x32_i8 per l, exact in int32, combined as (hi << 3) + lo.
 // The scaled weight bytes come from ONE packed 16-bit multiply per dword (a byte times 7 cannot carry into its neighbour).
 // The f32 side — acc[l] = fma(y.d * fp16(x.d), (float)sumi[l], acc[l]), the four min-term accumulators, hsum_float_8 —
 // is the decode kernels', now entirely in-lane (no cross-lane reduction is left: the matrix core did the sums).
@@ -23,8 +24,7 @@
 #pragma once
 #include "kernels_pf.h"
 
-// All blocks of one 16-row item.  TOK (16 or 8) = token images in LDS; with 8 the upper half of the token axis repeats
-// the lower (K > 8192 does not leave room for 16 images) and is dropped at the store.
+// All blocks of one 16-row item against 16 token images (K <= 8192; pfm_item_q45_t8 below is the form for fewer images).
 // Q5_K (TYPE == GT_Q5_K) differs in three places: the fifth bit comes from the row's 32 qh bytes (bit 2q / 2q+1 of byte e =
 // sub-block 2q / 2q+1), q5 * 7 would not fit int8 so the scale goes in three 2-bit digits (q5 * 3 <= 93, three MFMAs per
 // l), and the min term is one scalar: summs = fma(-y.d * dmin, (float)(prod[0] + .. + prod[3]), summs) (k_quants.c:3183-3262).
