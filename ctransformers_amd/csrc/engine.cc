@@ -372,20 +372,21 @@ bool Engine::alloc_state(std::string& err) {
     d_tokens_ = d_state_ + 4;
     // prompt chunks (kernels_pf.h, kernels_pfm.h): llama graph, K-quant tile layout, n_embd <= 12288, n_ff <= 32768
     use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
-    pf_ok_ = !hp_.gpt2() && E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
-    {   // every layer matrix a K-quant in the tile layout, or (llama graph) every one Q8_0 / Q4_0 of one type with K <= 12288
+    pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
+    {   // every layer matrix a K-quant in the tile layout (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 12288
+        // (llama, gpt2)
         int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
         for (int i = l0_; i < l1_; ++i) {
             const Layer& L = layers_[i];
             const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
-            const std::initializer_list<const DevMat*> falcon_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};
-            for (const DevMat* m : hp_.falcon() ? falcon_mats : llama_mats) {
+            const std::initializer_list<const DevMat*> fused_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};   // falcon, gpt2
+            for (const DevMat* m : (hp_.falcon() || hp_.gpt2()) ? fused_mats : llama_mats) {
                 ++n_all;
                 if (m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K)) ++n_kq;
                 if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
             }
         }
-        pf_ok_ = pf_ok_ && (n_kq == n_all || (n_q32 == n_all && !hp_.falcon()));
+        pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || (n_q32 == n_all && !hp_.falcon()));
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
@@ -399,6 +400,7 @@ bool Engine::alloc_state(std::string& err) {
         if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
                              !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))
             return false;
+        if (hp_.gpt2() && !dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * 3 * E, err)) return false;
     }
     HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
     h_emb_ = h_logits_ + V;
@@ -709,7 +711,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 images, the dot4 chunk kernel (no matrix-core form)
         const int aw32 = pf_act_words_q32(m.K);
-        CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32);
+        CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
         PfArgs a;
         a.m = m;
         a.acts = acts_; a.act_words = aw32; a.n_tok = nt;
@@ -811,6 +813,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 // each over rows [c0, c0 + nt) of the chunk (kernels_pf.h).  The cursor in d_state_ is at token c0 on entry.
 bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
     if (hp_.falcon()) return chunk_step_falcon(c0, nt, want_logits, err);
+    if (hp_.gpt2()) return chunk_step_gpt2(nt, want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -953,6 +956,66 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
                   d_emb_, E, hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_LAYERNORM; a.x = xl; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
+    return true;
+}
+
+// gpt2_eval (models/llms/gpt2.cc:391-699) for the nt tokens of a chunk: token_step_gpt2's launches over rows of the chunk; the
+// K / V rows of all its tokens are appended to the F32 cache before the attention launch.
+bool Engine::chunk_step_gpt2(int nt, bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256), (unsigned)nt), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+              (const int*)d_tokens_, (const int*)d_state_, xb_, (const float*)wpe_);
+    MatvecArgs base = MatvecArgs();
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = E;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    const float kq_scale = 1.0f / (float)sqrt((double)((float)E / (float)hp_.n_head));   // gpt2.cc:540
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        float* km = kmem_ + (size_t)il * n_ctx_ * E;
+        float* vm = vmem_ + (size_t)il * n_ctx_ * E;
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b;
+            a.out = qkv_tmp_b_; a.bias = L.b_qkv;
+            set_jobs(a, {{&L.wqkv, EPI_BIAS_STORE}});
+            if (!pf_matvec(a, xb_, E, nt, 3 * E, 0, "qkv", (double)L.wqkv.bytes, err)) return false;
+        }
+        CT_LAUNCH(gpt2_kv_append_kernel, dim3((unsigned)nt), dim3(256), stream_, (const float*)qkv_tmp_b_, km, vm, d_pos, E);
+        CT_LAUNCH(attn_f32_exact_kernel, dim3((unsigned)hp_.n_head, (unsigned)nt), dim3(256), stream_, (const float*)qkv_tmp_b_, km, vm,
+                  attn_out_b_, (const uint16_t*)exp_tab_, d_pos, (const int*)(d_state_ + 2), E, hd, kq_scale, 0);
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_; a.bias = L.b_wo;
+            set_jobs(a, {{&L.wo, EPI_BIAS_ADD}});
+            if (!pf_matvec(a, attn_out_b_, E, nt, E, E, "wo", (double)L.wo.bytes, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.norm_w = L.ffn_norm; a.norm_b = L.ffn_norm_b; a.out = hb_; a.bias = L.b_up;
+            set_jobs(a, {{&L.w_up, EPI_BIAS_GELU}});
+            if (!pf_matvec(a, xb_, E, nt, F, 0, "ffn_up", (double)L.w_up.bytes, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_; a.bias = L.b_down;
+            set_jobs(a, {{&L.w_down, EPI_BIAS_ADD}});
+            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+        }
+    }
+    if (want_logits) {
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = xb_ + (size_t)(nt - 1) * E; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
         if (!run_matvec(a, err)) return false;
     }

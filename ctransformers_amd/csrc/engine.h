@@ -100,6 +100,7 @@ class Engine {
     bool token_step(bool want_logits, std::string& err);
     bool chunk_step(int c0, int nt, bool want_logits, std::string& err);
     bool chunk_step_falcon(int c0, int nt, bool want_logits, std::string& err);
+    bool chunk_step_gpt2(int nt, bool want_logits, std::string& err);
     bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);

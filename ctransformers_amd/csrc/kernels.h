@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
             const int is = l >> 4;
             y = d * (float)sc[is + 2 * grp] * (float)q;
         }
-        if (wpe) y = y + wpe[(size_t)state[1] * K + e];   // gpt2: wte[token] + wpe[pos] (gpt2.cc:441-444)
+        if (wpe) y = y + wpe[(size_t)(state[1] + (int)blockIdx.y) * K + e];   // gpt2: wte[token] + wpe[pos] (gpt2.cc:441-444)
         out[e] = y;
     }
 }
@@ -243,21 +243,46 @@ DEV float dot_f32_reduce(const float (&s)[4][8]) {
     for (int m = 0; m < 4; ++m) t0[m] = S[m] + S[m + 4];
     return (t0[0] + t0[1]) + (t0[2] + t0[3]);
 }
+// Prompt chunks: blockIdx.y = token inside the chunk (qkv / out rows of 3E / E floats per token); the K / V rows of ALL the
+// chunk's tokens are then appended beforehand by gpt2_kv_append_kernel (append = 0 here), because a token attends to the
+// earlier tokens of its chunk whose workgroups may not have run yet.
+__global__ void gpt2_kv_append_kernel(const float* __restrict__ qkv, float* __restrict__ kmem, float* __restrict__ vmem,
+                                      const int* __restrict__ pos_p, int n_embd) {
+    const int tok = (int)blockIdx.x, pos = *pos_p + tok, E = n_embd;
+    const float* row = qkv + (size_t)tok * 3 * E;
+    for (int i = (int)threadIdx.x; i < E; i += (int)blockDim.x) {
+        kmem[(size_t)pos * E + i] = row[E + i];
+        vmem[(size_t)pos * E + i] = row[2 * E + i];
+    }
+}
 __global__ void __launch_bounds__(256) attn_f32_exact_kernel(const float* __restrict__ qkv, float* __restrict__ kmem,
                                                              float* __restrict__ vmem, float* __restrict__ out,
                                                              const uint16_t* __restrict__ exp_tab, const int* __restrict__ pos_p,
                                                              const int* __restrict__ n_total_p, int n_embd, int head_dim,
-                                                             float kq_scale) {
+                                                             float kq_scale, int append = 1) {
     __shared__ float prob[kMaxCtx];
     __shared__ double red[4];
     __shared__ float redf[4];
-    const int h = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pos = *pos_p, n_kv = pos + 1, n_tot = *n_total_p, E = n_embd, hd = head_dim;
-    for (int i = tid; i < hd; i += 256) {
-        kmem[(size_t)pos * E + h * hd + i] = qkv[E + h * hd + i];
-        vmem[(size_t)pos * E + h * hd + i] = qkv[2 * E + h * hd + i];
+    const int h = (int)blockIdx.x, tok = (int)blockIdx.y, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pos = *pos_p + tok, n_kv = pos + 1, E = n_embd, hd = head_dim;
+    int n_tot = *n_total_p;
+    {   // the reference batch this token belongs to inside the eval: cursor = {step, pos, n_past + n, batch} (kernels_exact.h)
+        const int bs = n_total_p[1];
+        if (bs > 0) {
+            const int idx = pos_p[-1] + tok, base = *pos_p - pos_p[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = n_tot - base;
+            n_tot = base + (end < n_eval ? end : n_eval);
+        }
     }
-    __syncthreads();
+    qkv += (size_t)tok * 3 * E;
+    out += (size_t)tok * E;
+    if (append) {
+        for (int i = tid; i < hd; i += 256) {
+            kmem[(size_t)pos * E + h * hd + i] = qkv[E + h * hd + i];
+            vmem[(size_t)pos * E + h * hd + i] = qkv[2 * E + h * hd + i];
+        }
+        __syncthreads();
+    }
     const float* q = qkv + h * hd;
     float mx = -INFINITY;
     for (int p = tid; p < n_kv; p += 256) {

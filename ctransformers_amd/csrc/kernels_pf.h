@@ -178,10 +178,11 @@ constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }
 
 template <int MAXK>
 __global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
-                                                               int pro, float eps, int* __restrict__ acts, int act_words) {
+                                                               int pro, float eps, int* __restrict__ acts, int act_words,
+                                                               const float* __restrict__ nb_ = nullptr) {
     __shared__ ActLdsQ32<MAXK> L;
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
-    prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
+    prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // nb_: LayerNorm bias (gpt2)
     int* o = acts + (size_t)t * act_words;
     const int nq = K >> 2, nb = K >> 5;
     for (int i = tid; i < nq; i += 1024) o[i] = L.q8[i];
@@ -320,6 +321,12 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[t] + m.res[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_STORE) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[t];
+                } else if (epi == EPI_BIAS_STORE) {   // gpt2 (row biases): same operand order as the decode kernels
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = m.bias[row] + res[t];
+                } else if (epi == EPI_BIAS_ADD) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = (m.bias[row] + res[t]) + m.res[(size_t)tok * a.ld_res + row];
+                } else if (epi == EPI_BIAS_GELU) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.gelu_tab[f32_to_f16_bits(m.bias[row] + res[t])]);
                 } else if (epi == EPI_V) {
                     if (own) m.vcache[(size_t)row * m.v_stride + pos] = f32_to_f16_bits(res[t]);
                 } else {   // EPI_ROPE_Q / EPI_ROPE_K (normal mode, ggml.c:12522-12539): rows 2i, 2i+1 are adjacent rows of the tile

@@ -35,8 +35,8 @@ def test_logits_bit_identical_to_reference(emu_lib, name, steps):
     assert len(m.logits) == 0  # nothing evaluated yet
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
-    # llama and K-quant falcon files take the prompt-chunk kernels (chunks of 8 + 3 tokens here); falcon Q8_0 and gpt2 run token by token
-    assert chunk_tokens(m) == (len(g["prompt"]) if name.endswith(("q4km", "q5km")) or name in ("tiny-q80", "tiny-q40") else 0)
+    # every golden model takes the prompt-chunk kernels (the 11 tokens in one pass; batches of 8 + 3 for the arithmetic)
+    assert chunk_tokens(m) == len(g["prompt"])
     if name.startswith("gpt2"):
         assert len(m.embeddings) == 0   # legacy models expose no embeddings (reference models/llm.h:73)
     else:
