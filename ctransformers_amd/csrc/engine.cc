@@ -374,7 +374,6 @@ bool Engine::alloc_state(std::string& err) {
     use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
     pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
     {   // every layer matrix a K-quant in the tile layout (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 12288
-        // (llama, gpt2)
         int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
         for (int i = l0_; i < l1_; ++i) {
             const Layer& L = layers_[i];
@@ -386,7 +385,7 @@ bool Engine::alloc_state(std::string& err) {
                 if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
             }
         }
-        pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || (n_q32 == n_all && !hp_.falcon()));
+        pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || n_q32 == n_all);
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));

@@ -321,6 +321,10 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[t] + m.res[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_STORE) {
                     if (own) m.out[(size_t)tok * a.ld_out + row] = res[t];
+                } else if (epi == EPI_GELU) {         // falcon
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.gelu_tab[f32_to_f16_bits(res[t])]);
+                } else if (epi == EPI_ADD2) {
+                    if (own) m.out[(size_t)tok * a.ld_out + row] = (res[t] + m.res[(size_t)tok * a.ld_res + row]) + m.res2[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_BIAS_STORE) {   // gpt2 (row biases): same operand order as the decode kernels
                     if (own) m.out[(size_t)tok * a.ld_out + row] = m.bias[row] + res[t];
                 } else if (epi == EPI_BIAS_ADD) {

@@ -102,6 +102,7 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     toks = synth.prompt_tokens(n_prompt, hp["n_vocab"])
     r.eval(toks)
     m.eval(toks)
+    assert chunk_tokens(m) == n_prompt   # every model family / weight type evaluates prompts through the chunk kernels
     for i in range(n_decode):
         a, b = r.logits.to_numpy(), m.logits.to_numpy()
         assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())
