@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/r9; rm -rf $O; mkdir -p $O
+O=gpurun_out/r10; rm -rf $O; mkdir -p $O
 export CTAMD_BENCH_MODEL=/tmp/l7b.gguf
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /root/repo/$O/pmc_fetch -o v6 -- python /root/repo/tools/decode_loop.py --model /tmp/l7b.gguf --shape llama-2-7b --prompt 8 --decode 8 > /root/repo/$O/pmc_fetch.log 2>&1
