@@ -167,6 +167,16 @@ int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, in
     return 0;
 }
 
+int ctamd_stage_eval_batched(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
+                             void* x_out_dev, int batch) {
+    std::string err;
+    if (!llm->engine.eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err, batch)) {
+        fprintf(stderr, "ctransformers_amd: stage eval failed: %s\n", err.c_str());
+        return -1;
+    }
+    return 0;
+}
+
 int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine.hparams().n_layer; }
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine.hparams().n_embd; }
 long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine.chunk_tokens(); }

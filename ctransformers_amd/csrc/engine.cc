@@ -1379,6 +1379,7 @@ bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_
     h_scalars_[1] = n_past;      // position of the first token of this chunk
     h_scalars_[2] = n_past + n;  // end of the eval; with [3] the attention kernels derive the reference batch each token belongs to
     h_scalars_[3] = batch > 0 && batch < n ? batch : 0;   // 0: the reference runs these n tokens as ONE batch
+    if (env_int("CT_AMD_DBG_ONE_BATCH", 0)) h_scalars_[3] = 0;   // tests of the tests: ignore the batch structure on purpose
     HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
     int done = 0;
     if (pf_ok_ && n >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights

@@ -67,6 +67,9 @@ class HipStage:
         L.ctamd_stage_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p]
         L.ctamd_stage_eval.restype = ctypes.c_int
+        L.ctamd_stage_eval_batched.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ctamd_stage_eval_batched.restype = ctypes.c_int
         for name in ("ctamd_n_layer", "ctamd_n_embd"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
@@ -86,9 +89,10 @@ class HipStage:
         self.first = layer_begin == 0
         self.last = layer_end == self.n_layer
 
-    def forward(self, tokens, n_past, x_in=None):
+    def forward(self, tokens, n_past, x_in=None, batch=0):
         """tokens: this chunk's ids (stage 0) or just its length as `[0]*n` elsewhere.  Returns the [n, n_embd] hand-off
-        tensor, or on the last stage the logits of the chunk's last token as a float32 CPU tensor."""
+        tensor, or on the last stage the logits of the chunk's last token as a float32 CPU tensor.  batch > 0: the chunk
+        is evaluated as the reference would in batches of that size (the chunk has to start on a batch boundary)."""
         n = len(tokens)
         ids = (ctypes.c_int * n)(*[int(t) for t in tokens])
         x_out = None
@@ -98,8 +102,8 @@ class HipStage:
             x_in = x_in.contiguous()
         if not self.last:
             x_out = torch.empty((n, self.n_embd), dtype=torch.float32, device=self.device)
-        rc = self._lib.ctamd_stage_eval(self._h, ids, n, int(n_past), None if self.first else x_in.data_ptr(),
-                                        None if self.last else x_out.data_ptr())
+        rc = self._lib.ctamd_stage_eval_batched(self._h, ids, n, int(n_past), None if self.first else x_in.data_ptr(),
+                                                None if self.last else x_out.data_ptr(), int(batch))
         if rc != 0:
             raise RuntimeError("stage eval failed")
         if not self.last:
@@ -131,8 +135,8 @@ class Pipeline:
         if self.stage_device.type == "cuda":
             torch.cuda.current_stream(self.stage_device).synchronize()
 
-    def eval_chunk(self, tokens, n_past):
-        """One chunk through this rank's stage.  Returns logits on the last rank, None elsewhere."""
+    def eval_chunk(self, tokens, n_past, batch=0):
+        """One chunk through this rank's stage.  Returns logits on the last rank, None elsewhere.  batch: see prefill."""
         n = len(tokens)
         x_in = None
         if self.rank > 0:
@@ -140,7 +144,7 @@ class Pipeline:
             dist.recv(x_in, src=self.rank - 1, group=self.group)
             x_in = x_in.to(self.stage_device)
             self._sync()  # the stage runs on the library's own stream: the hand-off must have landed
-        out = self.stage.forward(tokens, n_past, x_in)
+        out = self.stage.forward(tokens, n_past, x_in, batch) if batch else self.stage.forward(tokens, n_past, x_in)
         if self.rank < self.world - 1:
             out = out.to(self.device)
             dist.send(out, dst=self.rank + 1, group=self.group)
@@ -148,12 +152,17 @@ class Pipeline:
             return None
         return out
 
-    def prefill(self, prompt, n_past=0, micro_batch=32):
-        """Micro-batched prompt evaluation: stage s works on chunk c while stage s-1 already works on c+1."""
+    def prefill(self, prompt, n_past=0, micro_batch=32, batch_size=0):
+        """Micro-batched prompt evaluation: stage s works on chunk c while stage s-1 already works on c+1.
+        By default a micro-batch is evaluated as ONE reference batch (results = the reference with batch_size = micro_batch).
+        batch_size > 0 (a divisor of micro_batch) reproduces the reference run with that batch size instead, whatever the
+        micro-batch: the pipelining granularity no longer decides the bits."""
+        if batch_size and micro_batch % batch_size:
+            raise ValueError("micro_batch must be a multiple of batch_size")
         logits = None
         for start in range(0, len(prompt), micro_batch):
             chunk = prompt[start:start + micro_batch]
-            logits = self.eval_chunk(chunk, n_past + start)
+            logits = self.eval_chunk(chunk, n_past + start, batch_size if batch_size and batch_size < len(chunk) else 0)
         return logits
 
     def _return_token(self, logits):

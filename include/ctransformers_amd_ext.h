@@ -33,6 +33,10 @@ ctransformers_llm* ctamd_stage_create(const char* model_path, int context_length
  * The call returns after the stage's stream has drained, so x_out may be handed to a collective on any stream. */
 int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
                      void* x_out_dev);
+/* ctamd_stage_eval with the reference batch size inside the n_tokens (0: they are one batch).  Lets a pipeline use micro-batches
+   larger than the batch size whose results it has to reproduce: the attention kernels derive each token's batch from it. */
+int ctamd_stage_eval_batched(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
+                             void* x_out_dev, int batch);
 int ctamd_n_layer(ctransformers_llm* llm);
 int ctamd_n_embd(ctransformers_llm* llm);
 /* Tokens this handle has evaluated through the prompt-chunk kernels (kernels_pf.h) rather than token by token; lets a

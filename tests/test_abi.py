@@ -33,7 +33,7 @@ def test_hip_library_exports_every_extension_symbol(hip_lib):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     syms = re.findall(r"\b(ctamd_\w+)\s*\(", text)
     assert {"ctamd_profile_decode", "ctamd_weight_bytes", "ctamd_trace_site", "ctamd_stage_create", "ctamd_stage_eval",
-            "ctamd_n_layer", "ctamd_n_embd", "ctamd_chunk_tokens"} <= set(syms)
+            "ctamd_stage_eval_batched", "ctamd_n_layer", "ctamd_n_embd", "ctamd_chunk_tokens"} <= set(syms)
     lib = ctypes.CDLL(hip_lib)
     for s in syms:
         assert hasattr(lib, s), s

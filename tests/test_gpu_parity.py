@@ -306,3 +306,18 @@ def test_batch_coalescing_many_shapes(ref, tmp_path):
         n_done += n
         assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy()), (case, n, bs, n_done)
         assert np.array_equal(r.embeddings.to_numpy(), m.embeddings.to_numpy()), (case, n, bs, n_done)
+
+
+def test_batch_structure_matters(ref, tmp_path, monkeypatch):
+    """Test of the tests above: with the batch structure deliberately ignored (CT_AMD_DBG_ONE_BATCH=1: the coalesced request
+    treated as ONE reference batch) the logits of the same 77-token, batch_size-8 request differ from the reference's — so
+    the equality asserted by test_batches_coalesced_equal_reference_batches does exercise the per-token batch end."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-7b-2l", "Q4_K_M", seed=9)
+    toks = synth.prompt_tokens(77, hp["n_vocab"])
+    r = ref.open_llm(p, context_length=128, batch_size=8, threads=16)
+    r.eval(toks)
+    monkeypatch.setenv("CT_AMD_DBG_ONE_BATCH", "1")
+    m = open_hip(p, context_length=128, batch_size=8)
+    m.eval(toks)
+    assert not np.array_equal(r.logits.to_numpy(), m.logits.to_numpy())

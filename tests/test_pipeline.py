@@ -57,6 +57,29 @@ def test_stage_chain_equals_whole_model(emu_lib, mirror):
     assert not lib.ctransformers_llm_batch_eval(s1._h, (ctypes.c_int * 1)(1), 1, 0, 8, 1)
 
 
+def test_stage_chain_micro_batches_larger_than_the_batch(emu_lib):
+    """ctamd_stage_eval_batched: micro-batches of 24 tokens evaluated as reference batches of 8 through two stages equal the
+    reference's batch-by-batch result for the 45-token prompt (golden long_chunked)."""
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    lib = ctypes.CDLL(emu_lib)
+    s0 = pipeline.HipStage(path, 0, 1, context_length=96, device="cpu", lib=lib)
+    s1 = pipeline.HipStage(path, 1, 2, context_length=96, device="cpu", lib=lib)
+    prompt = [int(t) for t in g["long_prompt"]]
+    pipe = pipeline.Pipeline(_Chain(s0, s1), 0, 1, "cpu")
+    logits = pipe.prefill(prompt, 0, micro_batch=24, batch_size=8)
+    assert np.array_equal(logits.numpy(), g["long_chunked"])
+
+
+class _Chain:
+    """Two stages behind the one-stage interface Pipeline drives (world 1)."""
+    def __init__(self, s0, s1):
+        self.s0, self.s1, self.first, self.last, self.n_embd = s0, s1, True, True, s0.n_embd
+
+    def forward(self, tokens, n_past, x_in=None, batch=0):
+        return self.s1.forward([0] * len(tokens), n_past, self.s0.forward(tokens, n_past, None, batch), batch)
+
+
 def test_falcon_stage_chain(emu_lib, mirror):
     """The falcon graph through two stages (40B-style block: two norms, GQA) == the reference goldens."""
     path = os.path.join(GOLDEN, "falcon-tiny-q4km.gguf")
