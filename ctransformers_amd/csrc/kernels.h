@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 
 // Device-side cursor {step, pos}: lets N token steps (eager launches or hipGraph replays) be queued back to back with
 // no host round trip — every kernel reads the position from memory, this one advances it.
-// state = {step, pos, n_total}; n_total (= n_past + N of the chunk) stays fixed for the whole chunk.
+// state (the cursor) = {step, pos, n_total, batch}: n_total = n_past + n of the eval and batch = the reference batch size inside it
+// (0: one batch) stay fixed for the whole eval; step and pos advance token by token (or chunk by chunk).
 // Falcon: the fused QKV mat-mul leaves f32 rows [Q heads | K heads | V heads]; rotate Q and K in NEOX mode (pairs
 // (i, i + head_dim/2), reference ggml.c:12543-12561; the reference build evaluates out[i] = fma(x0, cos, -(x1*sin)),
 // out[i + n/2] = fma(x0, sin, x1*cos) — oracle/mirror.c:mir_rope_neox) and store fp16 Q / K cache / V cache.

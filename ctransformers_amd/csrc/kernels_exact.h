@@ -73,8 +73,9 @@ struct AttnArgsX {
     const uint16_t* vcache;  // layer base [n_embd_gqa][v_stride]
     float* scores;           // [n_head][n_ctx]
     float* out;
-    const int* pos;
-    const int* n_total;      // device scalar: n_past + N of the batch this token belongs to (see attn_softmax_pv_exact_kernel)
+    const int* pos;          // &cursor[1] (position of token 0 of this launch); the kernel also reads cursor[0] = step through it
+    const int* n_total;      // &cursor[2] = n_past + n of the eval; cursor[3] = reference batch size inside the eval (0: one batch):
+                             // together they give the end of the reference batch a token belongs to (length of its V*P dot)
     const uint16_t* exp_tab;
     int n_head, n_head_kv, head_dim, n_embd_gqa, n_ctx, v_stride;
     float kq_scale;
