@@ -180,6 +180,7 @@ int ctamd_stage_eval_batched(ctransformers_llm* llm, const int* tokens, int n_to
 int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine.hparams().n_layer; }
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine.hparams().n_embd; }
 long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine.chunk_tokens(); }
+long long ctamd_v7_launches(void) { return ctamd::v7_launches(); }
 
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {

@@ -10,6 +10,7 @@
 
 #include "gguf_reader.h"
 #include "kernels_v6.h"
+#include "kernels_v7.h"
 #include "kernels_q32.h"
 #include "kernels_ks.h"
 #include "kernels_pfm.h"
@@ -77,6 +78,76 @@ static void parallel_rows(int M, const std::function<void(int, int)>& fn) {
     for (auto& t : th) t.join();
 }
 
+// One file-layout K-quant block -> slot `r` (0..7) of a record in the tile8S field order (quant.h); the 6-bit scale/min
+// field of Q4_K / Q5_K headers is re-encoded as four 24-bit groups (reference packing: k_quants.c:306-314).
+static void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
+    uint8_t hdr[16];
+    if (type != GT_Q6_K) {
+        memcpy(hdr, blk, 16);
+        const uint8_t* q = blk + 4;
+        uint8_t sc[8], mn[8];
+        for (int jj = 0; jj < 8; ++jj) {
+            if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
+            else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
+        }
+        for (int cc = 0; cc < 4; ++cc) {
+            const uint32_t g24 = sc[2 * cc] | (sc[2 * cc + 1] << 6) | (mn[2 * cc] << 12) | (mn[2 * cc + 1] << 18);
+            hdr[4 + 3 * cc] = g24 & 0xFF; hdr[5 + 3 * cc] = (g24 >> 8) & 0xFF; hdr[6 + 3 * cc] = (g24 >> 16) & 0xFF;
+        }
+    }
+    if (type == GT_Q4_K) {
+        memcpy(rp + r * 16, hdr, 16);
+        memcpy(rp + 128 + r * 128, blk + 16, 128);
+    } else if (type == GT_Q5_K) {
+        memcpy(rp + r * 16, hdr, 16);
+        memcpy(rp + 128 + r * 32, blk + 16, 32);
+        memcpy(rp + 384 + r * 128, blk + 48, 128);
+    } else {  // GT_Q6_K
+        memcpy(rp + r * 2, blk + 208, 2);
+        memcpy(rp + 16 + r * 16, blk + 192, 16);
+        memcpy(rp + 144 + r * 64, blk + 128, 64);
+        memcpy(rp + 656 + r * 128, blk, 128);
+    }
+}
+
+// LAYOUT_R2C4 copy of a K-quant matrix for the decode mat-vec (kernels_v7.h).  tb != nullptr: fused gate/up matrix, unit u =
+// (row u of ta, row u of tb); else unit u = rows (2u, 2u + 1) of ta.
+bool Engine::upload_r2c4(const GgufTensor* ta, const GgufTensor* tb, DevMat& m, std::string& err) {
+    const int type = ta->type;
+    if (!is_kquant(type)) { err = "tensor " + ta->name + ": R2C4 layout is for K-quants"; return false; }
+    if (tb && (tb->type != type || tb->ne[0] != ta->ne[0] || tb->ne[1] != ta->ne[1])) { err = "gate/up tensors differ in type or shape"; return false; }
+    const int K = (int)ta->ne[0], M = (int)ta->ne[1], nb = K / 256, bb = ggml_block_bytes(type);
+    if (K > 32768) { err = "tensor " + ta->name + ": rows longer than 32768 are not supported yet"; return false; }
+    const int rec = tile8_record_bytes(type), spu = (nb + 3) / 4;
+    const int n_units = tb ? M : (M + 1) / 2;
+    std::vector<uint8_t> st((size_t)n_units * spu * rec, 0);
+    const uint8_t* sa = ta->data;
+    const uint8_t* sb = tb ? tb->data : nullptr;
+    parallel_rows(n_units, [&](int u0, int u1) {
+        for (int u = u0; u < u1; ++u)
+            for (int s = 0; s < spu; ++s) {
+                uint8_t* rp = &st[((size_t)u * spu + s) * rec];
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int row = sb ? u : 2 * u + rr;
+                    if (row >= M) continue;
+                    const uint8_t* src = (sb && rr) ? sb : sa;
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int b = 4 * s + cc;
+                        if (b < nb) place_kblock(type, rp, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+                    }
+                }
+            }
+    });
+    uint8_t* d = nullptr;
+    if (!dev_alloc(dev_allocs_, &d, st.size() + 64, err)) return false;
+    HIP_OK(hipMemcpy(d, st.data(), st.size(), hipMemcpyHostToDevice));
+    m.r2 = d;
+    if (tb) {   // the fused matrix is a DevMat of its own
+        m.type = type; m.K = K; m.M = M; m.nb = nb; m.layout = LAYOUT_R2C4; m.bytes = ta->nbytes + tb->nbytes;
+    }
+    return true;
+}
+
 bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::string& err) {
     m.type = t->type;
     m.K = (int)t->ne[0];
@@ -92,7 +163,6 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     if (is_kquant(t->type)) {
         // tile8S layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row, 6-bit scales re-encoded.
         if (m.K > 32768) { err = "tensor " + t->name + ": rows longer than 32768 are not supported yet"; return false; }
-        constexpr bool v4 = true;
         m.layout = LAYOUT_TILE8S;
         const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
         std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
@@ -104,36 +174,7 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
                     for (int r = 0; r < 8; ++r) {
                         const int row = tl * 8 + r;
                         if (row >= M) continue;
-                        const uint8_t* blk = src + ((size_t)row * nb + b) * bb;
-                        uint8_t hdr[16];
-                        if (type != GT_Q6_K) {
-                            memcpy(hdr, blk, 16);
-                            if (v4) {  // re-encode the 6-bit scale/min field (reference packing: k_quants.c:306-314)
-                                const uint8_t* q = blk + 4;
-                                uint8_t sc[8], mn[8];
-                                for (int jj = 0; jj < 8; ++jj) {
-                                    if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
-                                    else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
-                                }
-                                for (int cc = 0; cc < 4; ++cc) {
-                                    const uint32_t g24 = sc[2 * cc] | (sc[2 * cc + 1] << 6) | (mn[2 * cc] << 12) | (mn[2 * cc + 1] << 18);
-                                    hdr[4 + 3 * cc] = g24 & 0xFF; hdr[5 + 3 * cc] = (g24 >> 8) & 0xFF; hdr[6 + 3 * cc] = (g24 >> 16) & 0xFF;
-                                }
-                            }
-                        }
-                        if (type == GT_Q4_K) {
-                            memcpy(rp + r * 16, hdr, 16);
-                            memcpy(rp + 128 + r * 128, blk + 16, 128);
-                        } else if (type == GT_Q5_K) {
-                            memcpy(rp + r * 16, hdr, 16);
-                            memcpy(rp + 128 + r * 32, blk + 16, 32);
-                            memcpy(rp + 384 + r * 128, blk + 48, 128);
-                        } else {  // GT_Q6_K
-                            memcpy(rp + r * 2, blk + 208, 2);
-                            memcpy(rp + 16 + r * 16, blk + 192, 16);
-                            memcpy(rp + 144 + r * 64, blk + 128, 64);
-                            memcpy(rp + 656 + r * 128, blk, 128);
-                        }
+                        place_kblock(type, rp, r, src + ((size_t)row * nb + b) * bb);
                     }
                 }
         });
@@ -265,12 +306,14 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (n_ctx_ > kMaxCtx) { err = "context_length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
 
     HIP_OK(hipStreamCreate(&stream_));
+    use_v7_ = env_int("CT_AMD_V7", 1) != 0;
     const GgufTensor* t;
     auto mat = [&](const std::string& name, DevMat& m, int M, int K, bool raw = false) {
         t = f.tensor(name);
         if (!t) { err = "missing tensor " + name; return false; }
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (!upload_matrix(t, m, raw, err)) return false;
+        if (use_v7_ && is_kquant(t->type) && !upload_r2c4(t, nullptr, m, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -321,6 +364,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
             !mat(p + "ffn_down.weight", L.w_down, E, F))
             return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
+        if (use_v7_ && is_kquant(L.w_gate.type) &&
+            !upload_r2c4(f.tensor(p + "ffn_gate.weight"), f.tensor(p + "ffn_up.weight"), L.w_gu, err))
+            return false;
     }
     if (l1_ == hp_.n_layer) {
         if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
@@ -508,12 +554,87 @@ static int chip_cus() {
     return n_cu;
 }
 
+// Generation 7 (kernels_v7.h): every job a K-quant matrix with a LAYOUT_R2C4 copy (gate/up: ONE job, the fused matrix).
+// Units are row pairs; the jobs' units are concatenated, type group A first.
+static bool v7_can(const MatvecArgs& a) {
+    if (a.njobs < 1 || a.njobs > 3 || a.K > 32768) return false;
+    if (a.gateup) return a.njobs == 1 && a.job[0].w.layout == LAYOUT_R2C4 && a.job[0].w.r2;
+    for (int j = 0; j < a.njobs; ++j) {
+        const int e = a.job[j].epi;
+        if (!a.job[j].w.r2 || !is_kquant(a.job[j].w.type)) return false;
+        if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_GELU || e == EPI_ADD2)) return false;
+    }
+    return true;
+}
+
+static long long g_v7_launches = 0;   // test hook (ctamd_v7_launches): which generation produced the logits a test compared
+long long v7_launches() { return g_v7_launches; }
+
+static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
+    ++g_v7_launches;
+    const int ta = a.job[0].w.type;
+    int tb = 0, item0 = 0, na = 0;
+    double bytes_a = 0.0, bytes_b = 0.0;
+    const int spu = ((a.K >> 8) + 3) / 4;
+    for (int j = 0; j < a.njobs; ++j) {
+        const int tj = a.job[j].w.type;
+        const int units = a.gateup ? a.job[j].w.M : (a.job[j].w.M + 1) / 2;
+        a.job[j].pair0 = item0;
+        item0 += units;
+        const double bytes = (double)units * spu * tile8_record_bytes(tj);
+        if (tj == ta && tb == 0) { na += units; bytes_a += bytes; }
+        else if ((tb == 0 && tj == GT_Q6_K) || tj == tb) { tb = tj; bytes_b += bytes; }
+        else { err = "unsupported weight-type mix in one launch"; return false; }
+    }
+    a.n_pairs = item0;
+    a.n_groupA = na;
+    a.nwA = 16;
+    if (tb != 0) {
+        const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bytes_b / (bytes_a + bytes_b))));
+        a.nwA = 16 - nwb;
+    }
+    const bool ln = a.pro == PRO_LAYERNORM;
+    if (ln && tb != 0) { err = "LayerNorm prologue with a mixed-type launch"; return false; }
+    const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
+#define V7L(MK, TAV, TBV, LNV) do { \
+        auto kfn = matvec_v7_kernel<MK, TAV, TBV, LNV>; \
+        constexpr size_t smem = sizeof(SmemV7<MK>); \
+        static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
+        (void)once; \
+        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
+#define V7T(MK, TAV) do { \
+        if (ln) V7L(MK, TAV, 0, true); \
+        else if (tb != 0) V7L(MK, TAV, GT_Q6_K, false); \
+        else V7L(MK, TAV, 0, false); } while (0)
+#define V7(MK) do { \
+        if (ta == GT_Q4_K) V7T(MK, GT_Q4_K); \
+        else if (ta == GT_Q5_K) V7T(MK, GT_Q5_K); \
+        else if (ln) V7L(MK, GT_Q6_K, 0, true); \
+        else V7L(MK, GT_Q6_K, 0, false); } while (0)
+    if (a.K <= 16384) {
+        V7(16384);
+    } else {   // wide rows (ffn_down of the 70B / Falcon-40B class): single-matrix launches only
+        if (tb != 0) { err = "mixed-type launch with K > 16384"; return false; }
+        tb = 0;
+        if (ta == GT_Q4_K) { if (ln) V7L(32768, GT_Q4_K, 0, true); else V7L(32768, GT_Q4_K, 0, false); }
+        else if (ta == GT_Q5_K) { if (ln) V7L(32768, GT_Q5_K, 0, true); else V7L(32768, GT_Q5_K, 0, false); }
+        else { if (ln) V7L(32768, GT_Q6_K, 0, true); else V7L(32768, GT_Q6_K, 0, false); }
+    }
+#undef V7
+#undef V7T
+#undef V7L
+    return true;
+}
+
 // One mat-vec launch.  Work items are 8-row tiles ("units"); the jobs of a launch are concatenated into one item list.
 //   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h)
 //   LAYOUT_TILE8S, K > 12288           -> systolic wide-K K-quant kernel (kernels_ks.h)
 //   LAYOUT_TILE8S, K <= 12288          -> generation 6 (kernels_v6.h); launches with at most two units per workgroup and
 //                                         one weight type stay on generation 5 (one round: the counters buy nothing)
-static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
+static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err, bool use_v7) {
+    if (use_v7 && v7_can(a)) return launch_matvec_v7(a, s, err);
+    if (a.job[0].w.layout == LAYOUT_R2C4) { err = "fused gate/up matrix outside generation 7"; return false; }
+    a.emb_out = nullptr;
     int item0 = 0;
     for (int j = 0; j < a.njobs; ++j) {   // set_jobs counted row pairs; the kernels count tiles
         a.job[j].pair0 = a.gateup ? 0 : item0;
@@ -674,7 +795,7 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
     }
 }
 
-bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err); }
+bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err, use_v7_); }
 
 // One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
 void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
@@ -879,10 +1000,11 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
         HIP_OK(hipMemcpyAsync(xio_ + (size_t)c0 * E, xb_, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
     } else if (want_logits) {   // the chunk's last token only (llama.cpp:2955-2959 keeps the last column)
         const float* xl = xb_ + (size_t)(nt - 1) * E;
-        CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = xl; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        if (use_v7_ && v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        else CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
     }
     CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
@@ -1116,9 +1238,14 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.ffn_norm; a.out = h_;
-            a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
-            a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
-            a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            if (use_v7_ && L.w_gu.r2) {   // generation 7: one job, the fused matrix
+                a.job[0].w = L.w_gu; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
+                a.njobs = 1; a.gateup = 1; a.n_pairs = F;
+            } else {
+                a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
+                a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
+                a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            }
             apply_trace(a, "gate_up");
             if (site_on("gate_up")) {
                 prof_begin("gate_up", "matvec", (double)(L.w_gate.bytes + L.w_up.bytes));
@@ -1144,12 +1271,13 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)x_, xio_, E,
                   (const int*)d_state_, 1);
     } else if (want_logits) {
-        if (!only_site_)
-            CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
-                      hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        if (use_v7_ && v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        else if (!only_site_)
+            CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
+                      hp_.rms_eps);
         apply_trace(a, "lm_head");
         if (site_on("lm_head")) {
             prof_begin("lm_head", "matvec", (double)output_.bytes);

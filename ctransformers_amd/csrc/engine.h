@@ -30,6 +30,7 @@ struct Layer {
     float* attn_norm = nullptr;
     float* ffn_norm = nullptr;
     DevMat wq, wk, wv, wo, w_gate, w_up, w_down;
+    DevMat w_gu;   // fused gate/up matrix in LAYOUT_R2C4 (decode, kernels_v7.h): pair u = (gate row u, up row u)
     // falcon (llm_build_falcon, llama.cpp:2493-2798): LayerNorm biases, optional second norm (40B), fused QKV
     float* attn_norm_b = nullptr;
     float* attn_norm2 = nullptr;
@@ -39,6 +40,8 @@ struct Layer {
     float* ffn_norm_b = nullptr;
     float *b_qkv = nullptr, *b_wo = nullptr, *b_up = nullptr, *b_down = nullptr;
 };
+
+long long v7_launches();   // test hook: decode mat-vec launches of generation 7 issued by this process
 
 class Engine {
    public:
@@ -95,6 +98,7 @@ class Engine {
 
    private:
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
+    bool upload_r2c4(const struct GgufTensor* ta, const struct GgufTensor* tb, DevMat& m, std::string& err);
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
@@ -151,6 +155,7 @@ class Engine {
     float *h_logits_ = nullptr, *h_emb_ = nullptr;
     int* h_scalars_ = nullptr;  // pinned staging for the token ids + cursor
     bool use_graph_ = false;
+    bool use_v7_ = true;    // decode mat-vecs of K-quant matrices on generation 7 (CT_AMD_V7=0: generations 5/6, A/B)
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
     std::map<int, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by 2 * n_tokens + want_logits; captured on second use

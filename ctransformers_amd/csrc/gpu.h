@@ -188,6 +188,20 @@ template <class T> DEV T wave_sum_fast(T v) {
     return v;
 }
 
+// ---- wave-private LDS exchange: all lanes of a wave wrote, all lanes of the same wave read ---------------------------------
+// DS operations of one wave are executed in issue order; what is needed is that the compiler keeps the order and that the
+// written data has left the store queue: a workgroup-scope release/acquire pair on the LDS address space (lowers to
+// `s_waitcnt lgkmcnt(0)`, no vmcnt — weight loads stay in flight) around a scheduling barrier.
+#ifdef CT_EMU
+static inline void wave_lds_sync() { emu::wave_sync(); }
+#else
+DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 #ifdef CT_EMU
 static inline unsigned long long clock64_dev() { return 0; }
 #else

@@ -58,7 +58,9 @@ struct MatvecArgs {
     MatJob job[3];
     int njobs;
     int n_pairs;        // total pairs over all jobs
-    int n_groupA;       // generation-5 kernels: items of the first type-homogeneous job group (rest = group B)
+    int n_groupA;       // items of the first type-homogeneous job group (rest = group B)
+    int nwA;            // generation 7, two-type launches: waves 0..nwA-1 of every workgroup walk group A, the rest group B
+    float* emb_out;     // generation 7: block 0 also stores the normalised activation vector here (final-norm output of the ABI)
     int gateup;         // 1: job[0]=gate, job[1]=up, pair t = (gate row t, up row t), epilogue SiLU(gate)*up
     int K;              // input length
     int pro;            // PRO_*

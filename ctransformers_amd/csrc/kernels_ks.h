@@ -16,13 +16,14 @@ template <int MAXK> struct SmemKS {
 };
 
 // Integer work of one block -> this lane's chain operands (same arithmetic as img_to_chain<TYPE>).
-template <int TYPE, int MAXK>
-DEV void img_to_regs(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, const LaneGeom& G, float& sv, float& dv, float& mv,
+// b: block of the activation image (may differ per lane), q8w: word offset of that block's 64 quant words in L.q8.
+template <int TYPE, class ACT>
+DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const LaneGeom& G, float& sv, float& dv, float& mv,
                      float& pv) {
     const int c = G.c;
     const float yd = L.yd[b];
     if constexpr (TYPE == GT_Q4_K || TYPE == GT_Q5_K) {
-        const int* alo = &L.q8[b * 64 + G.a45];
+        const int* alo = &L.q8[q8w + G.a45];
         const int* ahi = alo + 8;
         const uint32_t lo_w = c < 2 ? R.hdr[1] : (c == 2 ? R.hdr[2] : R.hdr[3]);
         const uint32_t hi_w = c < 2 ? R.hdr[2] : R.hdr[3];
@@ -51,7 +52,7 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, const ActLdsX<MAXK>& L, const
         mv = -yd * f16_bits_to_f32((uint16_t)(R.hdr[0] >> 16));
     } else {
         const int n = G.g >> 2;
-        const int* alo = &L.q8[b * 64 + G.a6];
+        const int* alo = &L.q8[q8w + G.a6];
         const int* ahi = alo + 16;
         const uint32_t w_lo = n ? R.sc[2] : R.sc[0];
         const uint32_t w_hi = n ? R.sc[3] : R.sc[1];
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(1024) matvec_ks_kernel(const MatvecArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = 4 * ch + u;
-                if (k < bcnt) img_to_regs<TYPE, MAXK>(Q[u], bbeg + k, SM.L, G, sv[k], dv[k], mv[k], pv[k]);
+                if (k < bcnt) img_to_regs<TYPE>(Q[u], bbeg + k, (bbeg + k) * 64, SM.L, G, sv[k], dv[k], mv[k], pv[k]);
             }
         }
         const int slot = seq % kKsSlots;

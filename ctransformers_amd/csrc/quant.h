@@ -46,7 +46,10 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 // 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
-enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3 };
+// LAYOUT_R2C4 (K-quants, kernels_v7.h): a record = 2 rows x 4 consecutive K-blocks in the tile8S field order (slot p = 4*row + c
+// takes the place of row p), a row pair = ceil(nb/4) consecutive records; blocks past nb are zero slots that are never fetched.
+// A fused gate/up matrix pairs (gate row r, up row r).
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
@@ -56,6 +59,7 @@ struct DevMat {
     int nb = 0;                 // blocks per row (K/256 for K-quants, K/32 for Q4_0/Q8_0)
     const uint8_t* p[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
+    const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (decode mat-vec, kernels_v7.h)
     int layout = 0;                // LAYOUT_TILE8S / LAYOUT_G4 (records live in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };

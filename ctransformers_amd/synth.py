@@ -279,7 +279,7 @@ class BlockPool:
     blocks from the pool (fast path for multi-GB synthetic models; every block is a legal quantization of real
     Gaussian data, every tensor is a different random sequence of them)."""
 
-    def __init__(self, ggml_type, sigma, rng, n_blocks=1 << 15):
+    def __init__(self, ggml_type, sigma, rng, n_blocks=1 << 13):
         be, bb = G.TYPE_BLOCK[ggml_type]
         x = rng.standard_normal((n_blocks, be), dtype=np.float32) * np.float32(sigma)
         self.blocks = quantize(x, ggml_type).reshape(n_blocks, bb)

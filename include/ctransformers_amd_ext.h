@@ -42,6 +42,8 @@ int ctamd_n_embd(ctransformers_llm* llm);
 /* Tokens this handle has evaluated through the prompt-chunk kernels (kernels_pf.h) rather than token by token; lets a
    test assert which path produced the logits it compared. */
 long long ctamd_chunk_tokens(ctransformers_llm* llm);
+/* Decode mat-vec launches of generation 7 (kernels_v7.h) issued by this process so far (eager launches and graph captures). */
+long long ctamd_v7_launches(void);
 #ifdef __cplusplus
 }
 #endif

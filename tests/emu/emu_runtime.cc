@@ -75,6 +75,8 @@ uint64_t wave_exchange(uint64_t v, int src_lane) {
     return w.buf[slot][src_lane & 63];
 }
 
+void wave_sync() { arrive(g_waves[g_fibers[g_cur].lin / 64].r); }
+
 uint64_t wave_ballot(int pred) {
     Fiber& f = g_fibers[g_cur];
     Wave& w = g_waves[f.lin / 64];

@@ -33,6 +33,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void syncthreads();
 uint64_t wave_exchange(uint64_t v, int src_lane);
 uint64_t wave_ballot(int pred);
+void wave_sync();                  // rendezvous of the live lanes of the calling wave (wave-private LDS exchange)
 void spin_yield();                 // a polling loop hands the CPU to the other fibers of the block
 void dyn_smem_reserve(size_t n);   // dynamic LDS of the next launch (zero-filled per workgroup is NOT guaranteed, as on hardware)
 unsigned char* dyn_smem();
