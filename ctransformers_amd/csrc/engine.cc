@@ -110,40 +110,59 @@ static void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
     }
 }
 
-// LAYOUT_R2C4 copy of a K-quant matrix for the decode mat-vec (kernels_v7.h).  tb != nullptr: fused gate/up matrix, unit u =
-// (row u of ta, row u of tb); else unit u = rows (2u, 2u + 1) of ta.
-bool Engine::upload_r2c4(const GgufTensor* ta, const GgufTensor* tb, DevMat& m, std::string& err) {
-    const int type = ta->type;
-    if (!is_kquant(type)) { err = "tensor " + ta->name + ": R2C4 layout is for K-quants"; return false; }
-    if (tb && (tb->type != type || tb->ne[0] != ta->ne[0] || tb->ne[1] != ta->ne[1])) { err = "gate/up tensors differ in type or shape"; return false; }
-    const int K = (int)ta->ne[0], M = (int)ta->ne[1], nb = K / 256, bb = ggml_block_bytes(type);
-    if (K > 32768) { err = "tensor " + ta->name + ": rows longer than 32768 are not supported yet"; return false; }
-    const int rec = tile8_record_bytes(type), spu = (nb + 3) / 4;
-    const int n_units = tb ? M : (M + 1) / 2;
-    std::vector<uint8_t> st((size_t)n_units * spu * rec, 0);
-    const uint8_t* sa = ta->data;
-    const uint8_t* sb = tb ? tb->data : nullptr;
-    parallel_rows(n_units, [&](int u0, int u1) {
-        for (int u = u0; u < u1; ++u)
-            for (int s = 0; s < spu; ++s) {
-                uint8_t* rp = &st[((size_t)u * spu + s) * rec];
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int row = sb ? u : 2 * u + rr;
-                    if (row >= M) continue;
-                    const uint8_t* src = (sb && rr) ? sb : sa;
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int b = 4 * s + cc;
-                        if (b < nb) place_kblock(type, rp, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+// LAYOUT_R2C4 copies for the decode mat-vec (kernels_v7.h).  The matrices of `parts` are placed back to back in ONE device
+// allocation, in order: a launch walks the row pairs of all its jobs of one weight type as a single contiguous unit space
+// (attn_q | attn_k | attn_v).  `fuse` (two parts of the same type and shape): ONE fused gate/up matrix, unit u = (row u of
+// parts[0], row u of parts[1]), described by parts[0].second; else unit u of a part = its rows (2u, 2u + 1).
+bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err) {
+    struct Plan { const GgufTensor* ta; const GgufTensor* tb; DevMat* m; size_t off, bytes; int type, K, M, nb, n_units; };
+    std::vector<Plan> plan;
+    size_t total = 0;
+    for (size_t i = 0; i < parts.size(); i += fuse ? 2 : 1) {
+        const GgufTensor* ta = parts[i].first;
+        const GgufTensor* tb = fuse ? parts[i + 1].first : nullptr;
+        if (!ta || (fuse && !tb)) { err = "missing tensor for the R2C4 layout"; return false; }
+        if (!is_kquant(ta->type)) { err = "tensor " + ta->name + ": R2C4 layout is for K-quants"; return false; }
+        if (tb && (tb->type != ta->type || tb->ne[0] != ta->ne[0] || tb->ne[1] != ta->ne[1])) { err = "gate/up tensors differ in type or shape"; return false; }
+        Plan p;
+        p.ta = ta; p.tb = tb; p.m = parts[i].second; p.type = ta->type; p.K = (int)ta->ne[0]; p.M = (int)ta->ne[1]; p.nb = p.K / 256;
+        if (p.K > 32768) { err = "tensor " + ta->name + ": rows longer than 32768 are not supported yet"; return false; }
+        p.n_units = tb ? p.M : (p.M + 1) / 2;
+        p.off = total;
+        p.bytes = (size_t)p.n_units * ((p.nb + 3) / 4) * tile8_record_bytes(p.type);
+        total += p.bytes;
+        plan.push_back(p);
+    }
+    std::vector<uint8_t> st(total, 0);
+    for (const Plan& p : plan) {
+        const int type = p.type, nb = p.nb, M = p.M, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type), spu = (nb + 3) / 4;
+        const uint8_t* sa = p.ta->data;
+        const uint8_t* sb = p.tb ? p.tb->data : nullptr;
+        uint8_t* dst = st.data() + p.off;
+        parallel_rows(p.n_units, [&](int u0, int u1) {
+            for (int u = u0; u < u1; ++u)
+                for (int s = 0; s < spu; ++s) {
+                    uint8_t* rp = dst + ((size_t)u * spu + s) * rec;
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int row = sb ? u : 2 * u + rr;
+                        if (row >= M) continue;
+                        const uint8_t* src = (sb && rr) ? sb : sa;
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const int b = 4 * s + cc;
+                            if (b < nb) place_kblock(type, rp, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+                        }
                     }
                 }
-            }
-    });
+        });
+    }
     uint8_t* d = nullptr;
-    if (!dev_alloc(dev_allocs_, &d, st.size() + 64, err)) return false;
-    HIP_OK(hipMemcpy(d, st.data(), st.size(), hipMemcpyHostToDevice));
-    m.r2 = d;
-    if (tb) {   // the fused matrix is a DevMat of its own
-        m.type = type; m.K = K; m.M = M; m.nb = nb; m.layout = LAYOUT_R2C4; m.bytes = ta->nbytes + tb->nbytes;
+    if (!dev_alloc(dev_allocs_, &d, total + 64, err)) return false;
+    HIP_OK(hipMemcpy(d, st.data(), total, hipMemcpyHostToDevice));
+    for (const Plan& p : plan) {
+        p.m->r2 = d + p.off;
+        if (p.tb) {   // the fused matrix is a DevMat of its own
+            p.m->type = p.type; p.m->K = p.K; p.m->M = p.M; p.m->nb = p.nb; p.m->layout = LAYOUT_R2C4; p.m->bytes = p.ta->nbytes + p.tb->nbytes;
+        }
     }
     return true;
 }
@@ -307,13 +326,14 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
 
     HIP_OK(hipStreamCreate(&stream_));
     use_v7_ = env_int("CT_AMD_V7", 1) != 0;
+    bool r2_auto = true;   // mat() also makes the matrix's own R2C4 copy (false: the caller places several matrices in one arena)
     const GgufTensor* t;
     auto mat = [&](const std::string& name, DevMat& m, int M, int K, bool raw = false) {
         t = f.tensor(name);
         if (!t) { err = "missing tensor " + name; return false; }
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (!upload_matrix(t, m, raw, err)) return false;
-        if (use_v7_ && is_kquant(t->type) && !upload_r2c4(t, nullptr, m, err)) return false;
+        if (use_v7_ && is_kquant(t->type) && r2_auto && !upload_r2c4({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -358,14 +378,19 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         Layer& L = layers_[i];
         if (!upload_f32(f.tensor(p + "attn_norm.weight"), &L.attn_norm, E, err)) return false;
         if (!upload_f32(f.tensor(p + "ffn_norm.weight"), &L.ffn_norm, E, err)) return false;
+        r2_auto = false;   // q | k | v share one arena, gate/up are fused
         if (!mat(p + "attn_q.weight", L.wq, E, E) || !mat(p + "attn_k.weight", L.wk, G, E) ||
-            !mat(p + "attn_v.weight", L.wv, G, E) || !mat(p + "attn_output.weight", L.wo, E, E) ||
-            !mat(p + "ffn_gate.weight", L.w_gate, F, E) || !mat(p + "ffn_up.weight", L.w_up, F, E) ||
-            !mat(p + "ffn_down.weight", L.w_down, E, F))
+            !mat(p + "attn_v.weight", L.wv, G, E))
             return false;
+        if (!mat(p + "ffn_gate.weight", L.w_gate, F, E) || !mat(p + "ffn_up.weight", L.w_up, F, E)) return false;
+        r2_auto = true;
+        if (!mat(p + "attn_output.weight", L.wo, E, E) || !mat(p + "ffn_down.weight", L.w_down, E, F)) return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
+        if (use_v7_ && is_kquant(L.wq.type) && is_kquant(L.wk.type) && is_kquant(L.wv.type) &&
+            !upload_r2c4({{f.tensor(p + "attn_q.weight"), &L.wq}, {f.tensor(p + "attn_k.weight"), &L.wk}, {f.tensor(p + "attn_v.weight"), &L.wv}}, false, err))
+            return false;
         if (use_v7_ && is_kquant(L.w_gate.type) &&
-            !upload_r2c4(f.tensor(p + "ffn_gate.weight"), f.tensor(p + "ffn_up.weight"), L.w_gu, err))
+            !upload_r2c4({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
             return false;
     }
     if (l1_ == hp_.n_layer) {
@@ -588,6 +613,19 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     }
     a.n_pairs = item0;
     a.n_groupA = na;
+    // the units of a type group are one contiguous stream: job j + 1 of a group starts where job j ends (upload_r2c4 arenas)
+    a.baseA = a.job[0].w.r2;
+    a.baseB = nullptr;
+    for (int j = 0; j < a.njobs; ++j) {
+        const bool first_b = tb != 0 && a.job[j].pair0 == na;
+        if (first_b) { a.baseB = a.job[j].w.r2; continue; }
+        if (j == 0) continue;
+        const int uj = a.job[j].pair0 - a.job[j - 1].pair0;
+        if (a.job[j].w.r2 != a.job[j - 1].w.r2 + (size_t)uj * spu * tile8_record_bytes(a.job[j - 1].w.type)) {
+            err = "mat-vec jobs of one weight type are not contiguous in memory";
+            return false;
+        }
+    }
     a.nwA = 16;
     if (tb != 0) {
         const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bytes_b / (bytes_a + bytes_b))));
@@ -595,7 +633,28 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     }
     const bool ln = a.pro == PRO_LAYERNORM;
     if (ln && tb != 0) { err = "LayerNorm prologue with a mixed-type launch"; return false; }
-    const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
+    // one workgroup per CU; more only where a wave would otherwise own more than kV7MaxUnits units (its results wait in LDS
+    // for its epilogue pass) — no real model shape gets there on 256 CUs, the 4-CU emulated chip of the tests does
+    int gx = std::max(1, std::min(chip_cus(), a.n_pairs));
+    {
+        const int nb_units = a.n_pairs - na, nwb = 16 - a.nwA;
+        if (a.nwA > 0) gx = std::max(gx, (na + a.nwA * kV7MaxUnits - 1) / (a.nwA * kV7MaxUnits));
+        if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV7MaxUnits - 1) / (nwb * kV7MaxUnits));
+    }
+    const dim3 grid((unsigned)gx), block(1024);
+    if (a.emb_out) {   // lm_head: the instantiation that also stores the normalised vector (one launch per token)
+        if (tb != 0 || a.K > 16384) { err = "emb_out on a mixed-type or wide launch"; return false; }
+#define V7E(TAV) do { \
+            auto kfn = matvec_v7_kernel<16384, TAV, 0, false, true>; \
+            auto kfl = matvec_v7_kernel<16384, TAV, 0, true, true>; \
+            constexpr size_t smem = sizeof(SmemV7<16384>); \
+            static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem) && CT_SMEM_OPTIN(kfl, smem); }(); \
+            (void)once; \
+            if (ln) CT_LAUNCH_DYN(kfl, grid, block, smem, s, a); else CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
+        if (ta == GT_Q4_K) V7E(GT_Q4_K); else if (ta == GT_Q5_K) V7E(GT_Q5_K); else V7E(GT_Q6_K);
+#undef V7E
+        return true;
+    }
 #define V7L(MK, TAV, TBV, LNV) do { \
         auto kfn = matvec_v7_kernel<MK, TAV, TBV, LNV>; \
         constexpr size_t smem = sizeof(SmemV7<MK>); \

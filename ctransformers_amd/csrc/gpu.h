@@ -192,6 +192,25 @@ template <class T> DEV T wave_sum_fast(T v) {
 // DS operations of one wave are executed in issue order; what is needed is that the compiler keeps the order and that the
 // written data has left the store queue: a workgroup-scope release/acquire pair on the LDS address space (lowers to
 // `s_waitcnt lgkmcnt(0)`, no vmcnt — weight loads stay in flight) around a scheduling barrier.
+// One dword through the scalar data cache (lgkmcnt), load and wait in one statement: a device scalar such as the cursor position,
+// which hipcc otherwise fetches with a vector load followed by `s_waitcnt vmcnt(0)` — draining every weight load in flight.
+#ifdef CT_EMU
+static inline int sload_i32(const int* p) { return *p; }
+#else
+DEV int sload_i32(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+#endif
+
+// Scheduling fence on values: they are computed before this point, nothing that depends on them moves above it.
+#ifdef CT_EMU
+static inline void reg_fence(float&, float&, float&, float&) {}
+#else
+DEV void reg_fence(float& a, float& b, float& c, float& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+#endif
+
 #ifdef CT_EMU
 static inline void wave_lds_sync() { emu::wave_sync(); }
 #else

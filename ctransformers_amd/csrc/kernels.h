@@ -60,6 +60,8 @@ struct MatvecArgs {
     int n_pairs;        // total pairs over all jobs
     int n_groupA;       // items of the first type-homogeneous job group (rest = group B)
     int nwA;            // generation 7, two-type launches: waves 0..nwA-1 of every workgroup walk group A, the rest group B
+    const uint8_t* baseA;   // generation 7: first LAYOUT_R2C4 record of type group A / B (the group's jobs are contiguous)
+    const uint8_t* baseB;
     float* emb_out;     // generation 7: block 0 also stores the normalised activation vector here (final-norm output of the ABI)
     int gateup;         // 1: job[0]=gate, job[1]=up, pair t = (gate row t, up row t), epilogue SiLU(gate)*up
     int K;              // input length

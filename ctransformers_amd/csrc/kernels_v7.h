@@ -18,7 +18,12 @@
 //     state lives in registers from step to step; nothing is shared between waves after the prologue barrier.
 //   * a 4-deep register ring of records per wave keeps 16 x 4 x 1.1 KB = 73 KB per CU in flight; a wave walks its units
 //     (unit = first + i * stride, interleaved over workgroups so every CU gets the same bytes +- one unit) as one flat
-//     sequence of steps, the ring running across unit boundaries.
+//     sequence of steps, the ring running across unit boundaries.  The loop that consumes the ring contains NO other vector
+//     memory instruction and no conditional one: every step issues exactly one record's loads (past the end: the last
+//     record again), results go to an LDS row and the fused epilogues (with their stores and table lookups) run after the
+//     loop, their operands (residual, RoPE cos/sin) requested before it.  Only then does hipcc count the ring with
+//     `s_waitcnt vmcnt(6)`; a store or a branch around a load anywhere in the loop makes it wait `vmcnt(0)` at every step
+//     (loads and stores retire out of order on one counter), i.e. one memory latency per step and wave: 2.5 TB/s.
 //   * the activation vector is requested BEFORE the first weight records (vmcnt is in order: the prologue then waits for
 //     16 KB, not for the first 73 KB of weights), quantized once per workgroup (prologue of kernels_exact.h, unchanged
 //     arithmetic), and the Q8_K image is stored with a per-block skew (q8w_of) that keeps the four blocks a wave reads at
@@ -41,27 +46,37 @@ DEV int q8w_of(int b) { return 264 * (b >> 2) + 64 * (b & 3) + 8 * ((b >> 1) & 1
 
 template <int MAXK> struct ProRegs7 {
     static constexpr int ROUNDS = (MAXK / 256 + 63) / 64;
+    static constexpr bool EARLY_W = MAXK <= 16384;   // the norm weights are requested with the activations (16 more registers)
     float4 v[ROUNDS][4];
+    float4 w[EARLY_W ? ROUNDS : 1][4];
 };
 
-// Prologue part 1: request this thread's 16 consecutive activations (16 lanes per 256-block) — nothing waits here.
-template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restrict__ x, int K) {
+// Prologue part 1: request this thread's 16 consecutive activations (16 lanes per 256-block) and their norm weights —
+// nothing waits here.  The first instructions of the kernel: whatever is requested later queues behind the weight stream.
+template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro) {
     const int tid = (int)threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int nblk = K >> 8;
+    // every load is unconditional (block index clamped, the activations standing in for absent norm weights): a select
+    // between "load" and "constant" makes hipcc branch around the load and wait for it on the spot
+    const float* __restrict__ wsrc = pro != PRO_PLAIN ? nw : x;
 #pragma unroll
     for (int rd = 0; rd < ProRegs7<MAXK>::ROUNDS; ++rd) {
-        const int b = grp + rd * 64;
+        int b = grp + rd * 64;
+        b = b < nblk ? b : nblk - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            P.v[rd][k] = b < nblk ? *(const float4*)(x + b * 256 + sub * 16 + k * 4) : float4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k) P.v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
+        if constexpr (ProRegs7<MAXK>::EARLY_W) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P.w[rd][k] = *(const float4*)(wsrc + b * 256 + sub * 16 + k * 4);
+        }
     }
 }
 
 // Prologue part 2: (RMSNorm | LayerNorm | nothing) -> Q8_K into LDS.  Arithmetic of prologue_q8k_exact16 / _ln
 // (kernels_exact.h; reference k_quants.c:1191-1226 with the build's fused fma, RMSNorm ggml.c:10700-10716, LayerNorm
 // ggml.c:10605-10654).  Ends with a workgroup barrier.  `emb_out` (block 0 only): the normalised vector as f32 — the
-// final-norm "embeddings" output of the ABI, produced by the lm_head launch instead of a launch of its own.
-template <int MAXK, bool LN>
+// final-norm "embeddings" output of the ABI, produced by the lm_head launch (EMB instantiation) instead of a launch of its own.
+template <int MAXK, bool LN, bool EMB>
 DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K,
                      int pro, float eps, float* __restrict__ emb_out) {
     constexpr int ROUNDS = ProRegs7<MAXK>::ROUNDS, NW = 16;
@@ -150,7 +165,9 @@ DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK>& P, const float* __restric
             for (int k = 0; k < 4; ++k) {
                 float4 q = live ? P.v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
                 if (live && pro != PRO_PLAIN) {
-                    const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                    float4 w4;
+                    if constexpr (ProRegs7<MAXK>::EARLY_W) w4 = P.w[rd][k];
+                    else w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
                     q.x = (q.x * scale) * w4.x;
                     q.y = (q.y * scale) * w4.y;
                     q.z = (q.z * scale) * w4.z;
@@ -161,7 +178,9 @@ DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK>& P, const float* __restric
                             q.x += b4.x; q.y += b4.y; q.z += b4.z; q.w += b4.w;
                         }
                     }
-                    if (emb_out && blockIdx.x == 0) *(float4*)(emb_out + b * 256 + sub * 16 + k * 4) = q;
+                    if constexpr (EMB) {   // a store here is a pending write at the entry of the streaming loop: lm_head instantiation only
+                        if (emb_out && blockIdx.x == 0) *(float4*)(emb_out + b * 256 + sub * 16 + k * 4) = q;
+                    }
                 }
                 t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
             }
@@ -214,15 +233,18 @@ struct WaveBuf7 {
     float D[2][4];       // [row][c]      y.d * fp16(d)
     float DM[2][4];      // [row][c]     -y.d * fp16(dmin)
 };
+constexpr int kV7MaxUnits = 32;   // units one wave may own in a launch (its results wait in LDS for the epilogue pass)
 template <int MAXK> struct SmemV7 {
     ActLds7<MAXK> L;
     WaveBuf7 WB[16][2];
+    float RES[16][2 * kV7MaxUnits];   // [wave][2 * unit + row]
 };
 
 // All units of one wave: items first, first + stride, ... < end of the launch's concatenated unit list.
+// base / g0: first record and first item of the wave's type group.
 template <int TYPE, int MAXK, class Pro>
-DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, int first, int stride, int end, int lane, int wv, const LaneGeom& G, int pos,
-                Pro pro) {
+DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int g0, int first, int stride, int end, int lane, int wv,
+                const LaneGeom& G, Pro pro) {
     constexpr bool mins = TYPE != GT_Q6_K;
     constexpr uint32_t REC = rec_bytes<TYPE>();
     const int nb = a.K >> 8, spu = (nb + 3) >> 2;
@@ -230,25 +252,20 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, int first, int stride, in
     const size_t unit_bytes = (size_t)spu * REC;
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
-    auto job_of = [&](int it) __attribute__((always_inline)) {
-        int j = 0;
-        if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
-        if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
-        return j;
-    };
-    // ---- prefetch cursor: the step whose record is requested next ----
-    int pf_it = first, pf_s = 0;
-    const uint8_t* pf_ptr = nullptr;
-    if (pf_it < end) { const int j = job_of(pf_it); pf_ptr = a.job[j].w.r2 + (size_t)(pf_it - a.job[j].pair0) * unit_bytes; }
+    const int nu = first < end ? (end - first + stride - 1) / stride : 0;   // units of this wave (host: <= kV7MaxUnits)
+    // ---- prefetch cursor: the step whose record is requested next (stays on the last record once everything is requested) ----
+    int pf_it = first, pf_s = 0, pf_left = nu * spu;
+    const uint8_t* pf_ptr = base + (size_t)((nu > 0 ? first : g0) - g0) * unit_bytes;
     BlkImg<TYPE> ring[4];
     auto issue = [&](BlkImg<TYPE>& slot) __attribute__((always_inline)) {
-        if (pf_it < end) {
-            if (4 * pf_s + cb < nb) slot = img_load<TYPE>(pf_ptr, G);   // padding slots of a row's last record are never fetched
+        slot = img_load<TYPE>(pf_ptr, G);   // unconditional, same instruction count every step (see the header)
+        if (pf_left > 1) {
+            --pf_left;
             pf_ptr += REC;
             if (++pf_s == spu) {
                 pf_s = 0;
                 pf_it += stride;
-                if (pf_it < end) { const int j = job_of(pf_it); pf_ptr = a.job[j].w.r2 + (size_t)(pf_it - a.job[j].pair0) * unit_bytes; }
+                pf_ptr = base + (size_t)(pf_it - g0) * unit_bytes;
             }
         }
     };
@@ -256,30 +273,46 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, int first, int stride, in
     constexpr int PRE = (sizeof(BlkImg<TYPE>) > 32 || MAXK > 16384) ? 2 : 4;
 #pragma unroll
     for (int k = 0; k < PRE; ++k) issue(ring[k]);
-    if (trace) tr[1] = clock64_dev();
+    // trace stamps are kept in registers until the loop is over (a store before it would be a pending write at its entry)
+    const unsigned long long t1 = trace ? clock64_dev() : 0ull;
+    // ---- epilogue operands of lane l = (unit l >> 1, row l & 1), requested before the loop; unconditional loads (operands a
+    //      lane does not need are read from the activation vector, which is always there) ----
+    const int pos = a.pos ? sload_i32(a.pos) : 0;
+    const int p1 = a.njobs > 1 ? a.job[1].pair0 : 0x7fffffff, p2 = a.njobs > 2 ? a.job[2].pair0 : 0x7fffffff;
+    const int e_it = first + (lane >> 1) * stride;
+    const bool e_valid = (lane >> 1) < nu;
+    const int e_j = e_it >= p2 ? 2 : (e_it >= p1 ? 1 : 0);
+    const int e_p0 = e_j == 2 ? p2 : (e_j == 1 ? p1 : 0);
+    const int e_M = e_j == 2 ? a.job[2].w.M : (e_j == 1 ? a.job[1].w.M : a.job[0].w.M);
+    const int e_epi = e_j == 2 ? a.job[2].epi : (e_j == 1 ? a.job[1].epi : a.job[0].epi);
+    const int e_u = e_it - e_p0;
+    const int e_r = a.gateup ? e_u : 2 * e_u + (lane & 1);   // output row of this lane
+    const bool e_own = e_valid && e_r < e_M;
+    const bool need_res = e_own && (e_epi == EPI_ADD || e_epi == EPI_ADD2), need_res2 = e_own && e_epi == EPI_ADD2;
+    const bool need_rope = e_own && (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K);
+    const float e_res = (need_res ? a.res : a.x)[need_res ? e_r : 0];
+    const float e_res2 = (need_res2 ? a.res2 : a.x)[need_res2 ? e_r : 0];
+    const float2 e_cs = *(const float2*)((need_rope ? a.rope_cs : a.x) +
+                                         (need_rope ? ((size_t)pos * (a.head_dim >> 1) + ((e_r % a.head_dim) >> 1)) * 2 : 0));
     pro();
-    if (trace) tr[2] = clock64_dev();
+    const unsigned long long t2 = trace ? clock64_dev() : 0ull;
 #pragma unroll
     for (int k = PRE; k < 4; ++k) issue(ring[k]);
-    // ---- consume cursor ----
-    int it = first, s = 0, par = 0, j = 0;
-    float acc = 0.0f, accm = 0.0f, res_in = 0.0f;
-    while (it < end) {
+    // ---- consume: one flat sequence of nu * spu steps ----
+    const int total = nu * spu;
+    int s = 0, ui = 0, par = 0;
+    float acc = 0.0f, accm = 0.0f;
+    // Always whole iterations of four steps (no exit in the middle: the ring then keeps its registers from iteration to
+    // iteration — with a `break` hipcc shuffles the slots at the loop head, which reads all four and so waits for all four).
+    // The up to three surplus steps at the very end re-process the last record; their results are dropped (ui >= nu).
+    for (int st = 0; st < total; st += 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (it >= end) break;
-            if (s == 0) {   // unit start: the epilogue's residual operand is requested now
-                j = job_of(it);
-                const int epi = a.job[j].epi;
-                if (epi == EPI_ADD || epi == EPI_ADD2) {
-                    const int r = 2 * (it - a.job[j].pair0) + row;
-                    if ((lane & 31) == 0 && r < a.job[j].w.M) res_in = a.res[r];
-                }
-            }
             const int b = 4 * s + cb;
             const int bc = b < nb ? b : nb - 1;
             float sv, dv, mv, pv;
             img_to_regs<TYPE>(ring[k], bc, q8w_of(bc), SM.L, G, sv, dv, mv, pv);
+            reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
             issue(ring[k]);
             WaveBuf7& W = SM.WB[wv][par];
             par ^= 1;
@@ -306,7 +339,7 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, int first, int stride, in
             if (nv > 2) { acc = fmaf(d4.z, s4.z, acc); if constexpr (mins) accm = fmaf(m4.z, p4.z, accm); }
             if (nv > 3) { acc = fmaf(d4.w, s4.w, acc); if constexpr (mins) accm = fmaf(m4.w, p4.w, accm); }
             if (s + 1 < spu) { ++s; continue; }
-            // ---- unit end: the reference's reduction tree, then the fused epilogue ----
+            // ---- unit end: the reference's reduction tree; the row results wait in LDS for the epilogue pass ----
             float res = hsum8_exact_dpp(acc);
             if constexpr (mins) {
                 if constexpr (TYPE == GT_Q4_K) {
@@ -316,67 +349,63 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, int first, int stride, in
                 accm = __shfl(accm, lane & ~7);
                 res = res + accm;
             }
-            const int u = it - a.job[j].pair0;
-            const int epi = a.job[j].epi;
-            if (a.gateup) {   // fused matrix: row 0 of the pair = gate row u, row 1 = up row u
-                const float up = lane_xor32(res);
-                if (lane == 0 && u < a.job[j].w.M) a.out[u] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * up;
-            } else {
-                const int r = 2 * u + row;
-                const bool own = (lane & 31) == 0 && r < a.job[j].w.M;
-                if (epi == EPI_ADD) {
-                    if (own) a.out[r] = res + res_in;
-                } else if (epi == EPI_STORE) {
-                    if (own) a.out[r] = res;
-                } else if (epi == EPI_V) {
-                    if (own) a.vcache[(size_t)r * a.v_stride + pos] = f32_to_f16_bits(res);
-                } else if (epi == EPI_GELU) {
-                    if (own) a.out[r] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
-                } else if (epi == EPI_ADD2) {
-                    if (own) a.out[r] = (res + res_in) + a.res2[r];
-                } else {   // EPI_ROPE_Q / EPI_ROPE_K: the pair (2u, 2u + 1) is one rotation (reference ggml.c:12536-12537, fma forms of the build)
-                    const float other = lane_xor32(res);
-                    const int ip = (r % a.head_dim) >> 1;
-                    const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
-                    const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
-                    const float o = (r & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
-                    if (own) {
-                        if (epi == EPI_ROPE_Q) a.q_f16[r] = f32_to_f16_bits(o);
-                        else a.kcache[kcache_off(pos, r, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
-                    }
-                }
-            }
-            acc = 0.0f; accm = 0.0f; res_in = 0.0f;
+            if ((lane & 31) == 0 && ui < nu) SM.RES[wv][2 * ui + row] = res;
+            ++ui;
+            acc = 0.0f; accm = 0.0f;
             s = 0;
-            it += stride;
         }
+    }
+    if (trace) { tr[1] = t1; tr[2] = t2; tr[3] = clock64_dev(); }
+    if (nu == 0) return;
+    // ---- epilogue pass: lane l finishes row (l & 1) of unit l >> 1 ----
+    wave_lds_sync();
+    const float res = SM.RES[wv][lane];
+    const float other = lane_xor1(res);   // the unit's other row (RoPE partner / up projection)
+    if (a.gateup) {   // fused matrix: row 0 of the pair = gate row u, row 1 = up row u
+        if (e_own && (lane & 1) == 0) a.out[e_r] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * other;
+        return;
+    }
+    if (!e_own) return;
+    if (e_epi == EPI_ADD) {
+        a.out[e_r] = res + e_res;
+    } else if (e_epi == EPI_STORE) {
+        a.out[e_r] = res;
+    } else if (e_epi == EPI_V) {
+        a.vcache[(size_t)e_r * a.v_stride + pos] = f32_to_f16_bits(res);
+    } else if (e_epi == EPI_GELU) {
+        a.out[e_r] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+    } else if (e_epi == EPI_ADD2) {
+        a.out[e_r] = (res + e_res) + e_res2;
+    } else {   // EPI_ROPE_Q / EPI_ROPE_K: the pair (2u, 2u + 1) is one rotation (reference ggml.c:12536-12537, fma forms of the build)
+        const float o = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
+        if (e_epi == EPI_ROPE_Q) a.q_f16[e_r] = f32_to_f16_bits(o);
+        else a.kcache[kcache_off(pos, e_r, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
     }
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: one group).  Dynamic LDS: sizeof(SmemV7<MAXK>).
-template <int MAXK, int TA, int TB, bool LN>
+template <int MAXK, int TA, int TB, bool LN, bool EMB = false>
 __global__ void __launch_bounds__(1024) matvec_v7_kernel(const MatvecArgs a) {
     CT_DYN_SMEM(smem_raw);
     SmemV7<MAXK>& SM = *reinterpret_cast<SmemV7<MAXK>*>(smem_raw);
+    ProRegs7<MAXK> P;
+    pro7_load<MAXK>(P, a.x, a.norm_w, a.K, a.pro);
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
-    if (trace) tr[0] = clock64_dev();
-    const int pos = a.pos ? *a.pos : 0;
-    ProRegs7<MAXK> P;
-    pro7_load<MAXK>(P, a.x, a.K);
+    const unsigned long long t0 = trace ? clock64_dev() : 0ull;
     auto pro = [&]() __attribute__((always_inline)) {
-        pro7_finish<MAXK, LN>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
+        pro7_finish<MAXK, LN, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
     };
     const int grid = (int)gridDim.x, bx = (int)blockIdx.x;
     if constexpr (TB != 0) {
         const int nwA = a.nwA;
-        if (wv < nwA) v7_run<TA, MAXK>(a, SM, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, G, pos, pro);
-        else v7_run<TB, MAXK>(a, SM, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, G, pos, pro);
+        if (wv < nwA) v7_run<TA, MAXK>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, G, pro);
+        else v7_run<TB, MAXK>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, G, pro);
     } else {
-        v7_run<TA, MAXK>(a, SM, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, G, pos, pro);
+        v7_run<TA, MAXK>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, G, pro);
     }
-    if (trace) tr[6] = clock64_dev();
+    if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
 }
