@@ -56,6 +56,17 @@ DEV float wave_max(float v) {
 }
 
 DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+// dot4 with a zero accumulator: hipcc lowers sdot4(a, b, 0) to `v_mov v, 0` + the VOP2 accumulate form `v_dot4c`; the VOP3P form
+// takes the constant directly — one instruction instead of two in the hottest loop of the decode mat-vec (8 per block and lane).
+#ifdef CT_EMU
+static inline int sdot4z(int a, int b) { return __builtin_amdgcn_sdot4(a, b, 0, false); }
+#else
+DEV int sdot4z(int a, int b) {
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
 // 24-bit integer multiply (full rate; v_mul_lo_u32 is quarter rate).  All products on the hot path fit: |a|,|b| < 2^23.
 #ifdef CT_EMU
 static inline int mul24(int a, int b) { return a * b; }

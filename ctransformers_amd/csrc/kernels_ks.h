@@ -38,7 +38,7 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const 
                 lo |= ((R.qh[k] >> (2 * c)) & 0x01010101u) << 4;
                 hi |= ((R.qh[k] >> (2 * c + 1)) & 0x01010101u) << 4;
             }
-            part[k] = mul24(sc_lo, sdot4((int)lo, alo[k], 0)) + mul24(sc_hi, sdot4((int)hi, ahi[k], 0));
+            part[k] = mul24(sc_lo, sdot4z((int)lo, alo[k])) + mul24(sc_hi, sdot4z((int)hi, ahi[k]));
         }
         sv = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
         int prod = mul24(m_lo, L.sb[b * 8 + 2 * c]) + mul24(m_hi, L.sb[b * 8 + 2 * c + 1]);
@@ -63,8 +63,8 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const 
         for (int k = 0; k < 4; ++k) {
             const uint32_t lo = (R.ql[k] & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_lo6) & 0x03030303u) << 4);
             const uint32_t hi = ((R.ql[k] >> 4) & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_hi6) & 0x03030303u) << 4);
-            const int dl = sdot4((int)lo, alo[k], sdot4((int)0xE0E0E0E0u, alo[k], 0));
-            const int dh = sdot4((int)hi, ahi[k], sdot4((int)0xE0E0E0E0u, ahi[k], 0));
+            const int dl = sdot4((int)lo, alo[k], sdot4z((int)0xE0E0E0E0u, alo[k]));
+            const int dh = sdot4((int)hi, ahi[k], sdot4z((int)0xE0E0E0E0u, ahi[k]));
             part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
         }
         sv = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);

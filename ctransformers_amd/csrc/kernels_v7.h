@@ -36,8 +36,8 @@
 // Q8_K image of the activation vector (kernels_exact.h ActLdsX without the 16-sums nobody reads, q8 skewed).
 template <int MAXK> struct ActLds7 {
     int q8[MAXK / 4 + MAXK / 128 + 16];
-    float yd[MAXK / 256];
-    int sb[MAXK / 32];
+    float yd[MAXK / 256 + 4];   // + the padding slots of a last record (read, never used)
+    int sb[MAXK / 32 + 32];
     double red[16];
 };
 // word offset of block b's 64 quant words: groups of four blocks are 264 words apart and blocks 2, 3 of a group are skewed
@@ -56,8 +56,11 @@ template <int MAXK> struct ProRegs7 {
 template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro) {
     const int tid = (int)threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int nblk = K >> 8;
-    // every load is unconditional (block index clamped, the activations standing in for absent norm weights): a select
-    // between "load" and "constant" makes hipcc branch around the load and wait for it on the spot
+    // Only the waves that own blocks load (for K = 4096: 4 of 16 — the others would put 100 KB of redundant requests in front
+    // of the weight stream), under ONE wave-uniform branch; inside it every load is unconditional (block index clamped,
+    // the activations standing in for absent norm weights): a per-load select between "load" and "constant" makes hipcc
+    // branch around each load and wait for it on the spot.
+    if (uniform_int(((int)threadIdx.x >> 6) * 4) >= nblk) return;
     const float* __restrict__ wsrc = pro != PRO_PLAIN ? nw : x;
 #pragma unroll
     for (int rd = 0; rd < ProRegs7<MAXK>::ROUNDS; ++rd) {
@@ -249,6 +252,7 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int 
     constexpr uint32_t REC = rec_bytes<TYPE>();
     const int nb = a.K >> 8, spu = (nb + 3) >> 2;
     const int cb = G.r & 3, row = G.r >> 2;
+    const int q8c = 64 * cb + 8 * (cb >> 1);   // q8w_of(4 * s + cb) - 264 * s
     const size_t unit_bytes = (size_t)spu * REC;
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
@@ -308,10 +312,10 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int 
     for (int st = 0; st < total; st += 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b = 4 * s + cb;
-            const int bc = b < nb ? b : nb - 1;
+            // block 4 * s + cb of the row; q8w_of(b) = 264 * s + q8c.  The padding slots of a row's last record (b >= nb) hold zero
+            // blocks and read activation words past the image (inside the LDS arrays): their operands are never used (nv below).
             float sv, dv, mv, pv;
-            img_to_regs<TYPE>(ring[k], bc, q8w_of(bc), SM.L, G, sv, dv, mv, pv);
+            img_to_regs<TYPE>(ring[k], 4 * s + cb, 264 * s + q8c, SM.L, G, sv, dv, mv, pv);
             reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
             issue(ring[k]);
             WaveBuf7& W = SM.WB[wv][par];
@@ -335,9 +339,13 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int 
             const int nv = nb - 4 * s;   // blocks of this step that exist (wave-uniform)
             acc = fmaf(d4.x, s4.x, acc);
             if constexpr (mins) accm = fmaf(m4.x, p4.x, accm);   // lanes with h == 1 carry garbage here; never read
-            if (nv > 1) { acc = fmaf(d4.y, s4.y, acc); if constexpr (mins) accm = fmaf(m4.y, p4.y, accm); }
-            if (nv > 2) { acc = fmaf(d4.z, s4.z, acc); if constexpr (mins) accm = fmaf(m4.z, p4.z, accm); }
-            if (nv > 3) { acc = fmaf(d4.w, s4.w, acc); if constexpr (mins) accm = fmaf(m4.w, p4.w, accm); }
+            if (nv > 3) {   // the common case as one scalar branch (three selects per chain otherwise)
+                acc = fmaf(d4.y, s4.y, acc); acc = fmaf(d4.z, s4.z, acc); acc = fmaf(d4.w, s4.w, acc);
+                if constexpr (mins) { accm = fmaf(m4.y, p4.y, accm); accm = fmaf(m4.z, p4.z, accm); accm = fmaf(m4.w, p4.w, accm); }
+            } else {
+                if (nv > 1) { acc = fmaf(d4.y, s4.y, acc); if constexpr (mins) accm = fmaf(m4.y, p4.y, accm); }
+                if (nv > 2) { acc = fmaf(d4.z, s4.z, acc); if constexpr (mins) accm = fmaf(m4.z, p4.z, accm); }
+            }
             if (s + 1 < spu) { ++s; continue; }
             // ---- unit end: the reference's reduction tree; the row results wait in LDS for the epilogue pass ----
             float res = hsum8_exact_dpp(acc);
