@@ -56,15 +56,36 @@ DEV float wave_max(float v) {
 }
 
 DEV int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
-// dot4 with a zero accumulator: hipcc lowers sdot4(a, b, 0) to `v_mov v, 0` + the VOP2 accumulate form `v_dot4c`; the VOP3P form
-// takes the constant directly — one instruction instead of two in the hottest loop of the decode mat-vec (8 per block and lane).
+// Eight independent dot4 with zero accumulators in ONE statement: hipcc lowers sdot4(a, b, 0) to `v_mov v, 0` + the VOP2
+// accumulate form `v_dot4c`; the VOP3P form takes the constant directly.  The trailing `s_nop 2` is part of the contract: on
+// gfx940+ a DOT result needs 3 wait states before a non-DOT VALU may read it, and hipcc pads nothing inside or right after an
+// asm statement it cannot see into (found the hard way: a lone asm dot4 feeding v_mul_i32_i24 read stale registers).
 #ifdef CT_EMU
-static inline int sdot4z(int a, int b) { return __builtin_amdgcn_sdot4(a, b, 0, false); }
+static inline void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], 0, false);
+}
+// d[i] = dot4(w[i], a[i]) + dot4(bias, a[i])   (Q6_K: bias = 0xE0E0E0E0 = -32 per byte)
+static inline void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias) {
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], __builtin_amdgcn_sdot4(bias, a[i], 0, false), false);
+}
 #else
-DEV int sdot4z(int a, int b) {
-    int r;
-    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+DEV void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
+    asm("v_dot4_i32_i8 %0, %8, %16, 0\n\tv_dot4_i32_i8 %1, %9, %17, 0\n\tv_dot4_i32_i8 %2, %10, %18, 0\n\tv_dot4_i32_i8 %3, %11, %19, 0\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, 0\n\tv_dot4_i32_i8 %5, %13, %21, 0\n\tv_dot4_i32_i8 %6, %14, %22, 0\n\tv_dot4_i32_i8 %7, %15, %23, 0\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
+          "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+}
+DEV void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias) {
+    asm("v_dot4_i32_i8 %0, %24, %16, 0\n\tv_dot4_i32_i8 %1, %24, %17, 0\n\tv_dot4_i32_i8 %2, %24, %18, 0\n\tv_dot4_i32_i8 %3, %24, %19, 0\n\t"
+        "v_dot4_i32_i8 %4, %24, %20, 0\n\tv_dot4_i32_i8 %5, %24, %21, 0\n\tv_dot4_i32_i8 %6, %24, %22, 0\n\tv_dot4_i32_i8 %7, %24, %23, 0\n\t"
+        "v_dot4_i32_i8 %0, %8, %16, %0\n\tv_dot4_i32_i8 %1, %9, %17, %1\n\tv_dot4_i32_i8 %2, %10, %18, %2\n\tv_dot4_i32_i8 %3, %11, %19, %3\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, %4\n\tv_dot4_i32_i8 %5, %13, %21, %5\n\tv_dot4_i32_i8 %6, %14, %22, %6\n\tv_dot4_i32_i8 %7, %15, %23, %7\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
+          "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bias));
 }
 #endif
 // 24-bit integer multiply (full rate; v_mul_lo_u32 is quarter rate).  All products on the hot path fit: |a|,|b| < 2^23.

@@ -29,7 +29,7 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const 
         const uint32_t hi_w = c < 2 ? R.hdr[2] : R.hdr[3];
         const uint32_t x = alignbit32(hi_w, lo_w, (uint32_t)((24 * c) & 31));
         const int sc_lo = (int)(x & 63u), sc_hi = (int)bfe32(x, 6, 6), m_lo = (int)bfe32(x, 12, 6), m_hi = (int)bfe32(x, 18, 6);
-        int part[4];
+        int w8[8], a8[8], d8[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t lo = R.qs[k] & 0x0F0F0F0Fu;
@@ -38,8 +38,13 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const 
                 lo |= ((R.qh[k] >> (2 * c)) & 0x01010101u) << 4;
                 hi |= ((R.qh[k] >> (2 * c + 1)) & 0x01010101u) << 4;
             }
-            part[k] = mul24(sc_lo, sdot4z((int)lo, alo[k])) + mul24(sc_hi, sdot4z((int)hi, ahi[k]));
+            w8[k] = (int)lo; w8[4 + k] = (int)hi;
+            a8[k] = alo[k]; a8[4 + k] = ahi[k];
         }
+        dot4x8(d8, w8, a8);
+        int part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] = mul24(sc_lo, d8[k]) + mul24(sc_hi, d8[4 + k]);
         sv = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
         int prod = mul24(m_lo, L.sb[b * 8 + 2 * c]) + mul24(m_hi, L.sb[b * 8 + 2 * c + 1]);
         if constexpr (TYPE == GT_Q5_K) {
@@ -58,15 +63,17 @@ DEV void img_to_regs(const BlkImg<TYPE>& R, int b, int q8w, const ACT& L, const 
         const uint32_t w_hi = n ? R.sc[3] : R.sc[1];
         const int sc_lo = (int)(int8_t)((w_lo >> G.sc_sh6) & 0xFF);
         const int sc_hi = (int)(int8_t)((w_hi >> G.sc_sh6) & 0xFF);
-        int part[4];
+        int w8[8], a8[8], d8[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = (R.ql[k] & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_lo6) & 0x03030303u) << 4);
-            const uint32_t hi = ((R.ql[k] >> 4) & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_hi6) & 0x03030303u) << 4);
-            const int dl = sdot4((int)lo, alo[k], sdot4z((int)0xE0E0E0E0u, alo[k]));
-            const int dh = sdot4((int)hi, ahi[k], sdot4z((int)0xE0E0E0E0u, ahi[k]));
-            part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
+            w8[k] = (int)((R.ql[k] & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_lo6) & 0x03030303u) << 4));
+            w8[4 + k] = (int)(((R.ql[k] >> 4) & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_hi6) & 0x03030303u) << 4));
+            a8[k] = alo[k]; a8[4 + k] = ahi[k];
         }
+        dot4x8_bias(d8, w8, a8, (int)0xE0E0E0E0u);   // (q6 - 32) . a = q6 . a + (-32,-32,-32,-32) . a
+        int part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] = mul24(sc_lo, d8[k]) + mul24(sc_hi, d8[4 + k]);
         sv = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
         dv = yd * f16_bits_to_f32((uint16_t)(R.d & 0xFFFF));
         mv = 0.0f;
