@@ -273,15 +273,21 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int 
             }
         }
     };
-    // records requested before the prologue: as many as fit beside its registers (the rest right after it)
-    constexpr int PRE = (sizeof(BlkImg<TYPE>) > 32 || MAXK > 16384) ? 2 : 4;
+    // Records requested before the prologue: about 32 KB per CU over the 16 waves — what the CU's memory pipeline keeps in flight.
+    // More does not start the stream earlier; it only blocks the waves in the issue of loads the pipeline cannot take yet, and
+    // with them the prologue's barriers (measured: with four records per wave the last wave reached the first barrier 2.5 us
+    // after the kernel started).
+    constexpr int PRE = sizeof(BlkImg<TYPE>) > 40 ? 1 : 2;
 #pragma unroll
     for (int k = 0; k < PRE; ++k) issue(ring[k]);
     // trace stamps are kept in registers until the loop is over (a store before it would be a pending write at its entry)
     const unsigned long long t1 = trace ? clock64_dev() : 0ull;
-    // ---- epilogue operands of lane l = (unit l >> 1, row l & 1), requested before the loop; unconditional loads (operands a
-    //      lane does not need are read from the activation vector, which is always there) ----
-    const int pos = a.pos ? sload_i32(a.pos) : 0;
+    pro();
+    const unsigned long long t2 = trace ? clock64_dev() : 0ull;
+#pragma unroll
+    for (int k = PRE; k < 4; ++k) issue(ring[k]);
+    // ---- epilogue operands of lane l = (unit l >> 1, row l & 1), requested before the loop (its body must not contain a load
+    //      besides the ring's); unconditional loads: operands a lane does not need are read from the activation vector ----
     const int p1 = a.njobs > 1 ? a.job[1].pair0 : 0x7fffffff, p2 = a.njobs > 2 ? a.job[2].pair0 : 0x7fffffff;
     const int e_it = first + (lane >> 1) * stride;
     const bool e_valid = (lane >> 1) < nu;
@@ -294,14 +300,16 @@ DEV void v7_run(const MatvecArgs& a, SmemV7<MAXK>& SM, const uint8_t* base, int 
     const bool e_own = e_valid && e_r < e_M;
     const bool need_res = e_own && (e_epi == EPI_ADD || e_epi == EPI_ADD2), need_res2 = e_own && e_epi == EPI_ADD2;
     const bool need_rope = e_own && (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K);
+    // the cursor position: only launches that write the KV cache / rotate (QKV) read it; after the barriers, so that this
+    // scalar-cache round trip holds up no other wave
+    bool need_pos = false;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) need_pos = need_pos || (jj < a.njobs && (a.job[jj].epi == EPI_ROPE_Q || a.job[jj].epi == EPI_ROPE_K || a.job[jj].epi == EPI_V));
+    const int pos = (need_pos && a.pos) ? sload_i32(a.pos) : 0;
     const float e_res = (need_res ? a.res : a.x)[need_res ? e_r : 0];
     const float e_res2 = (need_res2 ? a.res2 : a.x)[need_res2 ? e_r : 0];
     const float2 e_cs = *(const float2*)((need_rope ? a.rope_cs : a.x) +
                                          (need_rope ? ((size_t)pos * (a.head_dim >> 1) + ((e_r % a.head_dim) >> 1)) * 2 : 0));
-    pro();
-    const unsigned long long t2 = trace ? clock64_dev() : 0ull;
-#pragma unroll
-    for (int k = PRE; k < 4; ++k) issue(ring[k]);
     // ---- consume: one flat sequence of nu * spu steps ----
     const int total = nu * spu;
     int s = 0, ui = 0, par = 0;
