@@ -1,0 +1,14 @@
+# SQ counters of the decode kernels (separate rocprofv3 --pmc passes, kernel-trace only)
+cd /root/repo
+O=gpurun_out/r2b; rm -rf $O; mkdir -p $O
+export CTAMD_BENCH_MODEL=/tmp/ctamd_llama2_7b_q4km_r2.gguf
+python -c "
+from ctransformers_amd import synth
+synth.write_llama_gguf('$CTAMD_BENCH_MODEL','llama-2-7b','Q4_K_M',seed=1234)" > $O/gen.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+CT_AMD_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d /root/repo/$O/pmc1 -o p -- python /root/repo/tools/decode_loop.py --model $CTAMD_BENCH_MODEL --prompt 8 --decode 6 > /root/repo/$O/pmc1.log 2>&1
+CT_AMD_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD --output-format csv -d /root/repo/$O/pmc2 -o p -- python /root/repo/tools/decode_loop.py --model $CTAMD_BENCH_MODEL --prompt 8 --decode 6 > /root/repo/$O/pmc2.log 2>&1
+cd /root/repo
+for d in pmc1 pmc2; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); echo "== $d $f"; python tools/pmc_sq.py $f matvec_v7 ; done 2>&1 | tee $O/sq.txt
+find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete
+tail -3 $O/pmc1.log $O/pmc2.log
