@@ -68,3 +68,4 @@ def test_v7_off_switch(emu_lib, monkeypatch):
     m.eval(list(g["prompt"]))
     assert v7_launches(m._lib) == n0
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+
