@@ -9,13 +9,22 @@ steps, bracketed by barrier + device synchronisation, MAX over ranks.
 Workload = BASELINE.json configs[1]: Llama-2-7B GGUF Q4_K_M (synthetic weights at the real shapes / tensor-type mix),
 all layers on the GPU(s), 128-token prefill + 256-token decode, context 512.
 
+N > 1 (north_star: whole layers spread over the GPUs of the node, activations handed from GPU to GPU): the product path is the
+in-process pipeline of the library (ctransformers_amd/csrc/pipeline.cc, CT_AMD_DEVICES): ONE process drives a stage per GPU,
+hand-off by hipMemcpyPeerAsync over xGMI.  `python bench.py --gpus N` therefore brings the N stages up itself.  When the
+driver launches N ranks with torch.distributed.run, rank 0 drives the N stages and the other ranks take part in the barriers
+and the MAX reduction only (backend gloo: they own no GPU work); where a rank cannot see N devices the one-process-per-GPU
+RCCL pipeline of ctransformers_amd/pipeline.py runs instead.  Decode of one sequence is serial over the stages (strong
+scaling: the model is fixed), so the roofline denominator stays ONE GPU's HBM.
+
 Extra objects on the JSON line:
-  roofline      dominant kernel (the K=4096 weight mat-vec launch: QKV / Wo / gate+up / lm_head sites) —
+  roofline      dominant kernel (the K=4096 weight mat-vec launches: QKV / Wo / gate+up / lm_head sites) —
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
   prefill       the 128-token prompt through the prompt-chunk kernels (third pass = steady state; the cold first pass beside it)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,42 +39,75 @@ from ctransformers_amd import measure, synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
-MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km.gguf")
-SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), "Q4_K_M"
+MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
+SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), os.environ.get("CTAMD_BENCH_FTYPE", "Q4_K_M")
+GEN_VERSION = "synth-r2:%s:%s:seed1234" % (SHAPE, FTYPE)
 
 
-def ensure_model(rank):
-    if rank == 0 and not os.path.exists(MODEL):
-        tmp = MODEL + ".tmp%d" % os.getpid()
+def _fingerprint(path):
+    """Size + SHA-256 of the first and last MiB (header, tensor table, tail of the data): cheap, and it changes with the shape, the
+    tensor-type mix and the generator."""
+    h = hashlib.sha256()
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        h.update(f.read(1 << 20))
+        if size > (2 << 20):
+            f.seek(size - (1 << 20))
+            h.update(f.read(1 << 20))
+    return dict(size=size, sha256_head_tail=h.hexdigest(), generator=GEN_VERSION)
+
+
+def ensure_model():
+    """The synthetic model file lives outside the repo (4 GB).  A file found at MODEL is accepted only with its stamp (written
+    next to it by the run that generated it: size, head/tail hash, generator version); anything else is regenerated.
+    Returns True when a cached file was reused."""
+    stamp = MODEL + ".stamp.json"
+    if os.path.exists(MODEL) and os.path.exists(stamp):
+        try:
+            if json.load(open(stamp)) == _fingerprint(MODEL):
+                return True
+        except (OSError, ValueError):
+            pass
+    tmp = MODEL + ".tmp%d" % os.getpid()
+    if SHAPE.startswith("falcon"):
+        synth.write_falcon_gguf(tmp, SHAPE, FTYPE, seed=1234)
+    else:
         synth.write_llama_gguf(tmp, SHAPE, FTYPE, seed=1234)
-        os.replace(tmp, MODEL)
+    os.replace(tmp, MODEL)
+    json.dump(_fingerprint(MODEL), open(stamp, "w"))
+    return False
 
 
 def cpu_baseline(n_vocab):
-    """The reference CPU build on this box's host cores, bounded sample (16-token prefill + 24 greedy decode steps).
-    When oracle/_ref did not travel with the snapshot, the scalar C restatement (oracle/mirror.c) is timed instead on a
-    smaller sample and reported as kind "port"."""
+    """BASELINE.md §3 on a bounded sample: the reference CPU build on this box's host cores — 128-token prefill with
+    batch_size=128, then 24 greedy decode steps (median), once with every core and once with the library default (threads=-1 ->
+    cores / 2, models/llm.h:129-130).  The headline `value` is the all-cores decode rate.  When oracle/_ref did not travel with the
+    snapshot, the scalar C restatement (oracle/mirror.c) is timed instead on a smaller sample and reported as kind "port"."""
     from oracle import mirror, ref
+    cores = os.cpu_count() or 1
     if ref.available():
-        threads = min(16, os.cpu_count() or 1)
-        r = ref.open_llm(MODEL, context_length=N_CTX, batch_size=16, threads=threads)
-        t0 = time.perf_counter()
-        r.eval(synth.prompt_tokens(16, n_vocab))     # includes the first touch of the mmap'ed weights (page cache warm from the GPU load)
-        t_first = time.perf_counter() - t0
-        r._context = []
-        t0 = time.perf_counter()
-        r.eval(synth.prompt_tokens(16, n_vocab))     # the same 16-token batch again: the reference's prompt rate
-        t_prefill = time.perf_counter() - t0
-        ts = []
-        for _ in range(24):
-            tok = r.sample(top_k=1, repetition_penalty=1.0)
+        def run(threads):
+            r = ref.open_llm(MODEL, context_length=N_CTX, batch_size=N_PROMPT, threads=threads)
+            prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
+            r.eval(prompt[:8])                       # throw-away: first touch of the mmap'ed weights
+            r._context = []
             t0 = time.perf_counter()
-            r.eval([tok])
-            ts.append(time.perf_counter() - t0)
-        return dict(value=round(1.0 / float(np.median(ts)), 3), unit="tokens/s", cores=threads, kind="reference",
-                    prefill_tok_s=round(16.0 / min(t_first, t_prefill), 2),
-                    sample="reference AVX2 build (oracle/_ref), threads=%d, same synthetic 7B file, 16-token prefill (one batch, "
-                           "best of two: prefill_tok_s) then 24 greedy decode steps, median step time" % threads)
+            r.eval(prompt)
+            t_prefill = time.perf_counter() - t0
+            ts = []
+            for _ in range(24):
+                tok = r.sample(top_k=1, repetition_penalty=1.0)
+                t0 = time.perf_counter()
+                r.eval([tok])
+                ts.append(time.perf_counter() - t0)
+            return round(1.0 / float(np.median(ts)), 3), round(N_PROMPT / t_prefill, 2)
+        dec_all, pre_all = run(cores)
+        dec_def, pre_def = run(-1)
+        return dict(value=dec_all, unit="tokens/s", cores=cores, kind="reference", prefill_tok_s=pre_all,
+                    default_threads=dict(threads=max(1, cores // 2), value=dec_def, prefill_tok_s=pre_def),
+                    sample="reference AVX2 build (oracle/_ref: gcc -O3 -mavx2 -mfma -mf16c, the reference's own CT_INSTRUCTIONS=avx2 "
+                           "flags), same synthetic file, host has %d cores: 128-token prefill (batch_size=128) then 24 greedy decode "
+                           "steps, median step time; threads=%d (value) and the library default threads=-1" % (cores, cores))
     if not mirror.available():
         return None
     o = mirror.MirrorLlama(MODEL, N_CTX)
@@ -74,7 +116,31 @@ def cpu_baseline(n_vocab):
     o.eval([int(np.argmax(lg))], 2)
     dt = time.perf_counter() - t0
     return dict(value=round(1.0 / dt, 4), unit="tokens/s", cores=1, kind="port",
-                sample="scalar C restatement (oracle/mirror.c), 1 thread, same synthetic 7B file, 2-token prefill then ONE decode step")
+                sample="scalar C restatement (oracle/mirror.c), 1 thread, same synthetic file, 2-token prefill then ONE decode step")
+
+
+def stage_ranges(llm):
+    import ctypes
+    L = llm._lib
+    L.ctamd_n_stages.restype, L.ctamd_n_stages.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    L.ctamd_stage_range.restype = ctypes.c_int
+    L.ctamd_stage_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    out = []
+    for s in range(L.ctamd_n_stages(llm._llm)):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        if L.ctamd_stage_range(llm._llm, s, ctypes.byref(a), ctypes.byref(b)) == 0:
+            out.append([a.value, b.value])
+    return L.ctamd_n_stages(llm._llm), out
+
+
+def visible_gpus():
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
 
 
 def main():
@@ -86,14 +152,37 @@ def main():
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 or world > 1 or os.environ.get("CTAMD_FORCE_PIPELINE") == "1":   # the env switch lets a 1-GPU box run the N > 1 code path with world_size 1
-        from ctransformers_amd import pipeline
-        return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
+    n_gpus = max(1, a.gpus)
+    devices = os.environ.get("CTAMD_BENCH_DEVICES", str(n_gpus) if n_gpus > 1 else "")   # e.g. "0,0": two stages on one GPU (1-GPU box)
+    group = None
+    if world > 1:
+        if os.environ.get("CTAMD_FORCE_RCCL_PIPELINE") == "1" or (n_gpus > 1 and not os.environ.get("CTAMD_BENCH_DEVICES") and visible_gpus() < n_gpus):
+            from ctransformers_amd import pipeline   # one process per GPU, RCCL point-to-point hand-off
+            return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        group = dist
 
-    ensure_model(rank)
+    def barrier():
+        if group is not None:
+            group.barrier()
+
+    if rank != 0:   # rank 0 drives every stage (in-process pipeline); the others only keep the contract's barriers
+        for _ in range(5):
+            barrier()
+        group.destroy_process_group()
+        return 0
+
+    cached = ensure_model()
+    barrier()
+    if devices:
+        os.environ["CT_AMD_DEVICES"] = devices
     t0 = time.perf_counter()
     llm = LLM(MODEL, config=Config(context_length=N_CTX, batch_size=N_PROMPT, gpu_layers=1000))
     load_s = time.perf_counter() - t0
+    n_stages, ranges = stage_ranges(llm)
     n_vocab = llm.vocab_size
     prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
     # prefill (timed separately; reported, not the headline value): once cold (first use of every kernel: code-object load,
@@ -112,26 +201,32 @@ def main():
         llm.eval([tok])
         tok = llm.sample(top_k=1, repetition_penalty=1.0)
     steps = min(a.steps, N_CTX - N_PROMPT - a.warmup - 1)
-    # llm.eval() returns only after the library synchronised its stream and copied the logits to the host, so the
+    # llm.eval() returns only after the library synchronised its stream(s) and copied the logits to the host, so the
     # wall clock below brackets exactly `steps` complete decode steps (device sync on both sides).
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         llm.eval([tok])
         tok = llm.sample(top_k=1, repetition_penalty=1.0)
     dt = time.perf_counter() - t0
+    barrier()
     tok_s = steps / dt
 
     sites = measure.profile_sites(llm._lib, llm._llm, 8)
     roof = measure.roofline(sites)
     wbytes = synth.weight_bytes_per_token(MODEL)
     kv_avg = 2 * 32 * (N_PROMPT + a.warmup + steps / 2.0) * 4096 * 2 if SHAPE == "llama-2-7b" else 0
-    out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=1, steps=steps, warmup=a.warmup,
-               ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int8",
-               data="synthetic",
-               config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on 1xMI355X, 128-tok prefill + 256-tok greedy decode, ctx 512",
-                           shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism="1 GPU"),
+    par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hipMemcpyPeerAsync hand-off)" % n_stages
+    out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,
+               ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
+               dtype="int8", data="synthetic",
+               config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + 256-tok greedy decode, ctx 512" % n_gpus
+                           if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "%s %s, %d x MI355X, 128-tok prefill + greedy decode, ctx 512" % (SHAPE, FTYPE, n_gpus),
+                           shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
+                           devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
-               token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4)),
+               token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4),
+                                   note="one sequence: the stages of a pipeline are serial, the denominator is ONE GPU's HBM"),
                roofline=roof)
     # prompt chunks: 2 ops per weight of the 2-D matrices per token, against the dense int8 MFMA
     # floor of the guide; the bound is VALU issue (the exact f32 chain step per block, AVX lane, row and token), not MFMA
@@ -140,11 +235,16 @@ def main():
                           kernel="matvec_pfm_kernel<TYPE,TOK,GU> (int8 MFMA, exact), one hipGraph per chunk shape",
                           int8_tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_peak_tops=3944,
                           bound="valu")
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and n_gpus == 1:
         del llm
         out["cpu_baseline"] = cpu_baseline(n_vocab)
+    barrier()
     print(json.dumps(out), flush=True)
+    barrier()
+    if group is not None:
+        group.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

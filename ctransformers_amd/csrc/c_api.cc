@@ -10,9 +10,14 @@
 #include <vector>
 
 #include "engine.h"
+#include "pipeline.h"
 
+// A handle = a pipeline of one or more stages (pipeline.h; one stage = the plain single-GPU engine).  `engine` is the stage that
+// answers for the model as a whole: hyper-parameters, vocabulary (stage 0) — logits and embeddings come from the last stage.
 struct ctransformers_llm {
-    ctamd::Engine engine;
+    ctamd::Pipeline pipe;
+    ctamd::Engine& engine() { return pipe.first(); }
+    ctamd::Engine& tail() { return pipe.last(); }
     std::string arch;
     std::string piece;  // storage behind ctransformers_llm_detokenize
 };
@@ -42,42 +47,44 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     }
     ctransformers_llm* llm = new ctransformers_llm;
     std::string err;
-    const bool ok = gguf ? llm->engine.load(model_path, config.context_length, config.gpu_layers, err)
-                         : llm->engine.load_gpt2(model_path, err);
+    // CT_AMD_DEVICES ("4" or "0,1,2,3"): the GPUs whose HBM the layers are spread over, as one in-process pipeline (the Config
+    // struct of the ABI cannot grow; gpu_layers keeps its meaning "offload": every layer lives on a GPU here).
+    const bool ok = gguf ? llm->pipe.load(model_path, config.context_length, config.gpu_layers, ctamd::parse_devices(getenv("CT_AMD_DEVICES")), err)
+                         : llm->pipe.load_gpt2(model_path, err);
     if (!ok) {
         fprintf(stderr, "ctransformers_amd: failed to load '%s': %s\n", model_path, err.c_str());
         delete llm;
         return nullptr;
     }
     if (!gguf) { llm->arch = ""; return llm; }   // legacy models report an empty architecture string (models/llm.h:113)
-    llm->arch = llm->engine.hparams().arch;
+    llm->arch = llm->engine().hparams().arch;
     return llm;
 }
 
 void ctransformers_llm_delete(ctransformers_llm* llm) { delete llm; }
 
 int ctransformers_llm_tokenize(ctransformers_llm* llm, const char* text, bool add_bos_token, int* output) {
-    const std::vector<int> t = llm->engine.vocab().tokenize(text, add_bos_token);
+    const std::vector<int> t = llm->engine().vocab().tokenize(text, add_bos_token);
     std::copy(t.begin(), t.end(), output);
     return (int)t.size();
 }
 
 const char* ctransformers_llm_detokenize(ctransformers_llm* llm, int token) {
-    llm->piece = llm->engine.vocab().piece(token);
+    llm->piece = llm->engine().vocab().piece(token);
     return llm->piece.c_str();
 }
 
-bool ctransformers_llm_is_eos_token(ctransformers_llm* llm, int token) { return token == llm->engine.vocab().eos_id; }
-int ctransformers_llm_eos_token_id(ctransformers_llm* llm) { return llm->engine.vocab().eos_id; }
-int ctransformers_llm_bos_token_id(ctransformers_llm* llm) { return llm->engine.vocab().bos_id; }
-int ctransformers_llm_vocab_size(ctransformers_llm* llm) { return llm->engine.hparams().n_vocab; }
-int ctransformers_llm_context_length(ctransformers_llm* llm) { return llm->engine.n_ctx(); }
+bool ctransformers_llm_is_eos_token(ctransformers_llm* llm, int token) { return token == llm->engine().vocab().eos_id; }
+int ctransformers_llm_eos_token_id(ctransformers_llm* llm) { return llm->engine().vocab().eos_id; }
+int ctransformers_llm_bos_token_id(ctransformers_llm* llm) { return llm->engine().vocab().bos_id; }
+int ctransformers_llm_vocab_size(ctransformers_llm* llm) { return llm->engine().hparams().n_vocab; }
+int ctransformers_llm_context_length(ctransformers_llm* llm) { return llm->engine().n_ctx(); }
 const char* ctransformers_llm_architecture(ctransformers_llm* llm) { return llm->arch.c_str(); }
 
 bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, int batch_size,
                                   int threads) {
     (void)threads;
-    const int n_ctx = llm->engine.n_ctx();
+    const int n_ctx = llm->engine().n_ctx();
     batch_size = std::min(n_ctx, batch_size);
     if (batch_size <= 0) return n_tokens <= 0;
     // The reference evaluates batch after batch (models/llm.h:40-54).  Where the prompt-chunk kernels apply, the whole request
@@ -85,9 +92,9 @@ bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int
     // dot product, which the attention kernel derives per token from the batch size (kernels_exact.h), so the result is
     // bit-identical to the batch-by-batch evaluation while the weights are passed over once per 128 tokens instead of
     // once per batch (the reference's default batch is 8).  Requests that run into the context clamp keep the loop.
-    if (n_tokens > batch_size && n_past >= 0 && n_past + n_tokens <= n_ctx && llm->engine.coalesces_batches()) {
+    if (n_tokens > batch_size && n_past >= 0 && n_past + n_tokens <= n_ctx && llm->pipe.coalesces_batches()) {
         std::string err;
-        if (!llm->engine.eval(tokens, n_tokens, n_past, err, batch_size)) {
+        if (!llm->pipe.eval(tokens, n_tokens, n_past, err, batch_size)) {
             fprintf(stderr, "ctransformers_amd: eval failed: %s\n", err.c_str());
             return false;
         }
@@ -97,7 +104,7 @@ bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int
         const int n = std::min(batch_size, n_tokens - start);
         const int past = std::min(n_ctx - n, n_past);  // reference models/llm.h:126
         std::string err;
-        if (!llm->engine.eval(tokens + start, n, past, err)) {
+        if (!llm->pipe.eval(tokens + start, n, past, err)) {
             fprintf(stderr, "ctransformers_amd: eval failed: %s\n", err.c_str());
             return false;
         }
@@ -106,18 +113,18 @@ bool ctransformers_llm_batch_eval(ctransformers_llm* llm, const int* tokens, int
     return true;
 }
 
-float* ctransformers_llm_logits_data(ctransformers_llm* llm) { return llm->engine.logits(); }
-int ctransformers_llm_logits_size(ctransformers_llm* llm) { return llm->engine.logits_size(); }
-const float* ctransformers_llm_embeddings_data(ctransformers_llm* llm) { return llm->engine.embeddings(); }
-int ctransformers_llm_embeddings_size(ctransformers_llm* llm) { return llm->engine.embeddings_size(); }
+float* ctransformers_llm_logits_data(ctransformers_llm* llm) { return llm->tail().logits(); }
+int ctransformers_llm_logits_size(ctransformers_llm* llm) { return llm->tail().logits_size(); }
+const float* ctransformers_llm_embeddings_data(ctransformers_llm* llm) { return llm->tail().embeddings(); }
+int ctransformers_llm_embeddings_size(ctransformers_llm* llm) { return llm->tail().embeddings_size(); }
 
 int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int n_last, int top_k, float top_p,
                              float temperature, float repetition_penalty, int seed) {
-    if (llm->engine.logits_size() == 0) return llm->engine.vocab().eos_id;
-    if (llm->engine.vocab().type == ctamd::VOCAB_GPT)
-        return ctamd::sample_token_gpt(llm->engine.logits(), llm->engine.hparams().n_vocab, last_tokens, n_last, top_k, top_p,
+    if (llm->tail().logits_size() == 0) return llm->engine().vocab().eos_id;
+    if (llm->engine().vocab().type == ctamd::VOCAB_GPT)
+        return ctamd::sample_token_gpt(llm->tail().logits(), llm->engine().hparams().n_vocab, last_tokens, n_last, top_k, top_p,
                                        temperature, repetition_penalty, seed);
-    return ctamd::sample_token(llm->engine.logits(), llm->engine.hparams().n_vocab, last_tokens, n_last, top_k, top_p,
+    return ctamd::sample_token(llm->tail().logits(), llm->engine().hparams().n_vocab, last_tokens, n_last, top_k, top_p,
                                temperature, repetition_penalty, seed);
 }
 
@@ -127,7 +134,7 @@ void ctransformers_llm_reset(ctransformers_llm* llm) { (void)llm; }
 int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* out, int max_out) {
     std::vector<ctamd::Engine::LaunchStat> st;
     std::string err;
-    if (!llm->engine.profile_decode(iters, st, err)) {
+    if (!llm->engine().profile_decode(iters, st, err)) {
         fprintf(stderr, "ctransformers_amd: profile failed: %s\n", err.c_str());
         return -1;
     }
@@ -147,20 +154,20 @@ ctransformers_llm* ctamd_stage_create(const char* model_path, int context_length
     if (!model_path) return nullptr;
     ctransformers_llm* llm = new ctransformers_llm;
     std::string err;
-    if (!llm->engine.load(model_path, context_length, 1000, err, layer_begin, layer_end, device)) {
+    if (!llm->pipe.load_stage(model_path, context_length, layer_begin, layer_end, device, err)) {
         fprintf(stderr, "ctransformers_amd: failed to load stage [%d,%d) of '%s': %s\n", layer_begin, layer_end, model_path,
                 err.c_str());
         delete llm;
         return nullptr;
     }
-    llm->arch = llm->engine.hparams().arch;
+    llm->arch = llm->engine().hparams().arch;
     return llm;
 }
 
 int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
                      void* x_out_dev) {
     std::string err;
-    if (!llm->engine.eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err)) {
+    if (!llm->engine().eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err)) {
         fprintf(stderr, "ctransformers_amd: stage eval failed: %s\n", err.c_str());
         return -1;
     }
@@ -170,22 +177,29 @@ int ctamd_stage_eval(ctransformers_llm* llm, const int* tokens, int n_tokens, in
 int ctamd_stage_eval_batched(ctransformers_llm* llm, const int* tokens, int n_tokens, int n_past, const void* x_in_dev,
                              void* x_out_dev, int batch) {
     std::string err;
-    if (!llm->engine.eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err, batch)) {
+    if (!llm->engine().eval_stage(tokens, n_tokens, n_past, (const float*)x_in_dev, (float*)x_out_dev, err, batch)) {
         fprintf(stderr, "ctransformers_amd: stage eval failed: %s\n", err.c_str());
         return -1;
     }
     return 0;
 }
 
-int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine.hparams().n_layer; }
-int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine.hparams().n_embd; }
-long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine.chunk_tokens(); }
+int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine().hparams().n_layer; }
+int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine().hparams().n_embd; }
+long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine().chunk_tokens(); }
 long long ctamd_v7_launches(void) { return ctamd::v7_launches(); }
+int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
+int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {
+    if (stage < 0 || stage >= llm->pipe.n_stages() || llm->pipe.ranges().empty()) return -1;
+    *layer_begin = llm->pipe.ranges()[stage].first;
+    *layer_end = llm->pipe.ranges()[stage].second;
+    return 0;
+}
 
-double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine.weight_bytes(); }
+double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine().weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
     std::string err;
-    if (!llm->engine.trace_site(site, out, n, err)) { fprintf(stderr, "ctransformers_amd: trace failed: %s\n", err.c_str()); return -1; }
+    if (!llm->engine().trace_site(site, out, n, err)) { fprintf(stderr, "ctransformers_amd: trace failed: %s\n", err.c_str()); return -1; }
     return 0;
 }
 

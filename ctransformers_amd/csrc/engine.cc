@@ -1548,56 +1548,84 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int ba
     return eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch);
 }
 
-bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err, int batch) {
-    if (n <= 0) return true;
+bool Engine::req_begin(const int* tokens, int n, int n_past, int batch, std::string& err) {
+    if (n <= 0) { err = "empty request"; return false; }
     if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
-    if (l0_ > 0 && !x_in_dev) { err = "stage with layer_begin > 0 needs x_in"; return false; }
-    if (l1_ < hp_.n_layer && !x_out_dev) { err = "stage with layer_end < n_layer needs x_out"; return false; }
+    if (l0_ == 0 && !tokens) { err = "first stage needs token ids"; return false; }
     HIP_OK(hipSetDevice(device_));
     for (int i = 0; i < n; ++i) {
         const int tk = (l0_ == 0 && tokens) ? tokens[i] : 0;
         if (tk < 0 || tk >= hp_.n_vocab) { err = "token id out of range"; return false; }
         h_scalars_[4 + i] = tk;
     }
-    if (l0_ == 0 && !tokens) { err = "first stage needs token ids"; return false; }
-    const size_t xbytes = (size_t)n * hp_.n_embd * sizeof(float);
-    if (l0_ > 0) HIP_OK(hipMemcpyAsync(xio_, x_in_dev, xbytes, hipMemcpyDeviceToDevice, stream_));
     h_scalars_[0] = 0;           // step
-    h_scalars_[1] = n_past;      // position of the first token of this chunk
+    h_scalars_[1] = n_past;      // position of the first token of this request
     h_scalars_[2] = n_past + n;  // end of the eval; with [3] the attention kernels derive the reference batch each token belongs to
     h_scalars_[3] = batch > 0 && batch < n ? batch : 0;   // 0: the reference runs these n tokens as ONE batch
     if (env_int("CT_AMD_DBG_ONE_BATCH", 0)) h_scalars_[3] = 0;   // tests of the tests: ignore the batch structure on purpose
     HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
-    int done = 0;
-    if (pf_ok_ && n >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights
+    req_n_ = n;
+    return true;
+}
+
+bool Engine::req_range(int c0, int nt, bool last_of_request, std::string& err) {
+    if (nt <= 0) return true;
+    if (c0 < 0 || c0 + nt > req_n_) { err = "range outside the request"; return false; }
+    HIP_OK(hipSetDevice(device_));
+    const int n = c0 + nt;
+    int done = c0;
+    if (pf_ok_ && nt >= pf_min_ && !dump_dir_) {   // prompt chunks: kPfChunk tokens per pass over the weights
         while (n - done >= pf_min_) {
-            const int nt = std::min(pf_chunk_, n - done);
-            if (!run_chunk(done, nt, done + nt == n, err)) return false;
-            done += nt;
-            chunk_tokens_ += nt;
+            const int k = std::min(pf_chunk_, n - done);
+            if (!run_chunk(done, k, last_of_request && done + k == n, err)) return false;
+            done += k;
+            chunk_tokens_ += k;
         }
     }
 #ifndef CT_EMU
     if (use_graph_) {
         if (done < n && !ensure_graphs(err)) return false;
-        for (int i = done; i < n; ++i) HIP_OK(hipGraphLaunch(i == n - 1 ? graph_step_head_ : graph_step_, stream_));
+        for (int i = done; i < n; ++i) HIP_OK(hipGraphLaunch(last_of_request && i == n - 1 ? graph_step_head_ : graph_step_, stream_));
     } else
 #endif
     {
         for (int i = done; i < n; ++i)
-            if (!token_step(i == n - 1, err)) return false;
+            if (!token_step(last_of_request && i == n - 1, err)) return false;
     }
-    if (l1_ == hp_.n_layer) {
-        HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost, stream_));
-    } else {
-        HIP_OK(hipMemcpyAsync(x_out_dev, xio_, xbytes, hipMemcpyDeviceToDevice, stream_));
-    }
+    return true;
+}
+
+bool Engine::req_logits(std::string& err) {
+    if (l1_ != hp_.n_layer) { err = "logits live on the last stage"; return false; }
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost, stream_));
+    return true;
+}
+
+bool Engine::req_wait(int n, int n_past, std::string& err) {
+    HIP_OK(hipSetDevice(device_));
     HIP_OK(hipStreamSynchronize(stream_));
     HIP_OK(hipGetLastError());
     have_logits_ = l1_ == hp_.n_layer;
     last_token_ = h_scalars_[4 + n - 1];
     last_pos_ = n_past + n - 1;
     return true;
+}
+
+bool Engine::eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err, int batch) {
+    if (n <= 0) return true;
+    if (l0_ > 0 && !x_in_dev) { err = "stage with layer_begin > 0 needs x_in"; return false; }
+    if (l1_ < hp_.n_layer && !x_out_dev) { err = "stage with layer_end < n_layer needs x_out"; return false; }
+    if (!req_begin(tokens, n, n_past, batch, err)) return false;
+    const size_t xbytes = (size_t)n * hp_.n_embd * sizeof(float);
+    if (l0_ > 0) HIP_OK(hipMemcpyAsync(xio_, x_in_dev, xbytes, hipMemcpyDeviceToDevice, stream_));
+    if (!req_range(0, n, true, err)) return false;
+    if (l1_ == hp_.n_layer) {
+        if (!req_logits(err)) return false;
+    } else {
+        HIP_OK(hipMemcpyAsync(x_out_dev, xio_, xbytes, hipMemcpyDeviceToDevice, stream_));
+    }
+    return req_wait(n, n_past, err);
 }
 
 void Engine::prof_begin(const char* site, const char* kernel, double bytes) {

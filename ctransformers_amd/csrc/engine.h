@@ -64,6 +64,19 @@ class Engine {
     // Stage form: x_in_dev / x_out_dev are DEVICE pointers to [n][n_embd] f32 residual-stream rows (the hand-off between
     // pipeline stages).  x_in_dev is required iff layer_begin > 0, x_out_dev iff layer_end < n_layer.
     bool eval_stage(const int* tokens, int n, int n_past, const float* x_in_dev, float* x_out_dev, std::string& err, int batch = 0);
+    // The same evaluation in pieces, all asynchronous on this stage's stream — what the in-process pipeline (pipeline.cc) drives:
+    //   req_begin   cursor + token ids of a whole request -> device (stage 0 uses the ids, every stage the cursor)
+    //   req_range   tokens [c0, c0 + nt) of the request through this stage's layers; the rows come from / go to xio() rows
+    //               [c0, c0 + nt) (ranges must be submitted in order: the device cursor advances with them)
+    //   req_logits  (last stage) logits + final-norm embedding of the request's last token -> pinned host buffers
+    //   req_wait    drain the stream; marks the logits valid
+    bool req_begin(const int* tokens, int n, int n_past, int batch, std::string& err);
+    bool req_range(int c0, int nt, bool last_of_request, std::string& err);
+    bool req_logits(std::string& err);
+    bool req_wait(int n, int n_past, std::string& err);
+    float* xio() { return xio_; }
+    hipStream_t stream() { return stream_; }
+    int device() const { return device_; }
     int layer_begin() const { return l0_; }
     int layer_end() const { return l1_; }
     bool has_head() const { return l1_ == hp_.n_layer; }
@@ -163,6 +176,7 @@ class Engine {
 #endif
     bool have_logits_ = false;
     int last_token_ = -1, last_pos_ = -1;
+    int req_n_ = 0;           // tokens of the request in flight (req_begin)
     struct ProfRec { const char* site; const char* kernel; double bytes; void* e0; void* e1; };
     std::vector<ProfRec>* prof_ = nullptr;
     void prof_begin(const char* site, const char* kernel, double bytes);

@@ -1,0 +1,187 @@
+#include "pipeline.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "gguf_reader.h"
+
+namespace ctamd {
+
+std::vector<std::pair<int, int>> partition_layers(const std::vector<double>& layer_bytes, double head_bytes, int n_stages) {
+    const int L = (int)layer_bytes.size();
+    std::vector<std::pair<int, int>> out;
+    if (n_stages < 1 || L < n_stages) return out;
+    double total = head_bytes;
+    for (double b : layer_bytes) total += b;
+    int begin = 0;
+    double acc = 0.0;
+    for (int s = 0; s < n_stages; ++s) {
+        int end;
+        if (s == n_stages - 1) {
+            end = L;
+        } else {
+            const double target = (total - acc) / (n_stages - s);   // what each remaining stage should stream
+            double got = 0.0;
+            end = begin;
+            while (end < L - (n_stages - 1 - s) && (end == begin || fabs(got + layer_bytes[end] - target) <= fabs(got - target))) got += layer_bytes[end++];
+            acc += got;
+        }
+        out.emplace_back(begin, end);
+        begin = end;
+    }
+    return out;
+}
+
+std::vector<int> parse_devices(const char* spec) {
+    std::vector<int> d;
+    if (!spec || !*spec) return {0};
+    std::string s(spec);
+    if (s.find(',') == std::string::npos) {
+        const int n = atoi(s.c_str());
+        for (int i = 0; i < std::max(1, n); ++i) d.push_back(i);
+        return d;
+    }
+    size_t p = 0;
+    while (p <= s.size()) {
+        const size_t q = s.find(',', p);
+        const std::string tok = s.substr(p, q == std::string::npos ? std::string::npos : q - p);
+        if (!tok.empty()) d.push_back(atoi(tok.c_str()));
+        if (q == std::string::npos) break;
+        p = q + 1;
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
+Pipeline::~Pipeline() {
+    for (size_t s = 0; s < ev_.size(); ++s) {
+        if (s < dev_.size()) (void)hipSetDevice(dev_[s]);
+        for (hipEvent_t e : ev_[s]) (void)hipEventDestroy(e);
+    }
+}
+
+bool Pipeline::load_gpt2(const std::string& path, std::string& err) {
+    st_.clear();
+    st_.emplace_back(new Engine());
+    dev_ = {0};
+    ranges_.clear();
+    return st_[0]->load_gpt2(path, err);
+}
+
+bool Pipeline::load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err) {
+    st_.clear();
+    st_.emplace_back(new Engine());
+    dev_ = {device};
+    ranges_.clear();
+    return st_[0]->load(path, context_length, 1000, err, layer_begin, layer_end, device);
+}
+
+bool Pipeline::load(const std::string& path, int context_length, int gpu_layers, const std::vector<int>& devices, std::string& err) {
+    st_.clear();
+    dev_ = devices.empty() ? std::vector<int>{0} : devices;
+    if (dev_.size() == 1) {
+        st_.emplace_back(new Engine());
+        ranges_.clear();
+        return st_[0]->load(path, context_length, gpu_layers, err, -1, -1, dev_[0]);
+    }
+    // per-layer bytes from the tensor table of the file (nothing is uploaded here)
+    std::vector<double> layer_bytes;
+    double head_bytes = 0.0;
+    {
+        GgufFile f;
+        if (!f.open(path)) { err = f.error(); return false; }
+        std::string arch;
+        uint32_t nl = 0;
+        if (!f.get_str("general.architecture", arch) || !f.get_u32(arch + ".block_count", nl) || nl == 0) { err = "block_count missing"; return false; }
+        layer_bytes.assign(nl, 0.0);
+        for (const GgufTensor& t : f.tensors()) {
+            if (t.name.compare(0, 4, "blk.") == 0) {
+                const int i = atoi(t.name.c_str() + 4);
+                if (i >= 0 && i < (int)nl) layer_bytes[i] += (double)t.nbytes;
+            } else if (t.name == "output.weight") {
+                head_bytes += (double)t.nbytes;
+            }
+        }
+    }
+    if ((int)layer_bytes.size() < (int)dev_.size()) { err = "more pipeline stages than layers"; return false; }
+    ranges_ = partition_layers(layer_bytes, head_bytes, (int)dev_.size());
+    if (ranges_.size() != dev_.size()) { err = "layer partitioning failed"; return false; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
+        return false;
+    }
+    for (int d : dev_)
+        if (d < 0 || d >= ndev) { err = "CT_AMD_DEVICES names device " + std::to_string(d) + " but " + std::to_string(ndev) + " are visible"; return false; }
+    for (size_t s = 0; s < dev_.size(); ++s) {
+        st_.emplace_back(new Engine());
+        if (!st_[s]->load(path, context_length, gpu_layers, err, ranges_[s].first, ranges_[s].second, dev_[s])) {
+            err = "stage " + std::to_string(s) + " (layers " + std::to_string(ranges_[s].first) + ".." + std::to_string(ranges_[s].second) + " on device " +
+                  std::to_string(dev_[s]) + "): " + err;
+            return false;
+        }
+    }
+    for (size_t s = 0; s + 1 < dev_.size(); ++s) {   // direct peer copies where the link allows them (hipMemcpyPeerAsync works either way)
+        if (dev_[s] == dev_[s + 1]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) == hipSuccess && can) {
+            (void)hipSetDevice(dev_[s]);
+            (void)hipDeviceEnablePeerAccess(dev_[s + 1], 0);
+            (void)hipGetLastError();   // "already enabled" is fine
+        }
+    }
+    ev_.assign(dev_.size(), {});
+    const char* mb = getenv("CT_AMD_PP_MB");
+    if (mb && atoi(mb) > 0) micro_batch_ = atoi(mb);
+    return true;
+}
+
+#define PIPE_OK(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            err = std::string(#expr) + " failed: " + hipGetErrorString(e_);                                 \
+            return false;                                                                                    \
+        }                                                                                                    \
+    } while (0)
+
+bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
+    if (st_.size() == 1) return st_[0]->eval(tokens, n, n_past, err, batch);
+    if (n <= 0) return true;
+    const int S = (int)st_.size(), E = st_[0]->hparams().n_embd;
+    for (int s = 0; s < S; ++s)
+        if (!st_[s]->req_begin(tokens, n, n_past, batch, err)) return false;
+    // micro-batches: every stage gets its ranges in order; stage s + 1's stream waits for the event behind stage s's copy
+    const int mb = n == 1 ? 1 : std::max(2, micro_batch_);
+    const int n_mb = (n + mb - 1) / mb;
+    for (int s = 0; s + 1 < S; ++s) {
+        PIPE_OK(hipSetDevice(dev_[s]));
+        while ((int)ev_[s].size() < n_mb) {
+            hipEvent_t e;
+            PIPE_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_[s].push_back(e);
+        }
+    }
+    for (int k = 0; k < n_mb; ++k) {
+        const int c0 = k * mb, nt = std::min(mb, n - c0);
+        const bool last_mb = k == n_mb - 1;
+        for (int s = 0; s < S; ++s) {
+            Engine& st = *st_[s];
+            PIPE_OK(hipSetDevice(dev_[s]));
+            if (s > 0) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));
+            if (!st.req_range(c0, nt, last_mb, err)) return false;
+            if (s + 1 < S) {
+                const size_t off = (size_t)c0 * E;
+                PIPE_OK(hipMemcpyPeerAsync(st_[s + 1]->xio() + off, dev_[s + 1], st.xio() + off, dev_[s], (size_t)nt * E * sizeof(float), st.stream()));
+                PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
+            }
+        }
+    }
+    if (!st_[S - 1]->req_logits(err)) return false;
+    for (int s = S - 1; s >= 0; --s)   // the last stage's stream drains last in time: wait for it first, the others are then idle
+        if (!st_[s]->req_wait(n, n_past, err)) return false;
+    return true;
+}
+
+}  // namespace ctamd

@@ -1,0 +1,49 @@
+// In-process layer pipeline over the GPUs of one node: what `ctransformers_llm_create` builds when
+// CT_AMD_DEVICES names more than one device.  One Engine stage per device, each owning a contiguous block of layers (weights +
+// that block's KV cache resident on its GPU; token embedding on stage 0, final norm + lm_head on the last stage).  The only
+// exchange is the [n_tokens][n_embd] f32 residual stream from stage s to stage s + 1: a peer copy over the direct xGMI link
+// (hipMemcpyPeerAsync) on the producer's stream, ordered for the consumer by an event — no host round trip, no collective, no
+// torch.  A prompt is cut into micro-batches so that stage s works on micro-batch c while stage s - 1 already works on c + 1;
+// results do not depend on the cut (the cursor carries the reference's batch structure, c_api.cc).
+// What the reference does instead: `gpu_layers` / `tensor_split` split tensors inside one process with peer copies per mat-mul
+// (reference models/ggml/llama.cpp:1913-1919, :1938-2070; ggml-cuda.cu:5798-6119).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ctamd {
+
+// Contiguous layer ranges, one per stage, balancing the per-token HBM bytes (`layer_bytes[i]`; the last stage also streams
+// `head_bytes`).  Pure host logic (tested without a GPU).
+std::vector<std::pair<int, int>> partition_layers(const std::vector<double>& layer_bytes, double head_bytes, int n_stages);
+
+// "4" -> {0,1,2,3}; "0,2" -> {0,2}; "0,0" -> two stages on device 0 (the 1-GPU test form).  Empty / unset -> {0}.
+std::vector<int> parse_devices(const char* spec);
+
+class Pipeline {
+   public:
+    // One stage per entry of `devices`.  A single entry is the plain single-GPU engine (no pipeline machinery on its path).
+    bool load(const std::string& path, int context_length, int gpu_layers, const std::vector<int>& devices, std::string& err);
+    bool load_gpt2(const std::string& path, std::string& err);
+    // one explicit stage (ctamd_stage_create: the multi-process pipeline of ctransformers_amd/pipeline.py drives it from outside)
+    bool load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err);
+    bool eval(const int* tokens, int n, int n_past, std::string& err, int batch = 0);
+    bool coalesces_batches() const { return st_.front()->coalesces_batches() || st_.size() > 1; }
+    Engine& first() { return *st_.front(); }
+    Engine& last() { return *st_.back(); }
+    int n_stages() const { return (int)st_.size(); }
+    const std::vector<std::pair<int, int>>& ranges() const { return ranges_; }
+    ~Pipeline();
+
+   private:
+    std::vector<std::unique_ptr<Engine>> st_;
+    std::vector<int> dev_;
+    std::vector<std::pair<int, int>> ranges_;
+    std::vector<std::vector<hipEvent_t>> ev_;   // ev_[s][k]: micro-batch k's rows have left stage s
+    int micro_batch_ = 32;
+};
+
+}  // namespace ctamd

@@ -2,9 +2,10 @@
 (ctamd_profile_decode, include/ctransformers_amd_ext.h) folded into the `roofline` object of the bench JSON line."""
 import ctypes
 
+PMC_FILE = "r02_v7_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 MATVEC_SITES = ("qkv", "wo", "gate_up", "lm_head")  # the K=4096 instantiation of the dominant kernel
-KERNEL = "matvec_v6_kernel<4096,1,T,NBUF,TA,TB,GU> (QKV, Wo, gate+up, lm_head launch sites; `down` is the <12288,3,2,3,...> instantiation)"
+KERNEL = "matvec_v7_kernel<16384,TA,TB,LN> at K = 4096 (QKV, Wo, gate+up, lm_head launch sites; `down` is the same kernel at K = 11008)"
 
 
 class LaunchStat(ctypes.Structure):
@@ -26,7 +27,7 @@ def pmc_traffic():
     `rocprofv3 --pmc FETCH_SIZE` run as the guide prescribes: it cannot share a pass with the timing run)."""
     import json
     import os
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_v6_pmc_traffic.json")
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", PMC_FILE)
     try:
         return int(json.load(open(p))["dominant_kernel"]["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
@@ -55,7 +56,9 @@ def roofline(sites, traffic="pmc"):
                                                us=round(s["ms"] * 1e3 / s["launches"], 2)) for s in lst}
 
     return dict(bound="hbm", kernel=KERNEL, achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                frac=round(ach / HBM_PEAK, 4), traffic=traffic, bytes_per_launch=round(b / nl),
+                frac=round(ach / HBM_PEAK, 4), traffic=traffic,
+                traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of an earlier run of the same kernel (x2 gfx950 correction), not measured in this run" % PMC_FILE if traffic else None,
+                bytes_per_launch=round(b / nl),
                 us_per_launch=round(ms * 1e3 / nl, 2),
                 timing="HIP events on the library stream around the back-to-back launches of all layers of a site" if sweep
                 else "HIP events around single eager launches",

@@ -72,7 +72,7 @@ typedef struct { double t; } *hipEvent_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("CT_EMU_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
@@ -85,6 +85,14 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 template <class P> static inline hipError_t hipMalloc(P** p, size_t n) { return hipMalloc((void**)p, n); }

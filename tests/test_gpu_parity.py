@@ -321,3 +321,52 @@ def test_batch_structure_matters(ref, tmp_path, monkeypatch):
     m = open_hip(p, context_length=128, batch_size=8)
     m.eval(toks)
     assert not np.array_equal(r.logits.to_numpy(), m.logits.to_numpy())
+
+
+def _stage_count(m):
+    import ctypes
+    f = m._lib.ctamd_n_stages
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny-q4km", "falcon-tiny-q4km"])
+def test_inprocess_pipeline_on_gpu(name, monkeypatch):
+    """The in-process pipeline of the library (csrc/pipeline.cc) on hardware: CT_AMD_DEVICES=0,0 puts two stages on the one GPU of
+    the test box — their own streams, the peer-copy hand-off and the event ordering are the N-GPU code path.  Goldens of the
+    reference build: prompt (reference batches 8 + 3, micro-batches of 4), greedy steps."""
+    monkeypatch.setenv("CT_AMD_DEVICES", "0,0")
+    monkeypatch.setenv("CT_AMD_PP_MB", "4")
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_hip(os.path.join(GOLDEN, name + ".gguf"))
+    assert _stage_count(m) == 2
+    m.eval(list(g["prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    for i, t in enumerate(g["greedy"]):
+        assert m.sample(top_k=1, repetition_penalty=1.0) == int(t)
+        m.eval([int(t)])
+        assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
+
+
+@pytest.mark.gpu
+def test_inprocess_pipeline_7b_widths_vs_reference(ref, tmp_path, monkeypatch):
+    """Two real-width 7B layers, one per stage: 40-token prompt in reference batches of 8 (micro-batches of 16) + greedy steps against
+    the reference build on the same file."""
+    monkeypatch.setenv("CT_AMD_DEVICES", "0,0")
+    monkeypatch.setenv("CT_AMD_PP_MB", "16")
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-7b-2l", "Q4_K_M", seed=5)
+    cfg = dict(context_length=128, batch_size=8, threads=8)
+    m = open_hip(p, **cfg)
+    r = ref.open_llm(p, **cfg)
+    toks = synth.prompt_tokens(40, hp["n_vocab"])
+    m.eval(toks)
+    r.eval(toks)
+    for _ in range(4):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b)
+        t = int(a.argmax())
+        m.eval([t])
+        r.eval([t])

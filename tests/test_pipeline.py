@@ -167,3 +167,66 @@ def test_gloo_pipeline_world3_middle_rank(emu_lib, tmp_path, mirror):
         pos += 1
     assert recs[2]["tokens"] == want
     assert np.array_equal(np.load(tmp_path / "logits.npy"), lg)
+
+
+# ---- the in-process pipeline behind ctransformers_llm_create (csrc/pipeline.cc): CT_AMD_DEVICES names the stages ---------------
+
+def _stages(m):
+    import ctypes
+    L = m._lib
+    L.ctamd_n_stages.restype, L.ctamd_n_stages.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    L.ctamd_stage_range.restype = ctypes.c_int
+    L.ctamd_stage_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    n = L.ctamd_n_stages(m._llm)
+    out = []
+    for s in range(n):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        if L.ctamd_stage_range(m._llm, s, ctypes.byref(a), ctypes.byref(b)) == 0:
+            out.append((a.value, b.value))
+    return n, out
+
+
+@pytest.mark.parametrize("name,devices", [("tiny-q4km", "2"), ("falcon-tiny-q4km", "0,1"), ("tiny-q5km", "2")])
+def test_inprocess_pipeline_equals_reference(emu_lib, monkeypatch, name, devices):
+    """`AutoModelForCausalLM`-style use, nothing but the C ABI: the handle spans two (emulated) devices, one stage each; logits,
+    embeddings and greedy tokens equal the reference build's goldens — prompt in reference batches of 8 (micro-batched through the
+    stages), then token by token; KV rollback across the stages."""
+    from conftest import GOLDEN
+    from ctransformers_amd.llm import LLM, Config
+    monkeypatch.setenv("CT_EMU_DEVICES", "2")
+    monkeypatch.setenv("CT_AMD_DEVICES", devices)
+    monkeypatch.setenv("CT_AMD_PP_MB", "4")   # several micro-batches inside the 11-token prompt (reference batches: 8 + 3)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    n, ranges = _stages(m)
+    assert n == 2 and ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 2
+    m.eval(list(g["prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    for i in range(2):
+        t = m.sample(top_k=1, repetition_penalty=1.0)
+        assert t == int(g["greedy"][i])
+        m.eval([t])
+        assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1])
+    # roll the context back by 3 tokens and re-evaluate them: same logits (every stage overwrites its own KV rows)
+    keep, redo = m._context[:-3], m._context[-3:]
+    m._context = list(keep)
+    m.eval(redo)
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][2])
+
+
+def test_inprocess_pipeline_long_prompt_batches(emu_lib, monkeypatch):
+    """More stages than layers is refused; two stages with micro-batches of 16 reproduce the reference's batch-by-batch result for
+    the 45-token prompt (reference batch size 8)."""
+    from conftest import GOLDEN
+    from ctransformers_amd.llm import LLM, Config
+    monkeypatch.setenv("CT_EMU_DEVICES", "3")
+    monkeypatch.setenv("CT_AMD_DEVICES", "3")
+    with pytest.raises(Exception):
+        LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    monkeypatch.setenv("CT_AMD_DEVICES", "2")
+    monkeypatch.setenv("CT_AMD_PP_MB", "16")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
