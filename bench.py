@@ -78,36 +78,63 @@ def ensure_model():
     return False
 
 
+def _cpu_worker(threads, n_vocab):
+    """One reference-build run (child process of cpu_baseline): prints {"decode": tok/s, "prefill": tok/s}."""
+    from oracle import ref
+    r = ref.open_llm(MODEL, context_length=N_CTX, batch_size=N_PROMPT, threads=threads)
+    prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
+    r.eval(prompt[:8])                       # throw-away: first touch of the mmap'ed weights
+    r._context = []
+    t0 = time.perf_counter()
+    r.eval(prompt)
+    t_prefill = time.perf_counter() - t0
+    ts = []
+    for _ in range(24):
+        tok = r.sample(top_k=1, repetition_penalty=1.0)
+        t0 = time.perf_counter()
+        r.eval([tok])
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps(dict(decode=round(1.0 / float(np.median(ts)), 3), prefill=round(N_PROMPT / t_prefill, 2))), flush=True)
+
+
 def cpu_baseline(n_vocab):
     """BASELINE.md §3 on a bounded sample: the reference CPU build on this box's host cores — 128-token prefill with
-    batch_size=128, then 24 greedy decode steps (median), once with every core and once with the library default (threads=-1 ->
-    cores / 2, models/llm.h:129-130).  The headline `value` is the all-cores decode rate.  When oracle/_ref did not travel with the
-    snapshot, the scalar C restatement (oracle/mirror.c) is timed instead on a smaller sample and reported as kind "port"."""
+    batch_size=128, then 24 greedy decode steps (median), with every core and with the library default (threads=-1 -> cores / 2,
+    models/llm.h:129-130).  Each run is a child process with a time limit: ggml's spinning thread pool can take minutes with
+    hundreds of threads on a many-core host, and this must stay a bounded sample — a run that does not finish is retried with
+    fewer threads and reported as such.  The headline `value` is the best decode rate found (its thread count in `threads`).
+    When oracle/_ref did not travel with the snapshot, the scalar C restatement (oracle/mirror.c) is timed instead on a smaller
+    sample and reported as kind "port"."""
+    import subprocess
     from oracle import mirror, ref
     cores = os.cpu_count() or 1
     if ref.available():
-        def run(threads):
-            r = ref.open_llm(MODEL, context_length=N_CTX, batch_size=N_PROMPT, threads=threads)
-            prompt = synth.prompt_tokens(N_PROMPT, n_vocab)
-            r.eval(prompt[:8])                       # throw-away: first touch of the mmap'ed weights
-            r._context = []
-            t0 = time.perf_counter()
-            r.eval(prompt)
-            t_prefill = time.perf_counter() - t0
-            ts = []
-            for _ in range(24):
-                tok = r.sample(top_k=1, repetition_penalty=1.0)
-                t0 = time.perf_counter()
-                r.eval([tok])
-                ts.append(time.perf_counter() - t0)
-            return round(1.0 / float(np.median(ts)), 3), round(N_PROMPT / t_prefill, 2)
-        dec_all, pre_all = run(cores)
-        dec_def, pre_def = run(-1)
-        return dict(value=dec_all, unit="tokens/s", cores=cores, kind="reference", prefill_tok_s=pre_all,
-                    default_threads=dict(threads=max(1, cores // 2), value=dec_def, prefill_tok_s=pre_def),
-                    sample="reference AVX2 build (oracle/_ref: gcc -O3 -mavx2 -mfma -mf16c, the reference's own CT_INSTRUCTIONS=avx2 "
-                           "flags), same synthetic file, host has %d cores: 128-token prefill (batch_size=128) then 24 greedy decode "
-                           "steps, median step time; threads=%d (value) and the library default threads=-1" % (cores, cores))
+        def run(threads, limit=75):
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), "--cpu-vocab", str(n_vocab)],
+                                   capture_output=True, text=True, timeout=limit)
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                return json.loads(lines[-1]) if lines else None
+            except subprocess.TimeoutExpired:
+                return None
+        tried, best = [], None
+        for t in [cores] + [c for c in (64, 32, 16) if c < cores]:
+            r = run(t)
+            tried.append(dict(threads=t, decode_tok_s=r["decode"] if r else None, prefill_tok_s=r["prefill"] if r else None,
+                              note=None if r else "did not finish within the 75 s limit"))
+            if r and (best is None or r["decode"] > best[1]["decode"]):
+                best = (t, r)
+            if r and len([x for x in tried if x["decode_tok_s"]]) >= 2:
+                break
+        rd = run(-1) if tried[0]["decode_tok_s"] else None
+        if best is None:
+            return dict(value=None, unit="tokens/s", cores=cores, kind="reference", runs=tried, sample="no reference run finished within its limit")
+        return dict(value=best[1]["decode"], unit="tokens/s", cores=cores, threads=best[0], kind="reference", prefill_tok_s=best[1]["prefill"],
+                    runs=tried, default_threads=dict(threads=max(1, cores // 2), value=rd["decode"] if rd else None,
+                                                     prefill_tok_s=rd["prefill"] if rd else None),
+                    sample="reference AVX2 build (oracle/_ref: gcc -O3 -mavx2 -mfma -mf16c, the reference's own CT_INSTRUCTIONS=avx2 flags), same "
+                           "synthetic file, host has %d cores: 128-token prefill (batch_size=128) then 24 greedy decode steps, median step "
+                           "time; value = threads=%d, the best of the thread counts in `runs`" % (cores, best[0]))
     if not mirror.available():
         return None
     o = mirror.MirrorLlama(MODEL, N_CTX)
@@ -149,7 +176,12 @@ def main():
     ap.add_argument("--steps", type=int, default=N_DECODE)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_worker is not None:
+        _cpu_worker(a.cpu_worker, a.cpu_vocab)
+        return 0
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = max(1, a.gpus)
