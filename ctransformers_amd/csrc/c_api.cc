@@ -45,7 +45,9 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
         fprintf(stderr, "Model type '%s' is not supported.\n", model_type);
         return nullptr;
     }
-    ctransformers_llm* llm = new ctransformers_llm;
+    ctransformers_llm* llm = nullptr;
+    try {   // nothing may propagate across the C boundary: a malformed file makes create return NULL (as the reference does)
+    llm = new ctransformers_llm;
     std::string err;
     // CT_AMD_DEVICES ("4" or "0,1,2,3"): the GPUs whose HBM the layers are spread over, as one in-process pipeline (the Config
     // struct of the ABI cannot grow; gpu_layers keeps its meaning "offload": every layer lives on a GPU here).
@@ -59,6 +61,11 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     if (!gguf) { llm->arch = ""; return llm; }   // legacy models report an empty architecture string (models/llm.h:113)
     llm->arch = llm->engine().hparams().arch;
     return llm;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "ctransformers_amd: failed to load '%s': %s\n", model_path, e.what());
+        delete llm;
+        return nullptr;
+    }
 }
 
 void ctransformers_llm_delete(ctransformers_llm* llm) { delete llm; }
@@ -128,7 +135,9 @@ int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int
                                temperature, repetition_penalty, seed);
 }
 
-void ctransformers_llm_reset(ctransformers_llm* llm) { (void)llm; }
+// Reference Reset() (models/llm.h:106) clears the logits of LEGACY models only: logits_size() is 0 and sample() returns EOS until the
+// next eval; GGUF models keep theirs.
+void ctransformers_llm_reset(ctransformers_llm* llm) { llm->tail().reset(); }
 
 // ---- measurement extensions (include/ctransformers_amd_ext.h); not part of the reference ABI ----------------------
 int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* out, int max_out) {

@@ -34,6 +34,7 @@ static int env_int(const char* name, int dflt) {
 Engine::~Engine() { free_all(); }
 
 void Engine::free_all() {
+    if (stream_ || !dev_allocs_.empty()) (void)hipSetDevice(device_);
     for (void* p : dev_allocs_) (void)hipFree(p);
     dev_allocs_.clear();
     if (h_logits_) (void)hipHostFree(h_logits_);   // h_emb_ lives in the same pinned block
@@ -204,7 +205,13 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         return true;
     }
     {   // Q8_0 / Q4_0
-        if (m.K % 128) { err = "tensor " + t->name + ": Q8_0/Q4_0 rows must be a multiple of 128 elements"; return false; }
+        // the 32-block kernels (kernels_q32.h) take rows in groups of four blocks and at most 12288 elements: real Falcon-7B
+        // (n_embd 4544) and the ffn_down rows of Llama-13B/70B Q4_0/Q8_0 files (13824, 28672) are outside that — said here, at
+        // load, not by a failing launch later
+        if (m.K % 128 || m.K > 12288) {
+            err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 128, at most 12288)";
+            return false;
+        }
         m.layout = LAYOUT_G4;
         const bool q8 = t->type == GT_Q8_0;
         const int n_tiles = (M + 7) / 8, ng = nb / 4, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512;
@@ -308,6 +315,11 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         return false;
     hp_.n_head_kv = hp_.n_head;
     if (f.get_u32(a + "attention.head_count_kv", u)) hp_.n_head_kv = (int)u;
+    if (hp_.n_embd <= 0 || hp_.n_head <= 0 || hp_.n_head_kv <= 0 || hp_.n_layer <= 0 || hp_.n_ff <= 0 || hp_.n_embd % hp_.n_head != 0 ||
+        hp_.n_head % hp_.n_head_kv != 0) {
+        err = "inconsistent hyper-parameters (embedding_length / head_count / head_count_kv / block_count / feed_forward_length)";
+        return false;
+    }
     hp_.n_rot = hp_.n_embd / hp_.n_head;
     if (f.get_u32(a + "rope.dimension_count", u)) hp_.n_rot = (int)u;
     if (hp_.falcon()) {
@@ -574,9 +586,27 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
 // ---------------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------------
-static int chip_cus() {
-    static const int n_cu = [] { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); return n > 0 ? n : 256; }();
-    return n_cu;
+// Dynamic-LDS opt-in of a kernel (more than 64 KB per workgroup), once per kernel AND device: the attribute belongs to the code
+// object loaded on the current device, and the in-process pipeline (pipeline.cc) launches the same kernels on several devices.
+static int current_device() {
+    int d = 0;
+#ifndef CT_EMU
+    (void)hipGetDevice(&d);
+#endif
+    return d >= 0 && d < 16 ? d : 0;
+}
+#define CT_OPTIN_ONCE(fn, bytes) \
+    do { static bool done_[16] = {}; const int dv_ = current_device(); if (!done_[dv_]) { done_[dv_] = true; (void)CT_SMEM_OPTIN(fn, bytes); } } while (0)
+
+static int chip_cus() {   // CUs of the current device (cached per device)
+    static int n_cu[16] = {};
+    const int d = current_device();
+    if (n_cu[d] == 0) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+        n_cu[d] = n > 0 ? n : 256;
+    }
+    return n_cu[d];
 }
 
 // Generation 7 (kernels_v7.h): every job a K-quant matrix with a LAYOUT_R2C4 copy (gate/up: ONE job, the fused matrix).
@@ -648,8 +678,8 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
             auto kfn = matvec_v7_kernel<16384, TAV, 0, false, true>; \
             auto kfl = matvec_v7_kernel<16384, TAV, 0, true, true>; \
             constexpr size_t smem = sizeof(SmemV7<16384>); \
-            static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem) && CT_SMEM_OPTIN(kfl, smem); }(); \
-            (void)once; \
+            CT_OPTIN_ONCE(kfn, smem); \
+            CT_OPTIN_ONCE(kfl, smem); \
             if (ln) CT_LAUNCH_DYN(kfl, grid, block, smem, s, a); else CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
         if (ta == GT_Q4_K) V7E(GT_Q4_K); else if (ta == GT_Q5_K) V7E(GT_Q5_K); else V7E(GT_Q6_K);
 #undef V7E
@@ -658,8 +688,7 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
 #define V7L(MK, TAV, TBV, LNV) do { \
         auto kfn = matvec_v7_kernel<MK, TAV, TBV, LNV>; \
         constexpr size_t smem = sizeof(SmemV7<MK>); \
-        static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
-        (void)once; \
+        CT_OPTIN_ONCE(kfn, smem); \
         CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
 #define V7T(MK, TAV) do { \
         if (ln) V7L(MK, TAV, 0, true); \
@@ -779,8 +808,7 @@ static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err, bool u
 #define V6L(MK, SS, TT, NB, TAV, TBV, GUV, LNV) do { \
         auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, TBV, GUV, LNV>; \
         constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
-        static bool once = [&] { return CT_SMEM_OPTIN(kfn, smem); }(); \
-        (void)once; \
+        CT_OPTIN_ONCE(kfn, smem); \
         CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
 #define V6T(MK, SS, TT, NB, TAV) do { \
         if (a.gateup) V6L(MK, SS, TT, NB, TAV, 0, true, false); \
@@ -907,13 +935,11 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         const size_t smem = (size_t)kPfTokens * aw32 * 4;
         if (m.gateup) {
             auto kfn = matvec_pf_kernel<kPfTokens, true, true>;
-            static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4); }();
-            (void)once;
+            CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
         } else {
             auto kfn = matvec_pf_kernel<kPfTokens, false, true>;
-            static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4); }();
-            (void)once;
+            CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
         }
         prof_end();
@@ -955,8 +981,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             const size_t smem = (size_t)tok * aw * 4;
 #define PFM(TYV, TOKV, GUV) do { \
                 auto kfn = matvec_pfm_kernel<TYV, TOKV, GUV>; \
-                static bool once = [&] { return CT_SMEM_OPTIN(kfn, 160 * 1024); }(); \
-                (void)once; \
+                CT_OPTIN_ONCE(kfn, 160 * 1024); \
                 CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
 #define PFM_T(TYV) do { if (tok == 16) { if (m.gateup) PFM(TYV, 16, true); else PFM(TYV, 16, false); } \
                         else if (tok == 8) { if (m.gateup) PFM(TYV, 8, true); else PFM(TYV, 8, false); } \
@@ -972,13 +997,11 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             const size_t smem = (size_t)kPfTokens * aw * 4;
             if (m.gateup) {
                 auto kfn = matvec_pf_kernel<kPfTokens, true>;
-                static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
-                (void)once;
+                CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4);
                 CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
             } else {
                 auto kfn = matvec_pf_kernel<kPfTokens, false>;
-                static bool once = [&] { return CT_SMEM_OPTIN(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4); }();
-                (void)once;
+                CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4);
                 CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
             }
         }
@@ -1649,6 +1672,7 @@ void Engine::prof_end() {
 
 bool Engine::trace_site(const char* site, unsigned long long* out, int n, std::string& err) {
 #ifndef CT_EMU
+    HIP_OK(hipSetDevice(device_));
     if (last_pos_ < 0) { err = "nothing evaluated yet"; return false; }
     h_scalars_[0] = 0; h_scalars_[1] = last_pos_; h_scalars_[2] = last_pos_ + 1; h_scalars_[4] = last_token_;
     HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], 4, hipMemcpyHostToDevice, stream_));
@@ -1668,6 +1692,7 @@ bool Engine::trace_site(const char* site, unsigned long long* out, int n, std::s
 bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string& err) {
     out.clear();
 #ifndef CT_EMU
+    HIP_OK(hipSetDevice(device_));
     if (last_pos_ < 0) { err = "profile_decode: nothing evaluated yet"; return false; }
     std::vector<ProfRec> recs;
     for (int it = 0; it < iters; ++it) {

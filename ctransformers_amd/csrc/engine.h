@@ -84,6 +84,7 @@ class Engine {
     const HParams& hparams() const { return hp_; }
     const Vocab& vocab() const { return vocab_; }
     int n_ctx() const { return n_ctx_; }
+    void reset() { if (hp_.gpt2()) have_logits_ = false; }   // reference models/llm.h:106: legacy models forget their logits
     float* logits() { return h_logits_; }
     int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
     const float* embeddings() const { return h_emb_; }

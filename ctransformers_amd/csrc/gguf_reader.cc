@@ -16,9 +16,10 @@ struct Cursor {
     const uint8_t* end;
     bool ok = true;
     bool v1 = false;
+    size_t left() const { return (size_t)(end - p); }   // sizes are compared against this, never by pointer addition (which can wrap)
     template <class T> T get() {
         T v{};
-        if (p + sizeof(T) > end) { ok = false; return v; }
+        if (sizeof(T) > left()) { ok = false; return v; }
         memcpy(&v, p, sizeof(T));
         p += sizeof(T);
         return v;
@@ -26,7 +27,7 @@ struct Cursor {
     uint64_t len() { return v1 ? (uint64_t)get<uint32_t>() : get<uint64_t>(); }
     std::string str() {
         const uint64_t n = len();
-        if (!ok || p + n > end) { ok = false; return std::string(); }
+        if (!ok || n > left()) { ok = false; return std::string(); }
         std::string s((const char*)p, (size_t)n);
         p += n;
         return s;
@@ -65,6 +66,8 @@ bool GgufFile::open(const std::string& path) {
     c.v1 = version_ == 1;
     const uint64_t n_tensors = c.len();
     const uint64_t n_kv = c.len();
+    // every tensor entry / key-value pair takes at least a length field: counts beyond the file size are corrupt headers
+    if (!c.ok || n_tensors > size_ / 8 || n_kv > size_ / 8) return fail("corrupt header (tensor / key counts exceed the file size)");
     for (uint64_t i = 0; i < n_kv && c.ok; ++i) {
         std::string key = c.str();
         GgufValue v;
@@ -85,6 +88,7 @@ bool GgufFile::open(const std::string& path) {
             case GV_ARR: {
                 v.elem_type = c.get<uint32_t>();
                 v.n = c.len();
+                if (!c.ok || v.n > c.left()) return fail("corrupt array length for key " + key);
                 if (v.elem_type == GV_STR) {
                     v.strs.reserve((size_t)v.n);
                     for (uint64_t k = 0; k < v.n && c.ok; ++k) v.strs.push_back(c.str());
@@ -92,7 +96,7 @@ bool GgufFile::open(const std::string& path) {
                     const size_t es = scalar_size(v.elem_type);
                     if (es == 0) return fail("bad array element type for key " + key);
                     v.arr = c.p;
-                    if (c.p + es * v.n > c.end) return fail("truncated array " + key);
+                    if (v.n > c.left() / es) return fail("truncated array " + key);
                     c.p += es * v.n;
                 }
                 break;
@@ -108,21 +112,32 @@ bool GgufFile::open(const std::string& path) {
         t.name = c.str();
         t.n_dims = (int)c.get<uint32_t>();
         if (t.n_dims < 1 || t.n_dims > 4) return fail("bad n_dims for tensor " + t.name);
-        for (int d = 0; d < t.n_dims; ++d) t.ne[d] = (int64_t)c.len();
+        size_t n_rows = 1;
+        for (int d = 0; d < t.n_dims; ++d) {
+            const uint64_t ne = c.len();
+            if (ne == 0 || ne > (1ull << 40)) return fail("bad dimension in tensor " + t.name);
+            t.ne[d] = (int64_t)ne;
+            if (d > 0) {
+                if (n_rows > size_ / (size_t)ne + 1) return fail("tensor larger than the file: " + t.name);
+                n_rows *= (size_t)ne;
+            }
+        }
         t.type = (int)c.get<uint32_t>();
         t.offset = c.get<uint64_t>();
         if (ggml_block_elems(t.type) == 0) return fail("unsupported tensor type in " + t.name);
         if (t.ne[0] % ggml_block_elems(t.type) != 0) return fail("row length not a multiple of the block size: " + t.name);
-        t.nbytes = ggml_row_bytes(t.type, t.ne[0]) * (size_t)(t.ne[1] * t.ne[2] * t.ne[3]);
+        if (ggml_row_bytes(t.type, t.ne[0]) != 0 && n_rows > size_ / ggml_row_bytes(t.type, t.ne[0]) + 1) return fail("tensor larger than the file: " + t.name);
+        t.nbytes = ggml_row_bytes(t.type, t.ne[0]) * n_rows;
         tindex_[t.name] = (size_t)i;
     }
     if (!c.ok) return fail("truncated tensor table");
     uint32_t align = 32;
     get_u32("general.alignment", align);
+    if (align == 0 || (align & (align - 1)) != 0) return fail("general.alignment must be a power of two");
     size_t base = (size_t)(c.p - map_);
     base = (base + align - 1) / align * align;
     for (auto& t : tensors_) {
-        if (base + t.offset + t.nbytes > size_) return fail("tensor data out of file bounds: " + t.name);
+        if (base > size_ || t.offset > size_ - base || t.nbytes > size_ - base - t.offset) return fail("tensor data out of file bounds: " + t.name);
         t.data = map_ + base + t.offset;
     }
     return true;
@@ -174,11 +189,11 @@ bool LegacyGgmlFile::open(const std::string& path) {
     for (int i = 0; i < 6; ++i) hparams[i] = c.get<int32_t>();
     hparams[5] %= 1000;   // GGML_QNT_VERSION_FACTOR (gpt2.cc:88-90)
     const int32_t nv = c.get<int32_t>();
-    if (!c.ok || nv != hparams[0] || nv <= 0) return fail("bad vocabulary size");
+    if (!c.ok || nv != hparams[0] || nv <= 0 || (size_t)nv > size_ / 4) return fail("bad vocabulary size");
     vocab.reserve((size_t)nv);
     for (int i = 0; i < nv; ++i) {
         const uint32_t len = c.get<uint32_t>();
-        if (!c.ok || c.p + len > c.end) return fail("truncated vocabulary");
+        if (!c.ok || len > c.left()) return fail("truncated vocabulary");
         vocab.emplace_back((const char*)c.p, (size_t)len);
         c.p += len;
     }
@@ -189,14 +204,18 @@ bool LegacyGgmlFile::open(const std::string& path) {
         t.type = c.get<int32_t>();
         if (!c.ok || t.n_dims < 1 || t.n_dims > 4 || name_len < 0) return fail("corrupt tensor header");
         int64_t n_el = 1;
-        for (int i = 0; i < t.n_dims; ++i) { t.ne[i] = c.get<int32_t>(); n_el *= t.ne[i]; }
-        if (!c.ok || c.p + name_len > c.end) return fail("corrupt tensor name");
+        for (int i = 0; i < t.n_dims; ++i) {
+            t.ne[i] = c.get<int32_t>();
+            if (!c.ok || t.ne[i] <= 0 || n_el > (int64_t)size_ * 8 / t.ne[i] + 1) return fail("corrupt tensor dimensions");
+            n_el *= t.ne[i];
+        }
+        if (!c.ok || (size_t)name_len > c.left()) return fail("corrupt tensor name");
         t.name.assign((const char*)c.p, (size_t)name_len);
         c.p += name_len;
         const int be = ggml_block_elems(t.type), bb = ggml_block_bytes(t.type);
         if (be == 0 || n_el % be) return fail("tensor " + t.name + ": unsupported type " + std::to_string(t.type));
         t.nbytes = (size_t)(n_el / be) * (size_t)bb;
-        if (c.p + t.nbytes > c.end) return fail("tensor " + t.name + ": truncated data");
+        if (t.nbytes > c.left()) return fail("tensor " + t.name + ": truncated data");
         t.data = c.p;
         t.offset = (uint64_t)(c.p - map_);
         c.p += t.nbytes;

@@ -255,7 +255,7 @@ class LLM:
         last_n_tokens, seed = _get(last_n_tokens, c.last_n_tokens), _get(seed, c.seed)
         if last_n_tokens < 0:
             last_n_tokens = self.context_length
-        last = self._context[-last_n_tokens:] if last_n_tokens else []
+        last = self._context[-last_n_tokens:]   # last_n_tokens=0 slices [-0:]: the whole context, as the reference does (llm.py:443)
         arr = (c_int * len(last))(*last)
         return self.ctransformers_llm_sample(arr, len(last), top_k, top_p, temperature, repetition_penalty, seed)
 

@@ -311,8 +311,37 @@ class _WeightSource:
         return (1.0 + 0.1 * self.rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
 
 
+def make_spm_vocab(n_vocab=512):
+    """A small sentencepiece-style vocabulary WITH real merge structure (the default `make_vocab` has only byte tokens and opaque
+    pieces): control and byte tokens, then pieces whose scores fall with their index the way trained SPM vocabularies do, so the
+    reference's score-ordered bigram merging (llama.cpp:3080-3210) has choices to make — "▁hello" exists as a piece, and so do the
+    intermediate pieces its merges pass through."""
+    toks = [b"<unk>", b"<s>", b"</s>"] + [b"<0x%02X>" % i for i in range(256)]
+    types = [2, 3, 3] + [6] * 256
+    words = ["▁", "e", "t", "a", "o", "i", "n", "s", "h", "r", "l", "d", "u", "w", "m", "c", "f", "g", "y", "p", "b", "v", "k", ",", ".", "!",
+             "▁t", "he", "▁a", "in", "▁the", "er", "▁s", "re", "on", "▁w", "at", "en", "nd", "▁o", "or", "▁c", "es", "is", "it", "an", "▁b",
+             "ing", "ed", "ou", "▁h", "ar", "ll", "▁he", "▁hel", "lo", "▁hell", "▁hello", "wor", "ld", "▁wor", "▁world", "▁an", "▁and", "▁in",
+             "▁th", "▁to", "▁of", "al", "le", "ion", "▁f", "▁m", "as", "▁is", "st", "▁p", "▁d", "ic", "▁it", "▁that", "th", "at", "▁wh",
+             "▁whe", "▁when", "ess", "▁you", "▁for", "ent", "ly", "▁be", "▁on", "▁we", "ver", "▁ha", "▁re", "ld", "gh", "ght", "▁▁", "▁▁▁",
+             "é", "ï", "na", "ve", "ca", "fé", "ca", "12", "34", "1", "2", "3", "4", "5"]
+    seen = set(toks)
+    for w in words:
+        b = w.encode("utf-8")
+        if b not in seen:
+            seen.add(b)
+            toks.append(b)
+            types.append(1)
+    i = 0
+    while len(toks) < n_vocab:
+        toks.append(("▁x%d" % i).encode("utf-8"))
+        types.append(1)
+        i += 1
+    scores = [0.0] * 259 + [-float(j + 1) for j in range(len(toks) - 259)]
+    return toks[:n_vocab], scores[:n_vocab], types[:n_vocab]
+
+
 def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_train=4096, pooled=None,
-                     rope_freq_base=None, rms_eps=1e-5, overrides=None):
+                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None):
     """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict."""
     hp = dict(LLAMA_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     if overrides:
@@ -339,7 +368,7 @@ def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_
     w.add_f32("llama.attention.layer_norm_rms_epsilon", rms_eps)
     if rope_freq_base is not None:
         w.add_f32("llama.rope.freq_base", rope_freq_base)
-    toks, scores, ttypes = make_vocab(n_vocab)
+    toks, scores, ttypes = vocab if vocab is not None else make_vocab(n_vocab)
     w.add_str("tokenizer.ggml.model", "llama")
     w.add_arr("tokenizer.ggml.tokens", G.T_STR, toks)
     w.add_arr("tokenizer.ggml.scores", G.T_F32, scores)

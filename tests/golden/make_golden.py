@@ -115,6 +115,37 @@ def falcon_ops_golden():
     np.savez_compressed(os.path.join(HERE, "falcon_ops.npz"), **out)
 
 
+SPM_TEXTS = ["hello world", "Hello, world!", "the and in that when", " hello", "hello  world   twice", "naïve café", "12345", "",
+             "a", "unknownzq", "▁already▁marked", "when you hear the thing", "\ttab and\nnewline", "日本"]
+BPE_TEXTS = ["ab cd\n", "Hello, world! it's 12345 times   spaced\n\nxyz abcab", " ", "a", "don't you're I'll\tTAB", "héllo ünicode ✓ 中文", "ababababab abc", "abab cdcd abcd"]
+GPT2_TEXTS = ["ab cd xyz\n", "Hello, it's 42!  aaa", " ", "don't stop\tnow", "héllo ✓", "xyzabc  qq"]
+
+
+def tokenizer_golden():
+    """Host-path vectors produced by the reference build: sentencepiece (score-ordered merges, byte fallback, the leading-space
+    rule), falcon's byte-level BPE, and the legacy gpt2 tokenizer + its sampler.  The SPM model file is committed (tiny, one layer:
+    only its vocabulary matters)."""
+    import json
+    p = os.path.join(HERE, "spm-vocab.gguf")
+    synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=12, overrides=dict(n_layer=1), vocab=synth.make_spm_vocab(512))
+    r = ref.open_llm(p, context_length=32, batch_size=8, threads=2)
+    spm = {t: [int(i) for i in r.tokenize(t)] for t in SPM_TEXTS}
+    spm_detok = {t: r.detokenize(r.tokenize(t)) for t in SPM_TEXTS}
+    json.dump(dict(tokenize=spm, detokenize=spm_detok), open(os.path.join(HERE, "spm_golden.json"), "w"), ensure_ascii=False, indent=1)
+    r = ref.open_llm(os.path.join(HERE, "falcon-tiny-q4km.gguf"), context_length=96, batch_size=8, threads=2)
+    json.dump({t: [int(i) for i in r.tokenize(t)] for t in BPE_TEXTS}, open(os.path.join(HERE, "falcon_bpe.json"), "w"), ensure_ascii=False, indent=1)
+    r = ref.open_llm(os.path.join(HERE, "gpt2-tiny-q40.bin"), model_type="gpt2", context_length=96, batch_size=8, threads=2)
+    g = np.load(os.path.join(HERE, "gpt2-tiny-q40.npz"))
+    tok = {t: [int(i) for i in r.tokenize(t)] for t in GPT2_TEXTS}
+    r.eval(list(g["prompt"]))
+    samples = []
+    for seed_s, (k, p_, temp, pen) in enumerate([(40, 0.95, 0.8, 1.1), (5, 0.5, 1.3, 1.0), (100, 1.0, 0.7, 1.3), (1, 1.0, 1.0, 1.0), (200, 0.9, 1.5, 1.2)]):
+        samples.append([k, p_, temp, pen, seed_s + 3, int(r.sample(top_k=k, top_p=p_, temperature=temp, repetition_penalty=pen, seed=seed_s + 3))])
+    json.dump(dict(tokenize=tok, samples=samples, detok_300_10=r.detokenize([300, 10])), open(os.path.join(HERE, "gpt2_host.json"), "w"),
+              ensure_ascii=False, indent=1)
+    print("tokenizer goldens:", {k: v for k, v in list(spm.items())[:4]})
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]   # e.g. `make_golden.py tiny-q80 tiny-q40` regenerates just those
     for name, ftype, seed, shape in (("tiny-q4km", "Q4_K_M", 3, "llama-tiny"), ("tiny-q5km", "Q5_K_M", 4, "llama-tiny"),
@@ -128,4 +159,6 @@ if __name__ == "__main__":
         ops_golden()
     if not only or "falcon_ops" in only:
         falcon_ops_golden()
+    if not only or "tokenizers" in only:
+        tokenizer_golden()
     print("golden vectors written to", HERE)

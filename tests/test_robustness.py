@@ -1,0 +1,92 @@
+"""Malformed model files must make ctransformers_llm_create return NULL (the Python side raises) — never kill the process; the reference
+does the same through its loaders' exceptions (models/llm.cc:36-65).  Plus the ABI corners the advisor listed: reset() on legacy
+models, last_n_tokens = 0."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ctransformers_amd.llm import LLM, Config
+
+
+def _try_open(path, lib):
+    return LLM(path, config=Config(context_length=32, batch_size=8, threads=1), lib=lib)
+
+
+def _patched(tmp_path, name, edit):
+    raw = bytearray(open(os.path.join(GOLDEN, "tiny-q4km.gguf"), "rb").read())
+    raw = edit(raw)
+    p = str(tmp_path / name)
+    open(p, "wb").write(bytes(raw))
+    return p
+
+
+def _set_u32_kv(raw, key, value):
+    k = key.encode()
+    i = raw.find(struct.pack("<Q", len(k)) + k)
+    assert i >= 0
+    off = i + 8 + len(k)
+    assert struct.unpack_from("<I", raw, off)[0] == 4   # GGUF type u32
+    struct.pack_into("<I", raw, off + 4, value)
+    return raw
+
+
+@pytest.mark.parametrize("case", ["truncated", "huge_tensor_count", "huge_kv_count", "zero_heads", "heads_not_dividing", "huge_dim", "garbage_tail"])
+def test_malformed_gguf_is_refused(emu_lib, tmp_path, case):
+    def edit(raw):
+        if case == "truncated":
+            return raw[:len(raw) // 3]
+        if case == "huge_tensor_count":
+            struct.pack_into("<Q", raw, 8, 1 << 60)
+        elif case == "huge_kv_count":
+            struct.pack_into("<Q", raw, 16, 1 << 61)
+        elif case == "zero_heads":
+            _set_u32_kv(raw, "llama.attention.head_count", 0)
+        elif case == "heads_not_dividing":
+            _set_u32_kv(raw, "llama.attention.head_count", 7)
+        elif case == "huge_dim":
+            k = b"token_embd.weight"
+            i = raw.find(struct.pack("<Q", len(k)) + k)
+            struct.pack_into("<Q", raw, i + 8 + len(k) + 4, 1 << 50)   # ne[0]
+        elif case == "garbage_tail":
+            return raw[:4096] + bytes(np.random.default_rng(1).integers(0, 256, 4096, dtype=np.uint8))
+        return raw
+    p = _patched(tmp_path, case + ".gguf", edit)
+    with pytest.raises(Exception):
+        _try_open(p, emu_lib)
+    # the process is alive and a good file still loads
+    m = _try_open(os.path.join(GOLDEN, "tiny-q4km.gguf"), emu_lib)
+    assert m.vocab_size == 512
+
+
+def test_reset_semantics(emu_lib):
+    """reference models/llm.h:106: Reset() forgets the logits of legacy models (sample() then returns EOS, logits_size() 0); GGUF
+    models keep theirs."""
+    g = np.load(os.path.join(GOLDEN, "gpt2-tiny-q40.npz"))
+    m = LLM(os.path.join(GOLDEN, "gpt2-tiny-q40.bin"), "gpt2", config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    m.eval(list(g["prompt"]))
+    assert len(m.logits) == 512
+    m.reset()
+    assert len(m.logits) == 0 and m.sample(top_k=1) == m.eos_token_id
+    m.eval(list(g["prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    m.eval(list(g["prompt"]))
+    m.reset()
+    assert len(m.logits) == 512
+
+
+def test_last_n_tokens_zero_means_whole_context(emu_lib, ref):
+    """`last_n_tokens=0` slices [-0:] in the reference's Python (llm.py:443): the repetition penalty sees the whole context."""
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    m = LLM(path, config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    r = ref.open_llm(path, context_length=96, batch_size=8, threads=1)
+    m.eval(list(g["prompt"]))
+    r.eval(list(g["prompt"]))
+    for seed in (1, 2, 3):
+        assert m.sample(top_k=50, top_p=0.9, temperature=0.9, repetition_penalty=1.5, last_n_tokens=0, seed=seed) == \
+            r.sample(top_k=50, top_p=0.9, temperature=0.9, repetition_penalty=1.5, last_n_tokens=0, seed=seed)
