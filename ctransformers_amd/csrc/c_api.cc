@@ -197,6 +197,7 @@ int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine().hparams().n_lay
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine().hparams().n_embd; }
 long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine().chunk_tokens(); }
 long long ctamd_v7_launches(void) { return ctamd::v7_launches(); }
+long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {
     if (stage < 0 || stage >= llm->pipe.n_stages() || llm->pipe.ranges().empty()) return -1;

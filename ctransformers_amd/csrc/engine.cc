@@ -14,6 +14,7 @@
 #include "kernels_q32.h"
 #include "kernels_ks.h"
 #include "kernels_pfm.h"
+#include "kernels_pg.h"
 
 namespace ctamd {
 
@@ -157,7 +158,10 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
         });
     }
     uint8_t* d = nullptr;
-    if (!dev_alloc(dev_allocs_, &d, total + 64, err)) return false;
+    // + 4 KB: the prompt-chunk kernels request up to two block slots past a row's last block (kernels_pg.h), i.e. past the arena's
+    // last record for its last unit
+    if (!dev_alloc(dev_allocs_, &d, total + 4096, err)) return false;
+    HIP_OK(hipMemset(d + total, 0, 4096));
     HIP_OK(hipMemcpy(d, st.data(), total, hipMemcpyHostToDevice));
     for (const Plan& p : plan) {
         p.m->r2 = d + p.off;
@@ -479,6 +483,13 @@ bool Engine::alloc_state(std::string& err) {
             !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
             !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
             return false;
+        use_pg_ = env_int("CT_AMD_PG", 1) != 0;
+        pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
+        if (use_pg_) {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
+            acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max({(kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES, (kPfChunk / 64) * PgStage<64>::BYTES}) + 4096;
+            if (!dev_alloc(dev_allocs_, &acts_h_, 2 * acts_h_half_, err)) return false;
+            HIP_OK(hipMemset(acts_h_, 0, 2 * acts_h_half_));   // token slots past the chunk's end are read (and their results dropped)
+        }
         if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
                              !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))
             return false;
@@ -624,6 +635,8 @@ static bool v7_can(const MatvecArgs& a) {
 
 static long long g_v7_launches = 0;   // test hook (ctamd_v7_launches): which generation produced the logits a test compared
 long long v7_launches() { return g_v7_launches; }
+static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
+long long pg_launches() { return g_pg_launches; }
 
 static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     ++g_v7_launches;
@@ -908,6 +921,58 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
 }
 
+// One mat-vec site of a prompt chunk on the f16 matrix cores (kernels_pg.h): stage images of the nt activation rows in the
+// layout(s) the site's weight types read, then one launch per weight type over the LAYOUT_R2C4 records of the decode path.
+bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err) {
+    int tg = nt > 16 ? 32 : 16;
+    if (pg_force_tg_ == 16 || pg_force_tg_ == 32 || pg_force_tg_ == 64) tg = pg_force_tg_;
+    const int groups = (nt + tg - 1) / tg, nb = m.K / 256;
+    if ((size_t)groups * nb * pg_stage_bytes(tg) > acts_h_half_) { err = "stage images exceed their buffer"; return false; }
+    bool has45 = false, has6 = false;
+    for (int j = 0; j < m.njobs; ++j) (m.job[j].w.type == GT_Q6_K ? has6 : has45) = true;
+    uint8_t* img45 = has45 ? acts_h_ : nullptr;
+    uint8_t* img6 = has6 ? acts_h_ + acts_h_half_ : nullptr;
+    const dim3 qg((unsigned)nt), qb(1024);
+    if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
+        if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b);
+        else CT_LAUNCH((pg_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b);
+    } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
+    else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
+    else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
+    constexpr int NW = 8;
+    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
+        PgArgs a;
+        a.m = m;
+        a.acts = ty == GT_Q6_K ? img6 : img45;
+        a.n_tok = nt; a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
+        int nj = 0, item0 = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            if (m.job[j].w.type != ty) continue;
+            a.m.job[nj] = m.job[j];
+            a.m.job[nj].pair0 = item0;
+            item0 += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;   // 8 row pairs per item
+            ++nj;
+        }
+        if (nj == 0) continue;
+        a.m.njobs = nj;
+        a.n_items = item0;
+        const int gx = ((item0 + NW - 1) / NW + 7) / 8 * 8;
+        const dim3 grid((unsigned)gx, (unsigned)groups), block(NW * 64);
+        const size_t smem = 3 * (size_t)pg_stage_bytes(tg);   // three stage buffers (kernels_pg.h)
+#define PG(TYV, TGV, GUV) do { \
+            auto kfn = matmul_pg_kernel<TYV, TGV, NW, GUV>; \
+            CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<TGV>::BYTES); ++g_pg_launches; \
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
+#define PG_T(TYV) do { if (tg == 16) { if (m.gateup) PG(TYV, 16, true); else PG(TYV, 16, false); } \
+                       else if (tg == 32) { if (m.gateup) PG(TYV, 32, true); else PG(TYV, 32, false); } \
+                       else { if (m.gateup) PG(TYV, 64, true); else PG(TYV, 64, false); } } while (0)
+        if (ty == GT_Q4_K) PG_T(GT_Q4_K); else if (ty == GT_Q5_K) PG_T(GT_Q5_K); else PG_T(GT_Q6_K);
+#undef PG_T
+#undef PG
+    }
+    return true;
+}
+
 // One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernel(s) on the
 // matrix cores (kernels_pfm.h; the dot4 form of kernels_pf.h is kept for A/B runs).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
@@ -944,6 +1009,17 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         }
         prof_end();
         return true;
+    }
+    {
+        bool pg = use_pg_ && acts_h_;
+        for (int j = 0; j < m.njobs; ++j) pg = pg && is_kquant(m.job[j].w.type) && m.job[j].w.r2;
+        if (pg && m.gateup) pg = m.njobs == 1 && m.job[0].w.layout == LAYOUT_R2C4;
+        if (pg) {
+            const bool ok = pg_matvec(m, x, ldx, nt, ld_out, ld_res, err);
+            prof_end();
+            return ok;
+        }
+        if (m.gateup && m.njobs == 1) { err = "fused gate/up matrix outside kernels_pg.h"; return false; }
     }
     if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
         if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
@@ -1061,6 +1137,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
             a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
+            if (use_pg_ && acts_h_ && L.w_gu.r2) { a.job[0].w = L.w_gu; a.njobs = 1; }   // kernels_pg.h: the fused matrix of the decode path
             if (!pf_matvec(a, xb_, E, nt, F, 0, "gate_up", (double)(L.w_gate.bytes + L.w_up.bytes), err)) return false;
         }
         {

@@ -41,6 +41,7 @@ struct Layer {
     float *b_qkv = nullptr, *b_wo = nullptr, *b_up = nullptr, *b_down = nullptr;
 };
 
+long long pg_launches();   // test hook: prompt-chunk launches of kernels_pg.h issued by this process
 long long v7_launches();   // test hook: decode mat-vec launches of generation 7 issued by this process
 
 class Engine {
@@ -120,6 +121,7 @@ class Engine {
     bool chunk_step_falcon(int c0, int nt, bool want_logits, std::string& err);
     bool chunk_step_gpt2(int nt, bool want_logits, std::string& err);
     bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
+    bool pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err);
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     bool token_step_falcon(bool want_logits, std::string& err);
@@ -162,6 +164,10 @@ class Engine {
     int pf_chunk_ = 128;    // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
     long long chunk_tokens_ = 0;
     bool use_mfma_ = true;
+    bool use_pg_ = true;    // K-quant prompt chunks on the f16 matrix cores (kernels_pg.h; CT_AMD_PG=0: the int8 form of kernels_pfm.h, A/B)
+    int pg_force_tg_ = 0;   // tests: 16 / 32 / 64 tokens per workgroup
+    uint8_t* acts_h_ = nullptr;   // stage images (kernels_pg.h): [layout 45 | layout 6]
+    size_t acts_h_half_ = 0;
     int pfm_force_tok_ = 0;
     float* rope_cs_ = nullptr;
     uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;

@@ -173,6 +173,68 @@ DEV uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
 }
 #endif
 
+// ---- f16 matrix core on INTEGER-valued operands (kernels_pg.h) -------------------------------------------------------------
+// v_mfma_f32_16x16x32_f16 / v_mfma_f32_16x16x16_f16 with every operand an integer that fp16 holds exactly: all products and
+// partial sums are integers below 2^24, so the f32 result is exact whatever the internal summation order — it equals
+// (float) of the integer sum (checked on hardware by tools/experiments/mfma_f16_exact.cpp, also chained through C).
+// Pairing (all the callers rely on): half e of lane (n, g)'s A meets half e of lane (m, g)'s B (n, m = lane & 15, g = lane >> 4);
+// lane (m, g) holds D[4g + j][m] in register j.
+#ifdef CT_EMU
+struct f32x4 {
+    float v[4];
+    float operator[](int i) const { return v[i]; }
+    float& operator[](int i) { return v[i]; }
+};
+static inline double emu_h2_dot(uint32_t a, uint32_t b) {
+    return (double)f16_bits_to_f32((uint16_t)(a & 0xFFFF)) * (double)f16_bits_to_f32((uint16_t)(b & 0xFFFF)) +
+           (double)f16_bits_to_f32((uint16_t)(a >> 16)) * (double)f16_bits_to_f32((uint16_t)(b >> 16));
+}
+static inline f32x4 mfma_f16_16x16x16(uint64_t a, uint64_t b, f32x4 c) {
+    const int lane = (int)(threadIdx.x & 63), g = lane >> 4, n = lane & 15;
+    uint64_t bk[4];
+    for (int kc = 0; kc < 4; ++kc) bk[kc] = emu_shfl_any(b, n + 16 * kc);
+    for (int j = 0; j < 4; ++j) {
+        double s = (double)c[j];
+        for (int kc = 0; kc < 4; ++kc) {
+            const uint64_t am = emu_shfl_any(a, 4 * g + j + 16 * kc);
+            s += emu_h2_dot((uint32_t)am, (uint32_t)bk[kc]) + emu_h2_dot((uint32_t)(am >> 32), (uint32_t)(bk[kc] >> 32));
+        }
+        c[j] = (float)s;
+    }
+    return c;
+}
+static inline f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    const uint64_t a01 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a23 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    const uint64_t b01 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b23 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    return mfma_f16_16x16x16(a23, b23, mfma_f16_16x16x16(a01, b01, c));   // exact integer sums: any grouping gives the same f32
+}
+static inline uint32_t emu_pack_h2(float lo, float hi) { return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16); }
+// packed fp16: a * b + c with one rounding, a * b
+static inline uint32_t pk_fma_f16(uint32_t a, uint32_t b, uint32_t c) {
+    const double lo = (double)f16_bits_to_f32((uint16_t)a) * (double)f16_bits_to_f32((uint16_t)b) + (double)f16_bits_to_f32((uint16_t)c);
+    const double hi = (double)f16_bits_to_f32((uint16_t)(a >> 16)) * (double)f16_bits_to_f32((uint16_t)(b >> 16)) + (double)f16_bits_to_f32((uint16_t)(c >> 16));
+    return emu_pack_h2((float)lo, (float)hi);   // callers' results are small integers: exact in float and in fp16
+}
+static inline uint32_t pk_mul_f16(uint32_t a, uint32_t b) { return pk_fma_f16(a, b, 0u); }
+static inline uint32_t h2_from_int(int v) { return emu_pack_h2((float)v, (float)v); }   // |v| <= 2048: exact
+#else
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+DEV f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+DEV f32x4 mfma_f16_16x16x16(uint64_t a, uint64_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+DEV uint32_t pk_fma_f16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), __builtin_bit_cast(f16x2, c)));
+}
+DEV uint32_t pk_mul_f16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, b)); }
+DEV uint32_t h2_from_int(int v) { const _Float16 h = (_Float16)(short)v; const f16x2 r = {h, h}; return __builtin_bit_cast(uint32_t, r); }
+#endif
+
 // ---- cross-lane moves without the LDS crossbar where the ISA allows it ----------------------------------------------
 // __shfl_xor always lowers to ds_bpermute_b32 (address VGPR + LDS pipe, ~100 cycles dependent latency).  Butterflies
 // inside a row of 16 lanes can use DPP modifiers instead: quad_perm for xor 1/2, row_half_mirror o quad_perm(3,2,1,0)
@@ -234,6 +296,63 @@ DEV int sload_i32(const int* p) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+#endif
+
+// sched_fence: nothing is moved across this point by the instruction scheduler.  sgpr_const: a constant the compiler keeps in a scalar
+// register instead of re-materialising it as a literal operand.
+#ifdef CT_EMU
+static inline void sched_fence() {}
+static inline uint32_t sgpr_const(uint32_t v) { return v; }
+#else
+DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+DEV uint32_t sgpr_const(uint32_t v) { uint32_t r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(v)); return r; }
+#endif
+
+// Four f32 chain steps a[j] = fma(d[j], s[j], a[j]) as two v_pk_fma_f32 (each half is the IEEE fma), pinned where they are written:
+// the asm names the two register pairs, so the steps are neither split into four scalar fmas nor moved to the end of the block.
+#ifdef CT_EMU
+static inline void chain4(float (&a)[4], const float (&d)[4], const f32x4& s) {
+    for (int j = 0; j < 4; ++j) a[j] = fmaf(d[j], s[j], a[j]);
+}
+static inline uint32_t vgpr_const(uint32_t v) { return v; }
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV void chain4(float (&a)[4], const float (&d)[4], const f32x4& s) {
+    f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]};
+    const f32x2 d0 = {d[0], d[1]}, d1 = {d[2], d[3]}, s0 = {s[0], s[1]}, s1 = {s[2], s[3]};
+    a0 = __builtin_elementwise_fma(d0, s0, a0);
+    a1 = __builtin_elementwise_fma(d1, s1, a1);
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    a[0] = a0[0]; a[1] = a0[1]; a[2] = a1[0]; a[3] = a1[1];
+}
+// a constant held in a vector register (gfx9 VOP3 takes one scalar / constant operand: v_and_or_b32 needs the other one here)
+DEV uint32_t vgpr_const(uint32_t v) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "i"(v)); return r; }
+#endif
+
+// ---- LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + 16 * lane, no VGPRs --------------
+// Issued as one asm statement (M0 = destination base is written in the statement that reads it).  hipcc does not count it:
+// its own `s_waitcnt vmcnt(N)` stay correct (memory operations retire in order, an uncounted younger one can only make them wait
+// longer) and the DATA needs vm_wait<N>() by hand, then a barrier, before any lane reads it.
+#ifdef CT_EMU
+static inline void glds16(const void* gsrc, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
+static inline void glds4(const void* gsrc, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 4 * (threadIdx.x & 63), gsrc, 4); }
+template <int N> static inline void vm_wait() {}
+template <int N> static inline void sleep_cycles() {}
+#else
+DEV void glds4(const void* gsrc, unsigned char* lds_wave_base) {   // 4 bytes per lane: 256 B per wave instruction
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+DEV void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int N> DEV void sleep_cycles() { __builtin_amdgcn_s_sleep(N); }   // N * 64 clocks
+template <int N> DEV void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 #endif
 
 // Scheduling fence on values: they are computed before this point, nothing that depends on them moves above it.

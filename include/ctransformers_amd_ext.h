@@ -44,6 +44,8 @@ int ctamd_n_embd(ctransformers_llm* llm);
 long long ctamd_chunk_tokens(ctransformers_llm* llm);
 /* Decode mat-vec launches of generation 7 (kernels_v7.h) issued by this process so far (eager launches and graph captures). */
 long long ctamd_v7_launches(void);
+/* prompt-chunk launches on the f16 matrix cores (kernels_pg.h) issued by this process so far */
+long long ctamd_pg_launches(void);
 /* In-process pipeline (CT_AMD_DEVICES, csrc/pipeline.h): number of stages of this handle (1 = single GPU) and the layer range of a
    stage (returns -1 for a single-stage handle). */
 int ctamd_n_stages(ctransformers_llm* llm);

@@ -1,0 +1,54 @@
+"""Prompt chunks of K-quant models on the f16 matrix cores (ctransformers_amd/csrc/kernels_pg.h), run through the CPU emulation of
+the HIP sources: golden logits of the real reference build, every token-group size, ragged groups, and the int8 form it replaced
+as the A/B path."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_emu_engine import open_emu, chunk_tokens
+
+
+def pg_launches(lib):
+    f = lib.ctamd_pg_launches
+    f.restype, f.argtypes = ctypes.c_longlong, []
+    return int(f())
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "falcon-tiny-q4km", "falcon-tiny7-q4km"])
+def test_prompt_on_f16_matrix_cores_matches_reference(emu_lib, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_emu(emu_lib, name)
+    n0 = pg_launches(m._lib)
+    m.eval(list(g["prompt"]))
+    assert pg_launches(m._lib) > n0 and chunk_tokens(m) == len(g["prompt"])
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
+    t = m.sample(top_k=1, repetition_penalty=1.0)
+    m.eval([t])
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][1])
+
+
+@pytest.mark.parametrize("name,tg,batch,key", [("tiny-q4km", 16, 64, "long_one"), ("tiny-q4km", 32, 64, "long_one"),
+                                               ("tiny-q4km", 64, 8, "long_chunked"), ("tiny-q5km", 32, 8, "long_chunked")])
+def test_token_group_sizes_and_ragged_groups(emu_lib, monkeypatch, name, tg, batch, key):
+    """45 tokens = 2 groups of 32 (13 live slots in the second), 3 of 16, or one of 64: same bits as the reference."""
+    monkeypatch.setenv("CT_AMD_PG_TG", str(tg))
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_emu(emu_lib, name, batch_size=batch)
+    n0 = pg_launches(m._lib)
+    m.eval(list(g["long_prompt"]))
+    assert pg_launches(m._lib) > n0 and chunk_tokens(m) == 45
+    assert np.array_equal(m.logits.to_numpy(), g[key])
+
+
+def test_int8_form_stays_selectable(emu_lib, monkeypatch):
+    monkeypatch.setenv("CT_AMD_PG", "0")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = open_emu(emu_lib, "tiny-q4km")
+    n0 = pg_launches(m._lib)
+    m.eval(list(g["prompt"]))
+    assert pg_launches(m._lib) == n0 and chunk_tokens(m) == len(g["prompt"])
+    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])

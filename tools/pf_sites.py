@@ -12,9 +12,10 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in rows:
         n, dur = r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         z = int(r.get("Grid_Size_Z", r.get("Grid_Size_z", 1)) or 1)
-        if "matvec_pf_kernel" in n or "matvec_pfm_kernel" in n:   # belongs to the site of the preceding quantize launch
-            agg[("mfma " if "pfm" in n else "dot4 ") + ("qkv", "wo", "gate_up", "down")[(k - 1) % 4]].append(dur)
-        elif "pf_quantize" in n:
+        if "matvec_pf_kernel" in n or "matvec_pfm_kernel" in n or "matmul_pg_kernel" in n:   # belongs to the site of the preceding quantize launch
+            kind = "f16mc " + n.split("<")[1].split(",")[0] + " " if "matmul_pg" in n else ("mfma " if "pfm" in n else "dot4 ")
+            agg[kind + ("qkv", "wo", "gate_up", "down")[(k - 1) % 4]].append(dur)
+        elif "pf_quantize" in n or "pg_quantize" in n:
             agg["pf quantize"].append(dur)
             k += 1
         elif "attn_fused" in n:
