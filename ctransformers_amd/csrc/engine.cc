@@ -924,7 +924,14 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
 // One mat-vec site of a prompt chunk on the f16 matrix cores (kernels_pg.h): stage images of the nt activation rows in the
 // layout(s) the site's weight types read, then one launch per weight type over the LAYOUT_R2C4 records of the decode path.
 bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err) {
+    // Tokens per workgroup: 32 amortise the weight unpack over two matrix products — unless the site then has fewer workgroups than
+    // the chip has CUs (Wo, ffn_down of a 7B: 32 x 4): 16-token groups double the workgroups and every CU gets one.
     int tg = nt > 16 ? 32 : 16;
+    if (tg == 32) {
+        int items = 0;
+        for (int j = 0; j < m.njobs; ++j) items += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;
+        if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus()) tg = 16;
+    }
     if (pg_force_tg_ == 16 || pg_force_tg_ == 32 || pg_force_tg_ == 64) tg = pg_force_tg_;
     const int groups = (nt + tg - 1) / tg, nb = m.K / 256;
     if ((size_t)groups * nb * pg_stage_bytes(tg) > acts_h_half_) { err = "stage images exceed their buffer"; return false; }
@@ -966,6 +973,21 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 #define PG_T(TYV) do { if (tg == 16) { if (m.gateup) PG(TYV, 16, true); else PG(TYV, 16, false); } \
                        else if (tg == 32) { if (m.gateup) PG(TYV, 32, true); else PG(TYV, 32, false); } \
                        else { if (m.gateup) PG(TYV, 64, true); else PG(TYV, 64, false); } } while (0)
+        static const char* pg_trace = getenv("CT_AMD_PG_TRACE");   // measurement only: "gate_up" / "qkv" / "wo" / "down": in-kernel stamps of that site
+        if (pg_trace && ty == GT_Q4_K && tg == 32 && pg_trace_site_ && !strcmp(pg_trace, pg_trace_site_) && nt > 32) {
+            a.m.dbg |= 32; a.m.dbg_sink = (float*)trace_buf_;
+            if (m.gateup) { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, true, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a); }
+            else { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, false, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a); }
+            HIP_OK(hipStreamSynchronize(stream_));
+            unsigned long long h[120];
+            HIP_OK(hipMemcpy(h, trace_buf_, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pg_trace %s: start->prologue %llu, total %llu;", pg_trace, h[1] - h[0], h[2] - h[0]);
+            for (int b = 0; b < 16 && 8 + 6 * b + 5 < 120; ++b)
+                fprintf(stderr, " [b%d issue %llu, l0-3 %llu, midwait %llu, l4-7 %llu, endbar %llu]", b, h[8 + 6 * b + 1] - h[8 + 6 * b], h[8 + 6 * b + 2] - h[8 + 6 * b + 1],
+                        h[8 + 6 * b + 3] - h[8 + 6 * b + 2], h[8 + 6 * b + 4] - h[8 + 6 * b + 3], h[8 + 6 * b + 5] - h[8 + 6 * b + 4]);
+            fprintf(stderr, "\n");
+            continue;
+        }
         if (ty == GT_Q4_K) PG_T(GT_Q4_K); else if (ty == GT_Q5_K) PG_T(GT_Q5_K); else PG_T(GT_Q6_K);
 #undef PG_T
 #undef PG
@@ -1015,6 +1037,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         for (int j = 0; j < m.njobs; ++j) pg = pg && is_kquant(m.job[j].w.type) && m.job[j].w.r2;
         if (pg && m.gateup) pg = m.njobs == 1 && m.job[0].w.layout == LAYOUT_R2C4;
         if (pg) {
+            pg_trace_site_ = site;
             const bool ok = pg_matvec(m, x, ldx, nt, ld_out, ld_res, err);
             prof_end();
             return ok;

@@ -165,6 +165,7 @@ class Engine {
     long long chunk_tokens_ = 0;
     bool use_mfma_ = true;
     bool use_pg_ = true;    // K-quant prompt chunks on the f16 matrix cores (kernels_pg.h; CT_AMD_PG=0: the int8 form of kernels_pfm.h, A/B)
+    const char* pg_trace_site_ = nullptr;   // measurement only (CT_AMD_PG_TRACE)
     int pg_force_tg_ = 0;   // tests: 16 / 32 / 64 tokens per workgroup
     uint8_t* acts_h_ = nullptr;   // stage images (kernels_pg.h): [layout 45 | layout 6]
     size_t acts_h_half_ = 0;

@@ -166,8 +166,36 @@ template <int TYPE> struct PgAcc {   // accumulators of one 16-token group: [AVX
 // lane and a register fence on the accumulators just stepped — left to itself hipcc places every chain step of the (branch-free)
 // loop body at its very end and spills the matrix products of four blocks on the way there; and a reload from scratch is an
 // `s_waitcnt vmcnt(0)` on the prefetched weight loads.
-template <int TYPE, int TG>
-DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16, int p, PgAcc<TYPE> (&acc)[TG / 16], const PgConst& C, bool live) {
+// What a step requests besides computing: the copy of stage b + 2 (DMA pieces of this wave) and the refill of the weight ring slot.
+// Issued from inside the block's lane loop, the refill at AVX lane 0 and two DMA pieces per lane from lane 4: a burst of six memory
+// instructions at the top of the step costs the wave ~400 cycles of issue stalls (in-kernel stamps), spread out they hide behind the
+// unpack and the matrix products.
+struct PgFeed { const uint8_t* src; uint8_t* dst; const uint8_t* rec0; int wv, lane16, lane4; };
+template <int TYPE, int TG, int RD, int CB>
+DEV void pg_feed(int l, const PgFeed& F, const PgLane& LN, PgRec<TYPE>& ring) {
+    using ST = PgStage<TG>;
+    constexpr int G = TG / 16, NW = kPgWaves;
+    // The refill goes first: hipcc does not see the DMA and counts its own loads only, so its `s_waitcnt vmcnt(N)` for an older ring
+    // slot lets exactly its N youngest loads stay in flight — with the DMA pieces younger than the refill they stay in flight too,
+    // issued before it they would have to land first.
+    if (l == 0) ring = pg_load<TYPE, RD, CB>(F.rec0, LN);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = 2 * (l - 4) + k;   // after the step's barrier (behind lane 3): every wave has left the previous step, whose stage
+        if (i < 0) continue;              // buffer this copy overwrites
+        if (i < G) glds16(F.src + (size_t)(i * NW + F.wv) * 1024 + F.lane16, F.dst + (size_t)(i * NW + F.wv) * 1024);
+        else if (i < G + ST::TAILP) glds4(F.src + ST::SUMS + (size_t)((i - G) * NW + F.wv) * 256 + F.lane4, F.dst + ST::SUMS + (size_t)((i - G) * NW + F.wv) * 256);
+    }
+}
+
+// measurement only (CT_AMD_PG_TRACE): s_memtime stamps of wave 0 of workgroup (0, 0), kept in LDS and written out at the end
+template <bool TRACE> DEV void pg_stamp(unsigned long long* tr, int idx) {
+    if constexpr (TRACE) { if (tr && idx < 120) tr[idx] = clock64_dev(); }
+}
+
+template <int TYPE, int TG, int MIDWAIT, bool TRACE, int RD, int CB>
+DEV void pg_block(const PgRec<TYPE>& R, PgRec<TYPE>& ring, const PgFeed& F, const PgLane& LN, const uint8_t* __restrict__ buf, int r16, int p,
+                  PgAcc<TYPE> (&acc)[TG / 16], const PgConst& C, bool live, unsigned long long* tr, int ti) {
     using ST = PgStage<TG>;
     constexpr int G = TG / 16;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -182,6 +210,7 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
         const uint32_t xp = alignbit32(hi, lo, C.gsh);
         const uint32_t s_lo = h2_from_int((int)(xp & 63u)), s_hi = h2_from_int((int)bfe32(xp, 6, 6));
         const uint32_t c_lo = pk_mul_f16(s_lo, 0xE400E400u), c_hi = pk_mul_f16(s_hi, 0xE400E400u);   // -1024 * scale
+        const uint32_t s_hi16 = pk_mul_f16(s_hi, 0x2C002C00u), c_hi16 = pk_mul_f16(s_hi, 0xD400D400u);   // Q4_K high nibbles in place: scale / 16, -64 * scale
         const uint32_t m_lo = h2_from_int((int)bfe32(xp, 12, 6)), m_hi = h2_from_int((int)bfe32(xp, 18, 6));
         const float dw = live ? f16_bits_to_f32((uint16_t)(H[0] & 0xFFFF)) : 0.0f, dmw = live ? f16_bits_to_f32((uint16_t)(H[0] >> 16)) : 0.0f;
         float D[G][4], DM[G][4];
@@ -198,26 +227,44 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
         // t: the other k-groups zeroed); Q5_K: summs = fma(-y.d * dmin, (float)(prod[0] + .. + prod[3]), summs).
         const uint64_t MB = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
         f32x4 pend[G], pendm[G];
+        u32x4 An[G];   // token operands are fetched one AVX lane ahead: the LDS latency hides behind the previous lane's unpack and products
+#pragma unroll
+        for (int g = 0; g < G; ++g) An[g] = *(const u32x4*)(buf + ST::VALS + (p * TG + g * 16 + r16) * 16);
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
+            u32x4 Ac[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                Ac[g] = An[g];
+                if (l < 7) An[g] = *(const u32x4*)(buf + ST::VALS + (((l + 1) * 4 + p) * TG + g * 16 + r16) * 16);
+            }
             const uint32_t w = l < 4 ? R.qa[l & 3] : R.qb[l & 3];
             constexpr uint32_t NIB = 0x000F000Fu;   // C.one = 0x64006400: 0x6400 | n = 1024 + n
-            uint32_t p0 = (w & NIB) | C.one, p1 = ((w >> 8) & NIB) | C.one, p2 = ((w >> 4) & NIB) | C.one, p3 = ((w >> 12) & NIB) | C.one;
-            if constexpr (Q5) {   // fifth bit: qh byte e, bit 2p / 2p+1 = element e of vector 2p / 2p+1
+            u32x4 W;
+            if constexpr (Q5) {
+                uint32_t p0 = (w & NIB) | C.one, p1 = ((w >> 8) & NIB) | C.one, p2 = ((w >> 4) & NIB) | C.one, p3 = ((w >> 12) & NIB) | C.one;
+                // fifth bit: qh byte e, bit 2p / 2p+1 = element e of vector 2p / 2p+1
                 const uint32_t hq = (l < 4 ? R.ha[l & 3] : R.hb[l & 3]) >> (2 * p);
                 p0 |= (hq << 4) & 0x00100010u; p1 |= (hq >> 4) & 0x00100010u;
                 p2 |= (hq << 3) & 0x00100010u; p3 |= (hq >> 5) & 0x00100010u;
+                // (1024 + n) * sc - 1024 * sc = n * sc: one rounding of an exactly representable integer
+                W = u32x4{pk_fma_f16(p0, s_lo, c_lo), pk_fma_f16(p1, s_lo, c_lo), pk_fma_f16(p2, s_hi, c_hi), pk_fma_f16(p3, s_hi, c_hi)};
+            } else {
+                // the high nibbles stay where they are: 0x6400 | (n << 4) = 1024 + 16 n, and (1024 + 16 n) * (sc / 16) - 64 sc = n * sc
+                // (sc / 16 and 64 sc are exact in fp16) — one shift per dword instead of three
+                constexpr uint32_t NIBH = 0x00F000F0u;
+                const uint32_t w8 = w >> 8;
+                const uint32_t p0 = (w & NIB) | C.one, p1 = (w8 & NIB) | C.one, p2 = (w & NIBH) | C.one, p3 = (w8 & NIBH) | C.one;
+                W = u32x4{pk_fma_f16(p0, s_lo, c_lo), pk_fma_f16(p1, s_lo, c_lo), pk_fma_f16(p2, s_hi16, c_hi16), pk_fma_f16(p3, s_hi16, c_hi16)};
             }
-            // (1024 + n) * sc - 1024 * sc = n * sc: one rounding of an exactly representable integer
-            const u32x4 W = {pk_fma_f16(p0, s_lo, c_lo), pk_fma_f16(p1, s_lo, c_lo), pk_fma_f16(p2, s_hi, c_hi), pk_fma_f16(p3, s_hi, c_hi)};
             f32x4 cur[G], curm[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const u32x4 A = *(const u32x4*)(buf + ST::VALS + ((l * 4 + p) * TG + g * 16 + r16) * 16);
-                cur[g] = mfma_f16_16x16x32(A, W, zero);
+                cur[g] = mfma_f16_16x16x32(Ac[g], W, zero);
                 if (l < NMT) curm[g] = mfma_f16_16x16x16(AS[g], (Q5 || p == l) ? MB : (uint64_t)0, zero);
                 else curm[g] = zero;
             }
+            pg_feed<TYPE, TG, RD, CB>(l, F, LN, ring);
             if (l > 0) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -228,6 +275,7 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
 #pragma unroll
             for (int g = 0; g < G; ++g) { pend[g] = cur[g]; pendm[g] = curm[g]; }
             sched_fence();
+            if (l == 3) { pg_stamp<TRACE>(tr, ti + 2); vm_wait<MIDWAIT>(); __syncthreads(); pg_stamp<TRACE>(tr, ti + 3); sched_fence(); }   // the copy issued ONE step ago has landed: see the kernel
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -247,6 +295,9 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
         }
         const uint32_t w_a = n ? R.sc[2] : R.sc[0], w_b = n ? R.sc[3] : R.sc[1];   // scales 8n .. 8n+3 / 8n+4 .. 8n+7
         f32x4 pend[G];
+        u32x4 An[G];   // token operands one AVX lane ahead (see the Q4_K branch)
+#pragma unroll
+        for (int g = 0; g < G; ++g) An[g] = *(const u32x4*)(buf + ST::VALS + (p * TG + g * 16 + r16) * 16);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int sa = (int)(int8_t)((w_a >> (8 * (2 * kq + h))) & 0xFFu), sb = (int)(int8_t)((w_b >> (8 * (2 * kq + h))) & 0xFFu);
@@ -257,6 +308,12 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int l = 4 * h + k;
+                u32x4 Ac[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    Ac[g] = An[g];
+                    if (l < 7) An[g] = *(const u32x4*)(buf + ST::VALS + (((l + 1) * 4 + p) * TG + g * 16 + r16) * 16);
+                }
                 const uint32_t ql = l < 4 ? R.qa[k] : R.qb[k];
                 const uint32_t qh = (l < 4 ? R.ha[k] : R.hb[k]) >> (2 * kq);
                 constexpr uint32_t NIB = 0x00780078u, HB = 0x01800180u;   // C.one6 = 0x58005800: 0x5800 | (q6 << 3) = 128 + q6
@@ -268,9 +325,9 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
                 f32x4 cur[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const u32x4 A = *(const u32x4*)(buf + ST::VALS + ((l * 4 + p) * TG + g * 16 + r16) * 16);
-                    cur[g] = mfma_f16_16x16x32(A, WE, mfma_f16_16x16x32(A, WB, zero));
+                    cur[g] = mfma_f16_16x16x32(Ac[g], WE, mfma_f16_16x16x32(Ac[g], WB, zero));
                 }
+                pg_feed<TYPE, TG, RD, CB>(l, F, LN, ring);
                 if (l > 0) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -280,6 +337,7 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
 #pragma unroll
                 for (int g = 0; g < G; ++g) pend[g] = cur[g];
                 sched_fence();
+                if (l == 3) { pg_stamp<TRACE>(tr, ti + 2); vm_wait<MIDWAIT>(); __syncthreads(); pg_stamp<TRACE>(tr, ti + 3); sched_fence(); }
             }
         }
 #pragma unroll
@@ -292,7 +350,7 @@ DEV void pg_block(const PgRec<TYPE>& R, const uint8_t* __restrict__ buf, int r16
 // Launch over the jobs of a site that have weight type TYPE.  grid (ceil(n_items / NW) rounded up to a multiple of 8, token
 // groups): the workgroups of one row range differ by a multiple of 8 in their linear id, i.e. run on the same XCD, whose L2
 // then serves the re-reads of the range's weights by the other token groups.
-template <int TYPE, int TG, int NW, bool GU>
+template <int TYPE, int TG, int NW, bool GU, bool TRACE = false>
 __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
     CT_DYN_SMEM(smem);
     using ST = PgStage<TG>;
@@ -347,11 +405,20 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
         for (int c = 0; c < G; ++c) glds16((SRC) + (size_t)(c * NW + wv) * 1024 + lane16, (DST) + (size_t)(c * NW + wv) * 1024); \
         _Pragma("unroll") \
         for (int c = 0; c < ST::TAILP; ++c) glds4((SRC) + ST::SUMS + (size_t)(c * NW + wv) * 256 + lane4, (DST) + ST::SUMS + (size_t)(c * NW + wv) * 256); } while (0)
-    // Three LDS buffers (rotating byte offsets; all below 64 KB, the reach of the DMA's M0 base), the copy runs TWO blocks ahead: stage b + 2 is requested at the top of step b, waited for at the end of step b
-    // (before its barrier) and first read in step b + 2, a whole step and a second barrier later.  Reading it right after the wait's
-    // own barrier is not enough on this hardware: the wave's vmcnt retires an LDS-DMA slightly before the bytes are visible to
-    // another wave's ds_read (seen as rare wrong stage data on the 32-layer model; guide: "read a staged buffer one phase AFTER
-    // the wait that retires it, never in the same phase").
+    // Three LDS buffers (rotating byte offsets; all below 64 KB, the reach of the DMA's M0 base) and ONE barrier per step, in its
+    // middle (behind AVX lane 3).  Stage b + 2 is requested in the second half of step b, waited for (vmcnt) right before the barrier
+    // of step b + 1 and first read at the top of step b + 2:
+    //   landing  an LDS-DMA takes ~1.1 us under load, about a step: waited for inside its own step it IS the step time;
+    //   RAW      the barrier after the wait is not enough by itself on this hardware — the wave's vmcnt retires an LDS-DMA slightly
+    //            before the bytes are visible to another wave's ds_read (seen as rare wrong stage data on the 32-layer model; guide:
+    //            "read a staged buffer one phase AFTER the wait that retires it") — here half a step lies between that barrier and the read;
+    //   WAR      the copy overwrites the buffer of stage b - 1; it is issued behind the barrier of step b, which a wave reaches only after
+    //            it has finished step b - 1.
+    // The wait leaves the younger requests in flight: this step's ring refill (NRING; memory operations retire in order).
+    constexpr int NDMA = G + ST::TAILP;   // DMA instructions per stage and wave
+    unsigned long long* tr = nullptr;
+    if constexpr (TRACE) { if ((m.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && wv == 0 && lane == 0) tr = (unsigned long long*)(smem + 3 * SB); }
+    pg_stamp<TRACE>(tr, 0);
     PG_STAGE(src, smem);
     PG_STAGE(src + (size_t)(1 < nb ? 1 : nb - 1) * SB, smem + (size_t)SB);
     // Weight ring: block b + 2 is requested while block b is used.  The requests run past the row's last block by up to two slots
@@ -362,6 +429,7 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
     __syncthreads();
     sleep_cycles<8>();   // the prologue's stand-in for the step between wait and first read
     __syncthreads();
+    pg_stamp<TRACE>(tr, 1);
     const uint8_t* rec0 = ub;
     uint32_t o_cur = 0, o_nxt = SB, o_dma = 2 * SB;
     for (int b0 = 0; b0 < nb; b0 += 4) {
@@ -373,12 +441,13 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
 #define PG_STEP(U, RING, RD, CB) do { \
             const int b = b0 + U; \
             const PgRec<TYPE> R = RING; \
-            PG_STAGE(src + (size_t)(b + 2 < nb ? b + 2 : nb - 1) * SB, smem + o_dma); \
-            RING = pg_load<TYPE, RD, CB>(rec0, LN); \
-            pg_block<TYPE, TG>(R, smem + o_cur, r16, p, acc, C, b < nb); \
+            pg_stamp<TRACE>(tr, 8 + 6 * b); \
+            const PgFeed F = {src + (size_t)(b + 2 < nb ? b + 2 : nb - 1) * SB, smem + o_dma, rec0, wv, lane16, lane4}; \
+            pg_stamp<TRACE>(tr, 8 + 6 * b + 1); \
+            pg_block<TYPE, TG, NRING, TRACE, RD, CB>(R, RING, F, LN, smem + o_cur, r16, p, acc, C, b < nb, tr, 8 + 6 * b); \
             { const uint32_t t = o_cur; o_cur = o_nxt; o_nxt = o_dma; o_dma = t; } \
-            vm_wait<NRING>(); \
-            __syncthreads(); } while (0)
+            pg_stamp<TRACE>(tr, 8 + 6 * b + 4); \
+            pg_stamp<TRACE>(tr, 8 + 6 * b + 5); } while (0)
         PG_STEP(0, ring0, 0, 2);
         PG_STEP(1, ring1, 0, 3);
         PG_STEP(2, ring0, 1, 0);
@@ -387,6 +456,7 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
 #undef PG_STAGE
         rec0 += REC;
     }
+    if constexpr (TRACE) { if (tr) { tr[2] = clock64_dev(); for (int i = 0; i < 120; ++i) ((unsigned long long*)m.dbg_sink)[i] = tr[i]; } }
     // hsum_float_8 (k_quants.c:90-97) and the min-term tree, in-lane; then the epilogues of the decode kernels, per token
     const int nt = a.n_tok - t0 < TG ? a.n_tok - t0 : TG;
     const int pos0 = (m.pos ? *m.pos : 0) + t0;
