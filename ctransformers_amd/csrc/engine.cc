@@ -911,8 +911,9 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     if (nt > 0 && (hd == 128 || hd == 64)) {
         // prompt chunk: n_head x nt workgroups, each latency-bound — 256-thread workgroups let three of them share a CU
         // (the arithmetic does not depend on the workgroup size: scores, softmax and V*P are per position / per channel)
-        if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<256, 128>), ag, dim3(256), stream_, ax);
-        else CT_LAUNCH((attn_fused_exact_kernel<256, 64>), ag, dim3(256), stream_, ax);
+        const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)nt);   // all channels of a head in one workgroup (ALLCH)
+        if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<256, 128, true>), ag1, dim3(256), stream_, ax);
+        else CT_LAUNCH((attn_fused_exact_kernel<256, 64, true>), ag1, dim3(256), stream_, ax);
         return;
     }
     if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);

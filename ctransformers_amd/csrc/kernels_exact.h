@@ -88,7 +88,9 @@ struct AttnArgsX {
 // then runs the softmax and its 64 channels of V*P exactly as attn_softmax_pv_exact_kernel does.  The double-precision
 // exp sum is order-free here: the addends are fp16 values in (0, 1] (multiples of 2^-24), so any summation order of up
 // to 8192 of them is exact in binary64.
-template <int NT, int HD>
+// ALLCH (prompt chunks): one workgroup per (head, token) runs ALL head_dim channels of V*P, 64 at a time, instead of one workgroup
+// per 64 channels each recomputing the score row — half the workgroups for the latency-bound chunk launch.
+template <int NT, int HD, bool ALLCH = false>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
     constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     const uint16_t* qrow = a.q_f16 + (size_t)tok * a.q_stride + (size_t)h * HD;
     const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
     const bool pv_thread = tid < 256;           // 64 channels x 4 lanes run the V*P part
-    const int d = (int)blockIdx.y * 64 + ((tid & 255) >> 2);
+    int d = (int)blockIdx.y * 64 + ((tid & 255) >> 2);
     const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
     // The V rows do not depend on the probabilities: their first VB chunks are requested now, so that their latency
     // overlaps the score and softmax phases instead of following them.
@@ -195,6 +197,14 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     __syncthreads();
     if (trace) tr[4] = clock64_dev();
     if (!pv_thread) return;
+#pragma unroll 1
+    for (int half = 0; half < (ALLCH ? HD / 64 : 1); ++half) {
+    if (half > 0) {   // the next 64 channels of this head
+        d += 64;
+        vrow += (size_t)64 * a.v_stride;
+#pragma unroll
+        for (int u = 0; u < VB; ++u) vv[u] = (32 * u < np) ? ld16(vrow + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+    }
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i0 = 0; i0 < np; i0 += 32 * VB) {
         if (i0 > 0) {
@@ -218,6 +228,7 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     if (trace) tr[5] = clock64_dev();
     for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
     if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
+    }
     if (trace) tr[6] = clock64_dev();
 }
 
