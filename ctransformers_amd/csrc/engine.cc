@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <functional>
 #include <thread>
+#include <atomic>
+#include <chrono>
+#include <unistd.h>
 
 #include "gguf_reader.h"
 #include "kernels_v6.h"
@@ -35,6 +38,7 @@ static int env_int(const char* name, int dflt) {
 Engine::~Engine() { free_all(); }
 
 void Engine::free_all() {
+    release_staged();
     if (stream_ || !dev_allocs_.empty()) (void)hipSetDevice(device_);
     for (void* p : dev_allocs_) (void)hipFree(p);
     dev_allocs_.clear();
@@ -82,7 +86,7 @@ static void parallel_rows(int M, const std::function<void(int, int)>& fn) {
 
 // One file-layout K-quant block -> slot `r` (0..7) of a record in the tile8S field order (quant.h); the 6-bit scale/min
 // field of Q4_K / Q5_K headers is re-encoded as four 24-bit groups (reference packing: k_quants.c:306-314).
-static void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
+CT_HD static inline void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
     uint8_t hdr[16];
     if (type != GT_Q6_K) {
         memcpy(hdr, blk, 16);
@@ -112,6 +116,86 @@ static void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
     }
 }
 
+// The same placement on the GPU: one thread per block slot of the arena, reading the tensor in FILE layout from the staged copy of
+// the model file (stage_file).  `sb` != null: fused gate/up (unit u = row u of sa and of sb), else unit u = rows 2u, 2u + 1 of sa.
+__global__ void __launch_bounds__(256) repack_r2c4_kernel(int type, const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
+                                                          uint8_t* __restrict__ dst, int M, int nb, int n_units) {
+    const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type);
+    const long long n = (long long)n_units * spu * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(i & 7), rr = slot >> 2, cc = slot & 3;
+        const long long us = i >> 3;
+        const int s = (int)(us % spu), u = (int)(us / spu);
+        const int row = sb ? u : 2 * u + rr, b = 4 * s + cc;
+        if (row >= M || b >= nb) continue;   // zero slot (the arena is cleared first)
+        place_kblock(type, dst + (size_t)us * rec, slot, ((sb && rr) ? sb : sa) + ((size_t)row * nb + b) * bb);
+    }
+}
+
+// Load pipeline, stage 1: the byte range of the mapping that holds the tensors in `need` -> device memory, unchanged.  pread() by
+// worker threads straight into pinned slots (no page faults on the mapping, no pageable bounce inside the runtime), one async copy
+// per slot; reading slot k + 1 overlaps the copy of slot k.
+bool Engine::stage_file(const GgufFile& f, const std::vector<const GgufTensor*>& need, std::string& err) {
+    file_lo_ = file_hi_ = nullptr;
+    for (const GgufTensor* t : need) {
+        if (!t) continue;
+        if (!file_lo_ || t->data < file_lo_) file_lo_ = t->data;
+        if (!file_hi_ || t->data + t->nbytes > file_hi_) file_hi_ = t->data + t->nbytes;
+    }
+    if (!file_lo_) return true;
+    const size_t total = (size_t)(file_hi_ - file_lo_);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc((void**)&dev_file_, total + 256);
+    if (e != hipSuccess) { dev_file_ = nullptr; err = "hipMalloc for the staged model file failed"; return false; }
+#ifdef CT_EMU
+    memcpy(dev_file_, file_lo_, total);
+#else
+    constexpr int NSLOT = 4;
+    constexpr size_t SLOT = (size_t)64 << 20;
+    uint8_t* pin[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSLOT];
+    hipStream_t cs;
+    HIP_OK(hipStreamCreate(&cs));
+    for (int k = 0; k < NSLOT; ++k) { HIP_OK(hipHostMalloc((void**)&pin[k], SLOT)); HIP_OK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+    const off_t base = (off_t)(file_lo_ - f.map_base());
+    const int fd = f.fd();
+    bool ok = true;
+    int k = 0;
+    for (size_t off = 0; off < total && ok; off += SLOT, k = (k + 1) % NSLOT) {
+        const size_t len = std::min(SLOT, total - off);
+        if (off >= NSLOT * SLOT) HIP_OK(hipEventSynchronize(ev[k]));   // the copy that last used this slot
+        uint8_t* dstp = pin[k];
+        std::atomic<bool> good(true);
+        parallel_rows((int)((len + (1 << 20) - 1) >> 20), [&](int m0, int m1) {   // 1 MB pieces
+            for (int mi = m0; mi < m1; ++mi) {
+                size_t o = (size_t)mi << 20;
+                const size_t end = std::min(len, o + ((size_t)1 << 20));
+                while (o < end) {
+                    const ssize_t r = pread(fd, dstp + o, end - o, base + (off_t)(off + o));
+                    if (r <= 0) { good = false; return; }
+                    o += (size_t)r;
+                }
+            }
+        });
+        if (!good) { ok = false; break; }
+        HIP_OK(hipMemcpyAsync(dev_file_ + off, dstp, len, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipEventRecord(ev[k], cs));
+    }
+    HIP_OK(hipStreamSynchronize(cs));
+    for (int q = 0; q < NSLOT; ++q) { hipHostFree(pin[q]); hipEventDestroy(ev[q]); }
+    hipStreamDestroy(cs);
+    if (!ok) { err = "reading the model file failed"; return false; }
+#endif
+    load_stage_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+const uint8_t* Engine::staged(const GgufTensor* t) const { return dev_file_ ? dev_file_ + (t->data - file_lo_) : nullptr; }
+
+void Engine::release_staged() {
+    if (dev_file_) { hipFree(dev_file_); dev_file_ = nullptr; }
+}
+
 // LAYOUT_R2C4 copies for the decode mat-vec (kernels_v7.h).  The matrices of `parts` are placed back to back in ONE device
 // allocation, in order: a launch walks the row pairs of all its jobs of one weight type as a single contiguous unit space
 // (attn_q | attn_k | attn_v).  `fuse` (two parts of the same type and shape): ONE fused gate/up matrix, unit u = (row u of
@@ -134,6 +218,21 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
         p.bytes = (size_t)p.n_units * ((p.nb + 3) / 4) * tile8_record_bytes(p.type);
         total += p.bytes;
         plan.push_back(p);
+    }
+    if (dev_file_) {   // tensors already on the device in file layout: repack there
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, total + 4096, err)) return false;
+        HIP_OK(hipMemsetAsync(d, 0, total + 4096, stream_));
+        for (const Plan& p : plan) {
+            const long long n = (long long)p.n_units * ((p.nb + 3) / 4) * 8;
+            const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16);
+            CT_LAUNCH(repack_r2c4_kernel, dim3(gx), dim3(256), stream_, p.type, staged(p.ta), p.tb ? staged(p.tb) : (const uint8_t*)nullptr, d + p.off, p.M, p.nb, p.n_units);
+        }
+        for (const Plan& p : plan) {
+            p.m->r2 = d + p.off;
+            if (p.tb) { p.m->type = p.type; p.m->K = p.K; p.m->M = p.M; p.m->nb = p.nb; p.m->layout = LAYOUT_R2C4; p.m->bytes = p.ta->nbytes + p.tb->nbytes; }
+        }
+        return true;
     }
     std::vector<uint8_t> st(total, 0);
     for (const Plan& p : plan) {
@@ -187,6 +286,7 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     if (is_kquant(t->type)) {
         // tile8S layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row, 6-bit scales re-encoded.
         if (m.K > 32768) { err = "tensor " + t->name + ": rows longer than 32768 are not supported yet"; return false; }
+        if (!keep_tile8s_) { m.layout = LAYOUT_R2C4; return true; }   // only the R2C4 arena (upload_r2c4): kernels_v7.h and kernels_pg.h read that
         m.layout = LAYOUT_TILE8S;
         const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
         std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
@@ -252,7 +352,8 @@ bool Engine::upload_f32(const GgufTensor* t, float** out, int n, std::string& er
     if (!t) { err = "missing f32 tensor"; return false; }
     if (t->type != GT_F32 || t->ne[0] != n) { err = "tensor " + t->name + " must be f32[" + std::to_string(n) + "]"; return false; }
     if (!dev_alloc(dev_allocs_, out, (size_t)n, err)) return false;
-    HIP_OK(hipMemcpy(*out, t->data, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (dev_file_ && t->data >= file_lo_ && t->data + (size_t)n * 4 <= file_hi_) HIP_OK(hipMemcpyAsync(*out, staged(t), (size_t)n * 4, hipMemcpyDeviceToDevice, stream_));
+    else HIP_OK(hipMemcpy(*out, t->data, (size_t)n * 4, hipMemcpyHostToDevice));
     return true;
 }
 
@@ -357,13 +458,29 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     l0_ = layer_begin < 0 ? 0 : layer_begin;
     l1_ = layer_end < 0 ? hp_.n_layer : layer_end;
     if (l0_ >= l1_ || l1_ > hp_.n_layer) { err = "bad pipeline stage layer range"; return false; }
+    {   // Load pipeline.  The tensors of this handle's layers: all matrices K-quants -> stage the file range on the GPU and repack there.
+        std::vector<const GgufTensor*> need;
+        bool all_kq = true;
+        for (const GgufTensor& x : f.tensors()) {
+            bool mine = false;
+            if (x.name.compare(0, 4, "blk.") == 0) { const int li = atoi(x.name.c_str() + 4); mine = li >= l0_ && li < l1_; }
+            else if (x.name.compare(0, 10, "token_embd") == 0) mine = l0_ == 0;
+            else if (x.name.compare(0, 6, "output") == 0) mine = l1_ == hp_.n_layer;
+            if (!mine) continue;
+            need.push_back(&x);
+            if (x.n_dims >= 2 && x.name.compare(0, 10, "token_embd") != 0 && !is_kquant(x.type)) all_kq = false;
+        }
+        keep_tile8s_ = !use_v7_ || env_int("CT_AMD_PG", 1) == 0 || env_int("CT_AMD_PF_MFMA", 1) == 0 || env_int("CT_AMD_TILE8S", 0) != 0 || !all_kq;
+        if (all_kq && use_v7_ && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;
+    }
     t = f.tensor("token_embd.weight");
     if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
     if (l0_ == 0) {   // token_embd is only used by row lookup: keep the file layout, no planes
         tok_embd_.type = t->type; tok_embd_.K = E; tok_embd_.M = V;
         uint8_t* d = nullptr;
         if (!dev_alloc(dev_allocs_, &d, t->nbytes, err)) return false;
-        HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
+        if (dev_file_) HIP_OK(hipMemcpyAsync(d, staged(t), t->nbytes, hipMemcpyDeviceToDevice, stream_));
+        else HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
         tok_embd_.raw = d;
     }
     layers_.resize(hp_.n_layer);
@@ -419,6 +536,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
 
     if (!alloc_state(err)) return false;
     HIP_OK(hipDeviceSynchronize());
+    release_staged();
     if (!warm_up(err)) return false;
     return true;
 }
@@ -468,7 +586,7 @@ bool Engine::alloc_state(std::string& err) {
             const std::initializer_list<const DevMat*> fused_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};   // falcon, gpt2
             for (const DevMat* m : (hp_.falcon() || hp_.gpt2()) ? fused_mats : llama_mats) {
                 ++n_all;
-                if (m->layout == LAYOUT_TILE8S && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K)) ++n_kq;
+                if ((m->layout == LAYOUT_TILE8S || m->layout == LAYOUT_R2C4) && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K)) ++n_kq;
                 if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
             }
         }
@@ -1044,6 +1162,8 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             return ok;
         }
         if (m.gateup && m.njobs == 1) { err = "fused gate/up matrix outside kernels_pg.h"; return false; }
+        for (int j = 0; j < m.njobs; ++j)
+            if (is_kquant(m.job[j].w.type) && !m.job[j].w.p[0]) { err = "this chunk kernel reads the tile8S weight copies: load with CT_AMD_TILE8S=1"; return false; }
     }
     if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
         if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);

@@ -176,6 +176,16 @@ class Engine {
     float *h_logits_ = nullptr, *h_emb_ = nullptr;
     int* h_scalars_ = nullptr;  // pinned staging for the token ids + cursor
     bool use_graph_ = false;
+    // load pipeline: the file's tensor bytes go to the GPU once, in file layout, through pinned staging (pread in parallel, async
+    // copies), and kernels repack them into the LAYOUT_R2C4 arenas there; the tile8S copies are only made for the A/B kernels
+    bool stage_file(const class GgufFile& f, const std::vector<const struct GgufTensor*>& need, std::string& err);
+    void release_staged();
+    const uint8_t* staged(const struct GgufTensor* t) const;
+    uint8_t* dev_file_ = nullptr;        // [file_lo_, file_hi_) of the mapping, on the device; freed at the end of load()
+    const uint8_t* file_lo_ = nullptr;
+    const uint8_t* file_hi_ = nullptr;
+    bool keep_tile8s_ = false;           // CT_AMD_V7=0 / CT_AMD_PG=0 / CT_AMD_TILE8S=1: also keep the tile8S copies (kernels_v5/v6/ks/pfm.h)
+    double load_stage_s_ = 0.0, load_repack_s_ = 0.0;
     bool use_v7_ = true;    // decode mat-vecs of K-quant matrices on generation 7 (CT_AMD_V7=0: generations 5/6, A/B)
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;

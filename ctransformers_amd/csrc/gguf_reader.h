@@ -48,6 +48,10 @@ class GgufFile {
     bool get_str(const std::string& key, std::string& out) const;
     const GgufTensor* tensor(const std::string& name) const;
     const std::vector<GgufTensor>& tensors() const { return tensors_; }
+    // the open file and its mapping: the load pipeline reads tensor bytes with pread() into pinned staging (engine.cc:stage_file)
+    int fd() const { return fd_; }
+    const uint8_t* map_base() const { return map_; }
+    size_t map_size() const { return size_; }
 
    private:
     bool fail(const std::string& m) { err_ = m; return false; }
