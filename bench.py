@@ -17,6 +17,10 @@ and the MAX reduction only (backend gloo: they own no GPU work); where a rank ca
 RCCL pipeline of ctransformers_amd/pipeline.py runs instead.  Decode of one sequence is serial over the stages (strong
 scaling: the model is fixed), so the roofline denominator stays ONE GPU's HBM.
 
+`--config 3|4|5` runs the other single-GPU-capable BASELINE configs instead (3: Llama-2-7B Q8_0; 4: Falcon-40B Q4_K_M, 25 GB; 5:
+Llama-2-70B Q5_K_M, 49 GB — each fits one MI355X's 288 GB; with --gpus N their layers are spread over N GPUs); the default run is
+config 2.  The 40B / 70B files take minutes to synthesise on first use.
+
 Extra objects on the JSON line:
   roofline      dominant kernel (the K=4096 weight mat-vec launches: QKV / Wo / gate+up / lm_head sites) —
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
@@ -42,6 +46,13 @@ N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
 MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
 SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), os.environ.get("CTAMD_BENCH_FTYPE", "Q4_K_M")
 GEN_VERSION = "synth-r2:%s:%s:seed1234" % (SHAPE, FTYPE)
+CONFIG = 2
+CONFIGS = {2: ("llama-2-7b", "Q4_K_M", "/tmp/ctamd_llama2_7b_q4km_r2.gguf"), 3: ("llama-2-7b", "Q8_0", "/tmp/ctamd_llama2_7b_q80_r2.gguf"),
+           4: ("falcon-40b", "Q4_K_M", "/tmp/ctamd_falcon_40b_q4km_r2.gguf"), 5: ("llama-2-70b", "Q5_K_M", "/tmp/ctamd_llama2_70b_q5km_r2.gguf")}
+
+
+def shape_dims():
+    return synth.FALCON_SHAPES[SHAPE] if SHAPE.startswith("falcon") else synth.LLAMA_SHAPES[SHAPE]
 
 
 def _fingerprint(path):
@@ -111,7 +122,8 @@ def cpu_baseline(n_vocab):
     if ref.available():
         def run(threads, limit):
             try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), "--cpu-vocab", str(n_vocab)],
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), "--cpu-vocab", str(n_vocab),
+                                    "--config", str(CONFIG)],
                                    capture_output=True, text=True, timeout=limit)
                 lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
                 return json.loads(lines[-1]) if lines else None
@@ -180,9 +192,15 @@ def main():
     ap.add_argument("--steps", type=int, default=N_DECODE)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2: the headline)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    global SHAPE, FTYPE, MODEL, GEN_VERSION, CONFIG
+    CONFIG = a.config
+    if a.config != 2:
+        SHAPE, FTYPE, MODEL = CONFIGS[a.config]
+        GEN_VERSION = "synth-r2:%s:%s:seed1234" % (SHAPE, FTYPE)
     if a.cpu_worker is not None:
         _cpu_worker(a.cpu_worker, a.cpu_vocab)
         return 0
@@ -251,13 +269,14 @@ def main():
     sites = measure.profile_sites(llm._lib, llm._llm, 8)
     roof = measure.roofline(sites)
     wbytes = synth.weight_bytes_per_token(MODEL)
-    kv_avg = 2 * 32 * (N_PROMPT + a.warmup + steps / 2.0) * 4096 * 2 if SHAPE == "llama-2-7b" else 0
+    hd = shape_dims()   # K + V rows of every layer, fp16, at the average position of the timed steps
+    kv_avg = 2 * hd["n_layer"] * (N_PROMPT + a.warmup + steps / 2.0) * (hd["n_embd"] // hd["n_head"] * hd["n_head_kv"]) * 2
     par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hipMemcpyPeerAsync hand-off)" % n_stages
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,
                ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
-               dtype="int8", data="synthetic",
+               dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)", data="synthetic",
                config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + 256-tok greedy decode, ctx 512" % n_gpus
-                           if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "%s %s, %d x MI355X, 128-tok prefill + greedy decode, ctx 512" % (SHAPE, FTYPE, n_gpus),
+                           if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d-tok greedy decode, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
                            devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
@@ -267,10 +286,12 @@ def main():
     # prompt chunks: 2 ops per weight of the 2-D matrices per token, against the dense int8 MFMA
     # floor of the guide; the bound is VALU issue (the exact f32 chain step per block, AVX lane, row and token), not MFMA
     pf_flop = 2 * 6.607e9 if SHAPE == "llama-2-7b" else None
+    kq = FTYPE.endswith("_K_M")
     out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=128,
-                          kernel="matvec_pfm_kernel<TYPE,TOK,GU> (int8 MFMA, exact), one hipGraph per chunk shape",
-                          int8_tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_peak_tops=3944,
-                          bound="valu")
+                          kernel=("matmul_pg_kernel<TYPE,TG,8,GU> (exact integer sums on v_mfma_f32_16x16x32_f16, f32 chain on VALU)" if kq
+                                  else "matvec_pf_kernel<8,GU> (dot4, Q8_0 activations)") + ", one hipGraph per chunk shape",
+                          tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
+                          bound="valu + mfma issue (the exact f32 chain step per block, AVX lane, row and token)")
     if not a.no_cpu_baseline and n_gpus == 1:
         del llm
         out["cpu_baseline"] = cpu_baseline(n_vocab)

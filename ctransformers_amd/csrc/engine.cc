@@ -12,11 +12,9 @@
 #include <unistd.h>
 
 #include "gguf_reader.h"
-#include "kernels_v6.h"
 #include "kernels_v7.h"
 #include "kernels_q32.h"
-#include "kernels_ks.h"
-#include "kernels_pfm.h"
+#include "kernels_pf.h"
 #include "kernels_pg.h"
 
 namespace ctamd {
@@ -118,8 +116,10 @@ CT_HD static inline void place_kblock(int type, uint8_t* rp, int r, const uint8_
 
 // The same placement on the GPU: one thread per block slot of the arena, reading the tensor in FILE layout from the staged copy of
 // the model file (stage_file).  `sb` != null: fused gate/up (unit u = row u of sa and of sb), else unit u = rows 2u, 2u + 1 of sa.
-__global__ void __launch_bounds__(256) repack_r2c4_kernel(int type, const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
+template <int TYPE>
+__global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
                                                           uint8_t* __restrict__ dst, int M, int nb, int n_units) {
+    constexpr int type = TYPE;
     const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type);
     const long long n = (long long)n_units * spu * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -226,7 +226,11 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
         for (const Plan& p : plan) {
             const long long n = (long long)p.n_units * ((p.nb + 3) / 4) * 8;
             const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16);
-            CT_LAUNCH(repack_r2c4_kernel, dim3(gx), dim3(256), stream_, p.type, staged(p.ta), p.tb ? staged(p.tb) : (const uint8_t*)nullptr, d + p.off, p.M, p.nb, p.n_units);
+            const uint8_t* sa = staged(p.ta);
+            const uint8_t* sb = p.tb ? staged(p.tb) : nullptr;
+            if (p.type == GT_Q4_K) CT_LAUNCH((repack_r2c4_kernel<GT_Q4_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+            else if (p.type == GT_Q5_K) CT_LAUNCH((repack_r2c4_kernel<GT_Q5_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+            else CT_LAUNCH((repack_r2c4_kernel<GT_Q6_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
         }
         for (const Plan& p : plan) {
             p.m->r2 = d + p.off;
@@ -284,28 +288,8 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     m.bytes = t->nbytes;
     const int nb = m.nb, M = m.M;
     if (is_kquant(t->type)) {
-        // tile8S layout (quant.h): record (tile, block) = the 8 rows' blocks, fields grouped per row, 6-bit scales re-encoded.
         if (m.K > 32768) { err = "tensor " + t->name + ": rows longer than 32768 are not supported yet"; return false; }
-        if (!keep_tile8s_) { m.layout = LAYOUT_R2C4; return true; }   // only the R2C4 arena (upload_r2c4): kernels_v7.h and kernels_pg.h read that
-        m.layout = LAYOUT_TILE8S;
-        const int n_tiles = (M + 7) / 8, rec = tile8_record_bytes(t->type), type = t->type;
-        std::vector<uint8_t> st((size_t)n_tiles * nb * rec, 0);
-        const uint8_t* src = t->data;
-        parallel_rows(n_tiles, [&](int t0, int t1) {
-            for (int tl = t0; tl < t1; ++tl)
-                for (int b = 0; b < nb; ++b) {
-                    uint8_t* rp = &st[((size_t)tl * nb + b) * rec];
-                    for (int r = 0; r < 8; ++r) {
-                        const int row = tl * 8 + r;
-                        if (row >= M) continue;
-                        place_kblock(type, rp, r, src + ((size_t)row * nb + b) * bb);
-                    }
-                }
-        });
-        uint8_t* d = nullptr;
-        if (!dev_alloc(dev_allocs_, &d, st.size() + 64, err)) return false;
-        HIP_OK(hipMemcpy(d, st.data(), st.size(), hipMemcpyHostToDevice));
-        m.p[0] = d;
+        m.layout = LAYOUT_R2C4;   // the records live in an arena several matrices may share: upload_r2c4 places them
         return true;
     }
     {   // Q8_0 / Q4_0
@@ -442,7 +426,6 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (n_ctx_ > kMaxCtx) { err = "context_length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
 
     HIP_OK(hipStreamCreate(&stream_));
-    use_v7_ = env_int("CT_AMD_V7", 1) != 0;
     bool r2_auto = true;   // mat() also makes the matrix's own R2C4 copy (false: the caller places several matrices in one arena)
     const GgufTensor* t;
     auto mat = [&](const std::string& name, DevMat& m, int M, int K, bool raw = false) {
@@ -450,7 +433,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (!t) { err = "missing tensor " + name; return false; }
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (!upload_matrix(t, m, raw, err)) return false;
-        if (use_v7_ && is_kquant(t->type) && r2_auto && !upload_r2c4({{t, &m}}, false, err)) return false;
+        if (is_kquant(t->type) && r2_auto && !upload_r2c4({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -470,8 +453,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
             need.push_back(&x);
             if (x.n_dims >= 2 && x.name.compare(0, 10, "token_embd") != 0 && !is_kquant(x.type)) all_kq = false;
         }
-        keep_tile8s_ = !use_v7_ || env_int("CT_AMD_PG", 1) == 0 || env_int("CT_AMD_PF_MFMA", 1) == 0 || env_int("CT_AMD_TILE8S", 0) != 0 || !all_kq;
-        if (all_kq && use_v7_ && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;
+        if (all_kq && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;   // 0: host repack (A/B)
     }
     t = f.tensor("token_embd.weight");
     if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
@@ -519,10 +501,10 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         r2_auto = true;
         if (!mat(p + "attn_output.weight", L.wo, E, E) || !mat(p + "ffn_down.weight", L.w_down, E, F)) return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
-        if (use_v7_ && is_kquant(L.wq.type) && is_kquant(L.wk.type) && is_kquant(L.wv.type) &&
+        if (is_kquant(L.wq.type) && is_kquant(L.wk.type) && is_kquant(L.wv.type) &&
             !upload_r2c4({{f.tensor(p + "attn_q.weight"), &L.wq}, {f.tensor(p + "attn_k.weight"), &L.wk}, {f.tensor(p + "attn_v.weight"), &L.wv}}, false, err))
             return false;
-        if (use_v7_ && is_kquant(L.w_gate.type) &&
+        if (is_kquant(L.w_gate.type) &&
             !upload_r2c4({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
             return false;
     }
@@ -575,10 +557,10 @@ bool Engine::alloc_state(std::string& err) {
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
-    // prompt chunks (kernels_pf.h, kernels_pfm.h): llama graph, K-quant tile layout, n_embd <= 12288, n_ff <= 32768
-    use_mfma_ = env_int("CT_AMD_PF_MFMA", 1) != 0;
-    pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0 && (!hp_.falcon() || use_mfma_);
-    {   // every layer matrix a K-quant in the tile layout (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 12288
+    // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
+    pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
+    bool kq_model = false;
+    {   // every layer matrix a K-quant (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 12288
         int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
         for (int i = l0_; i < l1_; ++i) {
             const Layer& L = layers_[i];
@@ -586,25 +568,24 @@ bool Engine::alloc_state(std::string& err) {
             const std::initializer_list<const DevMat*> fused_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};   // falcon, gpt2
             for (const DevMat* m : (hp_.falcon() || hp_.gpt2()) ? fused_mats : llama_mats) {
                 ++n_all;
-                if ((m->layout == LAYOUT_TILE8S || m->layout == LAYOUT_R2C4) && (m->type == GT_Q4_K || m->type == GT_Q5_K || m->type == GT_Q6_K)) ++n_kq;
+                if (m->layout == LAYOUT_R2C4 && is_kquant(m->type)) ++n_kq;
                 if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
             }
         }
         pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || n_q32 == n_all);
+        kq_model = n_kq == n_all;
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
-        pfm_force_tok_ = env_int("CT_AMD_PFM_TOK", 0);   // tests: 8 or 4 forces that matrix-core form at any K
         pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
-        const size_t aw = (size_t)pf_act_words(std::max(E, F));
         if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
-            !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err) ||
-            !dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * aw, err))
+            !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err))
             return false;
-        use_pg_ = env_int("CT_AMD_PG", 1) != 0;
         pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
-        if (use_pg_) {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
-            acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max({(kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES, (kPfChunk / 64) * PgStage<64>::BYTES}) + 4096;
+        if (!kq_model) {   // Q8_0 activation images of the Q8_0 / Q4_0 chunk kernel
+            if (!dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * pf_act_words_q32(std::max(E, F)), err)) return false;
+        } else {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
+            acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max((kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES) + 4096;
             if (!dev_alloc(dev_allocs_, &acts_h_, 2 * acts_h_half_, err)) return false;
             HIP_OK(hipMemset(acts_h_, 0, 2 * acts_h_half_));   // token slots past the chunk's end are read (and their results dropped)
         }
@@ -845,14 +826,12 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     return true;
 }
 
-// One mat-vec launch.  Work items are 8-row tiles ("units"); the jobs of a launch are concatenated into one item list.
-//   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h)
-//   LAYOUT_TILE8S, K > 12288           -> systolic wide-K K-quant kernel (kernels_ks.h)
-//   LAYOUT_TILE8S, K <= 12288          -> generation 6 (kernels_v6.h); launches with at most two units per workgroup and
-//                                         one weight type stay on generation 5 (one round: the counters buy nothing)
-static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err, bool use_v7) {
-    if (use_v7 && v7_can(a)) return launch_matvec_v7(a, s, err);
-    if (a.job[0].w.layout == LAYOUT_R2C4) { err = "fused gate/up matrix outside generation 7"; return false; }
+// One mat-vec launch.
+//   K-quant jobs (LAYOUT_R2C4 arenas)  -> generation 7 (kernels_v7.h), work items are row pairs
+//   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h), work items are 8-row tiles
+static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
+    if (v7_can(a)) return launch_matvec_v7(a, s, err);
+    if (a.job[0].w.layout != LAYOUT_G4) { err = "mat-vec: this launch shape has no kernel (K-quant launch outside generation 7)"; return false; }
     a.emb_out = nullptr;
     int item0 = 0;
     for (int j = 0; j < a.njobs; ++j) {   // set_jobs counted row pairs; the kernels count tiles
@@ -860,108 +839,29 @@ static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err, bool u
         item0 += (a.job[j].w.M + 7) / 8;
     }
     a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
-    const int ty = a.job[0].w.type, layout = a.job[0].w.layout;
+    const int ty = a.job[0].w.type;
     const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
-    if (layout == LAYOUT_G4) {
-        for (int j = 1; j < a.njobs; ++j)
-            if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
-        if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
-        static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
-        if (!systolic) {   // A/B: wave-per-tile form
-            const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16)));
-            if (ty == GT_Q8_0) {
-                if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, block, s, a);
-                else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, block, s, a);
-            } else {
-                if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, block, s, a);
-                else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, block, s, a);
-            }
-            return true;
+    for (int j = 1; j < a.njobs; ++j)
+        if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
+    if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
+    static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
+    if (!systolic) {   // A/B: wave-per-tile form
+        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16)));
+        if (ty == GT_Q8_0) {
+            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, block, s, a);
+            else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, block, s, a);
+        } else {
+            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, block, s, a);
+            else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, block, s, a);
         }
+        return true;
+    }
 #define Q32S(TY, MG) do { if (a.gateup) CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, true>), grid, block, s, a); \
                           else CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, false>), grid, block, s, a); } while (0)
-        const int per_wave = ((a.K >> 7) + 15) / 16;
-        if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
-        else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
+    const int per_wave = ((a.K >> 7) + 15) / 16;
+    if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
+    else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
 #undef Q32S
-        return true;
-    }
-    if (layout != LAYOUT_TILE8S) { err = "mat-vec: unknown weight layout"; return false; }
-    if (a.K > 12288) {   // wide rows: one type, plain epilogues (ffn_down of the 70B / Falcon-40B class)
-        bool ok = !a.gateup && a.K <= 32768 && a.pro == PRO_PLAIN;
-        for (int j = 0; j < a.njobs; ++j) {
-            const int e = a.job[j].epi;
-            ok = ok && a.job[j].w.type == ty && (e == EPI_STORE || e == EPI_ADD || e == EPI_ADD2 || e == EPI_GELU);
-        }
-        if (!ok) { err = "wide-K mat-vec (K=" + std::to_string(a.K) + "): unsupported launch shape"; return false; }
-        if (ty == GT_Q4_K) CT_LAUNCH((matvec_ks_kernel<GT_Q4_K, 32768, 8>), grid, block, s, a);
-        else if (ty == GT_Q5_K) CT_LAUNCH((matvec_ks_kernel<GT_Q5_K, 32768, 8>), grid, block, s, a);
-        else CT_LAUNCH((matvec_ks_kernel<GT_Q6_K, 32768, 8>), grid, block, s, a);
-        return true;
-    }
-    // job groups: (TA ...)(TB ...) with TB == Q6_K or absent — K-quant files only ever mix one base type with Q6_K
-    int ta = ty, tb = 0, na = 0;
-    for (int j = 0; j < a.njobs; ++j) {
-        const int tj = a.job[j].w.type;
-        if (a.job[j].w.layout != LAYOUT_TILE8S) { err = "mixed weight layouts in one launch"; return false; }
-        const int items = a.gateup ? (j == 0 ? a.n_pairs : 0) : (a.job[j].w.M + 7) / 8;
-        if (tj == ta && tb == 0) na += items;
-        else if (tb == 0 && tj == GT_Q6_K) tb = tj;
-        else if (tj != tb) { err = "unsupported weight-type mix in one launch"; return false; }
-    }
-    if (a.gateup) {
-        if (a.job[0].w.type != a.job[1].w.type) { err = "gate/up weight types differ"; return false; }
-        na = a.n_pairs;
-        tb = 0;
-    }
-    a.n_groupA = na;
-    const bool ln = a.pro == PRO_LAYERNORM;
-    if (ln && (a.gateup || tb != 0)) { err = "LayerNorm prologue with a gate/up or mixed-type launch"; return false; }
-    const int units_per_wg = ((a.n_pairs + (int)grid.x - 1) / (int)grid.x) * (a.gateup ? 2 : 1);
-    static const int gen6 = env_int("CT_AMD_GEN6", 1);   // 0: A/B, generation 5 wherever it can run
-    const bool v5_ok = tb == 0 && (a.K <= 4096 || !a.gateup);
-    if (v5_ok && ((a.K <= 4096 && units_per_wg <= 2) || !gen6)) {
-#define V5L(MK, SS, TT, NB, TAV) do { \
-            if (a.gateup) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, true, false>), grid, block, s, a); \
-            else if (ln) CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, false, true>), grid, block, s, a); \
-            else CT_LAUNCH((matvec_v5_kernel<MK, SS, TT, NB, TAV, false, false>), grid, block, s, a); } while (0)
-#define V5(MK, SS, TT, NB) do { if (ta == GT_Q4_K) V5L(MK, SS, TT, NB, GT_Q4_K); else if (ta == GT_Q5_K) V5L(MK, SS, TT, NB, GT_Q5_K); \
-                                 else V5L(MK, SS, TT, NB, GT_Q6_K); } while (0)
-        if (a.K > 4096) V5(12288, 3, 2, 1);
-        else if (units_per_wg <= 2) V5(4096, 1, 2, 2);
-        else V5(4096, 1, 4, 2);
-#undef V5
-#undef V5L
-        return true;
-    }
-    if (a.gateup && a.K > 8192) { err = "gate/up launch with K > 8192 not supported yet"; return false; }
-    // generation 6 uses dynamic LDS (up to 146 KB): the per-function opt-in is done once per instantiation
-#define V6L(MK, SS, TT, NB, TAV, TBV, GUV, LNV) do { \
-        auto kfn = matvec_v6_kernel<MK, SS, TT, NB, TAV, TBV, GUV, LNV>; \
-        constexpr size_t smem = sizeof(SmemV6<MK, TT, NB>); \
-        CT_OPTIN_ONCE(kfn, smem); \
-        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
-#define V6T(MK, SS, TT, NB, TAV) do { \
-        if (a.gateup) V6L(MK, SS, TT, NB, TAV, 0, true, false); \
-        else if (ln) V6L(MK, SS, TT, NB, TAV, 0, false, true); \
-        else if (tb != 0) V6L(MK, SS, TT, NB, TAV, GT_Q6_K, false, false); \
-        else V6L(MK, SS, TT, NB, TAV, 0, false, false); } while (0)
-#define V6(MK, SS, TT, NB) do { if (ta == GT_Q4_K) V6T(MK, SS, TT, NB, GT_Q4_K); else if (ta == GT_Q5_K) V6T(MK, SS, TT, NB, GT_Q5_K); \
-                                 else V6L(MK, SS, TT, NB, GT_Q6_K, 0, false, false); } while (0)
-    if (ta == GT_Q6_K && (a.gateup || ln)) {   // all-Q6_K files: gate/up and LayerNorm launches of a Q6_K base type
-        if (a.K <= 4096) { if (a.gateup) V6L(4096, 1, 4, 4, GT_Q6_K, 0, true, false); else V6L(4096, 1, 4, 4, GT_Q6_K, 0, false, true); }
-        else if (a.K <= 8192) { if (a.gateup) V6L(8192, 2, 2, 4, GT_Q6_K, 0, true, false); else V6L(8192, 2, 2, 4, GT_Q6_K, 0, false, true); }
-        else V6L(12288, 3, 2, 3, GT_Q6_K, 0, false, true);
-    } else if (a.K <= 4096) {
-        V6(4096, 1, 4, 4);
-    } else if (a.K <= 8192) {   // n_embd of Llama-2-70B / Falcon-40B: 32 blocks, two per wave
-        V6(8192, 2, 2, 4);
-    } else {
-        V6(12288, 3, 2, 3);
-    }
-#undef V6
-#undef V6T
-#undef V6L
     return true;
 }
 
@@ -1013,7 +913,7 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
     }
 }
 
-bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err, use_v7_); }
+bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err); }
 
 // One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
 void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
@@ -1051,7 +951,7 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         for (int j = 0; j < m.njobs; ++j) items += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;
         if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus()) tg = 16;
     }
-    if (pg_force_tg_ == 16 || pg_force_tg_ == 32 || pg_force_tg_ == 64) tg = pg_force_tg_;
+    if (pg_force_tg_ == 16 || pg_force_tg_ == 32) tg = pg_force_tg_;
     const int groups = (nt + tg - 1) / tg, nb = m.K / 256;
     if ((size_t)groups * nb * pg_stage_bytes(tg) > acts_h_half_) { err = "stage images exceed their buffer"; return false; }
     bool has45 = false, has6 = false;
@@ -1090,8 +990,7 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<TGV>::BYTES); ++g_pg_launches; \
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
 #define PG_T(TYV) do { if (tg == 16) { if (m.gateup) PG(TYV, 16, true); else PG(TYV, 16, false); } \
-                       else if (tg == 32) { if (m.gateup) PG(TYV, 32, true); else PG(TYV, 32, false); } \
-                       else { if (m.gateup) PG(TYV, 64, true); else PG(TYV, 64, false); } } while (0)
+                       else { if (m.gateup) PG(TYV, 32, true); else PG(TYV, 32, false); } } while (0)
         static const char* pg_trace = getenv("CT_AMD_PG_TRACE");   // measurement only: "gate_up" / "qkv" / "wo" / "down": in-kernel stamps of that site
         if (pg_trace && ty == GT_Q4_K && tg == 32 && pg_trace_site_ && !strcmp(pg_trace, pg_trace_site_) && nt > 32) {
             a.m.dbg |= 32; a.m.dbg_sink = (float*)trace_buf_;
@@ -1114,11 +1013,10 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     return true;
 }
 
-// One mat-vec site for a prompt chunk: Q8_K images of the nt activation rows, then the token-batched kernel(s) on the
-// matrix cores (kernels_pfm.h; the dot4 form of kernels_pf.h is kept for A/B runs).
+// One mat-vec site of a prompt chunk: activation images of the nt rows, then the token-batched kernel(s) — kernels_pg.h for
+// K-quant weights (f16 matrix cores), kernels_pf.h for Q8_0 / Q4_0 (dot4).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
                        std::string& err) {
-    const int aw = pf_act_words(m.K);
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
@@ -1140,95 +1038,25 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
         const size_t smem = (size_t)kPfTokens * aw32 * 4;
         if (m.gateup) {
-            auto kfn = matvec_pf_kernel<kPfTokens, true, true>;
+            auto kfn = matvec_pf_kernel<kPfTokens, true>;
             CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
         } else {
-            auto kfn = matvec_pf_kernel<kPfTokens, false, true>;
+            auto kfn = matvec_pf_kernel<kPfTokens, false>;
             CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
         }
         prof_end();
         return true;
     }
-    {
-        bool pg = use_pg_ && acts_h_;
-        for (int j = 0; j < m.njobs; ++j) pg = pg && is_kquant(m.job[j].w.type) && m.job[j].w.r2;
-        if (pg && m.gateup) pg = m.njobs == 1 && m.job[0].w.layout == LAYOUT_R2C4;
-        if (pg) {
-            pg_trace_site_ = site;
-            const bool ok = pg_matvec(m, x, ldx, nt, ld_out, ld_res, err);
-            prof_end();
-            return ok;
-        }
-        if (m.gateup && m.njobs == 1) { err = "fused gate/up matrix outside kernels_pg.h"; return false; }
-        for (int j = 0; j < m.njobs; ++j)
-            if (is_kquant(m.job[j].w.type) && !m.job[j].w.p[0]) { err = "this chunk kernel reads the tile8S weight copies: load with CT_AMD_TILE8S=1"; return false; }
-    }
-    if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
-        if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
-        else CT_LAUNCH((pf_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, m.norm_b);
-    } else if (m.K <= 4096) CT_LAUNCH((pf_quantize_kernel<4096>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
-    else if (m.K <= 12288) CT_LAUNCH((pf_quantize_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
-    else CT_LAUNCH((pf_quantize_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw, (const float*)nullptr);
-    const int use_mfma = use_mfma_ ? 1 : 0;
-    static const int gx_mul = std::max(1, env_int("CT_AMD_PFM_GX", 1));
-    // one launch per weight type present in the site's jobs (matrix-core kernel; CT_AMD_PF_MFMA=0: the dot4 kernel, A/B)
-    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
-        PfArgs a;
-        a.m = m;
-        a.acts = acts_; a.act_words = aw; a.n_tok = nt;
-        a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
-        const int rows_per_item = use_mfma ? 16 : 8;
-        int nj = 0, item0 = 0;
-        for (int j = 0; j < m.njobs; ++j) {
-            if (m.job[j].w.type != ty) continue;
-            a.m.job[nj] = m.job[j];
-            a.m.job[nj].pair0 = m.gateup ? 0 : item0;
-            item0 += (m.job[j].w.M + rows_per_item - 1) / rows_per_item;
-            ++nj;
-        }
-        if (nj == 0) continue;
-        a.m.njobs = nj;
-        a.m.n_pairs = m.gateup ? (m.job[0].w.M + rows_per_item - 1) / rows_per_item : item0;
-        if (use_mfma) {
-            // token images per workgroup: 16 where they fit LDS (and the chunk has more than 8 tokens), else 8, else 4
-            int tok = ((size_t)16 * aw * 4 <= 160 * 1024 && nt > 8) ? 16 : ((size_t)8 * aw * 4 <= 160 * 1024 ? 8 : 4);
-            if (pfm_force_tok_ == 8 || pfm_force_tok_ == 4) tok = std::min(tok, pfm_force_tok_);
-            const int groups = (nt + tok - 1) / tok;
-            const int gx = std::max(1, std::min(gx_mul * chip_cus() / groups, a.m.n_pairs));
-            const dim3 grid((unsigned)gx, (unsigned)groups), block(512);
-            const size_t smem = (size_t)tok * aw * 4;
-#define PFM(TYV, TOKV, GUV) do { \
-                auto kfn = matvec_pfm_kernel<TYV, TOKV, GUV>; \
-                CT_OPTIN_ONCE(kfn, 160 * 1024); \
-                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
-#define PFM_T(TYV) do { if (tok == 16) { if (m.gateup) PFM(TYV, 16, true); else PFM(TYV, 16, false); } \
-                        else if (tok == 8) { if (m.gateup) PFM(TYV, 8, true); else PFM(TYV, 8, false); } \
-                        else { if (m.gateup) PFM(TYV, 4, true); else PFM(TYV, 4, false); } } while (0)
-            if (ty == GT_Q4_K) PFM_T(GT_Q4_K); else if (ty == GT_Q5_K) PFM_T(GT_Q5_K); else PFM_T(GT_Q6_K);
-#undef PFM_T
-#undef PFM
-        } else {
-            const int groups = (nt + kPfTokens - 1) / kPfTokens;
-            // every CU gets a workgroup; a launch with few tiles then has one or two busy waves per SIMD instead of idle CUs
-            const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
-            const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
-            const size_t smem = (size_t)kPfTokens * aw * 4;
-            if (m.gateup) {
-                auto kfn = matvec_pf_kernel<kPfTokens, true>;
-                CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4);
-                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
-            } else {
-                auto kfn = matvec_pf_kernel<kPfTokens, false>;
-                CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words(12288) * 4);
-                CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
-            }
-        }
-    }
+    bool pg = acts_h_ != nullptr;
+    for (int j = 0; j < m.njobs; ++j) pg = pg && is_kquant(m.job[j].w.type) && m.job[j].w.r2;
+    if (pg && m.gateup) pg = m.njobs == 1 && m.job[0].w.layout == LAYOUT_R2C4;
+    if (!pg) { err = "prompt chunk: this launch shape has no kernel"; return false; }
+    pg_trace_site_ = site;
+    const bool ok = pg_matvec(m, x, ldx, nt, ld_out, ld_res, err);
     prof_end();
-    (void)err;
-    return true;
+    return ok;
 }
 
 // llm_build_llama (llama.cpp:2162-2491) for nt tokens of one batch_eval chunk at once: the same launches as token_step,
@@ -1281,22 +1109,14 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
             a.job[0].w = L.w_gate; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
-            if (use_pg_ && acts_h_ && L.w_gu.r2) { a.job[0].w = L.w_gu; a.njobs = 1; }   // kernels_pg.h: the fused matrix of the decode path
+            if (L.w_gu.r2) { a.job[0].w = L.w_gu; a.njobs = 1; }   // K-quants: the fused matrix of the decode path (kernels_pg.h)
             if (!pf_matvec(a, xb_, E, nt, F, 0, "gate_up", (double)(L.w_gate.bytes + L.w_up.bytes), err)) return false;
         }
         {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
-            if (F <= 12288 || use_mfma_) {
-                if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
-            } else {   // dot4 A/B form: 8 Q8_K images of this length do not fit LDS — the decode kernel, one token at a time
-                for (int t = 0; t < nt; ++t) {
-                    MatvecArgs at = a;
-                    at.x = hb_ + (size_t)t * F; at.out = xb_ + (size_t)t * E; at.res = xb_ + (size_t)t * E;
-                    if (site_on("down") && !run_matvec(at, err)) return false;
-                }
-            }
+            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
         }
     }
     if (l1_ < hp_.n_layer) {
@@ -1306,7 +1126,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = xl; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (use_v7_ && v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
         else CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
     }
@@ -1541,7 +1361,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.ffn_norm; a.out = h_;
-            if (use_v7_ && L.w_gu.r2) {   // generation 7: one job, the fused matrix
+            if (L.w_gu.r2) {   // generation 7: one job, the fused matrix
                 a.job[0].w = L.w_gu; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
                 a.njobs = 1; a.gateup = 1; a.n_pairs = F;
             } else {
@@ -1577,7 +1397,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (use_v7_ && v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
         else if (!only_site_)
             CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
                       hp_.rms_eps);

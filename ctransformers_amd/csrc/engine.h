@@ -163,13 +163,10 @@ class Engine {
     int pf_min_ = 2;        // chunks shorter than this run token by token
     int pf_chunk_ = 128;    // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
     long long chunk_tokens_ = 0;
-    bool use_mfma_ = true;
-    bool use_pg_ = true;    // K-quant prompt chunks on the f16 matrix cores (kernels_pg.h; CT_AMD_PG=0: the int8 form of kernels_pfm.h, A/B)
     const char* pg_trace_site_ = nullptr;   // measurement only (CT_AMD_PG_TRACE)
-    int pg_force_tg_ = 0;   // tests: 16 / 32 / 64 tokens per workgroup
+    int pg_force_tg_ = 0;   // tests: 16 / 32 tokens per workgroup
     uint8_t* acts_h_ = nullptr;   // stage images (kernels_pg.h): [layout 45 | layout 6]
     size_t acts_h_half_ = 0;
-    int pfm_force_tok_ = 0;
     float* rope_cs_ = nullptr;
     uint16_t *exp_tab_ = nullptr, *silu_tab_ = nullptr, *gelu_tab_ = nullptr;
     int *d_tokens_ = nullptr, *d_state_ = nullptr;  // token ids of the current chunk; {step, pos} cursor
@@ -177,16 +174,14 @@ class Engine {
     int* h_scalars_ = nullptr;  // pinned staging for the token ids + cursor
     bool use_graph_ = false;
     // load pipeline: the file's tensor bytes go to the GPU once, in file layout, through pinned staging (pread in parallel, async
-    // copies), and kernels repack them into the LAYOUT_R2C4 arenas there; the tile8S copies are only made for the A/B kernels
+    // copies), and kernels repack them into the LAYOUT_R2C4 arenas there
     bool stage_file(const class GgufFile& f, const std::vector<const struct GgufTensor*>& need, std::string& err);
     void release_staged();
     const uint8_t* staged(const struct GgufTensor* t) const;
     uint8_t* dev_file_ = nullptr;        // [file_lo_, file_hi_) of the mapping, on the device; freed at the end of load()
     const uint8_t* file_lo_ = nullptr;
     const uint8_t* file_hi_ = nullptr;
-    bool keep_tile8s_ = false;           // CT_AMD_V7=0 / CT_AMD_PG=0 / CT_AMD_TILE8S=1: also keep the tile8S copies (kernels_v5/v6/ks/pfm.h)
-    double load_stage_s_ = 0.0, load_repack_s_ = 0.0;
-    bool use_v7_ = true;    // decode mat-vecs of K-quant matrices on generation 7 (CT_AMD_V7=0: generations 5/6, A/B)
+    double load_stage_s_ = 0.0;
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
     std::map<int, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by 2 * n_tokens + want_logits; captured on second use

@@ -1,28 +1,21 @@
-// Prompt chunks: the mat-vec of the decode kernels applied to a chunk of tokens per launch, so that a weight tile is fetched
-// and unpacked once for 8 tokens instead of once per token.  This file: the shared pieces (activation images, the
-// quantize kernels, launch arguments) and the dot4 form; kernels_pfm.h: the K-quants on the int8 matrix cores, which is
-// what the engine launches for them (the dot4 K-quant form stays selectable for A/B runs, CT_AMD_PF_MFMA=0).
+// Prompt chunks, shared pieces and the Q8_0 / Q4_0 form: the mat-vec of the decode kernels applied to a chunk of tokens per launch,
+// so that a weight tile is fetched and unpacked once for 8 tokens instead of once per token.  (K-quant weights take the f16
+// matrix-core kernels of kernels_pg.h; their round-1 forms — dot4 and int8 matrix cores — were retired in round 2.)
 //
 // The arithmetic per (row, token) is the decode kernels' — the reference's per-block integer sums and its per-block
-// fma `acc[l] = fma(y.d * fp16(x.d), (float)sumi[l], acc[l])` in block order, then hsum_float_8 (kernels_exact.h and
-// kernels_q32.h have the citations) — so a token evaluated inside a chunk produces the same bits as the token evaluated
-// alone.  What changes is where the chain lives.  The decode kernels split the K blocks of a tile over the 16 waves of a
-// workgroup (a CU sees only a handful of tiles per launch) and replay the serial f32 chain from LDS; here a launch has
-// tiles x token-groups units of work, enough for every wave to own (tile, 8 tokens) outright: it walks the tile's
-// blocks in order with the accumulators in registers and there is no chain storage and no intra-workgroup
-// synchronisation after the activations are in LDS.
+// fma in block order, then hsum_float_8 (kernels_q32.h has the citations) — so a token evaluated inside a chunk produces the
+// same bits as the token evaluated alone.  A launch has tiles x token-groups units of work, enough for every wave to own
+// (tile, 8 tokens) outright: it walks the tile's blocks in order with the accumulators in registers, no chain storage and no
+// intra-workgroup synchronisation after the activations are in LDS.
 //
-//   pf_quantize_kernel      one workgroup per token: (RMSNorm / LayerNorm ->) Q8_K exactly as the decode prologue does it (it
-//                           IS the decode prologue), written out as a compact image  q8[K/4] | yd[K/256] | sb[K/32]  (words)
-//   pf_quantize_q80_kernel  the same for the Q8_0 activations of Q8_0 / Q4_0 weights:  q8[K/4] | yd[K/32]
+//   pf_quantize_q80_kernel  one workgroup per token: (RMSNorm / LayerNorm ->) Q8_0 exactly as the decode prologue does it, written
+//                           out as a compact image  q8[K/4] | yd[K/32]  (words)
 //   matvec_pf_kernel        grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
 //                           w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first,
-//                           then over the SIMDs of a CU); epilogues as in the decode kernels, per token.
-//                           Q32 = true: Q8_0 / Q4_0 weights (the form the engine uses for them — their lane sums are
-//                           4-element dots, nothing for a matrix core to contract); Q32 = false: K-quants, dot4 form
+//                           then over the SIMDs of a CU); epilogues as in the decode kernels, per token.  Q8_0 / Q4_0 lane sums are
+//                           4-element dots — nothing for a matrix core to contract.
 //   embed / attention / falcon RoPE store   the decode kernels with a token index in blockIdx.y / blockIdx.z
 #pragma once
-#include "kernels_v6.h"
 #include "kernels_q32.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
@@ -36,142 +29,6 @@ struct PfArgs {
     int n_tok;           // tokens in this chunk
     int ld_out, ld_res, ld_q;   // element strides between the tokens' rows of m.out, m.res, m.q_f16
 };
-
-constexpr int pf_act_words(int K) { return ((K >> 2) + (K >> 8) + (K >> 5) + 3) & ~3; }
-
-template <int MAXK, bool LN = false>
-__global__ void __launch_bounds__(1024) pf_quantize_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
-                                                           int pro, float eps, int* __restrict__ acts, int act_words,
-                                                           const float* __restrict__ nb_ = nullptr) {
-    __shared__ ActLdsX<MAXK> L;
-    const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
-    if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // falcon: LayerNorm + bias
-    else prologue_q8k_exact16<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
-    int* o = acts + (size_t)t * act_words;
-    const int nq = K >> 2, nb = K >> 8, ns = K >> 5;
-    for (int i = tid; i < nq; i += 1024) o[i] = L.q8[i];
-    for (int i = tid; i < nb; i += 1024) o[nq + i] = (int)f32_to_bits(L.yd[i]);
-    for (int i = tid; i < ns; i += 1024) o[nq + nb + i] = L.sb[i];
-}
-
-// One block of one tile against the nt (<= TB) tokens in LDS.  Q4_K / Q5_K / Q6_K: img_to_chain + one step of chain_typed.
-template <int TYPE, int TB>
-DEV void pf_block(const BlkImg<TYPE>& R, int b, const int* __restrict__ lds, int act_words, int nq, int nbk, int nt,
-                  const LaneGeom& G, float (&acc)[TB], float (&accm)[TB]) {
-    const int c = G.c;
-    if constexpr (TYPE == GT_Q4_K || TYPE == GT_Q5_K) {
-        const uint32_t lo_w = c < 2 ? R.hdr[1] : (c == 2 ? R.hdr[2] : R.hdr[3]);
-        const uint32_t hi_w = c < 2 ? R.hdr[2] : R.hdr[3];
-        const uint32_t x = alignbit32(hi_w, lo_w, (uint32_t)((24 * c) & 31));
-        const int sc_lo = (int)(x & 63u), sc_hi = (int)bfe32(x, 6, 6), m_lo = (int)bfe32(x, 12, 6), m_hi = (int)bfe32(x, 18, 6);
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo[k] = R.qs[k] & 0x0F0F0F0Fu;
-            hi[k] = (R.qs[k] >> 4) & 0x0F0F0F0Fu;
-            if constexpr (TYPE == GT_Q5_K) {
-                lo[k] |= ((R.qh[k] >> (2 * c)) & 0x01010101u) << 4;
-                hi[k] |= ((R.qh[k] >> (2 * c + 1)) & 0x01010101u) << 4;
-            }
-        }
-        const float dw = f16_bits_to_f32((uint16_t)(R.hdr[0] & 0xFFFF));
-        const float dmw = f16_bits_to_f32((uint16_t)(R.hdr[0] >> 16));
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            if (t < nt) {
-                const int* img = lds + t * act_words;
-                const u32x4 alo = *(const u32x4*)(img + b * 64 + G.a45);
-                const u32x4 ahi = *(const u32x4*)(img + b * 64 + G.a45 + 8);
-                int part[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    part[k] = mul24(sc_lo, sdot4((int)lo[k], (int)alo[k], 0)) + mul24(sc_hi, sdot4((int)hi[k], (int)ahi[k], 0));
-                const float S = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
-                const int* sb = img + nq + nbk + b * 8 + 2 * c;
-                int prod = mul24(m_lo, sb[0]) + mul24(m_hi, sb[1]);
-                if constexpr (TYPE == GT_Q5_K) {
-                    if (G.h != 0) prod = 0;
-                    prod += lane_xor2(prod);
-                    prod += lane_xor4(prod);
-                }
-                const float yd = bits_to_f32((uint32_t)img[nq + b]);
-                acc[t] = fmaf(yd * dw, S, acc[t]);
-                accm[t] = fmaf(-yd * dmw, (float)prod, accm[t]);   // read back from the lanes with h == 0 only
-            }
-        }
-    } else {
-        const int n = G.g >> 2;
-        const uint32_t w_lo = n ? R.sc[2] : R.sc[0];
-        const uint32_t w_hi = n ? R.sc[3] : R.sc[1];
-        const int sc_lo = (int)(int8_t)((w_lo >> G.sc_sh6) & 0xFF);
-        const int sc_hi = (int)(int8_t)((w_hi >> G.sc_sh6) & 0xFF);
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo[k] = (R.ql[k] & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_lo6) & 0x03030303u) << 4);
-            hi[k] = ((R.ql[k] >> 4) & 0x0F0F0F0Fu) | (((R.qh[k] >> G.s_hi6) & 0x03030303u) << 4);
-        }
-        const float dw = f16_bits_to_f32((uint16_t)(R.d & 0xFFFF));
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            if (t < nt) {
-                const int* img = lds + t * act_words;
-                const u32x4 alo = *(const u32x4*)(img + b * 64 + G.a6);
-                const u32x4 ahi = *(const u32x4*)(img + b * 64 + G.a6 + 16);
-                int part[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int dl = sdot4((int)lo[k], (int)alo[k], sdot4((int)0xE0E0E0E0u, (int)alo[k], 0));
-                    const int dh = sdot4((int)hi[k], (int)ahi[k], sdot4((int)0xE0E0E0E0u, (int)ahi[k], 0));
-                    part[k] = mul24(sc_lo, dl) + mul24(sc_hi, dh);
-                }
-                const float S = (float)quad_transpose_reduce_dpp(part[0], part[1], part[2], part[3], c);
-                const float yd = bits_to_f32((uint32_t)img[nq + b]);
-                acc[t] = fmaf(yd * dw, S, acc[t]);
-            }
-        }
-    }
-}
-
-// All blocks of one tile; res[t] is the row's dot product for token t — valid in the row's lane g == 0 (the lane that
-// stores), which is all the epilogues need (the RoPE partner is lane g == 0 of the neighbouring row).
-template <int TYPE, int TB>
-DEV void pf_tile(const uint8_t* __restrict__ base, int nb, const int* __restrict__ lds, int act_words, int K, int nt,
-                 const LaneGeom& G, float (&res)[TB]) {
-    constexpr uint32_t REC = rec_bytes<TYPE>();
-    constexpr int PF = 2;   // weight records in flight per wave
-    float acc[TB], accm[TB];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) { acc[t] = 0.0f; accm[t] = 0.0f; }
-    BlkImg<TYPE> R[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) R[u] = img_load<TYPE>(base + (size_t)(u < nb ? u : nb - 1) * REC, G);
-    const int nq = K >> 2, nbk = K >> 8;
-    for (int b0 = 0; b0 < nb; b0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int b = b0 + u;
-            const BlkImg<TYPE> I = R[u];
-            const int bn = b + PF < nb ? b + PF : nb - 1;
-            R[u] = img_load<TYPE>(base + (size_t)bn * REC, G);
-            if (b < nb) pf_block<TYPE, TB>(I, b, lds, act_words, nq, nbk, nt, G, acc, accm);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < TB; ++t) {
-        const float tot = hsum8_exact_dpp(acc[t]);
-        if constexpr (TYPE == GT_Q6_K) {
-            res[t] = tot;
-        } else {
-            float am = accm[t];
-            if constexpr (TYPE == GT_Q4_K) {
-                const float w = am + lane_xor4(am);
-                am = w + lane_xor2(w);
-            }
-            res[t] = tot + am;
-        }
-    }
-}
 
 // ---- Q8_0 / Q4_0 weights (LAYOUT_G4, kernels_q32.h): Q8_0 activation images  q8[K/4] ([group][l][i] order) | yd[K/32] -----------
 constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }
@@ -252,22 +109,16 @@ DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __rest
     for (int t = 0; t < TB; ++t) res[t] = hsum8_exact_dpp(acc[t]);
 }
 
-template <int TB, bool Q32>
-DEV void pf_tile_any(int type, const uint8_t* __restrict__ w0, int tile, int nb, const int* __restrict__ lds, int act_words, int K,
+template <int TB>
+DEV void pf_tile_any(int type, const uint8_t* __restrict__ w0, int tile, const int* __restrict__ lds, int act_words, int K,
                      int nt, const LaneGeom& G, float (&res)[TB]) {
-    if constexpr (Q32) {
-        const int ng = K >> 7;
-        const int lane = G.r * 8 + G.g;
-        if (type == GT_Q8_0) pf_tile_q32<GT_Q8_0, TB>(w0 + (size_t)tile * ng * kRecQ8_0, ng, lds, act_words, K, nt, lane, res);
-        else pf_tile_q32<GT_Q4_0, TB>(w0 + (size_t)tile * ng * kRecQ4_0, ng, lds, act_words, K, nt, lane, res);
-        return;
-    }
-    if (type == GT_Q4_K) pf_tile<GT_Q4_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q4_K>(), nb, lds, act_words, K, nt, G, res);
-    else if (type == GT_Q5_K) pf_tile<GT_Q5_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q5_K>(), nb, lds, act_words, K, nt, G, res);
-    else pf_tile<GT_Q6_K, TB>(w0 + (size_t)tile * nb * rec_bytes<GT_Q6_K>(), nb, lds, act_words, K, nt, G, res);
+    const int ng = K >> 7;
+    const int lane = G.r * 8 + G.g;
+    if (type == GT_Q8_0) pf_tile_q32<GT_Q8_0, TB>(w0 + (size_t)tile * ng * kRecQ8_0, ng, lds, act_words, K, nt, lane, res);
+    else pf_tile_q32<GT_Q4_0, TB>(w0 + (size_t)tile * ng * kRecQ4_0, ng, lds, act_words, K, nt, lane, res);
 }
 
-template <int TB, bool GU, bool Q32 = false>
+template <int TB, bool GU>
 __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
     CT_DYN_SMEM(smem_raw);
     int* lds = reinterpret_cast<int*>(smem_raw);
@@ -291,13 +142,13 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
     }
     __syncthreads();
     const int pos0 = (m.pos ? *m.pos : 0) + t0;
-    const int GX = (int)gridDim.x, nb = m.K >> 8;
+    const int GX = (int)gridDim.x;
     const bool own_lane = G.g == 0;
     for (int item = wv * GX + (int)blockIdx.x; item < m.n_pairs; item += 16 * GX) {
         if constexpr (GU) {
             float gate[TB], up[TB];
-            pf_tile_any<TB, Q32>(m.job[0].w.type, m.job[0].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, gate);
-            pf_tile_any<TB, Q32>(m.job[1].w.type, m.job[1].w.p[0], item, nb, lds, a.act_words, m.K, nt, G, up);
+            pf_tile_any<TB>(m.job[0].w.type, m.job[0].w.p[0], item, lds, a.act_words, m.K, nt, G, gate);
+            pf_tile_any<TB>(m.job[1].w.type, m.job[1].w.p[0], item, lds, a.act_words, m.K, nt, G, up);
             const int row = item * 8 + G.r;
             const bool own = own_lane && row < m.job[0].w.M;
 #pragma unroll
@@ -309,7 +160,7 @@ __global__ void __launch_bounds__(1024) matvec_pf_kernel(const PfArgs a) {
             if (m.njobs > 2 && item >= m.job[2].pair0) j = 2;
             const int tile = item - m.job[j].pair0;
             float res[TB];
-            pf_tile_any<TB, Q32>(m.job[j].w.type, m.job[j].w.p[0], tile, nb, lds, a.act_words, m.K, nt, G, res);
+            pf_tile_any<TB>(m.job[j].w.type, m.job[j].w.p[0], tile, lds, a.act_words, m.K, nt, G, res);
             const int row = tile * 8 + G.r;
             const bool own = own_lane && row < m.job[j].w.M;
             const int epi = m.job[j].epi;

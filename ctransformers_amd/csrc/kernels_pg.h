@@ -40,7 +40,7 @@ template <int TG> struct PgStage {
     static constexpr int TAILP = (YD + 4 * TG - SUMS + kPgWaves * 256 - 1) / (kPgWaves * 256);
     static constexpr int BYTES = SUMS + TAILP * kPgWaves * 256;
 };
-constexpr int pg_stage_bytes(int tg) { return tg == 16 ? PgStage<16>::BYTES : (tg == 32 ? PgStage<32>::BYTES : PgStage<64>::BYTES); }
+constexpr int pg_stage_bytes(int tg) { return tg == 16 ? PgStage<16>::BYTES : PgStage<32>::BYTES; }
 
 struct PgArgs {
     MatvecArgs m;          // jobs (w.r2 = LAYOUT_R2C4 records) and epilogue operands

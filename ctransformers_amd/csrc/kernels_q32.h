@@ -16,7 +16,7 @@
 //       (lane l < 4 uses the low nibbles of its dword = elements 4l.., lane l >= 4 the high nibbles = elements 16+4(l-4)..)
 // The activation vector is quantized once per workgroup into LDS in the matching [group][l][i] order.
 #pragma once
-#include "kernels_v5.h"
+#include "kernels_kq.h"
 
 template <int MAXK> struct ActLdsQ32 {
     int q8[MAXK / 4];        // [g][l][i]: the 4 int8 of elements 4l..4l+3 of block 4g+i
@@ -248,7 +248,6 @@ __global__ void __launch_bounds__(1024) matvec_q32_kernel(const MatvecArgs a) {
 // wave-per-tile (matvec_q32_kernel above) kept a single wave walking 128 dependent block steps behind a 4-deep
 // prefetch: 18 us for Wo at 7B shapes, latency-bound (Q8_0 and Q4_0 took the same time).
 // ------------------------------------------------------------------------------------------------------------------
-#include "kernels_v6.h"
 
 constexpr int kQ32Slots = 8;
 template <int MAXK> struct SmemQ32S {

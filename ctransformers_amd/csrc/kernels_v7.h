@@ -31,7 +31,7 @@
 //   * a launch with two weight types (attn_q/k = Q4_K, attn_v = Q6_K) gives each type its own waves of every workgroup,
 //     split in proportion to the bytes.
 #pragma once
-#include "kernels_ks.h"
+#include "kernels_kq.h"
 
 // Q8_K image of the activation vector (kernels_exact.h ActLdsX without the 16-sums nobody reads, q8 skewed).
 template <int MAXK> struct ActLds7 {
@@ -44,16 +44,18 @@ template <int MAXK> struct ActLds7 {
 // by 8 words, so the b128 reads of a step (4 blocks, kernels_v7.h header) hit every bank once per 16-lane service group.
 DEV int q8w_of(int b) { return 264 * (b >> 2) + 64 * (b & 3) + 8 * ((b >> 1) & 1); }
 
-template <int MAXK> struct ProRegs7 {
+template <int MAXK, bool EW = true> struct ProRegs7 {
     static constexpr int ROUNDS = (MAXK / 256 + 63) / 64;
-    static constexpr bool EARLY_W = MAXK <= 16384;   // the norm weights are requested with the activations (16 more registers)
+    // the norm weights are requested with the activations (16 more registers) — not in the two-type launches, whose two inlined
+    // block loops leave no room for them (they spilled 16 registers there)
+    static constexpr bool EARLY_W = EW && MAXK <= 16384;
     float4 v[ROUNDS][4];
     float4 w[EARLY_W ? ROUNDS : 1][4];
 };
 
 // Prologue part 1: request this thread's 16 consecutive activations (16 lanes per 256-block) and their norm weights —
 // nothing waits here.  The first instructions of the kernel: whatever is requested later queues behind the weight stream.
-template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro) {
+template <int MAXK, bool EW> DEV void pro7_load(ProRegs7<MAXK, EW>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro) {
     const int tid = (int)threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int nblk = K >> 8;
     // Only the waves that own blocks load (for K = 4096: 4 of 16 — the others would put 100 KB of redundant requests in front
@@ -63,12 +65,12 @@ template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restric
     if (uniform_int(((int)threadIdx.x >> 6) * 4) >= nblk) return;
     const float* __restrict__ wsrc = pro != PRO_PLAIN ? nw : x;
 #pragma unroll
-    for (int rd = 0; rd < ProRegs7<MAXK>::ROUNDS; ++rd) {
+    for (int rd = 0; rd < ProRegs7<MAXK, EW>::ROUNDS; ++rd) {
         int b = grp + rd * 64;
         b = b < nblk ? b : nblk - 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) P.v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
-        if constexpr (ProRegs7<MAXK>::EARLY_W) {
+        if constexpr (ProRegs7<MAXK, EW>::EARLY_W) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) P.w[rd][k] = *(const float4*)(wsrc + b * 256 + sub * 16 + k * 4);
         }
@@ -79,10 +81,10 @@ template <int MAXK> DEV void pro7_load(ProRegs7<MAXK>& P, const float* __restric
 // (kernels_exact.h; reference k_quants.c:1191-1226 with the build's fused fma, RMSNorm ggml.c:10700-10716, LayerNorm
 // ggml.c:10605-10654).  Ends with a workgroup barrier.  `emb_out` (block 0 only): the normalised vector as f32 — the
 // final-norm "embeddings" output of the ABI, produced by the lm_head launch (EMB instantiation) instead of a launch of its own.
-template <int MAXK, bool LN, bool EMB>
-DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K,
+template <int MAXK, bool LN, bool EMB, bool EW>
+DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK, EW>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K,
                      int pro, float eps, float* __restrict__ emb_out) {
-    constexpr int ROUNDS = ProRegs7<MAXK>::ROUNDS, NW = 16;
+    constexpr int ROUNDS = ProRegs7<MAXK, EW>::ROUNDS, NW = 16;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, sub = tid & 15, grp = tid >> 4;
     const int nblk = K >> 8;
@@ -169,7 +171,7 @@ DEV void pro7_finish(ActLds7<MAXK>& L, ProRegs7<MAXK>& P, const float* __restric
                 float4 q = live ? P.v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
                 if (live && pro != PRO_PLAIN) {
                     float4 w4;
-                    if constexpr (ProRegs7<MAXK>::EARLY_W) w4 = P.w[rd][k];
+                    if constexpr (ProRegs7<MAXK, EW>::EARLY_W) w4 = P.w[rd][k];
                     else w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
                     q.x = (q.x * scale) * w4.x;
                     q.y = (q.y * scale) * w4.y;
@@ -404,8 +406,8 @@ template <int MAXK, int TA, int TB, bool LN, bool EMB = false>
 __global__ void __launch_bounds__(1024) matvec_v7_kernel(const MatvecArgs a) {
     CT_DYN_SMEM(smem_raw);
     SmemV7<MAXK>& SM = *reinterpret_cast<SmemV7<MAXK>*>(smem_raw);
-    ProRegs7<MAXK> P;
-    pro7_load<MAXK>(P, a.x, a.norm_w, a.K, a.pro);
+    ProRegs7<MAXK, TB == 0> P;
+    pro7_load<MAXK, TB == 0>(P, a.x, a.norm_w, a.K, a.pro);
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const LaneGeom G = lane_geom(lane);
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(1024) matvec_v7_kernel(const MatvecArgs a) {
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
     const unsigned long long t0 = trace ? clock64_dev() : 0ull;
     auto pro = [&]() __attribute__((always_inline)) {
-        pro7_finish<MAXK, LN, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
+        pro7_finish<MAXK, LN, EMB, TB == 0>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
     };
     const int grid = (int)gridDim.x, bx = (int)blockIdx.x;
     if constexpr (TB != 0) {

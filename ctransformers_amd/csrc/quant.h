@@ -9,13 +9,14 @@
 //   Q6_K 210 B / 256 w: 128 B low nibbles | 64 B high 2-bits | 16 x int8 scales | f16 d
 // (a Q6_K row of K=11008 is 9030 B in the file: rows are only 2-byte aligned — the repack is what makes 16-byte loads legal)
 //
-// LAYOUT_TILE8S (K-quants): 8 consecutive rows form a tile; for every K-block b the 8 rows' blocks are stored together as
-// one record, fields grouped so that a wavefront (8 lanes per row) reads each field with one fully-coalesced
-// 16-byte-per-lane load, and a tile is one contiguous stream of nb records:
+// LAYOUT_R2C4 (K-quants; kernels_v7.h decode, kernels_pg.h prompt chunks): a record holds 2 rows x 4 consecutive K-blocks = 8 block
+// slots (slot p = 4 * row + c), fields grouped so that a wavefront reads each field with 16-byte-per-lane loads; a row pair
+// ("unit") = ceil(nb / 4) consecutive records, blocks past nb are zero slots.  The matrices of a launch site (attn_q | attn_k |
+// attn_v; the fused gate/up matrix: unit u = gate row u, up row u) share one arena, so a launch walks one contiguous unit space.
 //   Q4_K record 1152 B: hdr[8][16] | qs[8][128]
 //   Q5_K record 1408 B: hdr[8][16] | qh[8][32] | qs[8][128]
 //   Q6_K record 1680 B: d[8] f16 (16 B) | sc[8][16] | qh[8][64] | ql[8][128]
-// Record sizes are 8 x the file block size.  Rows beyond M in the last tile are zero blocks.
+// Record sizes are 8 x the file block size (the repack moves bytes, engine.cc:place_kblock / repack_r2c4_kernel).
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -42,13 +43,11 @@ CT_HD static inline int ggml_block_bytes(int t) {
 CT_HD static inline size_t ggml_row_bytes(int t, int64_t k) { return (size_t)(k / ggml_block_elems(t)) * ggml_block_bytes(t); }
 CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K || t == GT_Q6_K; }
 
-// In LAYOUT_TILE8S the 12-byte 6-bit scale/min field of Q4_K/Q5_K headers is re-encoded (losslessly, same size) as four
-// 24-bit groups g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
+// The 12-byte 6-bit scale/min field of Q4_K / Q5_K headers is re-encoded (losslessly, same size) as four 24-bit groups
+// g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
-// LAYOUT_R2C4 (K-quants, kernels_v7.h): a record = 2 rows x 4 consecutive K-blocks in the tile8S field order (slot p = 4*row + c
-// takes the place of row p), a row pair = ceil(nb/4) consecutive records; blocks past nb are zero slots that are never fetched.
-// A fused gate/up matrix pairs (gate row r, up row r).
+// (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
 enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 
@@ -59,7 +58,7 @@ struct DevMat {
     int nb = 0;                 // blocks per row (K/256 for K-quants, K/32 for Q4_0/Q8_0)
     const uint8_t* p[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
-    const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (decode mat-vec, kernels_v7.h)
-    int layout = 0;                // LAYOUT_TILE8S / LAYOUT_G4 (records live in p[0])
+    const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (inside an arena several matrices may share)
+    int layout = 0;                // LAYOUT_R2C4 (records in r2) / LAYOUT_G4 (records in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };

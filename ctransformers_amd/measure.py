@@ -57,7 +57,7 @@ def roofline(sites, traffic="pmc"):
 
     return dict(bound="hbm", kernel=KERNEL, achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                 frac=round(ach / HBM_PEAK, 4), traffic=traffic,
-                traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of an earlier run of the same kernel (x2 gfx950 correction), not measured in this run" % PMC_FILE if traffic else None,
+                traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of the same build (tools/run_r2n.sh; x2 gfx950 correction) — a counter pass cannot share a run with the timing" % PMC_FILE if traffic else None,
                 bytes_per_launch=round(b / nl),
                 us_per_launch=round(ms * 1e3 / nl, 2),
                 timing="HIP events on the library stream around the back-to-back launches of all layers of a site" if sweep

@@ -69,22 +69,9 @@ def test_batches_coalesced_into_one_pass(emu_lib, name):
     assert chunk_tokens(m) == 45
 
 
-@pytest.mark.parametrize("name,tok", [("tiny-q4km", 8), ("tiny-q5km", 4)])   # the other two combinations: tests/test_gpu_parity.py
-def test_prompt_chunk_half_slot_matrix_core_forms(emu_lib, monkeypatch, name, tok):
-    """kernels_pfm.h's wide-K forms (8 or 4 token images, v_mfma_i32_16x16x64_i8 with the AVX-lane halves in the token
-    slots), forced on the tiny models: golden logits of the reference for the 11-token prompt in chunks of 8 + 3."""
-    monkeypatch.setenv("CT_AMD_PFM_TOK", str(tok))
-    g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    m = open_emu(emu_lib, name)
-    m.eval(list(g["prompt"]))
-    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
-    assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
-    assert chunk_tokens(m) == len(g["prompt"])
-
-
 @pytest.mark.parametrize("name", ["tiny-q4km"])   # tiny-q5km: tests/test_gpu_parity.py
 def test_prompt_chunk_kernels_equal_token_by_token(emu_lib, name, monkeypatch):
-    """The chunk kernels (kernels_pf.h / kernels_pfm.h) against the decode kernels on the same batches: a full pass of
+    """The chunk kernels (kernels_pg.h) against the decode kernels on the same batches: a full pass of
     CT_AMD_PF_CHUNK tokens plus one on the decode path, a 2-token chunk at a non-zero n_past; logits and embeddings."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     toks = list(g["long_prompt"])[:19]
@@ -157,10 +144,10 @@ def test_bpe_tokenizer_matches_reference(emu_lib):
     assert m.detokenize(m.tokenize("ab cd\n")) == "ab cd\n"
 
 
-def test_wide_k_systolic_kernel(emu_lib, mirror, tmp_path):
-    """ffn_down with K > 12288 (70B / Falcon-40B class rows) runs on the systolic K-split kernel (kernels_ks.h): here a
-    Q6_K matrix (layer 0 is a use_more_bits layer) with 52 blocks over 16 waves (uneven split), checked against the
-    oracle.  (Q4_K / Q5_K at K = 28672 / 32768 are covered on hardware: tests/test_gpu_parity.py, 70b-2l / 40b-2l.)"""
+def test_wide_k_rows(emu_lib, mirror, tmp_path):
+    """ffn_down with K > 12288 (70B / Falcon-40B class rows; the MAXK = 32768 instantiation of kernels_v7.h): here a
+    Q6_K matrix (layer 0 is a use_more_bits layer) with 52 blocks (13 records of four, an uneven split over the waves), checked
+    against the oracle.  (Q4_K / Q5_K at K = 28672 / 32768 are covered on hardware: tests/test_gpu_parity.py, 70b-2l / 40b-2l.)"""
     from ctransformers_amd import synth
     p = str(tmp_path / "wide.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", "Q5_K_M", seed=31, overrides=dict(n_ff=13312, n_layer=1))

@@ -266,13 +266,13 @@ def test_long_context(ref, tmp_path):
         m.eval([t])
 
 
-@pytest.mark.parametrize("name,tok", [("tiny-q4km", 0), ("tiny-q5km", 0), ("tiny-q4km", 8), ("tiny-q5km", 8), ("tiny-q4km", 4),
-                                      ("tiny-q5km", 4)])
-def test_prompt_chunk_matrix_core_forms(name, tok, monkeypatch):
-    """kernels_pfm.h: the 16-token form (tok = 0: what these widths select) and the 8- / 4-token half-slot forms forced on the
-    tiny models (Q4_K + Q6_K and Q5_K + Q6_K files) against the reference's golden one-batch logits."""
-    if tok:
-        monkeypatch.setenv("CT_AMD_PFM_TOK", str(tok))
+@pytest.mark.parametrize("name,tg", [("tiny-q4km", 0), ("tiny-q5km", 0), ("tiny-q4km", 16), ("tiny-q5km", 16), ("tiny-q4km", 32),
+                                     ("tiny-q5km", 32)])
+def test_prompt_chunk_matrix_core_forms(name, tg, monkeypatch):
+    """kernels_pg.h: the token-group size the launch heuristics pick (tg = 0) and 16 / 32 tokens per workgroup forced, on the
+    tiny models (Q4_K + Q6_K and Q5_K + Q6_K files; 45 tokens: ragged last group) against the reference's golden one-batch logits."""
+    if tg:
+        monkeypatch.setenv("CT_AMD_PG_TG", str(tg))
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_hip(os.path.join(GOLDEN, name + ".gguf"), batch_size=64)
     m.eval(list(g["long_prompt"]))

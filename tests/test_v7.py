@@ -56,16 +56,3 @@ def test_v7_ragged_and_wide_rows(emu_lib, mirror, monkeypatch, tmp_path, ftype, 
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 3))
-
-
-def test_v7_off_switch(emu_lib, monkeypatch):
-    """CT_AMD_V7=0 keeps the earlier generations selectable for A/B runs; same bits."""
-    monkeypatch.setenv("CT_AMD_PF", "0")
-    monkeypatch.setenv("CT_AMD_V7", "0")
-    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
-    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
-    n0 = v7_launches(m._lib)
-    m.eval(list(g["prompt"]))
-    assert v7_launches(m._lib) == n0
-    assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
-
