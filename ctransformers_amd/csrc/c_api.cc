@@ -128,6 +128,11 @@ int ctransformers_llm_embeddings_size(ctransformers_llm* llm) { return llm->tail
 int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int n_last, int top_k, float top_p,
                              float temperature, float repetition_penalty, int seed) {
     if (llm->tail().logits_size() == 0) return llm->engine().vocab().eos_id;
+    // top_k <= 1 (llama_sample_top_k keeps max(k, 1) candidates) without an effective repetition penalty is the FIRST maximum of the
+    // logits whatever top_p / temperature / seed are (llama.cc:53-84: one candidate is left, llama_sample_token draws index 0): taken on
+    // the GPU — unless the caller has fetched, and possibly edited, the logits since the eval (then the host chain below runs on them)
+    int greedy = 0;
+    if (top_k <= 1 && (repetition_penalty == 1.0f || n_last <= 0) && llm->tail().greedy_token(greedy)) return greedy;
     if (llm->engine().vocab().type == ctamd::VOCAB_GPT)
         return ctamd::sample_token_gpt(llm->tail().logits(), llm->engine().hparams().n_vocab, last_tokens, n_last, top_k, top_p,
                                        temperature, repetition_penalty, seed);

@@ -553,7 +553,7 @@ bool Engine::alloc_state(std::string& err) {
         !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
         !dev_alloc(dev_allocs_, &d_logits_, (size_t)V + E, err) ||   // [logits | final-norm embedding]: one D2H copy per eval
-        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_state_, (size_t)n_ctx_ + 4, err))   // [cursor(4) | tokens]: one H2D copy
+        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_argmax_, 4, err) || !dev_alloc(dev_allocs_, &d_state_, (size_t)n_ctx_ + 4, err))   // [cursor(4) | tokens]: one H2D copy
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
@@ -1662,8 +1662,17 @@ bool Engine::req_range(int c0, int nt, bool last_of_request, std::string& err) {
 bool Engine::req_logits(std::string& err) {
     if (l1_ != hp_.n_layer) { err = "logits live on the last stage"; return false; }
     HIP_OK(hipSetDevice(device_));
-    HIP_OK(hipMemcpyAsync(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost, stream_));
+    CT_LAUNCH(argmax_first_kernel, dim3(1), dim3(1024), stream_, (const float*)d_logits_, hp_.n_vocab, d_argmax_);
+    HIP_OK(hipMemcpyAsync(&h_scalars_[n_ctx_ + 12], d_argmax_, 4, hipMemcpyDeviceToHost, stream_));
+    outputs_on_host_ = false;
     return true;
+}
+
+void Engine::fetch_outputs() {
+    if (outputs_on_host_ || !have_logits_) return;
+    (void)hipSetDevice(device_);
+    (void)hipMemcpy(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost);
+    outputs_on_host_ = true;
 }
 
 bool Engine::req_wait(int n, int n_past, std::string& err) {

@@ -86,9 +86,14 @@ class Engine {
     const Vocab& vocab() const { return vocab_; }
     int n_ctx() const { return n_ctx_; }
     void reset() { if (hp_.gpt2()) have_logits_ = false; }   // reference models/llm.h:106: legacy models forget their logits
-    float* logits() { return h_logits_; }
+    // Logits and embeddings stay on the GPU until somebody asks for them (fetch_outputs: one synchronous 144 KB copy for a 7B); a greedy
+    // step needs 4 bytes (greedy_token).  Once the host copy exists the caller may have edited it (the reference's Python exposes
+    // the logits as a writable view), so sampling then runs on the host copy as the reference does.
+    float* logits() { fetch_outputs(); return h_logits_; }
     int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
-    const float* embeddings() const { return h_emb_; }
+    const float* embeddings() { fetch_outputs(); return h_emb_; }
+    bool greedy_token(int& token) const { if (!have_logits_ || outputs_on_host_ || hp_.gpt2()) return false; token = h_scalars_[n_ctx_ + 12]; return true; }
+    void fetch_outputs();
     int embeddings_size() const { return have_logits_ && !hp_.gpt2() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
     long long chunk_tokens() const { return chunk_tokens_; }
@@ -188,6 +193,8 @@ class Engine {
     std::map<int, int> chunk_seen_;
 #endif
     bool have_logits_ = false;
+    bool outputs_on_host_ = true;   // false after an eval until logits() / embeddings() fetched them
+    int* d_argmax_ = nullptr;
     int last_token_ = -1, last_pos_ = -1;
     int req_n_ = 0;           // tokens of the request in flight (req_begin)
     struct ProfRec { const char* site; const char* kernel; double bytes; void* e0; void* e1; };

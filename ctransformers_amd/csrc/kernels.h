@@ -348,6 +348,34 @@ __global__ void stage_row_kernel(const float* src, float* dst, int E, const int*
     else dst[i] = src[off + i];
 }
 
+// Greedy pick on the GPU: index of the FIRST maximum of the logits — what the reference's sampler chain returns for top_k = 1 without a
+// repetition penalty (llama.cpp llama_sample_top_k: std::partial_sort with `a.logit > b.logit` keeps the first of equal maxima; one
+// candidate left, so top_p / temperature / the seeded draw cannot change it).  One workgroup; 4 bytes go to the host instead of the logits.
+__global__ void __launch_bounds__(1024) argmax_first_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int tid = (int)threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += 1024) {
+        const float x = v[i];
+        if (x > best || (x == best && i < idx)) { best = x; idx = i; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m);
+        const int oi = __shfl_xor(idx, m);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        *out = idx == 0x7fffffff ? 0 : idx;   // all -inf / NaN: the reference's heap keeps element 0
+    }
+}
+
 __global__ void advance_state_kernel(int* state) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state[0] += 1;

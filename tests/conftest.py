@@ -38,7 +38,10 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def emu_lib():
     """CPU emulation of the HIP kernels (tests/emu) — kernel-logic checks without a GPU."""
-    subprocess.run(["make"], cwd=os.path.join(ROOT, "tests", "emu"), check=True, stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(ROOT, "tests", "emu", ".build.lock"), "w") as lk:   # xdist workers: one of them builds, the rest wait
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make"], cwd=os.path.join(ROOT, "tests", "emu"), check=True, stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 

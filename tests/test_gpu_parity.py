@@ -266,6 +266,27 @@ def test_long_context(ref, tmp_path):
         m.eval([t])
 
 
+def test_context_2048_gqa_64_8(ref, tmp_path):
+    """a 2048-position context at the GQA shape of Llama-2-70B (64 query heads on 8 KV heads, head_dim 128; the
+    2-layer model at the real widths): a 1900-token prompt in reference batches of 128 (chunks of 128 here, 15 attention passes of
+    growing length, every query head of a group reading the same K/V rows), then 40 greedy steps up to position 1940, every
+    logits vector bit-identical to the reference CPU build."""
+    p = str(tmp_path / "g.gguf")
+    hp = synth.write_llama_gguf(p, "llama-70b-2l", "Q5_K_M", seed=41)
+    toks = synth.prompt_tokens(1900, hp["n_vocab"])
+    r = ref.open_llm(p, context_length=2048, batch_size=128, threads=16)
+    m = open_hip(p, context_length=2048, batch_size=128)
+    r.eval(toks)
+    m.eval(toks)
+    assert chunk_tokens(m) == 1900
+    for i in range(40):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "position %d" % (1900 + i)
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
+
+
 @pytest.mark.parametrize("name,tg", [("tiny-q4km", 0), ("tiny-q5km", 0), ("tiny-q4km", 16), ("tiny-q5km", 16), ("tiny-q4km", 32),
                                      ("tiny-q5km", 32)])
 def test_prompt_chunk_matrix_core_forms(name, tg, monkeypatch):

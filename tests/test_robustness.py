@@ -90,3 +90,21 @@ def test_last_n_tokens_zero_means_whole_context(emu_lib, ref):
     for seed in (1, 2, 3):
         assert m.sample(top_k=50, top_p=0.9, temperature=0.9, repetition_penalty=1.5, last_n_tokens=0, seed=seed) == \
             r.sample(top_k=50, top_p=0.9, temperature=0.9, repetition_penalty=1.5, last_n_tokens=0, seed=seed)
+
+
+def test_greedy_pick_without_fetching_logits_and_edited_logits(emu_lib):
+    """A top_k = 1 step without repetition penalty is answered by the device-side first-maximum (4 bytes cross the bus); once the caller
+    has looked at the logits — the reference's Python hands out a WRITABLE view — sampling runs on that host copy, edits included."""
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    m.eval(list(g["prompt"]))
+    t1 = m.sample(top_k=1, repetition_penalty=1.0, temperature=0.7, top_p=0.5, seed=3)   # nothing fetched yet: the device-side pick
+    assert t1 == int(g["greedy"][0])
+    lg = m.logits                      # fetches the outputs
+    assert t1 == int(np.argmax(lg.to_numpy())) and np.array_equal(lg.to_numpy(), g["logits"][0])
+    lg[t1] = -1e30                     # the caller bans the token in place
+    t2 = m.sample(top_k=1, repetition_penalty=1.0)
+    assert t2 != t1 and t2 == int(np.argmax(lg.to_numpy()))
+    m.eval([t1])                       # a new eval: back to the device-side pick, equal to the reference's next greedy token
+    assert m.sample(top_k=1, repetition_penalty=1.0) == int(g["greedy"][1])
+    assert m.sample(top_k=0, repetition_penalty=1.3, last_n_tokens=0) == int(g["greedy"][1])   # k <= 1, no tokens to penalise
