@@ -423,7 +423,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     hp_.n_vocab = vocab_.size();
     // reference default n_ctx = 512 unless context_length is passed (llama.cpp:5281, llama.cc:90-92)
     n_ctx_ = context_length > 0 ? context_length : 512;
-    if (n_ctx_ > kMaxCtx) { err = "context_length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
+    if (n_ctx_ > kMaxCtxFused) { err = "context_length above " + std::to_string(kMaxCtxFused) + " not supported yet"; return false; }
 
     HIP_OK(hipStreamCreate(&stream_));
     bool r2_auto = true;   // mat() also makes the matrix's own R2C4 copy (false: the caller places several matrices in one arena)
@@ -926,18 +926,24 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
     if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
+    const size_t smem = (size_t)((n_ctx_ + 63) & ~63) * 4;   // the probability row
+#define ATTN(NTV, HDV, ALLV, GRID) do { \
+        auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV>; \
+        CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
+        CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
     if (nt > 0 && (hd == 128 || hd == 64)) {
         // prompt chunk: n_head x nt workgroups, each latency-bound — 256-thread workgroups let three of them share a CU
-        // (the arithmetic does not depend on the workgroup size: scores, softmax and V*P are per position / per channel)
-        const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)nt);   // all channels of a head in one workgroup (ALLCH)
-        if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<256, 128, true>), ag1, dim3(256), stream_, ax);
-        else CT_LAUNCH((attn_fused_exact_kernel<256, 64, true>), ag1, dim3(256), stream_, ax);
+        // (the arithmetic does not depend on the workgroup size: scores, softmax and V*P are per position / per channel),
+        // all channels of a head in one workgroup (ALLCH)
+        const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)nt);
+        if (hd == 128) ATTN(256, 128, true, ag1); else ATTN(256, 64, true, ag1);
         return;
     }
-    if (hd == 128) CT_LAUNCH((attn_fused_exact_kernel<512, 128>), ag, dim3(512), stream_, ax);
-    else if (hd == 64) CT_LAUNCH((attn_fused_exact_kernel<512, 64>), ag, dim3(512), stream_, ax);
-    else if (hd == 192) CT_LAUNCH((attn_fused_exact_kernel<512, 192>), ag, dim3(512), stream_, ax);
-    else CT_LAUNCH((attn_fused_exact_kernel<512, 256>), ag, dim3(512), stream_, ax);
+    if (hd == 128) ATTN(512, 128, false, ag);
+    else if (hd == 64) ATTN(512, 64, false, ag);
+    else if (hd == 192) ATTN(512, 192, false, ag);
+    else ATTN(512, 256, false, ag);
+#undef ATTN
 }
 
 // One mat-vec site of a prompt chunk on the f16 matrix cores (kernels_pg.h): stage images of the nt activation rows in the

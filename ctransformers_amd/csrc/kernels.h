@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
     }
 }
 
-constexpr int kMaxCtx = 8192;   // attention kernels keep one score / probability row of this length in LDS
+constexpr int kMaxCtx = 8192;        // the GPT-2 attention kernel keeps one score / probability row of this length in static LDS
+constexpr int kMaxCtxFused = 32768;  // llama / falcon (attn_fused_exact_kernel): the row lives in dynamic LDS, 4 bytes per position
 
 // ------------------------------------------------------------------------------------------------------------------
 // Final-norm output as f32 (the "embeddings" the ABI exposes: reference llama.cpp:2963-2968 copies result_norm).

@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
     constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
     constexpr int VB = 8;                       // V chunks (32 positions each) in flight together
-    __shared__ float prob[kMaxCtx];
+    CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats (dynamic: 2 KB at the default context, 128 KB at 32768)
+    float* prob = reinterpret_cast<float*>(smem_raw);
     __shared__ double red[NWV];
     __shared__ float redf[NWV];
     const int h = (int)blockIdx.x;

@@ -266,6 +266,26 @@ def test_long_context(ref, tmp_path):
         m.eval([t])
 
 
+def test_context_above_8192(ref, tmp_path):
+    """context_length 10240 (the probability row of the attention kernel lives in dynamic LDS, up to 32768 positions): a 9000-token
+    prompt, then greedy steps past position 9000, bit-identical to the reference CPU build."""
+    p = str(tmp_path / "c.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=43)
+    toks = synth.prompt_tokens(9000, hp["n_vocab"])
+    r = ref.open_llm(p, context_length=10240, batch_size=128, threads=16)
+    m = open_hip(p, context_length=10240, batch_size=128)
+    r.eval(toks)
+    m.eval(toks)
+    for i in range(8):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "position %d" % (9000 + i)
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
+    with pytest.raises(RuntimeError):
+        open_hip(p, context_length=40000)   # above the 32768 the kernel's LDS row can hold: refused at load
+
+
 def test_context_2048_gqa_64_8(ref, tmp_path):
     """a 2048-position context at the GQA shape of Llama-2-70B (64 query heads on 8 KV heads, head_dim 128; the
     2-layer model at the real widths): a 1900-token prompt in reference batches of 128 (chunks of 128 here, 15 attention passes of
