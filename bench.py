@@ -132,22 +132,22 @@ def cpu_baseline(n_vocab):
         tried, best = [], None
         # thread counts in the region where ggml's pool scales (its barriers spin: hundreds of threads are slower than a few dozen),
         # then every core and the library default for the record, each under its own limit
-        plan = [(t, 60) for t in (16, 32, 8) if t <= cores] or [(cores, 60)]
+        plan = [(t, 45) for t in (16, 32, 8) if t <= cores] or [(cores, 45)]
         if cores > 32:
-            plan.append((cores, 40))
+            plan.append((cores, 25))
         for t, limit in plan:
             r = run(t, limit)
             tried.append(dict(threads=t, decode_tok_s=r["decode"] if r else None, prefill_tok_s=r["prefill"] if r else None,
                               note=None if r else "did not finish within the %d s limit" % limit))
             if r and (best is None or r["decode"] > best[1]["decode"]):
                 best = (t, r)
-        rd = run(-1, 40)
+        rd = run(-1, 30)
         if best is None:
             return dict(value=None, unit="tokens/s", cores=cores, kind="reference", runs=tried, sample="no reference run finished within its limit")
         return dict(value=best[1]["decode"], unit="tokens/s", cores=cores, threads=best[0], kind="reference", prefill_tok_s=best[1]["prefill"],
                     runs=tried, default_threads=dict(threads=max(1, cores // 2), value=rd["decode"] if rd else None,
                                                      prefill_tok_s=rd["prefill"] if rd else None,
-                                                     note=None if rd else "did not finish within the 40 s limit"),
+                                                     note=None if rd else "did not finish within the 30 s limit"),
                     sample="reference AVX2 build (oracle/_ref: gcc -O3 -mavx2 -mfma -mf16c, the reference's own CT_INSTRUCTIONS=avx2 flags), same "
                            "synthetic file, host has %d cores: 128-token prefill (batch_size=128) then 24 greedy decode steps, median step "
                            "time; value = threads=%d, the best of the thread counts in `runs`" % (cores, best[0]))

@@ -227,7 +227,23 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     const float res = f16dot_reduce_exact(acc, j);
     double sumf = (double)res;
     if (trace) tr[5] = clock64_dev();
-    for (int i = np; i < n_kv; ++i) sumf += (double)(f16_bits_to_f32(vrow[i]) * prob[i]);
+    // Leftover positions np .. n_kv - 1 (fewer than 32; ggml_vec_dot_f16's scalar tail: sumf += (double)(x[i] * y[i]) in order).  Their V
+    // values are fetched with four 16-byte loads issued together — one memory latency instead of one per position (the dependent
+    // 2-byte loads of the plain loop cost ~280 cycles each, 2 us of a 6.5 us launch at the average of 15 leftovers) — and the
+    // double-precision chain then runs from registers.  The row is padded to a multiple of 32 positions (v_stride).
+    const int nl = n_kv - np;   // wave-uniform
+    if (nl > 0) {
+        u32x4 lv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lv[c] = ld16(vrow + np + 8 * c);
+        float lf[32];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) unpack8_f16(lv[c], lf + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < nl) sumf += (double)(lf[i] * prob[np + i]);
+        }
+    }
     if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
     }
     if (trace) tr[6] = clock64_dev();

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ctransformers_amd import synth
 from ctransformers_amd.llm import LLM, Config
-p = "/tmp/l7b.gguf"
+p = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
 if not os.path.exists(p):
     synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
 m = LLM(p, config=Config(context_length=512, batch_size=128))
