@@ -177,6 +177,27 @@ def test_config2_full_size(ref, model_7b):
     assert np.array_equal(r8.logits.to_numpy(), m8.logits.to_numpy())
 
 
+def test_chunk_path_repeatable_on_full_7b(ref, model_7b):
+    """The LDS-DMA staging of kernels_pg.h once produced RARE wrong stage data on the 32-layer model that single runs of the parity
+    tests did not catch: fresh handles, several prompt lengths (one group, ragged groups, a full chunk, two chunks),
+    four repetitions, every logits vector equal to the reference CPU build's (tools/stress_chunks.py is the longer form)."""
+    lens = (24, 33, 128, 200)
+    r = ref.open_llm(model_7b, context_length=512, batch_size=128, threads=16)
+    want = {}
+    for n in lens:
+        r._context = []
+        r.eval(synth.prompt_tokens(n, 32000))
+        want[n] = r.logits.to_numpy().copy()
+    del r
+    for rep in range(4):
+        m = open_hip(model_7b, context_length=512, batch_size=128)
+        for n in lens:
+            m._context = []
+            m.eval(synth.prompt_tokens(n, 32000))
+            assert np.array_equal(m.logits.to_numpy(), want[n]), "repetition %d, %d-token prompt" % (rep, n)
+        del m
+
+
 def test_config3_full_size_q8_0(ref, tmp_path_factory):
     """BASELINE.json configs[2]: the full 32-layer Llama-2-7B Q8_0 file — 128-token prompt + 32 greedy tokens against the reference
     build (kernels_q32.h decode, the dot4 chunk kernels for the prompt)."""
