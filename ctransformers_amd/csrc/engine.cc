@@ -931,6 +931,41 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV>; \
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
         CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
+    if (nt > 0 && (hd == 128 || hd == 64) && chunk_below_128_ && n_ctx_ >= 128 && env_int("CT_AMD_ATTN_TILE", 1) != 0) {
+        // every position of this chunk is below 128: K / V of a head go through LDS once per 16 tokens
+        const dim3 gt((unsigned)hp_.n_head, (unsigned)((nt + 15) / 16));
+        const size_t sm = (size_t)128 * (hd * 2 + 64) + (size_t)hd * 320 + (size_t)16 * 160 * 4;
+        static const char* pgt = getenv("CT_AMD_PG_TRACE");   // measurement only: "attn" = in-kernel stamps of this launch
+        const bool tr = pgt && !strcmp(pgt, "attn") && nt > 64;
+        if (tr) ax.trace = trace_buf_;
+        if (hd == 128) { auto kfn = attn_chunk_tile_kernel<128>; CT_OPTIN_ONCE(kfn, (size_t)96 * 1024); CT_LAUNCH_DYN(kfn, gt, dim3(1024), sm, stream_, ax, nt); }
+        else { auto kfn = attn_chunk_tile_kernel<64>; CT_OPTIN_ONCE(kfn, (size_t)96 * 1024); CT_LAUNCH_DYN(kfn, gt, dim3(1024), sm, stream_, ax, nt); }
+        if (tr) {
+            (void)hipStreamSynchronize(stream_);
+            unsigned long long hbuf[256];
+            (void)hipMemcpy(hbuf, trace_buf_, sizeof hbuf, hipMemcpyDeviceToHost);
+            fprintf(stderr, "attn_trace:");
+            for (int w : {0, 5, 15}) fprintf(stderr, " [wave %d n_kv %llu: load %llu, scores %llu, softmax %llu, pv %llu]", w, hbuf[16 * w + 5], hbuf[16 * w + 1] - hbuf[16 * w],
+                                              hbuf[16 * w + 2] - hbuf[16 * w + 1], hbuf[16 * w + 3] - hbuf[16 * w + 2], hbuf[16 * w + 4] - hbuf[16 * w + 3]);
+            fprintf(stderr, "\n");
+        }
+        return;
+    }
+    if (nt > 0 && (hd == 128 || hd == 64) && n_ctx_ <= 4096 && env_int("CT_AMD_ATTN_WAVE", 1) != 0) {
+        // prompt chunk, contexts whose probability rows fit LDS eight (four) at a time: one WAVE per (head, token)
+        const int row = (n_ctx_ + 63) & ~63;
+        const bool w8 = (size_t)8 * row * 4 <= (size_t)64 * 1024;
+        const size_t sm = (size_t)(w8 ? 8 : 4) * row * 4;
+        const dim3 gw((unsigned)hp_.n_head, (unsigned)((nt + (w8 ? 8 : 4) - 1) / (w8 ? 8 : 4)));
+#define ATTNW(HDV, WPBV) do { \
+            auto kfn = attn_chunk_wave_kernel<HDV, WPBV>; \
+            CT_OPTIN_ONCE(kfn, (size_t)64 * 1024); \
+            CT_LAUNCH_DYN(kfn, gw, dim3(WPBV * 64), sm, stream_, ax, nt, row); } while (0)
+        if (hd == 128) { if (w8) ATTNW(128, 8); else ATTNW(128, 4); }
+        else { if (w8) ATTNW(64, 8); else ATTNW(64, 4); }
+#undef ATTNW
+        return;
+    }
     if (nt > 0 && (hd == 128 || hd == 64)) {
         // prompt chunk: n_head x nt workgroups, each latency-bound — 256-thread workgroups let three of them share a CU
         // (the arithmetic does not depend on the workgroup size: scores, softmax and V*P are per position / per channel),
@@ -1277,9 +1312,10 @@ bool Engine::chunk_step_gpt2(int nt, bool want_logits, std::string& err) {
 // of a chunk shape seen before are replayed from a graph: the first use of a shape runs eagerly (it also performs the
 // one-time dynamic-LDS opt-ins), the second captures.
 bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
+    chunk_below_128_ = req_past_ + c0 + nt <= 128;   // positions of this chunk: [n_past + c0, n_past + c0 + nt)
 #ifndef CT_EMU
     if (use_graph_ && l0_ == 0 && l1_ == hp_.n_layer && !prof_ && !only_site_) {
-        const int key = 2 * nt + (want_logits ? 1 : 0);
+        const int key = 4 * nt + 2 * (chunk_below_128_ ? 1 : 0) + (want_logits ? 1 : 0);   // the attention kernel depends on the flag
         auto it = chunk_graphs_.find(key);
         if (it == chunk_graphs_.end() && chunk_seen_[key]++ >= 1) {
             hipGraph_t g = nullptr;
@@ -1635,6 +1671,7 @@ bool Engine::req_begin(const int* tokens, int n, int n_past, int batch, std::str
     if (env_int("CT_AMD_DBG_ONE_BATCH", 0)) h_scalars_[3] = 0;   // tests of the tests: ignore the batch structure on purpose
     HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
     req_n_ = n;
+    req_past_ = n_past;
     return true;
 }
 

@@ -187,9 +187,11 @@ class Engine {
     const uint8_t* file_lo_ = nullptr;
     const uint8_t* file_hi_ = nullptr;
     double load_stage_s_ = 0.0;
+    int req_past_ = 0;               // n_past of the request being evaluated
+    bool chunk_below_128_ = false;   // every position of the chunk being launched is < 128 (attn_chunk_tile_kernel applies)
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
-    std::map<int, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by 2 * n_tokens + want_logits; captured on second use
+    std::map<int, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by 4 * n_tokens + 2 * below-128 + want_logits; captured on second use
     std::map<int, int> chunk_seen_;
 #endif
     bool have_logits_ = false;

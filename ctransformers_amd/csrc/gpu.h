@@ -247,7 +247,7 @@ template <class T> static inline T lane_xor8(T v) { return __shfl_xor(v, 8); }
 template <class T> static inline T lane_xor16(T v) { return __shfl_xor(v, 16); }
 template <class T> static inline T lane_xor32(T v) { return __shfl_xor(v, 32); }
 #else
-template <int CTRL> DEV int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> DEV int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <class T, int CTRL> DEV T dpp_any(T v) {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dpp payload");
     if constexpr (sizeof(T) == 4) {

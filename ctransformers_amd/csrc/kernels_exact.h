@@ -249,6 +249,263 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     if (trace) tr[6] = clock64_dev();
 }
 
+// Prompt chunks: ONE WAVE per (head, token), WPB of them per workgroup, nothing shared and no workgroup barrier.  The arithmetic per
+// position / channel is attn_fused_exact_kernel's (a quad of lanes per position with the four AVX accumulators of ggml_vec_dot_f16,
+// the fp16 exp table, the order-free double sum, a quad per channel for V*P with the 32-wide fma part and the double-precision
+// leftovers) — only the thread mapping changes: 16 positions / 16 channels per pass instead of 64.  The fused kernel is a serial
+// latency chain of ~6 us per (head, token) that keeps a whole 256-thread workgroup (and its LDS row) for one token: three workgroups per
+// CU, 4096 of them for a 128-token chunk of a 7B = 36 us per layer.  A wave per token keeps 12 tokens in flight per CU.
+// Dynamic LDS: WPB probability rows of row_floats each (engine.cc picks WPB so that they fit).
+template <int HD, int WPB>
+__global__ void __launch_bounds__(WPB * 64) attn_chunk_wave_kernel(const AttnArgsX a, int n_tok, int row_floats) {
+    constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
+    constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
+    constexpr int VB = 4;                       // V chunks (32 positions each) in flight together
+    CT_DYN_SMEM(smem_raw);
+    const int lane = lane_id(), wv = uniform_int(wave_id()), j = lane & 3, quad = lane >> 2;
+    const int h = (int)blockIdx.x, tok = (int)blockIdx.y * WPB + wv;
+    if (tok >= n_tok) return;                   // whole wave; no workgroup barrier anywhere below
+    float* prob = reinterpret_cast<float*>(smem_raw) + (size_t)wv * row_floats;
+    const int n_kv = *a.pos + tok + 1;
+    int n_tot = *a.n_total;                     // end of the reference batch this token belongs to (see attn_fused_exact_kernel)
+    {
+        const int bs = a.n_total[1];
+        if (bs > 0) {
+            const int idx = a.pos[-1] + tok, base = *a.pos - a.pos[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = n_tot - base;
+            n_tot = base + (end < n_eval ? end : n_eval);
+        }
+    }
+    const int np = n_tot & ~31;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const uint16_t* qrow = a.q_f16 + (size_t)tok * a.q_stride + (size_t)h * HD;
+    const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
+    float qf[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) unpack8_f16(ld16(qrow + 32 * c + 8 * j), qf[c]);
+    float mx = -INFINITY;
+    for (int base = 0; base < n_kv; base += 16 * PB) {
+        u32x4 kv[PB][NC];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * 16 + quad;
+            const uint16_t* krow = kbase + (size_t)p * HD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kv[u][c] = (p < n_kv) ? ld16(krow + 32 * c) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * 16 + quad;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float kf[8];
+                unpack8_f16(kv[u][c], kf);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[c][l], acc[l]);
+            }
+            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if (p < n_kv) {
+                mx = fmaxf(mx, sc);
+                if (j == 0) prob[p] = sc;
+            }
+        }
+    }
+    mx = wave_max(mx);
+    wave_lds_sync();
+    double sum = 0.0;
+    for (int i0 = 0; i0 < n_kv; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < n_kv) { const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]); prob[i] = e; sum += (double)e; }
+    }
+    sum = wave_sum(sum);
+    const float inv = (float)(1.0 / sum);
+    for (int i = lane; i < n_kv; i += 64) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    for (int i = n_kv + lane; i < np; i += 64) prob[i] = 0.0f;   // masked columns of this batch
+    wave_lds_sync();
+    const int nl = n_kv - np;                   // leftover positions (< 32), wave-uniform
+    // 16 channels per pass (a quad each), TWO passes together: every batch of V loads is one memory latency on this wave's serial
+    // chain, and the chain is all a wave-per-token kernel has — 8 single passes cost 8 latencies (~1.3 us each), pairs cost 4.
+#pragma unroll 1
+    for (int pass = 0; pass < HD / 16; pass += 2) {
+        const uint16_t* vrow[2];
+        float acc[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            vrow[t] = a.vcache + ((size_t)hk * HD + (pass + t) * 16 + quad) * a.v_stride;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[t][l] = 0.0f;
+        }
+        for (int i0 = 0; i0 < np; i0 += 32 * VB) {
+            u32x4 vv[2][VB];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < VB; ++u) vv[t][u] = (i0 + 32 * u < np) ? ld16(vrow[t] + i0 + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < VB; ++u) {
+                    if (i0 + 32 * u < np) {
+                        float vf[8];
+                        unpack8_f16(vv[t][u], vf);
+                        const float* pr = &prob[i0 + 32 * u + 8 * j];
+#pragma unroll
+                        for (int l = 0; l < 8; ++l) acc[t][l] = fmaf(vf[l], pr[l], acc[t][l]);
+                    }
+                }
+        }
+        u32x4 lv[2][4];
+        if (nl > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lv[t][c] = ld16(vrow[t] + np + 8 * c);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            double sumf = (double)f16dot_reduce_exact(acc[t], j);
+            if (nl > 0) {
+                float lf[32];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) unpack8_f16(lv[t][c], lf + 8 * c);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    if (i < nl) sumf += (double)(lf[i] * prob[np + i]);
+                }
+            }
+            if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + (pass + t) * 16 + quad] = (float)sumf;
+        }
+    }
+}
+
+// Prompt chunks whose positions all lie below 128 (the first chunk of a prompt — every BASELINE prompt): the K rows and V rows of a
+// head are brought into LDS ONCE per 16 tokens and the 16 waves of the workgroup (a token each, as in attn_chunk_wave_kernel, same
+// arithmetic) read them from there.  Per (head, token) the wave kernel fetches 64 KB of K/V through L2 — 268 MB for a 128-token chunk of
+// a 7B, the launch is L2-bandwidth bound at ~20 us; here it is 17 MB and one workgroup per CU.
+// LDS: K tile [128 positions][HD halves + 32 pad] | V tile [HD channels][128 positions + 32 pad] | 16 probability rows of 160 floats.
+// The 64-byte pads put the four quads of a ds_read_b128 phase on different banks (row strides 320 / 192 bytes: 16 (p mod 4) + 4 j).
+template <int HD>
+__global__ void __launch_bounds__(1024) attn_chunk_tile_kernel(const AttnArgsX a, int n_tok) {
+    constexpr int NC = HD / 32, PB = 4, VB = 4;
+    constexpr int KS = HD * 2 + 64, VS = 256 + 64, ROW = 160, NCH = HD / 8;   // bytes, bytes, floats, 16-byte chunks per K row
+    CT_DYN_SMEM(smem_raw);
+    unsigned char* Kt = smem_raw;
+    unsigned char* Vt = smem_raw + 128 * KS;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = lane & 3, quad = lane >> 2;
+    // tokens are dealt to the workgroups round-robin (wave w of workgroup y: token y + w * gridDim.y): causal attention costs a token
+    // in proportion to its position, so consecutive tokens per workgroup would leave the last workgroup with 4x the average work
+    const int h = (int)blockIdx.x, tok = (int)blockIdx.y + wv * (int)gridDim.y;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const bool trace = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0;   // measurement only (CT_AMD_PG_TRACE=attn)
+    unsigned long long* tr = a.trace + 16 * wv;
+    if (trace) tr[0] = clock64_dev();
+    const int pos0 = *a.pos;
+    const int n_kv_wg = pos0 + n_tok;           // <= 128 (the host selects this kernel only then)
+    {
+        const uint16_t* kb = a.kcache + (size_t)hk * a.n_ctx * HD;
+        for (int i = tid; i < n_kv_wg * NCH; i += 1024) {
+            const int p = i / NCH, c = i - p * NCH;
+            *(u32x4*)(Kt + p * KS + c * 16) = ld16(kb + (size_t)p * HD + 8 * c);
+        }
+        const uint16_t* vb = a.vcache + (size_t)hk * HD * a.v_stride;
+        for (int i = tid; i < HD * 16; i += 1024) {   // 128 positions of every channel (positions past the batch's end are never used)
+            const int ch = i >> 4, c = i & 15;
+            *(u32x4*)(Vt + ch * VS + c * 16) = ld16(vb + (size_t)ch * a.v_stride + 8 * c);
+        }
+    }
+    __syncthreads();
+    if (tok >= n_tok) return;                   // whole wave, after the only barrier
+    if (trace) tr[1] = clock64_dev();
+    float* prob = reinterpret_cast<float*>(smem_raw + 128 * KS + HD * VS) + wv * ROW;
+    const int n_kv = pos0 + tok + 1;
+    int n_tot = *a.n_total;                     // end of the reference batch this token belongs to (see attn_fused_exact_kernel)
+    {
+        const int bs = a.n_total[1];
+        if (bs > 0) {
+            const int idx = a.pos[-1] + tok, base = pos0 - a.pos[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = n_tot - base;
+            n_tot = base + (end < n_eval ? end : n_eval);
+        }
+    }
+    const int np = n_tot & ~31;
+    const uint16_t* qrow = a.q_f16 + (size_t)tok * a.q_stride + (size_t)h * HD;
+    float qf[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) unpack8_f16(ld16(qrow + 32 * c + 8 * j), qf[c]);
+    float mx = -INFINITY;
+    for (int base = 0; base < n_kv; base += 16 * PB) {
+        u32x4 kv[PB][NC];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * 16 + quad;
+            const int pc = p < 128 ? p : 127;   // rows past n_kv_wg hold stale bytes: read, never used
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kv[u][c] = *(const u32x4*)(Kt + pc * KS + (32 * c + 8 * j) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = base + u * 16 + quad;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float kf[8];
+                unpack8_f16(kv[u][c], kf);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[c][l], acc[l]);
+            }
+            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if (p < n_kv) {
+                mx = fmaxf(mx, sc);
+                if (j == 0) prob[p] = sc;
+            }
+        }
+    }
+    mx = wave_max(mx);
+    wave_lds_sync();
+    if (trace) tr[2] = clock64_dev();
+    double sum = 0.0;
+    for (int i0 = 0; i0 < n_kv; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < n_kv) { const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]); prob[i] = e; sum += (double)e; }
+    }
+    sum = wave_sum(sum);
+    const float inv = (float)(1.0 / sum);
+    for (int i = lane; i < n_kv; i += 64) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    for (int i = n_kv + lane; i < np; i += 64) prob[i] = 0.0f;   // masked columns of this batch
+    wave_lds_sync();
+    const int nl = n_kv - np;                   // leftover positions (< 32), wave-uniform
+    if (trace) tr[3] = clock64_dev();
+#pragma unroll 1
+    for (int pass = 0; pass < HD / 16; ++pass) {   // 16 channels per pass, a quad each
+        const int d = pass * 16 + quad;
+        const unsigned char* vrow = Vt + d * VS;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {          // np <= 128: at most four steps of 32 positions
+            if (32 * u < np) {
+                float vf[8];
+                unpack8_f16(*(const u32x4*)(vrow + (32 * u + 8 * j) * 2), vf);
+                const float* pr = &prob[32 * u + 8 * j];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            }
+        }
+        double sumf = (double)f16dot_reduce_exact(acc, j);
+        if (nl > 0) {
+            float lf[32];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unpack8_f16(*(const u32x4*)(vrow + (np + 8 * c) * 2), lf + 8 * c);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                if (i < nl) sumf += (double)(lf[i] * prob[np + i]);
+            }
+        }
+        if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
+    }
+    if (trace) { tr[4] = clock64_dev(); tr[5] = (unsigned long long)n_kv; }
+}
+
 // Prologue, 16 lanes per 256-block: lane `sub` owns 16 consecutive elements, so the per-block reductions are 4 DPP
 // steps inside a row of 16 lanes and all 16 (32) blocks of a round proceed at once.  Same arithmetic as
 // prologue_q8k_exact (reference k_quants.c:1191-1226 with the fused fma; RMSNorm ggml.c:10700-10716).

@@ -41,3 +41,22 @@ def test_token_group_sizes_and_ragged_groups(emu_lib, monkeypatch, name, tg, bat
     m.eval(list(g["long_prompt"]))
     assert pg_launches(m._lib) > n0 and chunk_tokens(m) == 45
     assert np.array_equal(m.logits.to_numpy(), g[key])
+
+
+@pytest.mark.parametrize("name,mode", [("tiny-q4km", "tile"), ("tiny-q4km", "wave"), ("tiny-q4km", "fused"), ("falcon-tiny-q4km", "tile"),
+                                       ("tiny-q5km", "wave")])
+def test_chunk_attention_kernels(emu_lib, monkeypatch, name, mode):
+    """The three chunk-attention kernels (kernels_exact.h): K/V tiles of a head in LDS for 16 tokens (all positions below 128; needs
+    n_ctx >= 128), a wave per (head, token), and the decode kernel with all channels per workgroup — same goldens of the reference."""
+    if mode != "tile":
+        monkeypatch.setenv("CT_AMD_ATTN_TILE", "0")
+    if mode == "fused":
+        monkeypatch.setenv("CT_AMD_ATTN_WAVE", "0")
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = open_emu(emu_lib, name, context_length=160, batch_size=8)
+    if "long_prompt" in g.files:
+        m.eval(list(g["long_prompt"]))   # 45 tokens in reference batches of 8: ragged batch ends (leftover positions of V*P), one chunk
+        assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
+    else:
+        m.eval(list(g["prompt"]))
+        assert np.array_equal(m.logits.to_numpy(), g["logits"][0])

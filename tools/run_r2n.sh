@@ -18,7 +18,7 @@ cd /root/repo
 python tools/prof_summary.py $O/prof > $O/kernel_stats.txt 2>&1
 python tools/pmc_traffic.py $O/pmc_fetch/v7_counter_collection.csv $O/pmc_write/v7_counter_collection.csv > $O/pmc_traffic.json 2>&1
 python tools/pf_sites.py $O/prof_prefill > $O/prefill_sites.txt 2>&1
-for s in gate_up down; do CT_AMD_PG_TRACE=$s CT_AMD_GRAPH=0 timeout 300 python tools/decode_loop.py --model $M --prompt 128 --decode 1 2>&1 | grep pg_trace | sed -n 3,3p | cut -c1-1800 >> $O/pg_step_trace.txt; done
+for s in gate_up down attn; do CT_AMD_PG_TRACE=$s CT_AMD_GRAPH=0 timeout 300 python tools/decode_loop.py --model $M --prompt 128 --decode 1 2>&1 | grep -E "pg_trace|attn_trace" | sed -n 3,3p | cut -c1-1800 >> $O/pg_step_trace.txt; done
 timeout 300 python tools/prefill_sweep.py $M 8 16 32 64 128 > $O/prefill_sweep.txt 2>&1
 timeout 1500 python bench.py --config 4 --no-cpu-baseline --steps 64 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 rm -f /tmp/ctamd_falcon_40b_q4km_r2.gguf
