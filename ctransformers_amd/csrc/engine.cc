@@ -443,7 +443,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (l0_ >= l1_ || l1_ > hp_.n_layer) { err = "bad pipeline stage layer range"; return false; }
     {   // Load pipeline.  The tensors of this handle's layers: all matrices K-quants -> stage the file range on the GPU and repack there.
         std::vector<const GgufTensor*> need;
-        bool all_kq = true;
+        size_t kq_bytes = 0, other_bytes = 0;   // 2-D weight bytes that are K-quants (repacked on the GPU) / other types (host path)
         for (const GgufTensor& x : f.tensors()) {
             bool mine = false;
             if (x.name.compare(0, 4, "blk.") == 0) { const int li = atoi(x.name.c_str() + 4); mine = li >= l0_ && li < l1_; }
@@ -451,9 +451,11 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
             else if (x.name.compare(0, 6, "output") == 0) mine = l1_ == hp_.n_layer;
             if (!mine) continue;
             need.push_back(&x);
-            if (x.n_dims >= 2 && x.name.compare(0, 10, "token_embd") != 0 && !is_kquant(x.type)) all_kq = false;
+            if (x.n_dims >= 2 && x.name.compare(0, 10, "token_embd") != 0) (is_kquant(x.type) ? kq_bytes : other_bytes) += x.nbytes;
         }
-        if (all_kq && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;   // 0: host repack (A/B)
+        // staged when most of the bytes take the GPU repack (a Falcon-40B Q4_K_M file has a Q8_0 head: that one matrix keeps the host
+        // path, reading the mapping); CT_AMD_GPU_REPACK=0: host repack everywhere (A/B)
+        if (kq_bytes > other_bytes && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;
     }
     t = f.tensor("token_embd.weight");
     if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
