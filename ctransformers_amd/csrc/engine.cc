@@ -82,7 +82,7 @@ static void parallel_rows(int M, const std::function<void(int, int)>& fn) {
     for (auto& t : th) t.join();
 }
 
-// One file-layout K-quant block -> slot `r` (0..7) of a record in the tile8S field order (quant.h); the 6-bit scale/min
+// One file-layout K-quant block -> slot `r` (0..7) of a LAYOUT_R2C4 record (quant.h); the 6-bit scale/min
 // field of Q4_K / Q5_K headers is re-encoded as four 24-bit groups (reference packing: k_quants.c:306-314).
 CT_HD static inline void place_kblock(int type, uint8_t* rp, int r, const uint8_t* blk) {
     uint8_t hdr[16];

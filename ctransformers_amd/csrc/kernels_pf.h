@@ -24,7 +24,7 @@ constexpr int kPfChunk = 128;   // tokens per chunk_step (8 groups of 16 on the 
 
 struct PfArgs {
     MatvecArgs m;        // jobs and epilogue operands; x / norm_w / pro are the quantize kernel's business
-    const int* acts;     // n_tok activation images (pf_quantize_kernel)
+    const int* acts;     // n_tok activation images (pf_quantize_q80_kernel)
     int act_words;       // words per image (multiple of 4)
     int n_tok;           // tokens in this chunk
     int ld_out, ld_res, ld_q;   // element strides between the tokens' rows of m.out, m.res, m.q_f16

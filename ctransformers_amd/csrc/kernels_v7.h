@@ -8,7 +8,7 @@
 //
 // Here the unit of work is ONE PAIR OF ROWS, owned by one wave from its first byte to its epilogue:
 //   * layout LAYOUT_R2C4 (quant.h): a record holds 2 rows x 4 consecutive K-blocks (8 block slots, the same 1152 / 1408 /
-//     1680 bytes and the same field order as a tile8S record, so img_load / img_to_regs are shared); slot p = 4*row + c.
+//     1680 bytes as the 8 file blocks it holds, fields grouped: kernels_kq.h img_load / img_to_regs); slot p = 4*row + c.
 //     A row pair is `spu = ceil(nb / 4)` consecutive records = one contiguous stream (4.6 KB at K = 4096).  gate/up
 //     launches use a fused matrix whose pair is (gate row r, up row r).
 //   * a step = one record: lane (p, g) does the integer work of block 4*s + c of row `p >> 2` exactly as before (nibble
