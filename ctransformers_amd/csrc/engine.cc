@@ -132,6 +132,22 @@ __global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restr
     }
 }
 
+// LAYOUT_G4 (Q8_0 / Q4_0, quant.h) from the staged file copy: one thread per (tile, group of four blocks, row, block).
+__global__ void __launch_bounds__(256) repack_g4_kernel(int q8, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int M, int nb) {
+    const int ng = nb / 4, bb = q8 ? 34 : 18, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512, nl = q8 ? 8 : 4;
+    const long long n = (long long)((M + 7) / 8) * ng * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int bi = (int)(i & 3), r = (int)((i >> 2) & 7);
+        const long long tg = i >> 5;
+        const int g = (int)(tg % ng), tl = (int)(tg / ng), row = tl * 8 + r;
+        if (row >= M) continue;   // zero rows (the buffer is cleared first)
+        const uint8_t* blk = src + ((size_t)row * nb + (size_t)g * 4 + bi) * bb;
+        uint8_t* rp = dst + (size_t)tg * rec;
+        memcpy(rp + dbase + r * 8 + bi * 2, blk, 2);
+        for (int l = 0; l < nl; ++l) memcpy(rp + (r * nl + l) * 16 + bi * 4, blk + 2 + 4 * l, 4);
+    }
+}
+
 // Load pipeline, stage 1: the byte range of the mapping that holds the tensors in `need` -> device memory, unchanged.  pread() by
 // worker threads straight into pinned slots (no page faults on the mapping, no pageable bounce inside the runtime), one async copy
 // per slot; reading slot k + 1 overlaps the copy of slot k.
@@ -303,6 +319,16 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         m.layout = LAYOUT_G4;
         const bool q8 = t->type == GT_Q8_0;
         const int n_tiles = (M + 7) / 8, ng = nb / 4, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512;
+        if (dev_file_) {   // the tensor is already on the device in file layout (stage_file): repack there
+            const size_t bytes = (size_t)n_tiles * ng * rec;
+            uint8_t* d = nullptr;
+            if (!dev_alloc(dev_allocs_, &d, bytes + 64, err)) return false;
+            HIP_OK(hipMemsetAsync(d, 0, bytes + 64, stream_));
+            const long long n = (long long)n_tiles * ng * 32;
+            CT_LAUNCH(repack_g4_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16)), dim3(256), stream_, q8 ? 1 : 0, staged(t), d, M, nb);
+            m.p[0] = d;
+            return true;
+        }
         std::vector<uint8_t> st((size_t)n_tiles * ng * rec, 0);
         const uint8_t* src = t->data;
         parallel_rows(n_tiles, [&](int t0, int t1) {
@@ -453,9 +479,10 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
             need.push_back(&x);
             if (x.n_dims >= 2 && x.name.compare(0, 10, "token_embd") != 0) (is_kquant(x.type) ? kq_bytes : other_bytes) += x.nbytes;
         }
-        // staged when most of the bytes take the GPU repack (a Falcon-40B Q4_K_M file has a Q8_0 head: that one matrix keeps the host
-        // path, reading the mapping); CT_AMD_GPU_REPACK=0: host repack everywhere (A/B)
-        if (kq_bytes > other_bytes && env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;
+        // every weight type is repacked on the GPU (K-quants: repack_r2c4_kernel, Q8_0 / Q4_0: repack_g4_kernel); CT_AMD_GPU_REPACK=0: host
+        // repack everywhere (A/B)
+        (void)kq_bytes; (void)other_bytes;
+        if (env_int("CT_AMD_GPU_REPACK", 1) != 0 && !stage_file(f, need, err)) return false;
     }
     t = f.tensor("token_embd.weight");
     if (!t || t->ne[0] != E || t->ne[1] != V) { err = "bad token_embd.weight"; return false; }
