@@ -108,3 +108,37 @@ def test_greedy_pick_without_fetching_logits_and_edited_logits(emu_lib):
     m.eval([t1])                       # a new eval: back to the device-side pick, equal to the reference's next greedy token
     assert m.sample(top_k=1, repetition_penalty=1.0) == int(g["greedy"][1])
     assert m.sample(top_k=0, repetition_penalty=1.3, last_n_tokens=0) == int(g["greedy"][1])   # k <= 1, no tokens to penalise
+
+
+def test_edge_requests_match_reference_build(emu_lib, ref):
+    """The C ABI at its edges, the same raw calls on this library and on the reference build: an empty request, a request that runs
+    into the end of the context (the reference clamps n_past to n_ctx - N per batch, models/llm.h:126 — positions are overwritten),
+    a batch size larger than the context, and a single token at the last position."""
+    import ctypes
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    toks = [int(t) for t in g["long_prompt"]]
+    cfg = dict(context_length=32, batch_size=8, threads=1)
+    m = LLM(path, config=Config(**cfg), lib=emu_lib)
+    r = ref.open_llm(path, **cfg)
+
+    def raw(h, tokens, n_past, batch):
+        arr = (ctypes.c_int * max(1, len(tokens)))(*tokens)
+        return bool(h.ctransformers_llm_batch_eval(arr, len(tokens), n_past, batch, 1))
+
+    for h in (m, r):
+        assert raw(h, toks[:20], 0, 8)
+    assert np.array_equal(m.logits.to_numpy(), r.logits.to_numpy())
+    for h in (m, r):
+        assert raw(h, [], 20, 8)                      # nothing to do: true, outputs untouched
+    assert np.array_equal(m.logits.to_numpy(), r.logits.to_numpy())
+    for h in (m, r):
+        assert raw(h, toks[20:38], 20, 8)             # 18 tokens from position 20 of a 32-position context: the last batches are clamped
+    assert np.array_equal(m.logits.to_numpy(), r.logits.to_numpy())
+    for h in (m, r):
+        assert raw(h, toks[:5], 31, 64)               # batch_size above n_ctx, n_past at the last position
+    assert np.array_equal(m.logits.to_numpy(), r.logits.to_numpy())
+    for h in (m, r):
+        assert raw(h, toks[7:8], 31, 8)               # one token at the last position
+    assert np.array_equal(m.logits.to_numpy(), r.logits.to_numpy())
+    assert np.array_equal(m.embeddings.to_numpy(), r.embeddings.to_numpy())
