@@ -55,3 +55,29 @@ def test_reference_package_drives_this_library(ref_pkg, ref, emu_lib, name, mode
     assert ours.sample(top_k=1) == theirs.sample(top_k=1)
     assert ours.model_type == theirs.model_type and ours.context_length == theirs.context_length
     assert ours.eos_token_id == theirs.eos_token_id and ours.bos_token_id == theirs.bos_token_id
+
+
+def test_reference_hf_transformers_shim_on_this_library(ref_pkg, ref, emu_lib):
+    """the reference's Hugging Face shim (ctransformers/transformers.py: `from_pretrained(..., hf=True)`, one
+    `eval` per sequence) on top of this library — greedy `generate` of transformers gives the token ids it gives on the reference
+    build."""
+    pytest.importorskip("transformers")
+    import torch
+    from oracle import ref as oracle_ref
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    kw = dict(context_length=96, batch_size=8, threads=2, hf=True)
+    ours = ref_pkg.AutoModelForCausalLM.from_pretrained(path, lib=emu_lib, **kw)
+    theirs = ref_pkg.AutoModelForCausalLM.from_pretrained(path, lib=oracle_ref.REF_LIB, **kw)
+    # (the installed transformers no longer gives PreTrainedModel a `generate`: the shim's forward is driven by hand, greedily)
+    ids = torch.tensor([[int(t) for t in g["prompt"]]])
+    for step in range(4):
+        la = ours(ids, return_dict=True).logits
+        lb = theirs(ids, return_dict=True).logits
+        assert la.shape == (1, 1, ours.config.vocab_size) and torch.equal(la, lb), "step %d" % step
+        nxt = int(torch.argmax(lb[0, -1]))
+        assert nxt == int(g["greedy"][step])
+        ids = torch.cat([ids, torch.tensor([[nxt]])], dim=1)   # the shim re-evaluates only the new suffix (prefix reuse)
+    # (the shim's tokenizer class does not construct under the installed transformers on either library; its ids come from
+    #  LLM.tokenize, compared in test_reference_package_drives_this_library)
+    assert ours._llm.tokenize("ab cd") == theirs._llm.tokenize("ab cd")
