@@ -57,27 +57,39 @@ def test_reference_package_drives_this_library(ref_pkg, ref, emu_lib, name, mode
     assert ours.eos_token_id == theirs.eos_token_id and ours.bos_token_id == theirs.bos_token_id
 
 
+HF_SHIM_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); import ctransformers as C; sys.path.remove(sys.argv[1])
+import torch
+emu_lib, ref_lib, path, npz = sys.argv[2:6]
+g = np.load(npz)
+kw = dict(context_length=96, batch_size=8, threads=2, hf=True)
+ours = C.AutoModelForCausalLM.from_pretrained(path, lib=emu_lib, **kw)
+theirs = C.AutoModelForCausalLM.from_pretrained(path, lib=ref_lib, **kw)
+ids = torch.tensor([[int(t) for t in g["prompt"]]])
+for step in range(4):
+    la = ours(ids, return_dict=True).logits
+    lb = theirs(ids, return_dict=True).logits
+    assert la.shape == (1, 1, ours.config.vocab_size) and torch.equal(la, lb), "step %d" % step
+    nxt = int(torch.argmax(lb[0, -1]))
+    assert nxt == int(g["greedy"][step])
+    ids = torch.cat([ids, torch.tensor([[nxt]])], dim=1)   # the shim re-evaluates only the new suffix (prefix reuse)
+assert ours._llm.tokenize("ab cd") == theirs._llm.tokenize("ab cd")
+print("HF_SHIM_OK", flush=True)
+os._exit(0)   # the shim's PreTrainedModel objects do not survive interpreter teardown under the installed transformers
+"""
+
+
 def test_reference_hf_transformers_shim_on_this_library(ref_pkg, ref, emu_lib):
     """the reference's Hugging Face shim (ctransformers/transformers.py: `from_pretrained(..., hf=True)`, one
-    `eval` per sequence) on top of this library — greedy `generate` of transformers gives the token ids it gives on the reference
-    build."""
+    `eval` per sequence) on top of this library — its forward, driven greedily by hand (the installed transformers no longer gives
+    PreTrainedModel a `generate`, and the shim's tokenizer class does not construct under it, on either library), returns the logits
+    and tokens it returns on the reference build.  Runs in a child interpreter."""
     pytest.importorskip("transformers")
-    import torch
+    import subprocess
     from oracle import ref as oracle_ref
-    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
-    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
-    kw = dict(context_length=96, batch_size=8, threads=2, hf=True)
-    ours = ref_pkg.AutoModelForCausalLM.from_pretrained(path, lib=emu_lib, **kw)
-    theirs = ref_pkg.AutoModelForCausalLM.from_pretrained(path, lib=oracle_ref.REF_LIB, **kw)
-    # (the installed transformers no longer gives PreTrainedModel a `generate`: the shim's forward is driven by hand, greedily)
-    ids = torch.tensor([[int(t) for t in g["prompt"]]])
-    for step in range(4):
-        la = ours(ids, return_dict=True).logits
-        lb = theirs(ids, return_dict=True).logits
-        assert la.shape == (1, 1, ours.config.vocab_size) and torch.equal(la, lb), "step %d" % step
-        nxt = int(torch.argmax(lb[0, -1]))
-        assert nxt == int(g["greedy"][step])
-        ids = torch.cat([ids, torch.tensor([[nxt]])], dim=1)   # the shim re-evaluates only the new suffix (prefix reuse)
-    # (the shim's tokenizer class does not construct under the installed transformers on either library; its ids come from
-    #  LLM.tokenize, compared in test_reference_package_drives_this_library)
-    assert ours._llm.tokenize("ab cd") == theirs._llm.tokenize("ab cd")
+    r = subprocess.run([sys.executable, "-c", HF_SHIM_CHILD, REF_PKG, emu_lib, oracle_ref.REF_LIB, os.path.join(GOLDEN, "tiny-q4km.gguf"),
+                        os.path.join(GOLDEN, "tiny-q4km.npz")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))])))
+    assert "HF_SHIM_OK" in r.stdout, r.stderr[-2000:]
