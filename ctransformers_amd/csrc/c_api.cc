@@ -40,8 +40,11 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     for (const char* p = model_type; *p; ++p)
         if (isalnum((unsigned char)*p)) type.push_back(*p);
     const bool gguf = file_is_gguf(model_path);   // the GGUF magic overrides model_type (reference models/llm.cc:45)
-    if (!gguf && type != "gpt2") {
-        // Of the legacy (pre-GGUF) GGML architectures of the reference (models/llm.cc:47-65) only gpt2 is served.
+    const bool starcoder = type == "starcoder" || type == "gptbigcode";
+    const bool mpt = type == "mpt";
+    if (!gguf && type != "gpt2" && !starcoder && !mpt) {
+        // Of the legacy (pre-GGUF) GGML architectures of the reference (models/llm.cc:47-65) gpt2, starcoder / gptbigcode (one
+        // container, one graph) and mpt are served.
         fprintf(stderr, "Model type '%s' is not supported.\n", model_type);
         return nullptr;
     }
@@ -52,7 +55,8 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     // CT_AMD_DEVICES ("4" or "0,1,2,3"): the GPUs whose HBM the layers are spread over, as one in-process pipeline (the Config
     // struct of the ABI cannot grow; gpu_layers keeps its meaning "offload": every layer lives on a GPU here).
     const bool ok = gguf ? llm->pipe.load(model_path, config.context_length, config.gpu_layers, ctamd::parse_devices(getenv("CT_AMD_DEVICES")), err)
-                         : llm->pipe.load_gpt2(model_path, err);
+                         : mpt ? llm->pipe.load_mpt(model_path, config.context_length, err)
+                         : llm->pipe.load_gpt2(model_path, err, starcoder);
     if (!ok) {
         fprintf(stderr, "ctransformers_amd: failed to load '%s': %s\n", model_path, err.c_str());
         delete llm;

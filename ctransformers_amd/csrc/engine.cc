@@ -312,8 +312,8 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         // the 32-block kernels (kernels_q32.h) take rows in groups of four blocks and at most 12288 elements: real Falcon-7B
         // (n_embd 4544) and the ffn_down rows of Llama-13B/70B Q4_0/Q8_0 files (13824, 28672) are outside that — said here, at
         // load, not by a failing launch later
-        if (m.K % 128 || m.K > 12288) {
-            err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 128, at most 12288)";
+        if (m.K % 128 || m.K > 32768) {
+            err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 128, at most 32768)";
             return false;
         }
         m.layout = LAYOUT_G4;
@@ -589,16 +589,16 @@ bool Engine::alloc_state(std::string& err) {
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
     pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
     bool kq_model = false;
-    {   // every layer matrix a K-quant (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 12288
+    {   // every layer matrix a K-quant (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 32768
         int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
         for (int i = l0_; i < l1_; ++i) {
             const Layer& L = layers_[i];
             const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
             const std::initializer_list<const DevMat*> fused_mats = {&L.wqkv, &L.wo, &L.w_up, &L.w_down};   // falcon, gpt2
-            for (const DevMat* m : (hp_.falcon() || hp_.gpt2()) ? fused_mats : llama_mats) {
+            for (const DevMat* m : (hp_.falcon() || hp_.legacy()) ? fused_mats : llama_mats) {
                 ++n_all;
                 if (m->layout == LAYOUT_R2C4 && is_kquant(m->type)) ++n_kq;
-                if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 12288) { ++n_q32; ty32 = m->type; }
+                if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 32768) { ++n_q32; ty32 = m->type; }
             }
         }
         pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || n_q32 == n_all);
@@ -621,7 +621,7 @@ bool Engine::alloc_state(std::string& err) {
         if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
                              !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))
             return false;
-        if (hp_.gpt2() && !dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * 3 * E, err)) return false;
+        if (hp_.legacy() && !dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * 3 * E, err)) return false;
     }
     HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
     h_emb_ = h_logits_ + V;
@@ -636,8 +636,10 @@ bool Engine::alloc_state(std::string& err) {
     return true;
 }
 
-// GPT-2 from the legacy GGML container (reference gpt2_model_load, models/llms/gpt2.cc:61-381).
-bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
+// GPT-2 from the legacy GGML container (reference gpt2_model_load, models/llms/gpt2.cc:61-381).  `starcoder`: the reference's
+// starcoder / gptbigcode loader (models/llms/starcoder.cc:62-421) reads the same container, tensor names and shapes (its K/V stay
+// expanded to n_head heads, :162-164) and builds the same graph (:424-763); it differs in registering the StarChat markers.
+bool Engine::load_gpt2(const std::string& path, std::string& err, int device, bool starcoder) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
@@ -661,6 +663,7 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
     if (n_ctx_ > kMaxCtx) { err = "context length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
     if (hp_.n_embd % 128) { err = "gpt2: n_embd must be a multiple of 128 for the 32-block mat-vec kernels"; return false; }
     vocab_.load_legacy(f.vocab);
+    if (starcoder) vocab_.mark_starcoder_specials();
     l0_ = 0;
     l1_ = hp_.n_layer;
     HIP_OK(hipStreamCreate(&stream_));
@@ -717,6 +720,92 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device) {
         return false;
     HIP_OK(hipMemset(kmem_, 0, (size_t)hp_.n_layer * n_ctx_ * E * 4));
     HIP_OK(hipMemset(vmem_, 0, (size_t)hp_.n_layer * n_ctx_ * E * 4));
+    if (!alloc_state(err)) return false;
+    HIP_OK(hipDeviceSynchronize());
+    return true;
+}
+
+
+// MPT from the legacy GGML container (reference mpt_model_load, models/llms/mpt.cc:50-363): quantized wte (row lookup AND tied
+// output head), per layer two bias-free LayerNorms, fused Wqkv, out_proj, up_proj, down_proj; fp16 K / V memory.
+bool Engine::load_mpt(const std::string& path, int context_length, std::string& err, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        err = "no HIP device visible: this library runs on MI355X only and has no CPU fallback";
+        return false;
+    }
+    if (device < 0 || device >= ndev) { err = "HIP device ordinal out of range"; return false; }
+    device_ = device;
+    HIP_OK(hipSetDevice(device_));
+    LegacyGgmlFile f;
+    if (!f.open(path, true)) { err = f.error(); return false; }
+    hp_.arch = "mpt";
+    hp_.n_vocab = f.hparams[0];
+    hp_.n_ctx_train = f.hparams[1];
+    n_ctx_ = std::min(f.hparams[1], context_length > 0 ? context_length : 2048);   // mpt.cc:15, :80, :605-607
+    hp_.n_embd = f.hparams[2];
+    hp_.n_head = hp_.n_head_kv = f.hparams[3];
+    hp_.n_layer = f.hparams[4];
+    if (hp_.n_embd <= 0 || hp_.n_head <= 0 || hp_.n_layer <= 0 || n_ctx_ <= 0 || hp_.n_embd % hp_.n_head) { err = "mpt: bad hyper-parameters"; return false; }
+    hp_.n_ff = 4 * hp_.n_embd;
+    hp_.n_rot = hp_.head_dim();
+    hp_.rms_eps = 1e-5f;            // ggml_norm(ctx, a) wrapper: models/common.h:211-213
+    clip_qkv_ = f.clip_qkv;
+    if (n_ctx_ > kMaxCtxFused) { err = "context length above " + std::to_string(kMaxCtxFused) + " not supported yet"; return false; }
+    if (hp_.n_embd % 128) { err = "mpt: d_model must be a multiple of 128 for the 32-block mat-vec kernels"; return false; }
+    if (hp_.head_dim() != 64 && hp_.head_dim() != 128) { err = "mpt: head sizes other than 64 / 128 are not supported"; return false; }
+    vocab_.load_legacy(f.vocab);
+    l0_ = 0;
+    l1_ = hp_.n_layer;
+    HIP_OK(hipStreamCreate(&stream_));
+    const int E = hp_.n_embd, F = hp_.n_ff, V = hp_.n_vocab;
+    auto mat = [&](const std::string& name, DevMat& m, int M, int K) {
+        const GgufTensor* t = f.tensor(name);
+        if (!t) { err = "missing tensor " + name; return false; }
+        if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
+        if (t->type != GT_Q4_0 && t->type != GT_Q8_0) { err = name + ": only Q4_0 / Q8_0 legacy weights are supported"; return false; }
+        if (!upload_matrix(t, m, false, err)) return false;
+        weight_bytes_ += t->nbytes;
+        return true;
+    };
+    auto vec = [&](const std::string& name, float** out, int n) {
+        const GgufTensor* t = f.tensor(name);
+        if (!t || t->type != GT_F32 || t->ne[0] != n) { err = "bad or missing f32 tensor " + name; return false; }
+        return upload_f32(t, out, n, err);
+    };
+    const GgufTensor* wte = f.tensor("transformer.wte.weight");
+    if (!wte || wte->ne[0] != E || wte->ne[1] != V) { err = "bad transformer.wte.weight"; return false; }
+    {   // row lookup copy in file layout
+        tok_embd_.type = wte->type; tok_embd_.K = E; tok_embd_.M = V;
+        uint8_t* d = nullptr;
+        if (!dev_alloc(dev_allocs_, &d, wte->nbytes, err)) return false;
+        HIP_OK(hipMemcpy(d, wte->data, wte->nbytes, hipMemcpyHostToDevice));
+        tok_embd_.raw = d;
+    }
+    if (!mat("transformer.wte.weight", output_, V, E)) return false;   // the output head is the embedding matrix (mpt.cc:561)
+    if (!vec("transformer.norm_f.weight", &output_norm_, E)) return false;
+    if (!dev_alloc(dev_allocs_, &zero_bias_, (size_t)E, err)) return false;
+    HIP_OK(hipMemset(zero_bias_, 0, (size_t)E * 4));
+    output_norm_b_ = zero_bias_;
+    layers_.resize(hp_.n_layer);
+    for (int i = 0; i < hp_.n_layer; ++i) {
+        const std::string p = "transformer.blocks." + std::to_string(i) + ".";
+        Layer& L = layers_[i];
+        if (!vec(p + "norm_1.weight", &L.attn_norm, E) || !vec(p + "norm_2.weight", &L.ffn_norm, E) ||
+            !mat(p + "attn.Wqkv.weight", L.wqkv, 3 * E, E) || !mat(p + "attn.out_proj.weight", L.wo, E, E) ||
+            !mat(p + "ffn.up_proj.weight", L.w_up, F, E) || !mat(p + "ffn.down_proj.weight", L.w_down, E, F))
+            return false;
+        L.attn_norm_b = L.ffn_norm_b = zero_bias_;
+    }
+    {   // ALiBi slopes, computed as ggml_compute_forward_alibi_f32 computes them (ggml.c:12228-12247), with this host's powf
+        std::vector<float> m((size_t)hp_.n_head);
+        const int n2 = 1 << (int)floor(log2(hp_.n_head));
+        const float m0 = powf(2.0f, -(f.alibi_bias_max) / n2), m1 = powf(2.0f, -(f.alibi_bias_max / 2.0f) / n2);
+        for (int k = 0; k < hp_.n_head; ++k) m[(size_t)k] = k < n2 ? powf(m0, k + 1) : powf(m1, 2 * (k - n2) + 1);
+        if (!dev_alloc(dev_allocs_, &alibi_, m.size(), err)) return false;
+        HIP_OK(hipMemcpy(alibi_, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!dev_alloc(dev_allocs_, &qkv_tmp_, (size_t)3 * E, err)) return false;
     if (!alloc_state(err)) return false;
     HIP_OK(hipDeviceSynchronize());
     return true;
@@ -872,7 +961,14 @@ static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
     const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
     for (int j = 1; j < a.njobs; ++j)
         if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
-    if (a.K > 12288) { err = "Q8_0/Q4_0 mat-vec with K > 12288 not supported yet"; return false; }
+    if (a.K > 12288) {   // wide rows (K = 4 d_model of the MPT / StarCoder down projections): sub-batched systolic form
+        if (a.K > 32768 || a.gateup) { err = "Q8_0/Q4_0 mat-vec with K > 32768 (or a gate/up launch with K > 12288) not supported"; return false; }
+        for (int j = 0; j < a.njobs; ++j)
+            if (a.job[j].epi == EPI_ROPE_Q || a.job[j].epi == EPI_ROPE_K) { err = "rotary epilogue on a wide Q8_0/Q4_0 launch"; return false; }
+        if (ty == GT_Q8_0) CT_LAUNCH((matvec_q32w_kernel<GT_Q8_0, 32768, 6>), grid, block, s, a);
+        else CT_LAUNCH((matvec_q32w_kernel<GT_Q4_0, 32768, 6>), grid, block, s, a);
+        return true;
+    }
     static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
     if (!systolic) {   // A/B: wave-per-tile form
         const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16)));
@@ -953,6 +1049,7 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
     ax.n_embd_gqa = hp_.n_embd_gqa(); ax.n_ctx = n_ctx_; ax.v_stride = v_stride_;
     ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
+    ax.alibi = alibi_;
     if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
     const size_t smem = (size_t)((n_ctx_ + 63) & ~63) * 4;   // the probability row
@@ -960,6 +1057,17 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV>; \
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
         CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
+    if (alibi_) {   // MPT: the fused kernel with the ALiBi term (one workgroup per (head, token) for chunks); head sizes checked at load
+#define ATTN_ALIBI(NTV, HDV, ALLV, GRID) do { \
+        auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV, true>; \
+        CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
+        CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
+        const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)std::max(1, nt));
+        if (nt > 0) { if (hd == 128) ATTN_ALIBI(256, 128, true, ag1); else ATTN_ALIBI(256, 64, true, ag1); }
+        else { if (hd == 128) ATTN_ALIBI(512, 128, false, ag); else ATTN_ALIBI(512, 64, false, ag); }
+#undef ATTN_ALIBI
+        return;
+    }
     if (nt > 0 && (hd == 128 || hd == 64) && chunk_below_128_ && n_ctx_ >= 128 && env_int("CT_AMD_ATTN_TILE", 1) != 0) {
         // every position of this chunk is below 128: K / V of a head go through LDS once per 16 tokens
         const dim3 gt((unsigned)hp_.n_head, (unsigned)((nt + 15) / 16));
@@ -1092,7 +1200,8 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 images, the dot4 chunk kernel (no matrix-core form)
         const int aw32 = pf_act_words_q32(m.K);
-        CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
+        if (m.K <= 12288) CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
+        else CT_LAUNCH((pf_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
         PfArgs a;
         a.m = m;
         a.acts = acts_; a.act_words = aw32; a.n_tok = nt;
@@ -1103,19 +1212,19 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             item0 += (m.job[j].w.M + 7) / 8;
         }
         a.m.n_pairs = m.gateup ? (m.job[0].w.M + 7) / 8 : item0;
-        const int groups = (nt + kPfTokens - 1) / kPfTokens;
+        // 8 tokens per workgroup while their images fit the CU's LDS (K <= 16384: 144 KB), else 4 (K <= 32768)
+        const int tb = (size_t)kPfTokens * aw32 * 4 <= (size_t)150 * 1024 ? kPfTokens : kPfTokens / 2;
+        const int groups = (nt + tb - 1) / tb;
         const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
         const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
-        const size_t smem = (size_t)kPfTokens * aw32 * 4;
-        if (m.gateup) {
-            auto kfn = matvec_pf_kernel<kPfTokens, true>;
-            CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
-            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
-        } else {
-            auto kfn = matvec_pf_kernel<kPfTokens, false>;
-            CT_OPTIN_ONCE(kfn, (size_t)kPfTokens * pf_act_words_q32(12288) * 4);
-            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a);
-        }
+        const size_t smem = (size_t)tb * aw32 * 4;
+#define PF32(TBV, GUV) do { \
+            auto kfn = matvec_pf_kernel<TBV, GUV>; \
+            CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); \
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
+        if (tb == kPfTokens) { if (m.gateup) PF32(kPfTokens, true); else PF32(kPfTokens, false); }
+        else { if (m.gateup) PF32(kPfTokens / 2, true); else PF32(kPfTokens / 2, false); }
+#undef PF32
         prof_end();
         return true;
     }
@@ -1134,6 +1243,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
     if (hp_.falcon()) return chunk_step_falcon(c0, nt, want_logits, err);
     if (hp_.gpt2()) return chunk_step_gpt2(nt, want_logits, err);
+    if (hp_.mpt()) return chunk_step_mpt(nt, want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -1337,6 +1447,64 @@ bool Engine::chunk_step_gpt2(int nt, bool want_logits, std::string& err) {
     return true;
 }
 
+
+// mpt_eval for the nt tokens of a chunk: token_step_mpt's launches over the rows of the chunk.
+bool Engine::chunk_step_mpt(int nt, bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256), (unsigned)nt), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+              (const int*)d_tokens_, (const int*)d_state_, xb_);
+    MatvecArgs base = MatvecArgs();
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = E;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * E;
+        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * E;
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b; a.out = qkv_tmp_b_;
+            set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            if (!pf_matvec(a, xb_, E, nt, 3 * E, 0, "qkv", (double)L.wqkv.bytes, err)) return false;
+        }
+        CT_LAUNCH(mpt_store_kernel, dim3((unsigned)(3 * hp_.n_head), (unsigned)nt), dim3((unsigned)hd), stream_, (const float*)qkv_tmp_b_, q_f16_b_,
+                  kc, vc, d_pos, hp_.n_head, hd, n_ctx_, v_stride_, clip_qkv_);
+        launch_attention(kc, vc, nt);
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
+            set_jobs(a, {{&L.wo, EPI_ADD}});
+            if (!pf_matvec(a, attn_out_b_, E, nt, E, E, "wo", (double)L.wo.bytes, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.norm_w = L.ffn_norm; a.norm_b = L.ffn_norm_b; a.out = hb_;
+            set_jobs(a, {{&L.w_up, EPI_GELU}});
+            if (!pf_matvec(a, xb_, E, nt, F, 0, "ffn_up", (double)L.w_up.bytes, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.out = xb_; a.res = xb_;
+            set_jobs(a, {{&L.w_down, EPI_ADD}});
+            if (!pf_matvec(a, hb_, F, nt, E, E, "down", (double)L.w_down.bytes, err)) return false;
+        }
+    }
+    if (want_logits) {
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = xb_ + (size_t)(nt - 1) * E; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
+    return true;
+}
+
 // A whole-model handle launches nothing in chunk_step that depends on c0 (the cursor lives in d_state_), so the ~300 launches
 // of a chunk shape seen before are replayed from a graph: the first use of a shape runs eagerly (it also performs the
 // one-time dynamic-LDS opt-ins), the second captures.
@@ -1370,6 +1538,7 @@ bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
 bool Engine::token_step(bool want_logits, std::string& err) {
     if (hp_.falcon()) return token_step_falcon(want_logits, err);
     if (hp_.gpt2()) return token_step_gpt2(want_logits, err);
+    if (hp_.mpt()) return token_step_mpt(want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
     if (l0_ == 0) {
@@ -1643,6 +1812,67 @@ bool Engine::token_step_gpt2(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_; a.bias = L.b_down;
             set_jobs(a, {{&L.w_down, EPI_BIAS_ADD}});
+            if (!run_matvec(a, err)) return false;
+        }
+    }
+    if (want_logits) {
+        MatvecArgs a = base;
+        a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
+        set_jobs(a, {{&output_, EPI_STORE}});
+        if (!run_matvec(a, err)) return false;
+    }
+    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    return true;
+}
+
+
+// mpt_eval (models/llms/mpt.cc:365-590), one token: wte row, then per layer
+//   norm * ln_1 -> Q8_0 -> Wqkv -> clamp -> fp16 Q / K / V -> fp16 attention with the ALiBi term -> out_proj -> + x
+//   norm * ln_2 -> Q8_0 -> up_proj -> GELU table -> Q8_0 -> down_proj -> + x;   final norm * norm_f -> wte as the head
+bool Engine::token_step_mpt(bool want_logits, std::string& err) {
+    const int E = hp_.n_embd, F = hp_.n_ff, hd = hp_.head_dim();
+    const int* d_pos = d_state_ + 1;
+    CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
+              (const int*)d_tokens_, (const int*)d_state_, x_);
+    MatvecArgs base = MatvecArgs();
+    base.pos = d_pos;
+    base.n_ctx = n_ctx_;
+    base.head_dim = hd;
+    base.n_embd_gqa = E;
+    base.v_stride = v_stride_;
+    base.silu_tab = silu_tab_;
+    base.gelu_tab = gelu_tab_;
+    base.eps = hp_.rms_eps;
+    base.dbg_sink = scores_;
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        const Layer& L = layers_[il];
+        uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * E;
+        uint16_t* vc = vcache_ + (size_t)il * v_stride_ * E;
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = L.attn_norm; a.norm_b = L.attn_norm_b; a.out = qkv_tmp_;
+            set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            if (!run_matvec(a, err)) return false;
+        }
+        CT_LAUNCH(mpt_store_kernel, dim3((unsigned)(3 * hp_.n_head)), dim3((unsigned)hd), stream_, (const float*)qkv_tmp_, q_f16_, kc, vc, d_pos,
+                  hp_.n_head, hd, n_ctx_, v_stride_, clip_qkv_);
+        launch_attention(kc, vc);
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
+            set_jobs(a, {{&L.wo, EPI_ADD}});
+            if (!run_matvec(a, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = L.ffn_norm; a.norm_b = L.ffn_norm_b; a.out = h_;
+            set_jobs(a, {{&L.w_up, EPI_GELU}});
+            if (!run_matvec(a, err)) return false;
+        }
+        {
+            MatvecArgs a = base;
+            a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
+            set_jobs(a, {{&L.w_down, EPI_ADD}});
             if (!run_matvec(a, err)) return false;
         }
     }

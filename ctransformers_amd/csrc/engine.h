@@ -22,6 +22,8 @@ struct HParams {
     float rms_eps = 1e-5f, rope_freq_base = 10000.0f, rope_freq_scale = 1.0f;   // rms_eps doubles as falcon's LayerNorm eps
     bool falcon() const { return arch == "falcon"; }
     bool gpt2() const { return arch == "gpt2"; }
+    bool mpt() const { return arch == "mpt"; }
+    bool legacy() const { return gpt2() || mpt(); }   // pre-GGUF GGML files: the reference's LLM base class (models/llm.h) serves them
     int head_dim() const { return n_embd / n_head; }
     int n_embd_gqa() const { return head_dim() * n_head_kv; }
 };
@@ -55,7 +57,9 @@ class Engine {
     bool load(const std::string& path, int context_length, int gpu_layers, std::string& err, int layer_begin = -1,
               int layer_end = -1, int device = 0);
     // Legacy (pre-GGUF) GGML file of the GPT-2 family (reference models/llms/gpt2.cc); n_ctx comes from the file.
-    bool load_gpt2(const std::string& path, std::string& err, int device = 0);
+    bool load_gpt2(const std::string& path, std::string& err, int device = 0, bool starcoder = false);
+    // Legacy GGML file of the MPT family (reference models/llms/mpt.cc); n_ctx = min(max_seq_len, context_length or 2048).
+    bool load_mpt(const std::string& path, int context_length, std::string& err, int device = 0);
     // Evaluate `n` tokens at absolute positions n_past..n_past+n-1 (KV cache overwrite semantics); logits and the
     // final-norm embedding of the LAST token land in the pinned host buffers.
     // batch > 0: evaluate the n tokens exactly as the reference would in batches of `batch` (models/llm.h:40-54), in one go
@@ -85,16 +89,16 @@ class Engine {
     const HParams& hparams() const { return hp_; }
     const Vocab& vocab() const { return vocab_; }
     int n_ctx() const { return n_ctx_; }
-    void reset() { if (hp_.gpt2()) have_logits_ = false; }   // reference models/llm.h:106: legacy models forget their logits
+    void reset() { if (hp_.legacy()) have_logits_ = false; }   // reference models/llm.h:106: legacy models forget their logits
     // Logits and embeddings stay on the GPU until somebody asks for them (fetch_outputs: one synchronous 144 KB copy for a 7B); a greedy
     // step needs 4 bytes (greedy_token).  Once the host copy exists the caller may have edited it (the reference's Python exposes
     // the logits as a writable view), so sampling then runs on the host copy as the reference does.
     float* logits() { fetch_outputs(); return h_logits_; }
     int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
     const float* embeddings() { fetch_outputs(); return h_emb_; }
-    bool greedy_token(int& token) const { if (!have_logits_ || outputs_on_host_ || hp_.gpt2()) return false; token = h_scalars_[n_ctx_ + 12]; return true; }
+    bool greedy_token(int& token) const { if (!have_logits_ || outputs_on_host_ || hp_.legacy()) return false; token = h_scalars_[n_ctx_ + 12]; return true; }
     void fetch_outputs();
-    int embeddings_size() const { return have_logits_ && !hp_.gpt2() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
+    int embeddings_size() const { return have_logits_ && !hp_.legacy() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
     long long chunk_tokens() const { return chunk_tokens_; }
 
@@ -125,12 +129,14 @@ class Engine {
     bool chunk_step(int c0, int nt, bool want_logits, std::string& err);
     bool chunk_step_falcon(int c0, int nt, bool want_logits, std::string& err);
     bool chunk_step_gpt2(int nt, bool want_logits, std::string& err);
+    bool chunk_step_mpt(int nt, bool want_logits, std::string& err);
     bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
     bool pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err);
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     bool token_step_falcon(bool want_logits, std::string& err);
     bool token_step_gpt2(bool want_logits, std::string& err);
+    bool token_step_mpt(bool want_logits, std::string& err);
     bool warm_up(std::string& err);       // first-use costs (code object, LDS opt-ins, graph capture) paid at load
     bool alloc_state(std::string& err);   // KV cache, scratch, pinned host buffers, tables
     bool run_matvec(::MatvecArgs& a, std::string& err);
@@ -151,6 +157,9 @@ class Engine {
     float *qkv_tmp_ = nullptr, *attn_proj_ = nullptr;   // falcon scratch: un-rotated fused QKV rows, Wo output
     float* wpe_ = nullptr;                              // gpt2 learned position embeddings [n_ctx][n_embd]
     float *kmem_ = nullptr, *vmem_ = nullptr;           // gpt2 F32 KV cache [n_layer][n_ctx][n_embd] each
+    float* alibi_ = nullptr;                            // mpt: per-head ALiBi slopes m_k (ggml.c:12228-12247), else null
+    float* zero_bias_ = nullptr;                        // mpt: its LayerNorms have no bias; the shared prologue adds this +0 vector
+    float clip_qkv_ = 0.0f;                             // mpt: clamp of the fused QKV rows (0 = none)
     std::vector<Layer> layers_;
     size_t weight_bytes_ = 0;
 

@@ -1,5 +1,8 @@
 #include "gguf_reader.h"
 
+#include <codecvt>
+#include <locale>
+
 #include <fcntl.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -175,7 +178,7 @@ LegacyGgmlFile::~LegacyGgmlFile() {
     if (fd_ >= 0) close(fd_);
 }
 
-bool LegacyGgmlFile::open(const std::string& path) {
+bool LegacyGgmlFile::open(const std::string& path, bool mpt) {
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) return fail("cannot open " + path);
     struct stat st;
@@ -186,9 +189,20 @@ bool LegacyGgmlFile::open(const std::string& path) {
     map_ = (const uint8_t*)m;
     Cursor c{map_, map_ + size_};
     if (c.get<uint32_t>() != 0x67676d6cu) return fail("not a legacy GGML file (bad magic)");
-    for (int i = 0; i < 6; ++i) hparams[i] = c.get<int32_t>();
-    hparams[5] %= 1000;   // GGML_QNT_VERSION_FACTOR (gpt2.cc:88-90)
-    const int32_t nv = c.get<int32_t>();
+    int32_t nv = 0;
+    if (mpt) {
+        const int32_t d_model = c.get<int32_t>(), max_seq_len = c.get<int32_t>(), n_heads = c.get<int32_t>(), n_layers = c.get<int32_t>();
+        nv = c.get<int32_t>();
+        alibi_bias_max = c.get<float>();
+        clip_qkv = c.get<float>();
+        const int32_t ftype = c.get<int32_t>();
+        const int32_t h[6] = {nv, max_seq_len, d_model, n_heads, n_layers, ftype % 1000};
+        for (int i = 0; i < 6; ++i) hparams[i] = h[i];
+    } else {
+        for (int i = 0; i < 6; ++i) hparams[i] = c.get<int32_t>();
+        hparams[5] %= 1000;   // GGML_QNT_VERSION_FACTOR (gpt2.cc:88-90)
+        nv = c.get<int32_t>();
+    }
     if (!c.ok || nv != hparams[0] || nv <= 0 || (size_t)nv > size_ / 4) return fail("bad vocabulary size");
     vocab.reserve((size_t)nv);
     for (int i = 0; i < nv; ++i) {
@@ -196,6 +210,17 @@ bool LegacyGgmlFile::open(const std::string& path) {
         if (!c.ok || len > c.left()) return fail("truncated vocabulary");
         vocab.emplace_back((const char*)c.p, (size_t)len);
         c.p += len;
+        if (mpt) {   // mpt.cc:101-107: UTF-8 -> code points -> the low byte of each
+            std::string& w = vocab.back();
+            try {
+                std::wstring_convert<std::codecvt_utf8<wchar_t>> conv;
+                const std::wstring wide = conv.from_bytes(w);
+                w.resize(wide.size());
+                for (size_t k = 0; k < wide.size(); ++k) w[k] = (char)(uint8_t)wide[k];
+            } catch (const std::exception&) {
+                return fail("vocabulary piece " + std::to_string(i) + " is not valid UTF-8");
+            }
+        }
     }
     while (c.p < c.end) {
         GgufTensor t;

@@ -71,9 +71,12 @@ class GgufFile {
 class LegacyGgmlFile {
    public:
     ~LegacyGgmlFile();
-    bool open(const std::string& path);
+    // mpt: the MPT header (d_model, max_seq_len, n_heads, n_layers, n_vocab, alibi_bias_max, clip_qkv, ftype; no vocabulary count;
+    // pieces converted from UTF-8 to one byte per code point — reference mpt_model_load, models/llms/mpt.cc:70-112)
+    bool open(const std::string& path, bool mpt = false);
     const std::string& error() const { return err_; }
     int32_t hparams[6] = {0, 0, 0, 0, 0, 0};   // n_vocab, n_ctx, n_embd, n_head, n_layer, ftype (quantization version stripped)
+    float alibi_bias_max = 0.0f, clip_qkv = 0.0f;   // MPT only
     std::vector<std::string> vocab;
     const GgufTensor* tensor(const std::string& name) const;
 

@@ -72,6 +72,13 @@ void Vocab::load_legacy(const std::vector<std::string>& pieces) {
     unk_id = -1;
 }
 
+void Vocab::mark_starcoder_specials() {
+    special.clear();
+    for (const char* t : {"<|system|>", "<|user|>", "<|assistant|>", "<|end|>", "<fim-prefix>", "<fim-middle>", "<fim-suffix>", "<fim-pad>",
+                          "<|end_of_turn|>"})
+        if (to_id.count(t)) special.push_back(t);
+}
+
 namespace {
 size_t utf8_len(char c) {
     static const size_t lookup[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4};
@@ -249,13 +256,28 @@ std::vector<int> Vocab::tokenize(const std::string& raw, bool add_bos) const {
     std::vector<int> out;
     if (type == VOCAB_GPT) {   // gpt_tokenize (models/common.h:66-125; add_bos is ignored, models/llm.h:27-30): GPT-2 regex
         static const std::regex re(R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
-        std::string rest = raw;    // split, then the LONGEST vocabulary piece at every position of every word
-        std::smatch m;
-        std::vector<std::string> words;
-        while (std::regex_search(rest, m, re)) {
-            for (auto x : m) words.push_back(x);
-            rest = m.suffix();
+        std::vector<std::string> words;   // split, then the LONGEST vocabulary piece at every position of every word
+        auto split_words = [&](std::string rest) {
+            std::smatch m;
+            while (std::regex_search(rest, m, re)) {
+                for (auto x : m) words.push_back(x);
+                rest = m.suffix();
+            }
+        };
+        // Special pieces first (models/common.h:76-101): the reference searches an alternation of the escaped pieces, i.e. the
+        // leftmost position where any of them starts and, there, the first of them in registration order; each becomes a word of
+        // its own and the text between them goes through the word regex.
+        size_t from = 0;
+        for (size_t p = 0; !special.empty() && p < raw.size();) {
+            const std::string* hit = nullptr;
+            for (const std::string& t : special)
+                if (raw.compare(p, t.size(), t) == 0) { hit = &t; break; }
+            if (!hit) { ++p; continue; }
+            split_words(raw.substr(from, p - from));
+            words.push_back(*hit);
+            from = p = p + hit->size();
         }
+        split_words(raw.substr(from));
         for (const std::string& word : words) {
             for (int i = 0; i < (int)word.size();) {
                 for (int j = (int)word.size() - 1; j >= i; --j) {

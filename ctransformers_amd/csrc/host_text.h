@@ -25,10 +25,15 @@ struct Vocab {
     std::unordered_map<std::string, int> to_id;
     std::unordered_map<std::string, int> bpe_rank;   // "left\x01right" -> merge rank (BPE vocabularies)
     int bos_id = 1, eos_id = 2, unk_id = 0;
+    // legacy StarCoder files: pieces the text is split at before the word regex (gpt_vocab::special_tokens, models/common.h:35-39)
+    std::vector<std::string> special;
 
     bool load(const GgufFile& f, std::string& err);
     // legacy GGML files: raw pieces, eos = bos = id of "<|endoftext|>" or 0 (models/llm.h:104-110)
     void load_legacy(const std::vector<std::string>& pieces);
+    // the StarChat / fill-in-the-middle markers the reference registers for starcoder when the file's vocabulary holds them
+    // (starcoder_model_load, models/llms/starcoder.cc:123-138)
+    void mark_starcoder_specials();
     int size() const { return (int)text.size(); }
     std::vector<int> tokenize(const std::string& text, bool add_bos) const;
     std::string piece(int token) const;

@@ -209,6 +209,25 @@ __global__ void falcon_rope_store_kernel(const float* __restrict__ qkv, uint16_t
     }
 }
 
+// MPT (mpt_eval, models/llms/mpt.cc:404-434): the fused QKV mat-mul leaves f32 rows [Q | K | V] of n_embd each; ggml_clamp
+// (MAX(MIN(x, max), min), ggml.c clamp_f32) when clip_qkv > 0, then fp16 Q / K cache / V cache (ggml_cpy f32 -> f16) — no
+// rotation: positions enter through the ALiBi term of the attention kernel.  grid = (3 n_head, tokens), head_dim threads.
+__global__ void mpt_store_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ q_f16, uint16_t* __restrict__ kcache,
+                                 uint16_t* __restrict__ vcache, const int* __restrict__ pos_p, int n_head, int head_dim, int n_ctx,
+                                 int v_stride, float clip) {
+    const int hh = (int)blockIdx.x, i = (int)threadIdx.x, tok = (int)blockIdx.y, pos = *pos_p + tok, E = n_head * head_dim;
+    if (i >= head_dim) return;
+    float v = qkv[(size_t)tok * 3 * E + (size_t)hh * head_dim + i];
+    if (clip > 0.0f) {
+        v = v < clip ? v : clip;
+        v = v > -clip ? v : -clip;
+    }
+    const uint16_t hv = f32_to_f16_bits(v);
+    if (hh < n_head) q_f16[(size_t)tok * E + (size_t)hh * head_dim + i] = hv;
+    else if (hh < 2 * n_head) kcache[kcache_off(pos, (hh - n_head) * head_dim + i, head_dim, n_ctx)] = hv;
+    else vcache[(size_t)((hh - 2 * n_head) * head_dim + i) * v_stride + pos] = hv;
+}
+
 // LayerNorm of the final hidden state (falcon embeddings output): same arithmetic as the PRO_LAYERNORM prologue.
 template <int NT>
 __global__ void __launch_bounds__(NT) layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,

@@ -81,6 +81,7 @@ struct AttnArgsX {
     float kq_scale;
     unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
     int q_stride, out_stride;    // prompt chunks (kernels_pf.h): token blockIdx.z has position *pos + z, query row z, output row z
+    const float* alibi;          // MPT: per-head slope m_k; the scaled score of key position i becomes fma(m_k, i, score) (ggml.c:12193-12254)
 };
 
 // Fused form of the two kernels above (one launch per layer instead of two): grid (n_head, head_dim/64), 1024 threads.
@@ -90,7 +91,8 @@ struct AttnArgsX {
 // to 8192 of them is exact in binary64.
 // ALLCH (prompt chunks): one workgroup per (head, token) runs ALL head_dim channels of V*P, 64 at a time, instead of one workgroup
 // per 64 channels each recomputing the score row — half the workgroups for the latency-bound chunk launch.
-template <int NT, int HD, bool ALLCH = false>
+// ALIBI (MPT): ggml_alibi between the scale and the mask — the reference build contracts `i * m_k + src` into one fma.
+template <int NT, int HD, bool ALLCH = false, bool ALIBI = false>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
     constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
@@ -121,6 +123,7 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     const int np = n_tot & ~31;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3;
     const int hk = h / (a.n_head / a.n_head_kv);
+    const float slope = ALIBI ? a.alibi[h] : 0.0f;
     if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
     const uint16_t* qrow = a.q_f16 + (size_t)tok * a.q_stride + (size_t)h * HD;
     const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
@@ -159,7 +162,8 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
 #pragma unroll
                 for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[c][l], acc[l]);
             }
-            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if (ALIBI) sc = fmaf((float)p, slope, sc);
             if (p < n_kv) {
                 mx = fmaxf(mx, sc);
                 if (j == 0) prob[p] = sc;

@@ -389,3 +389,129 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wide rows (12288 < K <= 32768: the down projections of MPT-7B / StarCoder-7B and -15B, K = 4 d_model): the systolic
+// form with a wave's share of the row (up to 16 block groups) taken in sub-batches of MAXG groups — the (d, sumi) pairs of
+// the first sub-batch are ready before the mailbox wait as above, the later ones are formed while the wave holds the
+// accumulators, each sub-batch's loads requested as soon as the previous one's registers are consumed.  Same chain,
+// same order: block after block of the row.  Single-matrix and multi-job launches; no gate/up form (no such model).
+// ------------------------------------------------------------------------------------------------------------------
+template <int TYPE, int MAXK, int MAXG>
+__global__ void __launch_bounds__(1024) matvec_q32w_kernel(const MatvecArgs a) {
+    __shared__ SmemQ32S<MAXK> SM;
+    constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+    const int lane = lane_id();
+    const int wv = uniform_int(wave_id());
+    const int ng = a.K >> 7;
+    const int NA = ng < 16 ? ng : 16;
+    if (threadIdx.x < kQ32Slots) SM.ctr[threadIdx.x] = 0u;
+    const int pos = a.pos ? *a.pos : 0;
+    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
+    if (wv >= NA) return;
+    const int base = ng / NA, rem = ng % NA;
+    const int gcnt = base + (wv < rem ? 1 : 0);
+    const int gbeg = wv * base + (wv < rem ? wv : rem);
+    const int nsb = (gcnt + MAXG - 1) / MAXG;
+    const int r = lane >> 3, p3 = lane & 7, l = ((p3 & 1) << 2) | (p3 & 2) | (p3 >> 2);
+    const uint32_t qoff = TYPE == GT_Q8_0 ? (uint32_t)(r * 8 + l) * 16u : (uint32_t)(r * 4 + (l & 3)) * 16u;
+    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)r * 8u;
+    const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
+    const int stride = (int)gridDim.x, first = (int)blockIdx.x;
+    const int n_seq = first < a.n_pairs ? (a.n_pairs - first + stride - 1) / stride : 0;
+    auto tile_of = [&](int seq, int& j, int& tile) __attribute__((always_inline)) {
+        const int it = first + seq * stride;
+        j = 0;
+        if (a.njobs > 1 && it >= a.job[1].pair0) j = 1;
+        if (a.njobs > 2 && it >= a.job[2].pair0) j = 2;
+        tile = it - a.job[j].pair0;
+    };
+    u32x4 qv[MAXG];
+    uint64_t dv[MAXG];
+    auto load_sub = [&](int seq, int sb) __attribute__((always_inline)) {
+        int j, tile;
+        tile_of(seq, j, tile);
+        const uint8_t* tp = a.job[j].w.p[0] + ((size_t)tile * ng + gbeg + sb * MAXG) * REC;
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            if (sb * MAXG + u < gcnt) {
+                qv[u] = ld_stream16(tp + (size_t)u * REC + qoff);
+                dv[u] = *(const uint64_t*)(tp + (size_t)u * REC + doff);
+            }
+        }
+    };
+    if (n_seq > 0) load_sub(0, 0);
+    for (int seq = 0; seq < n_seq; ++seq) {
+        const int slot = seq % kQ32Slots;
+        const unsigned gen_base = (unsigned)(seq / kQ32Slots) * (unsigned)NA;
+        float acc = 0.0f;
+        for (int sb = 0; sb < nsb; ++sb) {
+            float dd[MAXG][4], ss[MAXG][4];
+#pragma unroll
+            for (int u = 0; u < MAXG; ++u) {
+                if (sb * MAXG + u < gcnt) {
+                    const int g = gbeg + sb * MAXG + u;
+                    const u32x4 y = *(const u32x4*)&SM.L.q8[(g * 8 + l) * 4];
+                    const float4 yd = *(const float4*)&SM.L.yd[g * 4];
+                    const float yds[4] = {yd.x, yd.y, yd.z, yd.w};
+                    const uint32_t dw[4] = {(uint32_t)(dv[u] & 0xFFFFu), (uint32_t)((dv[u] >> 16) & 0xFFFFu),
+                                            (uint32_t)((dv[u] >> 32) & 0xFFFFu), (uint32_t)(dv[u] >> 48)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int sumi;
+                        if constexpr (TYPE == GT_Q8_0) {
+                            sumi = sdot4((int)qv[u][i], (int)y[i], 0);
+                        } else {
+                            const int nib = (int)((qv[u][i] >> sh) & 0x0F0F0F0Fu);
+                            sumi = sdot4(nib, (int)y[i], 0) - 8 * sdot4(0x01010101, (int)y[i], 0);
+                        }
+                        dd[u][i] = f16_bits_to_f32((uint16_t)dw[i]) * yds[i];
+                        ss[u][i] = (float)sumi;
+                    }
+                }
+            }
+            if (sb + 1 < nsb) load_sub(seq, sb + 1);
+            else if (seq + 1 < n_seq) load_sub(seq + 1, 0);
+            if (sb == 0) {
+                lds_wait_ge(&SM.ctr[slot], gen_base + (unsigned)wv);
+                acc = (wv == 0) ? 0.0f : SM.mail[slot][lane];
+            }
+#pragma unroll
+            for (int u = 0; u < MAXG; ++u) {
+                if (sb * MAXG + u < gcnt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = fmaf(dd[u][i], ss[u][i], acc);
+                }
+            }
+        }
+        if (wv < NA - 1) {
+            SM.mail[slot][lane] = acc;
+            lds_signal(&SM.ctr[slot], lane, 1u);
+            continue;
+        }
+        lds_signal(&SM.ctr[slot], lane, 1u);
+        const float res = hsum8_exact_dpp(acc);
+        int j, tile;
+        tile_of(seq, j, tile);
+        const int row = tile * 8 + r;
+        const bool own = p3 == 0 && row < a.job[j].w.M;
+        const int epi = a.job[j].epi;
+        if (epi == EPI_ADD) {
+            if (own) a.out[row] = res + a.res[row];
+        } else if (epi == EPI_STORE) {
+            if (own) a.out[row] = res;
+        } else if (epi == EPI_V) {
+            if (own) a.vcache[(size_t)row * a.v_stride + pos] = f32_to_f16_bits(res);
+        } else if (epi == EPI_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+        } else if (epi == EPI_ADD2) {
+            if (own) a.out[row] = (res + a.res[row]) + a.res2[row];
+        } else if (epi == EPI_BIAS_STORE) {
+            if (own) a.out[row] = a.bias[row] + res;
+        } else if (epi == EPI_BIAS_ADD) {
+            if (own) a.out[row] = (a.bias[row] + res) + a.res[row];
+        } else if (epi == EPI_BIAS_GELU) {
+            if (own) a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(a.bias[row] + res)]);
+        }   // the rotary epilogues belong to the llama graph, whose K = n_embd rows never reach this kernel
+    }
+}

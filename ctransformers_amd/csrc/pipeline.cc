@@ -61,12 +61,20 @@ Pipeline::~Pipeline() {
     }
 }
 
-bool Pipeline::load_gpt2(const std::string& path, std::string& err) {
+bool Pipeline::load_gpt2(const std::string& path, std::string& err, bool starcoder) {
     st_.clear();
     st_.emplace_back(new Engine());
     dev_ = {0};
     ranges_.clear();
-    return st_[0]->load_gpt2(path, err);
+    return st_[0]->load_gpt2(path, err, 0, starcoder);
+}
+
+bool Pipeline::load_mpt(const std::string& path, int context_length, std::string& err) {
+    st_.clear();
+    st_.emplace_back(new Engine());
+    dev_ = {0};
+    ranges_.clear();
+    return st_[0]->load_mpt(path, context_length, err);
 }
 
 bool Pipeline::load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err) {

@@ -27,7 +27,8 @@ class Pipeline {
    public:
     // One stage per entry of `devices`.  A single entry is the plain single-GPU engine (no pipeline machinery on its path).
     bool load(const std::string& path, int context_length, int gpu_layers, const std::vector<int>& devices, std::string& err);
-    bool load_gpt2(const std::string& path, std::string& err);
+    bool load_gpt2(const std::string& path, std::string& err, bool starcoder = false);
+    bool load_mpt(const std::string& path, int context_length, std::string& err);
     // one explicit stage (ctamd_stage_create: the multi-process pipeline of ctransformers_amd/pipeline.py drives it from outside)
     bool load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err);
     bool eval(const int* tokens, int n, int n_past, std::string& err, int batch = 0);

@@ -548,7 +548,17 @@ def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ct
 GPT2_SHAPES = {
     "gpt2-117m": dict(n_vocab=50257, n_ctx=1024, n_embd=768, n_head=12, n_layer=12),
     "gpt2-tiny": dict(n_vocab=512, n_ctx=96, n_embd=256, n_head=4, n_layer=2),
+    # the reference's starcoder / gptbigcode loader reads the same container (models/llms/starcoder.cc); heads of 64 like the real ones
+    "starcoder-tiny": dict(n_vocab=512, n_ctx=96, n_embd=384, n_head=6, n_layer=2),
+    "starcoder-1b": dict(n_vocab=49152, n_ctx=8192, n_embd=2048, n_head=16, n_layer=24),
+    "starcoder-7b-2l": dict(n_vocab=49152, n_ctx=2048, n_embd=4096, n_head=32, n_layer=2),   # StarCoderBase-7B widths: c_proj rows of 16384
+    "starcoder-1b-4l": dict(n_vocab=49152, n_ctx=2048, n_embd=2048, n_head=16, n_layer=4),   # StarCoderBase-1B widths, heads of 128
 }
+
+# pieces the reference registers as special for starcoder when the vocabulary holds them (models/llms/starcoder.cc:123-138); the
+# synthetic vocabulary carries a subset, so the "only those present" rule is exercised too
+STARCODER_PIECES = [b"<|endoftext|>", b"<fim-prefix>", b"<fim-middle>", b"<fim-suffix>", b"<|system|>", b"<|user|>", b"<|assistant|>",
+                    b"<|end|>", b"<|", b"|>", b"<fim", b"end"]
 
 
 def make_gpt2_vocab(n_vocab):
@@ -564,7 +574,7 @@ def make_gpt2_vocab(n_vocab):
     return toks[:n_vocab]
 
 
-def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm_head=False):
+def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm_head=False, pieces=None):
     """Synthetic GPT-2 in the legacy GGML container (magic 0x67676d6c, 6 x i32 hparams, vocab, tensors; ftype 2 = Q4_0,
     stored as ftype + 1000*GGML_QNT_VERSION).  Returns the hparams dict."""
     import struct
@@ -579,6 +589,8 @@ def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm
         f.write(struct.pack("<I", 0x67676d6c))
         f.write(struct.pack("<6i", V, C, E, H, NL, ftype + 1000 * 2))
         toks = make_gpt2_vocab(V)
+        if pieces:   # named pieces take the last ids of the vocabulary
+            toks[V - len(pieces):] = list(pieces)
         f.write(struct.pack("<i", V))
         for t in toks:
             f.write(struct.pack("<I", len(t)) + t)
@@ -616,4 +628,60 @@ def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm
             mat(p + "mlp/c_fc/w", 4 * E, E, s_e); bias(p + "mlp/c_fc/b", 4 * E)
             mat(p + "mlp/c_proj/w", E, 4 * E, s_f); bias(p + "mlp/c_proj/b", E)
     hp.update(dict(ftype=ftype))
+    return hp
+
+
+MPT_SHAPES = {
+    # head sizes of 64 and 128 (MPT-7B: d_model 4096, 32 heads); a head count that is not a power of two exercises both ALiBi
+    # slope branches (ggml.c:12243-12247)
+    "mpt-tiny": dict(n_vocab=512, max_seq_len=96, n_embd=384, n_head=6, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.75),
+    "mpt-tiny128": dict(n_vocab=512, max_seq_len=2048, n_embd=512, n_head=4, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
+    "mpt-7b-2l": dict(n_vocab=50432, max_seq_len=2048, n_embd=4096, n_head=32, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
+}
+
+
+def write_mpt_ggml(path, shape="mpt-tiny", seed=1234, ftype=2, pooled=None, pieces=None):
+    """Synthetic MPT in the legacy GGML container as the reference's mpt loader reads it (models/llms/mpt.cc:50-363): magic,
+    d_model, max_seq_len, n_heads, n_layers, n_vocab, alibi_bias_max (f32), clip_qkv (f32), ftype; the vocabulary without a count,
+    pieces in UTF-8 (the loader keeps the low byte of every code point); quantized wte, f32 norm gains, four matrices per layer."""
+    import struct
+    hp = dict(MPT_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
+    V, C, E, H, NL = hp["n_vocab"], hp["max_seq_len"], hp["n_embd"], hp["n_head"], hp["n_layer"]
+    if pooled is None:
+        pooled = E >= 2048
+    src = _WeightSource(seed, pooled)
+    wtype = {2: G.Q4_0, 7: G.Q8_0}[ftype]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 0x67676d6c))
+        f.write(struct.pack("<5i2fi", E, C, H, NL, V, hp["alibi_bias_max"], hp["clip_qkv"], ftype + 1000 * 2))
+        toks = make_gpt2_vocab(V)
+        if pieces:
+            toks[V - len(pieces):] = list(pieces)
+        for t in toks:
+            u = "".join(chr(b) for b in t).encode("utf-8")   # code point b -> the loader's low byte b
+            f.write(struct.pack("<I", len(u)) + u)
+
+        def put(name, dims, ttype, data):
+            nb = name.encode("ascii")
+            f.write(struct.pack("<3i", len(dims), len(nb), ttype))
+            for d in dims:
+                f.write(struct.pack("<i", int(d)))
+            f.write(nb)
+            f.write(np.ascontiguousarray(data).tobytes())
+
+        def mat(name, rows, K, sigma):
+            put(name, (K, rows), wtype, src.matrix(rows, K, wtype, sigma))
+
+        s_e, s_f = 1.0 / np.sqrt(E), 1.0 / np.sqrt(4 * E)
+        mat("transformer.wte.weight", V, E, 0.06)
+        put("transformer.norm_f.weight", (E,), G.F32, src.norm(E))
+        for i in range(NL):
+            p = "transformer.blocks.%d." % i
+            put(p + "norm_1.weight", (E,), G.F32, src.norm(E))
+            mat(p + "attn.Wqkv.weight", 3 * E, E, s_e)
+            mat(p + "attn.out_proj.weight", E, E, s_e)
+            put(p + "norm_2.weight", (E,), G.F32, src.norm(E))
+            mat(p + "ffn.up_proj.weight", 4 * E, E, s_e)
+            mat(p + "ffn.down_proj.weight", E, 4 * E, s_f)
+    hp.update(dict(ftype=ftype, n_ctx=C))
     return hp

@@ -25,6 +25,14 @@ def model_golden(name, ftype, seed, shape="llama-tiny"):
         path = os.path.join(HERE, name + ".bin")     # legacy GGML container
         hp = synth.write_gpt2_ggml(path, shape, seed=seed)
         mt = "gpt2"
+    elif shape.startswith("starcoder"):
+        path = os.path.join(HERE, name + ".bin")     # same container, read by the reference's starcoder loader
+        hp = synth.write_gpt2_ggml(path, shape, seed=seed, ftype={"Q4_0": 2, "Q8_0": 7}[ftype], pieces=synth.STARCODER_PIECES)
+        mt = "starcoder"
+    elif shape.startswith("mpt"):
+        path = os.path.join(HERE, name + ".bin")     # legacy container with the MPT header (models/llms/mpt.cc)
+        hp = synth.write_mpt_ggml(path, shape, seed=seed, ftype={"Q4_0": 2, "Q8_0": 7}[ftype], pieces=[b"<|endoftext|>"])
+        mt = "mpt"
     elif shape.startswith("falcon"):
         hp = synth.write_falcon_gguf(path, shape, ftype, seed=seed)
     else:
@@ -118,6 +126,8 @@ def falcon_ops_golden():
 SPM_TEXTS = ["hello world", "Hello, world!", "the and in that when", " hello", "hello  world   twice", "naïve café", "12345", "",
              "a", "unknownzq", "▁already▁marked", "when you hear the thing", "\ttab and\nnewline", "日本"]
 BPE_TEXTS = ["ab cd\n", "Hello, world! it's 12345 times   spaced\n\nxyz abcab", " ", "a", "don't you're I'll\tTAB", "héllo ünicode ✓ 中文", "ababababab abc", "abab cdcd abcd"]
+STARCODER_TEXTS = ["<fim-prefix>ab cd<fim-suffix>xy<fim-middle>", "<|system|>\nab<|end|>\n<|user|>\ncd ef<|end|>\n<|assistant|>", "<|end_of_turn|> <fim-pad>",
+                   "ab<|endoftext|>cd", "<<|user|>>", "<fim-prefix", "plain text, no markers", "<|end|><|end|>", "", "<|user|>"]
 GPT2_TEXTS = ["ab cd xyz\n", "Hello, it's 42!  aaa", " ", "don't stop\tnow", "héllo ✓", "xyzabc  qq"]
 
 
@@ -143,6 +153,23 @@ def tokenizer_golden():
         samples.append([k, p_, temp, pen, seed_s + 3, int(r.sample(top_k=k, top_p=p_, temperature=temp, repetition_penalty=pen, seed=seed_s + 3))])
     json.dump(dict(tokenize=tok, samples=samples, detok_300_10=r.detokenize([300, 10])), open(os.path.join(HERE, "gpt2_host.json"), "w"),
               ensure_ascii=False, indent=1)
+    r = ref.open_llm(os.path.join(HERE, "mpt-tiny-q80.bin"), model_type="mpt", context_length=96, batch_size=8, threads=2)
+    g = np.load(os.path.join(HERE, "mpt-tiny-q80.npz"))
+    tok = {t: [int(i) for i in r.tokenize(t)] for t in GPT2_TEXTS + ["ab<|endoftext|>cd"]}
+    r.eval(list(g["prompt"]))
+    samples = []
+    for seed_s, (k, p_, temp, pen) in enumerate([(40, 0.95, 0.8, 1.1), (5, 0.5, 1.3, 1.0), (1, 1.0, 1.0, 1.0), (200, 0.9, 1.5, 1.2)]):
+        samples.append([k, p_, temp, pen, seed_s + 5, int(r.sample(top_k=k, top_p=p_, temperature=temp, repetition_penalty=pen, seed=seed_s + 5))])
+    json.dump(dict(tokenize=tok, samples=samples, eos=int(r.eos_token_id), detok=r.detokenize([300, 233, 10]),
+                   ctx_default=int(ref.open_llm(os.path.join(HERE, "mpt-tiny128-q40.bin"), model_type="mpt").context_length),
+                   ctx_capped=int(ref.open_llm(os.path.join(HERE, "mpt-tiny-q80.bin"), model_type="mpt", context_length=4096).context_length)),
+              open(os.path.join(HERE, "mpt_host.json"), "w"), ensure_ascii=False, indent=1)
+    sc = os.path.join(HERE, "starcoder-tiny-q80.bin")
+    host = {}
+    for mt in ("starcoder", "gpt_bigcode", "gpt2"):   # gpt2 on the same file: no special pieces registered
+        r = ref.open_llm(sc, model_type=mt, context_length=96, batch_size=8, threads=2)
+        host[mt] = dict(tokenize={t: [int(i) for i in r.tokenize(t)] for t in STARCODER_TEXTS}, eos=int(r.eos_token_id), model_type=r.model_type)
+    json.dump(host, open(os.path.join(HERE, "starcoder_host.json"), "w"), ensure_ascii=False, indent=1)
     print("tokenizer goldens:", {k: v for k, v in list(spm.items())[:4]})
 
 
@@ -152,7 +179,10 @@ if __name__ == "__main__":
                                      ("tiny-q80", "Q8_0", 5, "llama-tiny"), ("tiny-q40", "Q4_0", 6, "llama-tiny"),
                                      ("falcon-tiny-q4km", "Q4_K_M", 7, "falcon-tiny"),      # 40B style: two norms, GQA 4/2
                                      ("falcon-tiny7-q4km", "Q4_K_M", 8, "falcon-tiny7"),    # 7B style: one norm, MQA 4/1
-                                     ("gpt2-tiny-q40", "Q4_0", 9, "gpt2-tiny")):            # config 1 family: legacy GGML, F32 KV
+                                     ("gpt2-tiny-q40", "Q4_0", 9, "gpt2-tiny"),             # config 1 family: legacy GGML, F32 KV
+                                     ("starcoder-tiny-q80", "Q8_0", 10, "starcoder-tiny"),  # same container, starcoder loader
+                                     ("mpt-tiny-q80", "Q8_0", 11, "mpt-tiny"),              # ALiBi, clamp, 6 heads of 64
+                                     ("mpt-tiny128-q40", "Q4_0", 12, "mpt-tiny128")):       # heads of 128, no clamp
         if not only or name in only:
             model_golden(name, ftype, seed, shape)
     if not only or "ops" in only:

@@ -29,7 +29,8 @@ def ref_pkg():
     return ctransformers
 
 
-@pytest.mark.parametrize("name,model_type", [("tiny-q4km", None), ("falcon-tiny-q4km", None), ("gpt2-tiny-q40", "gpt2")])
+@pytest.mark.parametrize("name,model_type", [("tiny-q4km", None), ("falcon-tiny-q4km", None), ("gpt2-tiny-q40", "gpt2"),
+                                             ("starcoder-tiny-q80", "starcoder")])
 def test_reference_package_drives_this_library(ref_pkg, ref, emu_lib, name, model_type):
     from oracle import ref as oracle_ref
     path = os.path.join(GOLDEN, name + (".bin" if model_type else ".gguf"))
