@@ -178,7 +178,7 @@ class LegacyGgmlFile:
     magic 0x67676d6c, 6 x i32 hparams (n_vocab, n_ctx, n_embd, n_head, n_layer, ftype), vocab (i32 count, then u32 len +
     bytes each), tensors until EOF: i32 n_dims, i32 name_len, i32 type, dims, name, data (unaligned)."""
 
-    def __init__(self, path):
+    def __init__(self, path, mpt=False):
         import struct
         raw = np.memmap(path, dtype=np.uint8, mode="r")
         off = 0
@@ -192,9 +192,15 @@ class LegacyGgmlFile:
         (magic,) = rd("I")
         if magic != 0x67676d6c:
             raise ValueError("not a legacy GGML file")
-        n_vocab, n_ctx, n_embd, n_head, n_layer, ftype = rd("6i")
-        self.hparams = dict(n_vocab=n_vocab, n_ctx=n_ctx, n_embd=n_embd, n_head=n_head, n_layer=n_layer, ftype=ftype % 1000)
-        (nv,) = rd("i")
+        if mpt:   # models/llms/mpt.cc:70-84: d_model, max_seq_len, n_heads, n_layers, n_vocab, alibi_bias_max, clip_qkv, ftype; no count
+            n_embd, n_ctx, n_head, n_layer, n_vocab, alibi_bias_max, clip_qkv, ftype = rd("5i2fi")
+            self.hparams = dict(n_vocab=n_vocab, n_ctx=n_ctx, n_embd=n_embd, n_head=n_head, n_layer=n_layer, ftype=ftype % 1000,
+                                alibi_bias_max=alibi_bias_max, clip_qkv=clip_qkv)
+            nv = n_vocab
+        else:
+            n_vocab, n_ctx, n_embd, n_head, n_layer, ftype = rd("6i")
+            self.hparams = dict(n_vocab=n_vocab, n_ctx=n_ctx, n_embd=n_embd, n_head=n_head, n_layer=n_layer, ftype=ftype % 1000)
+            (nv,) = rd("i")
         self.vocab = []
         for _ in range(nv):
             (ln,) = rd("I")

@@ -351,3 +351,60 @@ class MirrorGpt2:
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         lib().mir_gpt2_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits))
         return self.logits
+
+
+class _Mpt(Structure):
+    _fields_ = [("n_vocab", c_int), ("n_ctx", c_int), ("n_embd", c_int), ("n_head", c_int), ("n_layer", c_int),
+                ("alibi_bias_max", ctypes.c_float), ("clip_qkv", ctypes.c_float), ("wte", c_void_p), ("wtype", c_int),
+                ("norm_f", c_void_p), ("norm_1", c_void_p), ("norm_2", c_void_p),
+                ("wqkv", c_void_p), ("out_proj", c_void_p), ("up_proj", c_void_p), ("down_proj", c_void_p),
+                ("memory_k", c_void_p), ("memory_v", c_void_p)]
+
+
+class MirrorMpt:
+    """The C restatement of mpt_eval over a legacy GGML file with the MPT header; n_ctx = min(max_seq_len, n_ctx or 2048)."""
+
+    def __init__(self, path, n_ctx=0):
+        self.f = G.LegacyGgmlFile(path, mpt=True)
+        hp = self.f.hparams
+        self.n_vocab, self.n_embd, self.n_layer = hp["n_vocab"], hp["n_embd"], hp["n_layer"]
+        self.n_ctx = min(hp["n_ctx"], n_ctx if n_ctx > 0 else 2048)
+        self._keep = []
+        m = _Mpt()
+        m.n_vocab, m.n_ctx, m.n_embd, m.n_head, m.n_layer = hp["n_vocab"], self.n_ctx, hp["n_embd"], hp["n_head"], hp["n_layer"]
+        m.alibi_bias_max, m.clip_qkv = hp["alibi_bias_max"], hp["clip_qkv"]
+
+        def tensor(name):
+            shape, t, data = self.f.tensors[name]
+            arr = np.ascontiguousarray(data)
+            self._keep.append(arr)
+            return arr.ctypes.data, t
+
+        m.wte, m.wtype = tensor("transformer.wte.weight")
+        m.norm_f, _ = tensor("transformer.norm_f.weight")
+
+        def per_layer(fmt):
+            ptrs = (c_void_p * self.n_layer)()
+            for i in range(self.n_layer):
+                ptrs[i], _ = tensor(fmt % i)
+            self._keep.append(ptrs)
+            return ctypes.cast(ptrs, c_void_p)
+
+        m.norm_1 = per_layer("transformer.blocks.%d.norm_1.weight")
+        m.norm_2 = per_layer("transformer.blocks.%d.norm_2.weight")
+        m.wqkv = per_layer("transformer.blocks.%d.attn.Wqkv.weight")
+        m.out_proj = per_layer("transformer.blocks.%d.attn.out_proj.weight")
+        m.up_proj = per_layer("transformer.blocks.%d.ffn.up_proj.weight")
+        m.down_proj = per_layer("transformer.blocks.%d.ffn.down_proj.weight")
+        self.mk = np.zeros(self.n_layer * self.n_ctx * self.n_embd, dtype=np.uint16)
+        self.mv = np.zeros(self.n_layer * self.n_ctx * self.n_embd, dtype=np.uint16)
+        m.memory_k, m.memory_v = self.mk.ctypes.data, self.mv.ctypes.data
+        self.m = m
+        self.logits = np.zeros(self.n_vocab, dtype=np.float32)
+        lib().mir_mpt_eval.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+        lib().mir_mpt_eval.restype = c_int
+
+    def eval(self, tokens, n_past):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        lib().mir_mpt_eval(ctypes.byref(self.m), _p(t), len(t), int(n_past), _p(self.logits))
+        return self.logits

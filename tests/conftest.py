@@ -54,8 +54,10 @@ def hip_lib():
 
 @pytest.fixture(scope="session")
 def mirror():
+    import fcntl
     from oracle import mirror as m
-    if not m.available():
+    with open(os.path.join(ROOT, "oracle", ".build.lock"), "w") as lk:   # make rebuilds a stale library; one xdist worker at a time
+        fcntl.flock(lk, fcntl.LOCK_EX)
         subprocess.run(["make", "mirror_lib"], cwd=os.path.join(ROOT, "oracle"), check=True, stdout=subprocess.DEVNULL)
     return m
 

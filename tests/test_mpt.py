@@ -67,6 +67,22 @@ def test_mpt_host_path_on_emulator_build(emu_lib):
     _check_host(emu_lib)
 
 
+@pytest.mark.parametrize("name", ["mpt-tiny-q80", "mpt-tiny128-q40"])
+def test_mpt_c_restatement_against_reference_vectors(mirror, name):
+    """oracle/mirror.c mir_mpt_eval (the CPU restatement of mpt_eval) reproduces the reference build's logits, token by token
+    and for the 45-token prompt as one batch."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = mirror.MirrorMpt(os.path.join(GOLDEN, name + ".bin"), 96)
+    logits = m.eval(g["prompt"], 0)
+    assert np.array_equal(logits, g["logits"][0])
+    for i, t in enumerate(g["greedy"][:12]):
+        assert int(np.argmax(logits)) == int(t)
+        logits = m.eval([int(t)], len(g["prompt"]) + i)
+        assert np.array_equal(logits, g["logits"][i + 1]), "step %d" % i
+    m = mirror.MirrorMpt(os.path.join(GOLDEN, name + ".bin"), 96)
+    assert np.array_equal(m.eval(g["long_prompt"], 0), g["long_one"])
+
+
 def test_truncated_and_mistyped_mpt_files_are_refused(emu_lib, tmp_path):
     raw = open(os.path.join(GOLDEN, "mpt-tiny-q80.bin"), "rb").read()
     for cut in (3, 20, 40, 700, len(raw) // 2):
