@@ -289,9 +289,9 @@ def main():
     kq = FTYPE.endswith("_K_M")
     out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=128,
                           kernel=("matmul_pg_kernel<TYPE,TG,8,GU> (exact integer sums on v_mfma_f32_16x16x32_f16, f32 chain on VALU)" if kq
-                                  else "matvec_pf_kernel<8,GU> (dot4, Q8_0 activations)") + ", one hipGraph per chunk shape",
+                                  else "matvec_pf_kernel<8,GU> (dot4 with the 1.5*2^23 addend, two-wide f32 chain steps, Q8_0 activation pair images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
-                          bound="valu + mfma issue (the exact f32 chain step per block, AVX lane, row and token)")
+                          bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
     if not a.no_cpu_baseline and n_gpus == 1:
         del llm
         out["cpu_baseline"] = cpu_baseline(n_vocab)

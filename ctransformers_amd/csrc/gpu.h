@@ -68,6 +68,10 @@ static inline void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
 static inline void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias) {
     for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], __builtin_amdgcn_sdot4(bias, a[i], 0, false), false);
 }
+// d[i] = dot4(w[i], a[i]) + c, c wave-uniform (VOP3P form with the addend in a scalar register: one instruction per dot)
+static inline void dot4x8_acc(int (&d)[8], const int (&w)[8], const int (&a)[8], int c) {
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], c, false);
+}
 #else
 DEV void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
     asm("v_dot4_i32_i8 %0, %8, %16, 0\n\tv_dot4_i32_i8 %1, %9, %17, 0\n\tv_dot4_i32_i8 %2, %10, %18, 0\n\tv_dot4_i32_i8 %3, %11, %19, 0\n\t"
@@ -86,6 +90,15 @@ DEV void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
           "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bias));
+}
+DEV void dot4x8_acc(int (&d)[8], const int (&w)[8], const int (&a)[8], int c) {
+    const int cs = __builtin_amdgcn_readfirstlane(c);
+    asm("v_dot4_i32_i8 %0, %8, %16, %24\n\tv_dot4_i32_i8 %1, %9, %17, %24\n\tv_dot4_i32_i8 %2, %10, %18, %24\n\tv_dot4_i32_i8 %3, %11, %19, %24\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, %24\n\tv_dot4_i32_i8 %5, %13, %21, %24\n\tv_dot4_i32_i8 %6, %14, %22, %24\n\tv_dot4_i32_i8 %7, %15, %23, %24\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
+          "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "s"(cs));
 }
 #endif
 // 24-bit integer multiply (full rate; v_mul_lo_u32 is quarter rate).  All products on the hot path fit: |a|,|b| < 2^23.
@@ -306,6 +319,21 @@ static inline uint32_t sgpr_const(uint32_t v) { return v; }
 #else
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 DEV uint32_t sgpr_const(uint32_t v) { uint32_t r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(v)); return r; }
+#endif
+
+// Two-wide f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, full rate on gfx950): each half is the IEEE operation.
+#ifdef CT_EMU
+struct F32x2 { float x, y; };
+static inline F32x2 pk2(float x, float y) { return F32x2{x, y}; }
+static inline F32x2 pk_fma_f32(F32x2 a, F32x2 b, F32x2 c) { return F32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+static inline F32x2 pk_mul_f32(F32x2 a, F32x2 b) { return F32x2{a.x * b.x, a.y * b.y}; }
+static inline F32x2 pk_add_f32(F32x2 a, F32x2 b) { return F32x2{a.x + b.x, a.y + b.y}; }
+#else
+typedef float F32x2 __attribute__((ext_vector_type(2)));
+DEV F32x2 pk2(float x, float y) { return F32x2{x, y}; }
+DEV F32x2 pk_fma_f32(F32x2 a, F32x2 b, F32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEV F32x2 pk_mul_f32(F32x2 a, F32x2 b) { return a * b; }
+DEV F32x2 pk_add_f32(F32x2 a, F32x2 b) { return a + b; }
 #endif
 
 // Four f32 chain steps a[j] = fma(d[j], s[j], a[j]) as two v_pk_fma_f32 (each half is the IEEE fma), pinned where they are written:

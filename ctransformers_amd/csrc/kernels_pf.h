@@ -9,7 +9,7 @@
 // intra-workgroup synchronisation after the activations are in LDS.
 //
 //   pf_quantize_q80_kernel  one workgroup per token: (RMSNorm / LayerNorm ->) Q8_0 exactly as the decode prologue does it, written
-//                           out as a compact image  q8[K/4] | yd[K/32]  (words)
+//                           out as compact images, two tokens per image:  q8 even[K/4] | q8 odd[K/4] | {yd even, yd odd}[K/32]  (words)
 //   matvec_pf_kernel        grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
 //                           w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first,
 //                           then over the SIMDs of a CU); epilogues as in the decode kernels, per token.  Q8_0 / Q4_0 lane sums are
@@ -40,17 +40,29 @@ __global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __re
     __shared__ ActLdsQ32<MAXK> L;
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
     prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // nb_: LayerNorm bias (gpt2)
-    int* o = acts + (size_t)t * act_words;
-    const int nq = K >> 2, nb = K >> 5;
-    for (int i = tid; i < nq; i += 1024) o[i] = L.q8[i];
-    for (int i = tid; i < nb; i += 1024) o[nq + i] = (int)f32_to_bits(L.yd[i]);
+    // tokens are stored in pairs (the chunk kernel's two-wide float steps): q8 of the even token | q8 of the odd token | block scales
+    // interleaved {even, odd} per block — 2 * act_words words per pair
+    int* o = acts + (size_t)(t >> 1) * 2 * act_words;
+    const int nq = K >> 2, nb = K >> 5, odd = t & 1;
+    for (int i = tid; i < nq; i += 1024) o[odd * nq + i] = L.q8[i];
+    for (int i = tid; i < nb; i += 1024) o[2 * nq + 2 * i + odd] = (int)f32_to_bits(L.yd[i]);
 }
 
 // q32_tile_dot for the nt tokens in LDS: one fma per 32-block, AVX lane and token (ggml.c:3321 / :2428, AVX2 forms), the
-// weight group fetched (and its nibbles extracted) once for all tokens.  res[t] valid in every lane of the row.
+// weight group fetched (and its nibbles turned into signed bytes) once for all tokens.  res[t] valid in every lane of the row.
+// The chunk kernel is VALU-bound (one (dot4, int->float, scale product, fma) per 4 multiply-adds), so the step is written for the
+// fewest instructions, two tokens at a time:
+//   * the dot carries the addend 0x4B400000 (VOP3P form, scalar operand): its result, read as a float, IS 12582912 + sumi
+//     (|sumi| <= 65024 < 2^22 keeps the sum in the binade whose ulp is 1), and one v_pk_add_f32 of -12582912 gives the two exact
+//     (float)sumi — no v_cvt, no zero-initialised accumulator;
+//   * Q4_0: nibble - 8 as a signed byte = ((nibble + 0x78) ^ 0x80) per byte, two operations per dword ONCE per weight group instead
+//     of a second dot per token (the reference's sum(nib * y) - 8 sum(y) is this integer);
+//   * v_pk_mul_f32 for the two block-scale products fp16(x.d) * fp16(y.d), v_pk_fma_f32 for the two chain steps.
+// Every float operation is the reference's, on the reference's operands, in its order: per token, block after block.
 template <int TYPE, int TB>
 DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __restrict__ lds, int act_words, int K, int nt, int lane,
                      float (&res)[TB]) {
+    static_assert(TB % 2 == 0, "tokens are taken in pairs");
     constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
     constexpr int PF = 4;
     const int r = lane >> 3, p3 = lane & 7, l = ((p3 & 1) << 2) | (p3 & 2) | (p3 >> 2);   // AVX lane = bitrev3(position), see q32_tile_dot
@@ -58,9 +70,11 @@ DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __rest
     const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)r * 8u;
     const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
     const int nq = K >> 2;
-    float acc[TB];
+    const int kMagic = 0x4B400000;                       // 12582912.0f = 1.5 * 2^23
+    const F32x2 unmagic = pk2(-12582912.0f, -12582912.0f);
+    F32x2 acc[TB / 2];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
+    for (int t = 0; t < TB / 2; ++t) acc[t] = pk2(0.0f, 0.0f);
     u32x4 qv[PF];
     uint64_t dv[PF];
 #pragma unroll
@@ -81,32 +95,45 @@ DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __rest
                 dv[u] = *(const uint64_t*)(tile + (size_t)gn * REC + doff);
             }
             if (g >= ng) continue;
-            int w[4];
-            float dw[4];
+            int w[8];
+            F32x2 dw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                w[i] = TYPE == GT_Q8_0 ? (int)q[i] : (int)((q[i] >> sh) & 0x0F0F0F0Fu);
-                dw[i] = f16_bits_to_f32((uint16_t)((dd >> (16 * i)) & 0xFFFFu));
+                w[i] = TYPE == GT_Q8_0 ? (int)q[i] : (int)((((q[i] >> sh) & 0x0F0F0F0Fu) + 0x78787878u) ^ 0x80808080u);
+                w[4 + i] = w[i];
+                const float d = f16_bits_to_f32((uint16_t)((dd >> (16 * i)) & 0xFFFFu));
+                dw[i] = pk2(d, d);
             }
 #pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                if (t < nt) {
-                    const int* img = lds + t * act_words;
-                    const u32x4 y = *(const u32x4*)(img + (g * 8 + l) * 4);
-                    const u32x4 yd = *(const u32x4*)(img + nq + g * 4);
+            for (int tp = 0; tp < TB / 2; ++tp) {
+                if (2 * tp < nt) {   // an odd chunk tail computes its unused second token on the (stale) image behind it: never stored
+                    const int* img = lds + tp * 2 * act_words;   // pair image: q8 even | q8 odd | {yd even, yd odd} per block
+                    const u32x4 y0 = *(const u32x4*)(img + (g * 8 + l) * 4), y1 = *(const u32x4*)(img + nq + (g * 8 + l) * 4);
+                    const u32x4 yda = *(const u32x4*)(img + 2 * nq + g * 8), ydb = *(const u32x4*)(img + 2 * nq + g * 8 + 4);
+                    const int y[8] = {(int)y0[0], (int)y0[1], (int)y0[2], (int)y0[3], (int)y1[0], (int)y1[1], (int)y1[2], (int)y1[3]};
+                    const F32x2 ydp[4] = {pk2(bits_to_f32(yda[0]), bits_to_f32(yda[1])), pk2(bits_to_f32(yda[2]), bits_to_f32(yda[3])),
+                                          pk2(bits_to_f32(ydb[0]), bits_to_f32(ydb[1])), pk2(bits_to_f32(ydb[2]), bits_to_f32(ydb[3]))};
+                    int s[8];
+                    dot4x8_acc(s, w, y, kMagic);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        int sumi;
-                        if constexpr (TYPE == GT_Q8_0) sumi = sdot4(w[i], (int)y[i], 0);
-                        else sumi = sdot4(w[i], (int)y[i], 0) - 8 * sdot4(0x01010101, (int)y[i], 0);
-                        acc[t] = fmaf(dw[i] * bits_to_f32(yd[i]), (float)sumi, acc[t]);
+                        const F32x2 f = pk_add_f32(pk2(bits_to_f32((uint32_t)s[i]), bits_to_f32((uint32_t)s[4 + i])), unmagic);
+                        acc[tp] = pk_fma_f32(pk_mul_f32(dw[i], ydp[i]), f, acc[tp]);
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < TB; ++t) res[t] = hsum8_exact_dpp(acc[t]);
+    for (int t = 0; t < TB / 2; ++t) {
+#ifdef CT_EMU
+        res[2 * t] = hsum8_exact_dpp(acc[t].x);
+        res[2 * t + 1] = hsum8_exact_dpp(acc[t].y);
+#else
+        res[2 * t] = hsum8_exact_dpp(acc[t][0]);
+        res[2 * t + 1] = hsum8_exact_dpp(acc[t][1]);
+#endif
+    }
 }
 
 template <int TB>
