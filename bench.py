@@ -289,7 +289,7 @@ def main():
     kq = FTYPE.endswith("_K_M")
     out["prefill"] = dict(tok_s=out["prefill_tok_s"], cold_tok_s=out["prefill_cold_tok_s"], chunk_tokens=128,
                           kernel=("matmul_pg_kernel<TYPE,TG,8,GU> (exact integer sums on v_mfma_f32_16x16x32_f16, f32 chain on VALU)" if kq
-                                  else "matvec_pf_kernel<8,GU> (dot4 with the 1.5*2^23 addend, two-wide f32 chain steps, Q8_0 activation pair images)") + ", one hipGraph per chunk shape",
+                                  else "matvec_pfm_kernel<GU> (lane sums on v_mfma_i32_4x4x4_16b_i8 with the 1.5*2^23 addend, packed f32 chain, Q8_0 activation images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
     if not a.no_cpu_baseline and n_gpus == 1:

@@ -1200,8 +1200,14 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 images, the dot4 chunk kernel (no matrix-core form)
         const int aw32 = pf_act_words_q32(m.K);
-        if (m.K <= 12288) CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
-        else CT_LAUNCH((pf_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b);
+        // 8 tokens per workgroup on the matrix-core form while their images fit the CU's LDS (K <= 16384: 144 KB); wider rows take
+        // the dot4 form with 4.  (Measured on config 3, profiles/r02_q80_chunk_sites.txt: 16 / 32 tokens per workgroup change
+        // nothing — the kernel is bound by instruction issue, not by the weight traffic — and the dot4 form at 8 tokens is 6 % slower.)
+        const int tb = (size_t)kPfTokens * aw32 * 4 <= (size_t)150 * 1024 ? kPfTokens : kPfTokens / 2;
+        const bool mfma = tb == kPfTokens;          // lane sums on v_mfma_i32_4x4x4_16b_i8 (one image per token)
+        const int paired = mfma ? 0 : 1;
+        if (m.K <= 12288) CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b, paired);
+        else CT_LAUNCH((pf_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b, paired);
         PfArgs a;
         a.m = m;
         a.acts = acts_; a.act_words = aw32; a.n_tok = nt;
@@ -1212,8 +1218,6 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             item0 += (m.job[j].w.M + 7) / 8;
         }
         a.m.n_pairs = m.gateup ? (m.job[0].w.M + 7) / 8 : item0;
-        // 8 tokens per workgroup while their images fit the CU's LDS (K <= 16384: 144 KB), else 4 (K <= 32768)
-        const int tb = (size_t)kPfTokens * aw32 * 4 <= (size_t)150 * 1024 ? kPfTokens : kPfTokens / 2;
         const int groups = (nt + tb - 1) / tb;
         const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
         const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
@@ -1222,8 +1226,10 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             auto kfn = matvec_pf_kernel<TBV, GUV>; \
             CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); \
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
-        if (tb == kPfTokens) { if (m.gateup) PF32(kPfTokens, true); else PF32(kPfTokens, false); }
-        else { if (m.gateup) PF32(kPfTokens / 2, true); else PF32(kPfTokens / 2, false); }
+        if (mfma) {
+            if (m.gateup) { auto kfn = matvec_pfm_kernel<true>; CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); }
+            else { auto kfn = matvec_pfm_kernel<false>; CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); }
+        } else { if (m.gateup) PF32(kPfTokens / 2, true); else PF32(kPfTokens / 2, false); }
 #undef PF32
         prof_end();
         return true;

@@ -168,6 +168,17 @@ static inline i32x4 mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
     }
     return c;
 }
+// v_mfma_i32_4x4x4_16b_i8: sixteen independent 4x4 blocks with K = 4.  Lane 4b + m gives row m of block b's A and column m of
+// its B as four int8 each, and holds D_b[i][m] = C + sum_k A_b[i][k] * B_b[k][m] in register i (checked on hardware by
+// tools/experiments/mfma_i8_4x4x4_layout.cpp, together with the float-addend form C = 0x4B400000).
+static inline i32x4 mfma_i8_4x4x4(int a, int b, i32x4 c) {
+    const int lane = (int)(threadIdx.x & 63), blk = lane >> 2;
+    for (int i = 0; i < 4; ++i) {
+        const int am = emu_shfl_any(a, 4 * blk + i);
+        for (int e = 0; e < 4; ++e) c[i] += (int)(int8_t)(am >> (8 * e)) * (int)(int8_t)(b >> (8 * e));
+    }
+    return c;
+}
 // two u16 lanes of `a` times the two u16 lanes of `s` (low 16 bits each): v_pk_mul_lo_u16
 static inline uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
     return (((a & 0xFFFFu) * (s & 0xFFFFu)) & 0xFFFFu) | (((a >> 16) * (s >> 16)) << 16);
@@ -180,6 +191,7 @@ DEV i32x4 mfma_i8_16x16x32(uint64_t a, uint64_t b, i32x4 c) {
 DEV i32x4 mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
 }
+DEV i32x4 mfma_i8_4x4x4(int a, int b, i32x4 c) { return __builtin_amdgcn_mfma_i32_4x4x4i8(a, b, c, 0, 0, 0); }
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 DEV uint32_t pk_mul_u16(uint32_t a, uint32_t s) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, s));

@@ -9,11 +9,13 @@
 // intra-workgroup synchronisation after the activations are in LDS.
 //
 //   pf_quantize_q80_kernel  one workgroup per token: (RMSNorm / LayerNorm ->) Q8_0 exactly as the decode prologue does it, written
-//                           out as compact images, two tokens per image:  q8 even[K/4] | q8 odd[K/4] | {yd even, yd odd}[K/32]  (words)
-//   matvec_pf_kernel        grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
-//                           w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first,
-//                           then over the SIMDs of a CU); epilogues as in the decode kernels, per token.  Q8_0 / Q4_0 lane sums are
-//                           4-element dots — nothing for a matrix core to contract.
+//                           out as compact images — one per token, q8[K/4] | yd[K/32] words, for the matrix-core kernel; per token
+//                           PAIR, q8 even | q8 odd | {yd even, yd odd} per block, for the dot4 kernel's two-wide steps
+//   matvec_pfm_kernel       K <= 16384.  grid (x, token-groups of 8): copies its 8 images into LDS, then wave w takes tiles
+//                           w * gridDim.x + blockIdx.x + k * 16 * gridDim.x (low tile counts spread over the CUs first, then over
+//                           the SIMDs of a CU); the lane sums on v_mfma_i32_4x4x4_16b_i8 (K = 4 per block IS a lane sum: 256 of
+//                           them per instruction); epilogues as in the decode kernels, per token
+//   matvec_pf_kernel        wider rows (K <= 32768, 4 tokens per workgroup): the same walk with v_dot4_i32_i8
 //   embed / attention / falcon RoPE store   the decode kernels with a token index in blockIdx.y / blockIdx.z
 #pragma once
 #include "kernels_q32.h"
@@ -31,15 +33,21 @@ struct PfArgs {
 };
 
 // ---- Q8_0 / Q4_0 weights (LAYOUT_G4, kernels_q32.h): Q8_0 activation images  q8[K/4] ([group][l][i] order) | yd[K/32] -----------
-constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }
+constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }   // (128 bytes of padding against same-bank images: measured, no change)
 
 template <int MAXK>
 __global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
                                                                int pro, float eps, int* __restrict__ acts, int act_words,
-                                                               const float* __restrict__ nb_ = nullptr) {
+                                                               const float* __restrict__ nb_ = nullptr, int paired = 1) {
     __shared__ ActLdsQ32<MAXK> L;
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
     prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // nb_: LayerNorm bias (gpt2)
+    if (!paired) {   // one image per token, q8[K/4] | yd[K/32]: the matrix-core form (matvec_pfm_kernel) reads a token per lane
+        int* o1 = acts + (size_t)t * act_words;
+        for (int i = tid; i < (K >> 2); i += 1024) o1[i] = L.q8[i];
+        for (int i = tid; i < (K >> 5); i += 1024) o1[(K >> 2) + i] = (int)f32_to_bits(L.yd[i]);
+        return;
+    }
     // tokens are stored in pairs (the chunk kernel's two-wide float steps): q8 of the even token | q8 of the odd token | block scales
     // interleaved {even, odd} per block — 2 * act_words words per pair
     int* o = acts + (size_t)(t >> 1) * 2 * act_words;
@@ -133,6 +141,201 @@ DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __rest
         res[2 * t] = hsum8_exact_dpp(acc[t][0]);
         res[2 * t + 1] = hsum8_exact_dpp(acc[t][1]);
 #endif
+    }
+}
+
+// ---- matrix-core form: the lane sums on v_mfma_i32_4x4x4_16b_i8 -------------------------------------------------------------------
+// K = 4 per block is exactly the reference's lane sum (four products of one AVX lane), and the instruction runs sixteen independent
+// 4x4 blocks: block b = (AVX lane l, row group rg), A = the four rows 4rg..4rg+3 of the tile (bytes 4l..4l+3 of the 32-block),
+// B = four tokens, C = 0x4B400000 so that the result bits read as floats are 1.5 * 2^23 + sumi.  One instruction = 256 lane sums
+// (8 rows x 4 tokens x 8 AVX lanes of one 32-block); lane 32rg + 4l + m then owns the accumulators of rows 4rg..4rg+3, token
+// 4tg + m (tg = 0, 1: two instructions per 32-block for the 8 tokens of the workgroup) and AVX lane l, and runs the chain two rows
+// at a time: v_pk_add_f32 (-1.5 * 2^23), v_pk_mul_f32 (the two scale products), v_pk_fma_f32.  hsum_float_8 over l = lane bits
+// 2..4, in the reference's order (l^4, l^2, l^1).  Same floats, same order as pf_tile_q32: per token, block after block.
+// NTG token groups of four per workgroup (TB = 4 NTG tokens; 2 in the product: 16 and 32 tokens per workgroup — 512 threads for
+// the register budget — measured no faster on MI355X, the kernel is bound by instruction issue, not by re-reading the weights).
+template <int NTG> struct PfmAcc { F32x2 a[NTG][2]; };   // [token group][row pair]
+
+template <int TYPE, int NTG>
+DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __restrict__ lds, int act_words, int K, int nt, int lane,
+                      float (&res)[NTG][4]) {
+    constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+    constexpr int PF = 3;
+    const int m = lane & 3, l = (lane >> 2) & 7, rg = lane >> 5;
+    const int ra = 4 * rg + m;                                           // the row this lane feeds as A
+    const uint32_t qoff = TYPE == GT_Q8_0 ? (uint32_t)(ra * 8 + l) * 16u : (uint32_t)(ra * 4 + (l & 3)) * 16u;
+    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)rg * 32u;   // fp16 scales of rows 4rg..4rg+3, 8 bytes per row
+    const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
+    const int nq = K >> 2;
+    i32x4 magic;
+    magic[0] = magic[1] = magic[2] = magic[3] = 0x4B400000;
+    const F32x2 unmagic = pk2(-12582912.0f, -12582912.0f);
+    PfmAcc<NTG> acc;
+#pragma unroll
+    for (int tg = 0; tg < NTG; ++tg) acc.a[tg][0] = acc.a[tg][1] = pk2(0.0f, 0.0f);
+    // weight dwords: a ring PF groups deep (HBM latency); the 64 scale bytes share the record's last cache line with them and are
+    // requested one group ahead
+    u32x4 qv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int g = u < ng ? u : ng - 1;
+        qv[u] = ld_stream16(tile + (size_t)g * REC + qoff);
+    }
+    u32x4 sa_n = ld16(tile + doff), sb_n = ld16(tile + doff + 16);
+    const int* img0 = lds + m * act_words;          // token m of group 0; group tg is 4 tg images further
+    (void)nt;   // chunk tails run all eight token slots (the images behind the tail are stale, their results are never stored): no
+                // branch in the block step, the two groups' matrix instructions interleave
+    for (int g0 = 0; g0 < ng; g0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int g = g0 + u;
+            const u32x4 q = qv[u], sa = sa_n, sb = sb_n;
+            {
+                const int gn = (g + PF < ng) ? g + PF : ng - 1;
+                qv[u] = ld_stream16(tile + (size_t)gn * REC + qoff);
+                const int g1 = (g + 1 < ng) ? g + 1 : ng - 1;
+                sa_n = ld16(tile + (size_t)g1 * REC + doff);
+                sb_n = ld16(tile + (size_t)g1 * REC + doff + 16);
+            }
+            if (g >= ng) continue;
+            // scales: sa = rows 0, 1 (two dwords = four fp16 each), sb = rows 2, 3 of this lane's row group
+            F32x2 dw01[4], dw23[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t r0 = sa[i >> 1], r1 = sa[2 + (i >> 1)], r2 = sb[i >> 1], r3 = sb[2 + (i >> 1)];
+                const int hs = (i & 1) * 16;
+                dw01[i] = pk2(f16_bits_to_f32((uint16_t)(r0 >> hs)), f16_bits_to_f32((uint16_t)(r1 >> hs)));
+                dw23[i] = pk2(f16_bits_to_f32((uint16_t)(r2 >> hs)), f16_bits_to_f32((uint16_t)(r3 >> hs)));
+            }
+            int w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                w[i] = TYPE == GT_Q8_0 ? (int)q[i] : (int)((((q[i] >> sh) & 0x0F0F0F0Fu) + 0x78787878u) ^ 0x80808080u);
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                const int* img = img0 + 4 * tg * act_words;
+                const u32x4 y = *(const u32x4*)(img + (g * 8 + l) * 4);
+                const u32x4 yd = *(const u32x4*)(img + nq + g * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const i32x4 d = mfma_i8_4x4x4(w[i], (int)y[i], magic);
+                    const float ys = bits_to_f32(yd[i]);
+                    const F32x2 f01 = pk_add_f32(pk2(bits_to_f32((uint32_t)d[0]), bits_to_f32((uint32_t)d[1])), unmagic);
+                    const F32x2 f23 = pk_add_f32(pk2(bits_to_f32((uint32_t)d[2]), bits_to_f32((uint32_t)d[3])), unmagic);
+                    acc.a[tg][0] = pk_fma_f32(pk_mul_f32(dw01[i], pk2(ys, ys)), f01, acc.a[tg][0]);
+                    acc.a[tg][1] = pk_fma_f32(pk_mul_f32(dw23[i], pk2(ys, ys)), f23, acc.a[tg][1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#ifdef CT_EMU
+            float x = (i & 1) ? acc.a[tg][i >> 1].y : acc.a[tg][i >> 1].x;
+#else
+            float x = acc.a[tg][i >> 1][i & 1];
+#endif
+            x = x + __shfl_xor(x, 16);   // (x0 + x4), (x1 + x5), (x2 + x6), (x3 + x7)      hsum_float_8, k_quants.c:90-97
+            x = x + __shfl_xor(x, 8);    // (x0 + x4) + (x2 + x6), (x1 + x5) + (x3 + x7)
+            x = x + __shfl_xor(x, 4);    // the sum
+            res[tg][i] = x;
+        }
+}
+
+// grid (x, token-groups of 8), 1024 threads: as matvec_pf_kernel, the tile product on the matrix cores.  A lane with l == 0 owns
+// rows 4rg..4rg+3 of the tile for tokens m, 4 + m, ... of the group.
+template <bool GU>
+__global__ void __launch_bounds__(1024) matvec_pfm_kernel(const PfArgs a) {
+    constexpr int TB = kPfTokens, NTG = TB / 4, NT = 1024, NW = NT / 64;
+    CT_DYN_SMEM(smem_raw);
+    int* lds = reinterpret_cast<int*>(smem_raw);
+    const MatvecArgs& m = a.m;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const int wv = uniform_int(wave_id());
+    const int t0 = (int)blockIdx.y * TB;
+    const int nt = a.n_tok - t0 < TB ? a.n_tok - t0 : TB;
+    {
+        const u32x4* src = (const u32x4*)(a.acts + (size_t)t0 * a.act_words);
+        const int n16 = TB * (a.act_words >> 2);
+        for (int i0 = 0; i0 < n16; i0 += 4 * NT) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT + tid; v[u] = ld16(src + (i < n16 ? i : n16 - 1)); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT + tid; ((u32x4*)lds)[i < n16 ? i : n16 - 1] = v[u]; }
+        }
+    }
+    __syncthreads();
+    const int pos0 = (m.pos ? *m.pos : 0) + t0;
+    const int GX = (int)gridDim.x;
+    const int ng = m.K >> 7;
+    const int tm = lane & 3, rg = lane >> 5;
+    const bool own_lane = ((lane >> 2) & 7) == 0;
+    for (int item = wv * GX + (int)blockIdx.x; item < m.n_pairs; item += NW * GX) {
+        int j = 0;
+        if (!GU) {
+            if (m.njobs > 1 && item >= m.job[1].pair0) j = 1;
+            if (m.njobs > 2 && item >= m.job[2].pair0) j = 2;
+        }
+        const int tile = GU ? item : item - m.job[j].pair0;
+        const DevMat& wj = m.job[j].w;
+        const size_t rec = wj.type == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+        float res[NTG][4];
+        if (wj.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
+        else pf_tile_q32m<GT_Q4_0, NTG>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
+        float up[GU ? NTG : 1][4];
+        if constexpr (GU) {
+            const DevMat& wu = m.job[1].w;
+            const size_t recu = wu.type == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
+            if (wu.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, up);
+            else pf_tile_q32m<GT_Q4_0, NTG>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, up);
+        }
+        const int epi = m.job[j].epi;
+#pragma unroll
+        for (int tg = 0; tg < NTG; ++tg) {
+            const int t = 4 * tg + tm;
+            if (t >= nt || !own_lane) continue;
+            int tok = t0 + t;
+            const int pos = pos0 + t;
+#ifndef CT_EMU
+            asm volatile("" : "+v"(tok));   // the row addresses are formed here, not hoisted above the tile loop (where they would be spilled)
+#endif
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = tile * 8 + 4 * rg + i;
+                if (row >= wj.M) continue;
+                const float v = res[tg][i];
+                if constexpr (GU) {
+                    m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.silu_tab[f32_to_f16_bits(v)]) * up[tg][i];
+                } else if (epi == EPI_ADD) {
+                    m.out[(size_t)tok * a.ld_out + row] = v + m.res[(size_t)tok * a.ld_res + row];
+                } else if (epi == EPI_STORE) {
+                    m.out[(size_t)tok * a.ld_out + row] = v;
+                } else if (epi == EPI_GELU) {
+                    m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.gelu_tab[f32_to_f16_bits(v)]);
+                } else if (epi == EPI_ADD2) {
+                    m.out[(size_t)tok * a.ld_out + row] = (v + m.res[(size_t)tok * a.ld_res + row]) + m.res2[(size_t)tok * a.ld_res + row];
+                } else if (epi == EPI_BIAS_STORE) {
+                    m.out[(size_t)tok * a.ld_out + row] = m.bias[row] + v;
+                } else if (epi == EPI_BIAS_ADD) {
+                    m.out[(size_t)tok * a.ld_out + row] = (m.bias[row] + v) + m.res[(size_t)tok * a.ld_res + row];
+                } else if (epi == EPI_BIAS_GELU) {
+                    m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.gelu_tab[f32_to_f16_bits(m.bias[row] + v)]);
+                } else if (epi == EPI_V) {
+                    m.vcache[(size_t)row * m.v_stride + pos] = f32_to_f16_bits(v);
+                } else {   // EPI_ROPE_Q / EPI_ROPE_K (normal mode, ggml.c:12522-12539): rows 2k, 2k+1 are registers i, i ^ 1 of this lane
+                    const float other = res[tg][i ^ 1];
+                    const int ip = (row % m.head_dim) >> 1;
+                    const float cs = m.rope_cs[((size_t)pos * (m.head_dim >> 1) + ip) * 2 + 0];
+                    const float sn = m.rope_cs[((size_t)pos * (m.head_dim >> 1) + ip) * 2 + 1];
+                    const float o = (i & 1) ? fmaf(v, cs, other * sn) : fmaf(v, cs, -(other * sn));
+                    if (epi == EPI_ROPE_Q) m.q_f16[(size_t)tok * a.ld_q + row] = f32_to_f16_bits(o);
+                    else m.kcache[kcache_off(pos, row, m.head_dim, m.n_ctx)] = f32_to_f16_bits(o);
+                }
+            }
+        }
     }
 }
 
