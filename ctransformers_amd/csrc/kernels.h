@@ -377,9 +377,15 @@ __global__ void __launch_bounds__(1024) argmax_first_kernel(const float* __restr
     const int tid = (int)threadIdx.x;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 1024) {
-        const float x = v[i];
-        if (x > best || (x == best && i < idx)) { best = x; idx = i; }
+    // eight loads in flight per thread (a load-compare-branch loop runs at one memory latency per element: 12 us for 32000 logits);
+    // a thread's indices ascend, so the strict comparison keeps its first maximum
+    for (int i0 = tid; i0 < n; i0 += 8 * 1024) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; x[u] = i < n ? v[i] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (x[u] > best) { best = x[u]; idx = i0 + u * 1024; }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
