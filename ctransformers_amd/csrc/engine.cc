@@ -1192,13 +1192,13 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 }
 
 // One mat-vec site of a prompt chunk: activation images of the nt rows, then the token-batched kernel(s) — kernels_pg.h for
-// K-quant weights (f16 matrix cores), kernels_pf.h for Q8_0 / Q4_0 (dot4).
+// K-quant weights (f16 matrix cores), kernels_pf.h for Q8_0 / Q4_0 (4x4x4 int8 matrix cores; dot4 for rows above 16384).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
                        std::string& err) {
     if (!site_on(site)) return true;
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
-    if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 images, the dot4 chunk kernel (no matrix-core form)
+    if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 activation images, kernels_pf.h
         const int aw32 = pf_act_words_q32(m.K);
         // 8 tokens per workgroup on the matrix-core form while their images fit the CU's LDS (K <= 16384: 144 KB); wider rows take
         // the dot4 form with 4.  (Measured on config 3, profiles/r02_q80_chunk_sites.txt: 16 / 32 tokens per workgroup change
