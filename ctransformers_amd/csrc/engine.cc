@@ -1088,6 +1088,26 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         }
         return;
     }
+    if (nt > 0 && (hd == 128 || hd == 64) && env_int("CT_AMD_ATTN_LONG", 1) != 0) {
+        // prompt chunk beyond position 128: K / V tiles of 64 positions through LDS, fetched once per 16 (8) tokens of a head; the
+        // tokens' probability rows live in LDS, which bounds the context this kernel takes (2048 with 16 tokens, 4096 with 8)
+        const int row = (n_ctx_ + 63) & ~63;
+        const size_t tile_bytes = hd == 128 ? (size_t)128 * 192 : (size_t)64 * 192;
+        const size_t cap = (size_t)160 * 1024;
+        const int ntok = tile_bytes + (size_t)16 * row * 4 <= cap ? 16 : (tile_bytes + (size_t)8 * row * 4 <= cap ? 8 : 0);
+        if (ntok) {
+            const dim3 gl((unsigned)hp_.n_head, (unsigned)((nt + ntok - 1) / ntok));
+            const size_t sm = tile_bytes + (size_t)ntok * row * 4;
+#define ATTNL(HDV, NTV) do { \
+                auto kfn = attn_chunk_long_kernel<HDV, NTV>; \
+                CT_OPTIN_ONCE(kfn, cap); \
+                CT_LAUNCH_DYN(kfn, gl, dim3(NTV * 64), sm, stream_, ax, nt, row); } while (0)
+            if (hd == 128) { if (ntok == 16) ATTNL(128, 16); else ATTNL(128, 8); }
+            else { if (ntok == 16) ATTNL(64, 16); else ATTNL(64, 8); }
+#undef ATTNL
+            return;
+        }
+    }
     if (nt > 0 && (hd == 128 || hd == 64) && n_ctx_ <= 4096 && env_int("CT_AMD_ATTN_WAVE", 1) != 0) {
         // prompt chunk, contexts whose probability rows fit LDS eight (four) at a time: one WAVE per (head, token)
         const int row = (n_ctx_ + 63) & ~63;

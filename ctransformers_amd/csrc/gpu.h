@@ -340,12 +340,16 @@ static inline F32x2 pk2(float x, float y) { return F32x2{x, y}; }
 static inline F32x2 pk_fma_f32(F32x2 a, F32x2 b, F32x2 c) { return F32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 static inline F32x2 pk_mul_f32(F32x2 a, F32x2 b) { return F32x2{a.x * b.x, a.y * b.y}; }
 static inline F32x2 pk_add_f32(F32x2 a, F32x2 b) { return F32x2{a.x + b.x, a.y + b.y}; }
+static inline float pk_lo(F32x2 a) { return a.x; }
+static inline float pk_hi(F32x2 a) { return a.y; }
 #else
 typedef float F32x2 __attribute__((ext_vector_type(2)));
 DEV F32x2 pk2(float x, float y) { return F32x2{x, y}; }
 DEV F32x2 pk_fma_f32(F32x2 a, F32x2 b, F32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 DEV F32x2 pk_mul_f32(F32x2 a, F32x2 b) { return a * b; }
 DEV F32x2 pk_add_f32(F32x2 a, F32x2 b) { return a + b; }
+DEV float pk_lo(F32x2 a) { return a[0]; }
+DEV float pk_hi(F32x2 a) { return a[1]; }
 #endif
 
 // Four f32 chain steps a[j] = fma(d[j], s[j], a[j]) as two v_pk_fma_f32 (each half is the IEEE fma), pinned where they are written:

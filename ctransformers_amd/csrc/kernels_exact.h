@@ -825,3 +825,191 @@ DEV LaneGeom lane_geom(int lane) {
 }
 
 // rec_base: wave-uniform pointer to the (tile, block) record.
+
+// Prompt chunks at long contexts (positions beyond 128): attn_chunk_tile_kernel's staging applied tile after tile.  A workgroup takes
+// one head and NTOK consecutive tokens (a wave each); the K rows, then the V rows, of the positions they attend to pass through ONE
+// LDS buffer in tiles of 64 positions, fetched once for the NTOK tokens instead of once per token (attn_chunk_wave_kernel reads
+// ~1 MB of K / V per (head, token) at 2k positions through L2).  Each wave keeps its score / probability row in LDS (row_floats
+// each) and carries the 8 x 8 V*P accumulators of its 128 (64) channels through the position tiles.  Arithmetic per position and
+// channel, and its order, are the other kernels': scores by quads of lanes, fp16 exp table, order-free double sum, V*P in steps of
+// 32 positions in order, leftovers in double after the reduce.  Barriers are workgroup-uniform: every wave — also one without a
+// token, or past its own last position — walks all tiles of the workgroup.
+template <int HD, int NTOK>
+__global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnArgsX a, int n_tok, int row_floats) {
+    constexpr int NC = HD / 32, PB = 4, TP = 64, NT = NTOK * 64;
+    constexpr int KS = HD * 2 + 64, VS = TP * 2 + 64, NCH = HD / 8, NPASS = HD / 16;   // bytes per staged K row / V row
+    constexpr int TILE_BYTES = TP * KS > HD * VS ? TP * KS : HD * VS;
+    CT_DYN_SMEM(smem_raw);
+    unsigned char* T = smem_raw;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = lane & 3, quad = lane >> 2;
+    const int h = (int)blockIdx.x, tok0 = (int)blockIdx.y * NTOK, tok = tok0 + wv;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const bool live = tok < n_tok;
+    const int pos0 = *a.pos;
+    float* prob = reinterpret_cast<float*>(smem_raw + TILE_BYTES) + wv * row_floats;
+    // end of the reference batch a token belongs to (see attn_fused_exact_kernel); monotone in the token index
+    auto batch_end = [&](int t) {
+        int nt_ = *a.n_total;
+        const int bs = a.n_total[1];
+        if (bs > 0) {
+            const int idx = a.pos[-1] + t, base = pos0 - a.pos[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = nt_ - base;
+            nt_ = base + (end < n_eval ? end : n_eval);
+        }
+        return nt_;
+    };
+    const int t_last = (tok0 + NTOK < n_tok ? tok0 + NTOK : n_tok) - 1;   // last token of this workgroup
+    const int n_kv_wg = pos0 + t_last + 1, n_tot_wg = batch_end(t_last);
+    const int n_kv = live ? pos0 + tok + 1 : 0;
+    const int n_tot = live ? batch_end(tok) : 0;
+    const int np = n_tot & ~31, nl = n_kv - np;         // full 32-steps; leftover positions (< 32 when > 0), wave-uniform
+    // ---- scores ------------------------------------------------------------------------------------------------------------
+    float mx = -INFINITY;
+    {
+        F32x2 qf[NC][4];   // the fma chains of the eight AVX lanes run two lanes per instruction (v_pk_fma_f32: each half is the IEEE fma)
+        const uint16_t* qrow = a.q_f16 + (size_t)(live ? tok : 0) * a.q_stride + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float q8[8];
+            unpack8_f16(ld16(qrow + 32 * c + 8 * j), q8);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) qf[c][l] = pk2(q8[2 * l], q8[2 * l + 1]);
+        }
+        const uint16_t* kb = a.kcache + (size_t)hk * a.n_ctx * HD;
+        // the next tile's 16-byte pieces travel in registers while the current tile is used (a tile load is a ~1.5 us round trip to
+        // L2 that nothing else hides: one workgroup per CU)
+        constexpr int KPT = (TP * NCH + NT - 1) / NT;   // pieces per thread
+        u32x4 nx[KPT];
+        auto k_fetch = [&](int t0) {
+            const int rows = n_kv_wg - t0 < TP ? n_kv_wg - t0 : TP;
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const int i = tid + q * NT, p = i / NCH, c = i - p * NCH;
+                if (i < rows * NCH) nx[q] = ld16(kb + (size_t)(t0 + p) * HD + 8 * c);
+            }
+        };
+        k_fetch(0);
+        for (int t0 = 0; t0 < n_kv_wg; t0 += TP) {
+            __syncthreads();                        // the previous tile has been read by every wave
+            {
+                const int rows = n_kv_wg - t0 < TP ? n_kv_wg - t0 : TP;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    const int i = tid + q * NT, p = i / NCH, c = i - p * NCH;
+                    if (i < rows * NCH) *(u32x4*)(T + p * KS + c * 16) = nx[q];
+                }
+            }
+            __syncthreads();
+            if (t0 + TP < n_kv_wg) k_fetch(t0 + TP);
+            if (t0 < n_kv) {
+                u32x4 kv[PB][NC];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) kv[u][c] = *(const u32x4*)(T + (u * 16 + quad) * KS + (32 * c + 8 * j) * 2);   // rows past `rows`: stale, unused
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const int p = t0 + u * 16 + quad;
+                    F32x2 ac[4] = {pk2(0.0f, 0.0f), pk2(0.0f, 0.0f), pk2(0.0f, 0.0f), pk2(0.0f, 0.0f)};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        float kf[8];
+                        unpack8_f16(kv[u][c], kf);
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) ac[l] = pk_fma_f32(pk2(kf[2 * l], kf[2 * l + 1]), qf[c][l], ac[l]);
+                    }
+                    float acc[8];
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { acc[2 * l] = pk_lo(ac[l]); acc[2 * l + 1] = pk_hi(ac[l]); }
+                    const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+                    if (p < n_kv) {
+                        mx = fmaxf(mx, sc);
+                        if (j == 0) prob[p] = sc;
+                    }
+                }
+            }
+        }
+    }
+    // ---- softmax over the wave's own row -----------------------------------------------------------------------------------
+    mx = wave_max(mx);
+    wave_lds_sync();
+    {
+        double sum = 0.0;
+        for (int i0 = 0; i0 < n_kv; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < n_kv) { const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]); prob[i] = e; sum += (double)e; }
+        }
+        sum = wave_sum(sum);
+        const float inv = (float)(1.0 / sum);
+        for (int i = lane; i < n_kv; i += 64) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+        for (int i = n_kv + lane; i < np; i += 64) prob[i] = 0.0f;   // masked columns of this batch
+    }
+    wave_lds_sync();
+    // ---- V * P: 16 channels per pass (a quad each), the accumulators of all passes carried through the position tiles ----------
+    F32x2 acc[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[ps][l] = pk2(0.0f, 0.0f);
+    const uint16_t* vb = a.vcache + (size_t)hk * HD * a.v_stride;
+    // the tile after whose full steps this wave is finished: the one that holds the leftover positions np .. n_kv - 1, or (no
+    // leftovers: np >= n_kv >= 1) the one that holds its last full step
+    const int t_left = (nl > 0 ? np : np - 1) & ~(TP - 1);
+    constexpr int VPT = (HD * (TP / 8) + NT - 1) / NT;
+    u32x4 nv[VPT];
+    auto v_fetch = [&](int t0) {                        // 64 positions of every channel (past the row's end: slack bytes, never used)
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int i = tid + q * NT, ch = i / (TP / 8), c = i - ch * (TP / 8);
+            if (i < HD * (TP / 8)) nv[q] = ld16(vb + (size_t)ch * a.v_stride + t0 + 8 * c);
+        }
+    };
+    v_fetch(0);
+    for (int t0 = 0; t0 < n_tot_wg; t0 += TP) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int i = tid + q * NT, ch = i / (TP / 8), c = i - ch * (TP / 8);
+            if (i < HD * (TP / 8)) *(u32x4*)(T + ch * VS + c * 16) = nv[q];
+        }
+        __syncthreads();
+        if (t0 + TP < n_tot_wg) v_fetch(t0 + TP);
+        if (t0 < np) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned char* vrow = T + (ps * 16 + quad) * VS;
+#pragma unroll
+                for (int u = 0; u < TP / 32; ++u) {
+                    if (t0 + 32 * u < np) {
+                        float vf[8];
+                        unpack8_f16(*(const u32x4*)(vrow + (32 * u + 8 * j) * 2), vf);
+                        const float* pr = &prob[t0 + 32 * u + 8 * j];
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) acc[ps][l] = pk_fma_f32(pk2(vf[2 * l], vf[2 * l + 1]), pk2(pr[2 * l], pr[2 * l + 1]), acc[ps][l]);
+                    }
+                }
+            }
+        }
+        if (live && t0 == t_left) {                     // every full step of this wave is done: reduce, leftovers, store
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int d = ps * 16 + quad;
+                float a8[8];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) { a8[2 * l] = pk_lo(acc[ps][l]); a8[2 * l + 1] = pk_hi(acc[ps][l]); }
+                double sumf = (double)f16dot_reduce_exact(a8, j);
+                if (nl > 0) {
+                    const unsigned char* vrow = T + d * VS + (np - t0) * 2;
+                    float lf[32];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) unpack8_f16(*(const u32x4*)(vrow + c * 16), lf + 8 * c);
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        if (i < nl) sumf += (double)(lf[i] * prob[np + i]);
+                    }
+                }
+                if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
+            }
+        }
+    }
+}

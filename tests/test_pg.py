@@ -43,13 +43,16 @@ def test_token_group_sizes_and_ragged_groups(emu_lib, monkeypatch, name, tg, bat
     assert np.array_equal(m.logits.to_numpy(), g[key])
 
 
-@pytest.mark.parametrize("name,mode", [("tiny-q4km", "tile"), ("tiny-q4km", "wave"), ("tiny-q4km", "fused"), ("falcon-tiny-q4km", "tile"),
-                                       ("tiny-q5km", "wave")])
+@pytest.mark.parametrize("name,mode", [("tiny-q4km", "tile"), ("tiny-q4km", "long"), ("tiny-q4km", "wave"), ("tiny-q4km", "fused"),
+                                       ("falcon-tiny-q4km", "tile"), ("falcon-tiny-q4km", "long"), ("tiny-q5km", "wave"), ("tiny-q80", "long")])
 def test_chunk_attention_kernels(emu_lib, monkeypatch, name, mode):
-    """The three chunk-attention kernels (kernels_exact.h): K/V tiles of a head in LDS for 16 tokens (all positions below 128; needs
-    n_ctx >= 128), a wave per (head, token), and the decode kernel with all channels per workgroup — same goldens of the reference."""
+    """The four chunk-attention kernels (kernels_exact.h): K/V of a head in LDS for 16 tokens (all positions below 128; needs
+    n_ctx >= 128), K/V tiles of 64 positions through LDS for any position (contexts up to 4096), a wave per (head, token), and the
+    decode kernel with all channels per workgroup — same goldens of the reference."""
     if mode != "tile":
         monkeypatch.setenv("CT_AMD_ATTN_TILE", "0")
+    if mode in ("wave", "fused"):
+        monkeypatch.setenv("CT_AMD_ATTN_LONG", "0")
     if mode == "fused":
         monkeypatch.setenv("CT_AMD_ATTN_WAVE", "0")
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -60,3 +63,24 @@ def test_chunk_attention_kernels(emu_lib, monkeypatch, name, mode):
     else:
         m.eval(list(g["prompt"]))
         assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+
+
+@pytest.mark.parametrize("tile_first", ["1", "0"])
+@pytest.mark.parametrize("name,n_prompt,bs", [("tiny-q4km", 150, 8), ("falcon-tiny-q4km", 139, 64)])
+def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, n_prompt, bs, tile_first):
+    """Prompts longer than one chunk and one 64-position tile: the later chunk attends through several K / V tiles with the
+    accumulators carried from tile to tile (attn_chunk_long_kernel), ragged reference batch ends included; with the 128-position
+    kernel switched off the first chunk takes the tiled kernel as well.  Against the reference build on the same file."""
+    from ctransformers_amd import synth
+    monkeypatch.setenv("CT_AMD_ATTN_TILE", tile_first)
+    path = os.path.join(GOLDEN, name + ".gguf")
+    toks = synth.prompt_tokens(n_prompt, 512)
+    r = ref.open_llm(path, context_length=256, batch_size=bs, threads=4)
+    m = open_emu(emu_lib, name, context_length=256, batch_size=bs)
+    r.eval(toks)
+    m.eval(toks)
+    assert chunk_tokens(m) == n_prompt
+    assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy())
+    t = int(r.logits.to_numpy().argmax())
+    r.eval([t]); m.eval([t])
+    assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prompt throughput at a 2k context (BASELINE config 5 asks for a 2k-context prefill): the 7B Q4_K_M file, context 2048, a prompt of
 n tokens evaluated three times from position 0 (cold, graph capture, steady state) — 128-token chunks, the later ones attending to
-up to 2k positions.  usage (GPU box): prefill_2k.py [model.gguf] [n_tokens]"""
+up to 2k positions.  usage (GPU box): prefill_2k.py [model.gguf] [n_tokens] [batch_size]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,14 +12,15 @@ path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/ctamd_llama2_7b_q4km_r2.gguf"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 if not os.path.exists(path):
     synth.write_llama_gguf(path, "llama-2-7b", "Q4_K_M", seed=1234)
-m = LLM(path, config=Config(context_length=2048, batch_size=n, gpu_layers=1000))
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 128   # the reference's batch: the V*P dot of a token runs to the end of ITS batch
+m = LLM(path, config=Config(context_length=2048, batch_size=bs, gpu_layers=1000))
 toks = synth.prompt_tokens(n, m.vocab_size)
 ts = []
 for _ in range(3):
     m._context = []
     t0 = time.perf_counter(); m.eval(toks); ts.append(time.perf_counter() - t0)
-print("7B Q4_K_M, context 2048, %d-token prompt in 128-token chunks: %.0f / %.0f / %.0f tok/s (cold / capture / steady); steady %.1f ms" % (
-    n, n / ts[0], n / ts[1], n / ts[2], ts[2] * 1e3))
+print("7B Q4_K_M, context 2048, batch_size %d, %d-token prompt in 128-token chunks: %.0f / %.0f / %.0f tok/s (cold / capture / steady); steady %.1f ms" % (
+    bs, n, n / ts[0], n / ts[1], n / ts[2], ts[2] * 1e3))
 for k in (128, 512, 1024):
     m._context = []
     t0 = time.perf_counter(); m.eval(toks[:k]); dt = time.perf_counter() - t0
