@@ -65,8 +65,7 @@ def test_chunk_attention_kernels(emu_lib, monkeypatch, name, mode):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
 
 
-@pytest.mark.parametrize("tile_first", ["1", "0"])
-@pytest.mark.parametrize("name,n_prompt,bs", [("tiny-q4km", 150, 8), ("falcon-tiny-q4km", 139, 64)])
+@pytest.mark.parametrize("name,n_prompt,bs,tile_first", [("tiny-q4km", 150, 8, "1"), ("tiny-q4km", 139, 8, "0"), ("falcon-tiny-q4km", 139, 64, "1")])
 def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, n_prompt, bs, tile_first):
     """Prompts longer than one chunk and one 64-position tile: the later chunk attends through several K / V tiles with the
     accumulators carried from tile to tile (attn_chunk_long_kernel), ragged reference batch ends included; with the 128-position
