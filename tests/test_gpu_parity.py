@@ -277,6 +277,26 @@ def test_pipeline_two_processes_one_gpu(tmp_path):
     assert recs[0]["tokens"] == recs[1]["tokens"] and len(recs[0]["tokens"]) == 3
 
 
+@pytest.mark.parametrize("ctx,overrides", [(3072, dict(n_embd=512, n_head=4, n_head_kv=2, n_layer=2, n_ff=1024)),   # heads of 128, GQA 4/2
+                                            (3072, None)])                                                             # llama-small: heads of 64
+def test_chunk_attention_8_tokens_per_workgroup(ref, tmp_path, ctx, overrides):
+    """Contexts between 2048 and 4096: attn_chunk_long_kernel keeps 8 (not 16) probability rows in LDS.  A 300-token prompt in
+    reference batches of 24 (ragged batch ends), then decode, against the reference build."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-small", "Q4_K_M", seed=35, overrides=overrides)
+    r = ref.open_llm(p, context_length=ctx, batch_size=24, threads=8)
+    m = open_hip(p, context_length=ctx, batch_size=24)
+    toks = synth.prompt_tokens(300, hp["n_vocab"])
+    r.eval(toks)
+    m.eval(toks)
+    for i in range(6):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "position %d" % (300 + i)
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
+
+
 def test_long_context(ref, tmp_path):
     """A 630-token prompt (chunks of 64) and decode beyond it: several passes of the attention kernel's position loops,
     logits bit-identical to the reference build."""

@@ -65,8 +65,9 @@ def test_chunk_attention_kernels(emu_lib, monkeypatch, name, mode):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
 
 
-@pytest.mark.parametrize("name,n_prompt,bs,tile_first", [("tiny-q4km", 150, 8, "1"), ("tiny-q4km", 139, 8, "0"), ("falcon-tiny-q4km", 139, 64, "1")])
-def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, n_prompt, bs, tile_first):
+@pytest.mark.parametrize("name,n_prompt,bs,tile_first,ctx", [("tiny-q4km", 150, 8, "1", 256), ("tiny-q4km", 139, 8, "0", 2500),   # 2500: 8 tokens per workgroup
+                                                             ("falcon-tiny-q4km", 139, 64, "1", 256)])
+def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, n_prompt, bs, tile_first, ctx):
     """Prompts longer than one chunk and one 64-position tile: the later chunk attends through several K / V tiles with the
     accumulators carried from tile to tile (attn_chunk_long_kernel), ragged reference batch ends included; with the 128-position
     kernel switched off the first chunk takes the tiled kernel as well.  Against the reference build on the same file."""
@@ -74,8 +75,8 @@ def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, 
     monkeypatch.setenv("CT_AMD_ATTN_TILE", tile_first)
     path = os.path.join(GOLDEN, name + ".gguf")
     toks = synth.prompt_tokens(n_prompt, 512)
-    r = ref.open_llm(path, context_length=256, batch_size=bs, threads=4)
-    m = open_emu(emu_lib, name, context_length=256, batch_size=bs)
+    r = ref.open_llm(path, context_length=ctx, batch_size=bs, threads=4)
+    m = open_emu(emu_lib, name, context_length=ctx, batch_size=bs)
     r.eval(toks)
     m.eval(toks)
     assert chunk_tokens(m) == n_prompt
