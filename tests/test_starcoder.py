@@ -20,7 +20,7 @@ def _open(lib, model_type, **kw):
     return LLM(PATH, model_type, config=Config(**cfg), lib=lib)
 
 
-def _check(lib, greedy_steps):
+def _check(lib, greedy_steps, light=False):
     g = np.load(os.path.join(GOLDEN, "starcoder-tiny-q80.npz"))
     host = json.load(open(os.path.join(GOLDEN, "starcoder_host.json")))
     for mt in ("starcoder", "gpt_bigcode", "gpt2"):
@@ -39,14 +39,14 @@ def _check(lib, greedy_steps):
         assert m.sample(top_k=1, repetition_penalty=1.0) == int(t)
         m.eval([int(t)])
         assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
-    for bs, key in ((64, "long_one"), (8, "long_chunked")):
+    for bs, key in ((8, "long_chunked"),) if light else ((64, "long_one"), (8, "long_chunked")):   # light: the emulator build
         m = _open(lib, "starcoder", batch_size=bs)
         m.eval(list(g["long_prompt"]))
         assert np.array_equal(m.logits.to_numpy(), g[key])
 
 
 def test_starcoder_on_emulator_build(emu_lib):
-    _check(emu_lib, 3)
+    _check(emu_lib, 2, light=True)
 
 
 def test_starcoder_file_through_the_c_restatement(mirror):

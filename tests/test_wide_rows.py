@@ -14,10 +14,10 @@ from ctransformers_amd.llm import LLM, Config
 CASES = [("Q8_0", 13312), ("Q4_0", 16384), ("Q8_0", 16512), ("Q4_0", 32768)]
 
 
-def _run(lib, ref, tmp_path, ftype, n_ff, n_decode):
+def _run(lib, ref, tmp_path, ftype, n_ff, n_decode, n_prompt=21):
     p = str(tmp_path / "wide.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", ftype, seed=31, overrides=dict(n_layer=1, n_ff=n_ff))
-    toks = synth.prompt_tokens(21, hp["n_vocab"])
+    toks = synth.prompt_tokens(n_prompt, hp["n_vocab"])
     r = ref.open_llm(p, context_length=64, batch_size=64, threads=4)
     m = LLM(p, config=Config(context_length=64, batch_size=64, threads=1), lib=lib)
     r.eval(toks)
@@ -31,9 +31,9 @@ def _run(lib, ref, tmp_path, ftype, n_ff, n_decode):
     assert np.array_equal(r.logits.to_numpy(), m.logits.to_numpy())
 
 
-@pytest.mark.parametrize("ftype,n_ff", CASES)
+@pytest.mark.parametrize("ftype,n_ff", [("Q8_0", 13312), ("Q4_0", 32768)])   # one case per chunk kernel; all four run on the GPU
 def test_wide_rows_on_emulator_build(emu_lib, ref, tmp_path, ftype, n_ff):
-    _run(emu_lib, ref, tmp_path, ftype, n_ff, 2)
+    _run(emu_lib, ref, tmp_path, ftype, n_ff, 1, n_prompt=9)   # 9 tokens: a full group of 8 (4 + 4) and a ragged one
 
 
 def test_rows_above_32768_are_refused(emu_lib, tmp_path):
