@@ -13,6 +13,7 @@
 
 #include "gguf_reader.h"
 #include "kernels_v7.h"
+#include "kernels_v9.h"
 #include "kernels_q32.h"
 #include "kernels_pf.h"
 #include "kernels_pg.h"
@@ -114,13 +115,51 @@ CT_HD static inline void place_kblock(int type, uint8_t* rp, int r, const uint8_
     }
 }
 
+// One file-layout K-quant block -> slot `r` = 4 * row + c of a LAYOUT_L9 record (quant.h): the bytes each lane
+// (32 * row + 4 * l + c) of the decode wave consumes are contiguous, the 6-bit scales / mins of Q4_K / Q5_K sit word-aligned.
+CT_HD static inline void place_kblock9(int type, uint8_t* rp, int r, const uint8_t* blk) {
+    const int row = r >> 2, c = r & 3;
+    if (type != GT_Q6_K) {
+        const uint8_t* q = blk + 4;
+        uint32_t sc[8], mn[8];
+        for (int jj = 0; jj < 8; ++jj) {
+            if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
+            else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
+        }
+        const uint32_t W1 = sc[0] | (sc[1] << 6) | (sc[2] << 12) | (sc[3] << 18) | (sc[4] << 24) | ((mn[7] & 3u) << 30);
+        const uint32_t W2 = ((mn[7] >> 2) & 3u) | (sc[5] << 2) | (sc[6] << 8) | (sc[7] << 14) | (mn[5] << 20) | (mn[6] << 26);
+        const uint32_t W3 = ((mn[7] >> 4) & 3u) | (mn[0] << 2) | (mn[1] << 8) | (mn[2] << 14) | (mn[3] << 20) | (mn[4] << 26);
+        uint8_t* hdr = rp + (type == GT_Q4_K ? 1024 : 1280) + r * 16;
+        memcpy(hdr, blk, 4);
+        memcpy(hdr + 4, &W1, 4); memcpy(hdr + 8, &W2, 4); memcpy(hdr + 12, &W3, 4);
+        const uint8_t* qs = blk + (type == GT_Q4_K ? 16 : 48);
+        for (int l = 0; l < 8; ++l) {
+            const int lane = 32 * row + 4 * l + c;
+            for (int j = 0; j < 4; ++j) memcpy(rp + lane * 16 + 4 * j, qs + 32 * j + 4 * l, 4);
+            if (type == GT_Q5_K) memcpy(rp + 1024 + lane * 4, blk + 16 + 4 * l, 4);
+        }
+    } else {  // GT_Q6_K: ql[128] | qh[64] | scales[16] | d
+        for (int l = 0; l < 8; ++l) {
+            const int lane = 32 * row + 4 * l + c;
+            for (int n = 0; n < 2; ++n) {
+                memcpy(rp + lane * 16 + 8 * n, blk + 64 * n + 4 * l, 4);
+                memcpy(rp + lane * 16 + 8 * n + 4, blk + 64 * n + 32 + 4 * l, 4);
+                memcpy(rp + 1024 + lane * 8 + 4 * n, blk + 128 + 32 * n + 4 * l, 4);
+            }
+        }
+        for (int v = 0; v < 8; ++v) { rp[1536 + r * 16 + v] = blk[192 + 2 * v]; rp[1536 + r * 16 + 8 + v] = blk[192 + 2 * v + 1]; }
+        memcpy(rp + 1664 + r * 2, blk + 208, 2);
+    }
+}
+
 // The same placement on the GPU: one thread per block slot of the arena, reading the tensor in FILE layout from the staged copy of
 // the model file (stage_file).  `sb` != null: fused gate/up (unit u = row u of sa and of sb), else unit u = rows 2u, 2u + 1 of sa.
-template <int TYPE>
+// L9: place_kblock9 (decode arena) instead of place_kblock (prompt-chunk arena).
+template <int TYPE, bool L9 = false>
 __global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
                                                           uint8_t* __restrict__ dst, int M, int nb, int n_units) {
     constexpr int type = TYPE;
-    const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type);
+    const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = L9 ? l9_record_bytes(type) : tile8_record_bytes(type);
     const long long n = (long long)n_units * spu * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int slot = (int)(i & 7), rr = slot >> 2, cc = slot & 3;
@@ -128,7 +167,9 @@ __global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restr
         const int s = (int)(us % spu), u = (int)(us / spu);
         const int row = sb ? u : 2 * u + rr, b = 4 * s + cc;
         if (row >= M || b >= nb) continue;   // zero slot (the arena is cleared first)
-        place_kblock(type, dst + (size_t)us * rec, slot, ((sb && rr) ? sb : sa) + ((size_t)row * nb + b) * bb);
+        const uint8_t* blk = ((sb && rr) ? sb : sa) + ((size_t)row * nb + b) * bb;
+        if constexpr (L9) place_kblock9(type, dst + (size_t)us * rec, slot, blk);
+        else place_kblock(type, dst + (size_t)us * rec, slot, blk);
     }
 }
 
@@ -217,9 +258,9 @@ void Engine::release_staged() {
 // (attn_q | attn_k | attn_v).  `fuse` (two parts of the same type and shape): ONE fused gate/up matrix, unit u = (row u of
 // parts[0], row u of parts[1]), described by parts[0].second; else unit u of a part = its rows (2u, 2u + 1).
 bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err) {
-    struct Plan { const GgufTensor* ta; const GgufTensor* tb; DevMat* m; size_t off, bytes; int type, K, M, nb, n_units; };
+    struct Plan { const GgufTensor* ta; const GgufTensor* tb; DevMat* m; size_t off, bytes, off9; int type, K, M, nb, n_units; };
     std::vector<Plan> plan;
-    size_t total = 0;
+    size_t total = 0, total9 = 0;
     for (size_t i = 0; i < parts.size(); i += fuse ? 2 : 1) {
         const GgufTensor* ta = parts[i].first;
         const GgufTensor* tb = fuse ? parts[i + 1].first : nullptr;
@@ -233,57 +274,83 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
         p.off = total;
         p.bytes = (size_t)p.n_units * ((p.nb + 3) / 4) * tile8_record_bytes(p.type);
         total += p.bytes;
+        p.off9 = total9;
+        total9 += (size_t)p.n_units * ((p.nb + 3) / 4) * l9_record_bytes(p.type);
         plan.push_back(p);
     }
+    // Two arenas of the same geometry: LAYOUT_R2C4 for the prompt-chunk kernels (kernels_pg.h), LAYOUT_L9 for the decode mat-vec
+    // (kernels_v9.h).  HBM is sized for it (the 70B Q5_K_M model: 2 x 48.6 GB of 288); a token step reads the L9 arena only.
     if (dev_file_) {   // tensors already on the device in file layout: repack there
         uint8_t* d = nullptr;
+        uint8_t* d9 = nullptr;
         if (!dev_alloc(dev_allocs_, &d, total + 4096, err)) return false;
+        if (!dev_alloc(dev_allocs_, &d9, total9 + 4096, err)) return false;
         HIP_OK(hipMemsetAsync(d, 0, total + 4096, stream_));
+        HIP_OK(hipMemsetAsync(d9, 0, total9 + 4096, stream_));
         for (const Plan& p : plan) {
             const long long n = (long long)p.n_units * ((p.nb + 3) / 4) * 8;
             const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16);
             const uint8_t* sa = staged(p.ta);
             const uint8_t* sb = p.tb ? staged(p.tb) : nullptr;
-            if (p.type == GT_Q4_K) CT_LAUNCH((repack_r2c4_kernel<GT_Q4_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
-            else if (p.type == GT_Q5_K) CT_LAUNCH((repack_r2c4_kernel<GT_Q5_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
-            else CT_LAUNCH((repack_r2c4_kernel<GT_Q6_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+            if (p.type == GT_Q4_K) {
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q4_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q4_K, true>), dim3(gx), dim3(256), stream_, sa, sb, d9 + p.off9, p.M, p.nb, p.n_units);
+            } else if (p.type == GT_Q5_K) {
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q5_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q5_K, true>), dim3(gx), dim3(256), stream_, sa, sb, d9 + p.off9, p.M, p.nb, p.n_units);
+            } else {
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q6_K>), dim3(gx), dim3(256), stream_, sa, sb, d + p.off, p.M, p.nb, p.n_units);
+                CT_LAUNCH((repack_r2c4_kernel<GT_Q6_K, true>), dim3(gx), dim3(256), stream_, sa, sb, d9 + p.off9, p.M, p.nb, p.n_units);
+            }
         }
         for (const Plan& p : plan) {
             p.m->r2 = d + p.off;
+            p.m->r9 = d9 + p.off9;
             if (p.tb) { p.m->type = p.type; p.m->K = p.K; p.m->M = p.M; p.m->nb = p.nb; p.m->layout = LAYOUT_R2C4; p.m->bytes = p.ta->nbytes + p.tb->nbytes; }
         }
         return true;
     }
-    std::vector<uint8_t> st(total, 0);
+    std::vector<uint8_t> st(total, 0), st9(total9, 0);
     for (const Plan& p : plan) {
         const int type = p.type, nb = p.nb, M = p.M, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type), spu = (nb + 3) / 4;
         const uint8_t* sa = p.ta->data;
         const uint8_t* sb = p.tb ? p.tb->data : nullptr;
         uint8_t* dst = st.data() + p.off;
+        uint8_t* dst9 = st9.data() + p.off9;
+        const int rec9 = l9_record_bytes(type);
         parallel_rows(p.n_units, [&](int u0, int u1) {
             for (int u = u0; u < u1; ++u)
                 for (int s = 0; s < spu; ++s) {
                     uint8_t* rp = dst + ((size_t)u * spu + s) * rec;
+                    uint8_t* rp9 = dst9 + ((size_t)u * spu + s) * rec9;
                     for (int rr = 0; rr < 2; ++rr) {
                         const int row = sb ? u : 2 * u + rr;
                         if (row >= M) continue;
                         const uint8_t* src = (sb && rr) ? sb : sa;
                         for (int cc = 0; cc < 4; ++cc) {
                             const int b = 4 * s + cc;
-                            if (b < nb) place_kblock(type, rp, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+                            if (b < nb) {
+                                place_kblock(type, rp, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+                                place_kblock9(type, rp9, 4 * rr + cc, src + ((size_t)row * nb + b) * bb);
+                            }
                         }
                     }
                 }
         });
     }
     uint8_t* d = nullptr;
+    uint8_t* d9 = nullptr;
     // + 4 KB: the prompt-chunk kernels request up to two block slots past a row's last block (kernels_pg.h), i.e. past the arena's
     // last record for its last unit
     if (!dev_alloc(dev_allocs_, &d, total + 4096, err)) return false;
+    if (!dev_alloc(dev_allocs_, &d9, total9 + 4096, err)) return false;
     HIP_OK(hipMemset(d + total, 0, 4096));
+    HIP_OK(hipMemset(d9 + total9, 0, 4096));
     HIP_OK(hipMemcpy(d, st.data(), total, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d9, st9.data(), total9, hipMemcpyHostToDevice));
     for (const Plan& p : plan) {
         p.m->r2 = d + p.off;
+        p.m->r9 = d9 + p.off9;
         if (p.tb) {   // the fused matrix is a DevMat of its own
             p.m->type = p.type; p.m->K = p.K; p.m->M = p.M; p.m->nb = p.nb; p.m->layout = LAYOUT_R2C4; p.m->bytes = p.ta->nbytes + p.tb->nbytes;
         }
@@ -855,8 +922,20 @@ long long v7_launches() { return g_v7_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
 long long pg_launches() { return g_pg_launches; }
 
+// CT_AMD_MATVEC_GEN=7: the previous generation on the LAYOUT_R2C4 arena (A/B partner); default: generation 9 on LAYOUT_L9.
+static int matvec_gen() {
+    static const int g = env_int("CT_AMD_MATVEC_GEN", 9);
+    return g;
+}
+
 static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     ++g_v7_launches;
+    const bool g9 = matvec_gen() != 7;
+    if (g9) {
+        for (int j = 0; j < a.njobs; ++j) {
+            if (!a.job[j].w.r9) { err = "mat-vec: K-quant matrix without a LAYOUT_L9 arena"; return false; }
+        }
+    }
     const int ta = a.job[0].w.type;
     int tb = 0, item0 = 0, na = 0;
     double bytes_a = 0.0, bytes_b = 0.0;
@@ -874,14 +953,17 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     a.n_pairs = item0;
     a.n_groupA = na;
     // the units of a type group are one contiguous stream: job j + 1 of a group starts where job j ends (upload_r2c4 arenas)
-    a.baseA = a.job[0].w.r2;
+    a.baseA = g9 ? a.job[0].w.r9 : a.job[0].w.r2;
     a.baseB = nullptr;
     for (int j = 0; j < a.njobs; ++j) {
         const bool first_b = tb != 0 && a.job[j].pair0 == na;
-        if (first_b) { a.baseB = a.job[j].w.r2; continue; }
+        if (first_b) { a.baseB = g9 ? a.job[j].w.r9 : a.job[j].w.r2; continue; }
         if (j == 0) continue;
         const int uj = a.job[j].pair0 - a.job[j - 1].pair0;
-        if (a.job[j].w.r2 != a.job[j - 1].w.r2 + (size_t)uj * spu * tile8_record_bytes(a.job[j - 1].w.type)) {
+        const uint8_t* here = g9 ? a.job[j].w.r9 : a.job[j].w.r2;
+        const uint8_t* prev = g9 ? a.job[j - 1].w.r9 : a.job[j - 1].w.r2;
+        const int recb = g9 ? l9_record_bytes(a.job[j - 1].w.type) : tile8_record_bytes(a.job[j - 1].w.type);
+        if (here != prev + (size_t)uj * spu * recb) {
             err = "mat-vec jobs of one weight type are not contiguous in memory";
             return false;
         }
@@ -902,6 +984,31 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
         if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV7MaxUnits - 1) / (nwb * kV7MaxUnits));
     }
     const dim3 grid((unsigned)gx), block(1024);
+    if (g9) {
+        if (a.emb_out && (tb != 0 || a.K > 16384)) { err = "emb_out on a mixed-type or wide launch"; return false; }
+        if (tb != 0 && a.K > 16384) { err = "mixed-type launch with K > 16384"; return false; }
+#define V9L(MK, TAV, TBV, LNV, EMBV) do { \
+        auto kfn = matvec_v9_kernel<MK, TAV, TBV, LNV, EMBV>; \
+        constexpr size_t smem = sizeof(SmemV9<MK>); \
+        CT_OPTIN_ONCE(kfn, smem); \
+        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
+#define V9T(MK, TAV) do { \
+        if (a.emb_out) { if (ln) V9L(16384, TAV, 0, true, true); else V9L(16384, TAV, 0, false, true); } \
+        else if (ln) V9L(MK, TAV, 0, true, false); \
+        else if (tb != 0) V9L(16384, TAV, GT_Q6_K, false, false); \
+        else V9L(MK, TAV, 0, false, false); } while (0)
+#define V9(MK) do { \
+        if (ta == GT_Q4_K) V9T(MK, GT_Q4_K); \
+        else if (ta == GT_Q5_K) V9T(MK, GT_Q5_K); \
+        else if (a.emb_out) { if (ln) V9L(16384, GT_Q6_K, 0, true, true); else V9L(16384, GT_Q6_K, 0, false, true); } \
+        else if (ln) V9L(MK, GT_Q6_K, 0, true, false); \
+        else V9L(MK, GT_Q6_K, 0, false, false); } while (0)
+        if (a.K <= 16384) V9(16384); else V9(32768);
+#undef V9
+#undef V9T
+#undef V9L
+        return true;
+    }
     if (a.emb_out) {   // lm_head: the instantiation that also stores the normalised vector (one launch per token)
         if (tb != 0 || a.K > 16384) { err = "emb_out on a mixed-type or wide launch"; return false; }
 #define V7E(TAV) do { \

@@ -68,6 +68,10 @@ static inline void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
 static inline void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias) {
     for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], __builtin_amdgcn_sdot4(bias, a[i], 0, false), false);
 }
+// d[i] = dot4(w[i], a[i]) + c[i]
+static inline void dot4x8_add(int (&d)[8], const int (&w)[8], const int (&a)[8], const int (&c)[8]) {
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], c[i], false);
+}
 // d[i] = dot4(w[i], a[i]) + c, c wave-uniform (VOP3P form with the addend in a scalar register: one instruction per dot)
 static inline void dot4x8_acc(int (&d)[8], const int (&w)[8], const int (&a)[8], int c) {
     for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], c, false);
@@ -90,6 +94,15 @@ DEV void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
           "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bias));
+}
+DEV void dot4x8_add(int (&d)[8], const int (&w)[8], const int (&a)[8], const int (&c)[8]) {
+    asm("v_dot4_i32_i8 %0, %8, %16, %24\n\tv_dot4_i32_i8 %1, %9, %17, %25\n\tv_dot4_i32_i8 %2, %10, %18, %26\n\tv_dot4_i32_i8 %3, %11, %19, %27\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, %28\n\tv_dot4_i32_i8 %5, %13, %21, %29\n\tv_dot4_i32_i8 %6, %14, %22, %30\n\tv_dot4_i32_i8 %7, %15, %23, %31\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
+          "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
 }
 DEV void dot4x8_acc(int (&d)[8], const int (&w)[8], const int (&a)[8], int c) {
     const int cs = __builtin_amdgcn_readfirstlane(c);
@@ -302,6 +315,70 @@ template <class T> DEV T lane_xor16(T v) {
 template <class T> DEV T lane_xor32(T v) { return __shfl_xor(v, 32); }
 #endif
 
+// ---- generation-9 mat-vec primitives (kernels_v9.h) ---------------------------------------------------------------------------
+// quad_bcast<K>: every lane of a quad (lanes 4q .. 4q+3) reads lane 4q + K's value — DPP quad_perm:[K,K,K,K], one VALU move that
+// hipcc folds into the consuming VOP2 (v_fmac_f32_dpp) where it can.  wave_read_lane: v_readlane_b32 with a wave-uniform index.
+// ld_stream8: 8-byte streaming load.  bfe_i32: sign-extending bit-field extract.
+#ifdef CT_EMU
+template <int K, class T> static inline T quad_bcast(T v) { return __shfl(v, (int)((threadIdx.x & 63u) & ~3u) + K); }
+static inline float wave_read_lane(float v, int src) { return __shfl(v, src); }
+struct u32x2 {
+    uint32_t v[2];
+    uint32_t operator[](int i) const { return v[i]; }
+};
+static inline u32x2 ld_stream8(const void* p) { u32x2 r; memcpy(&r, p, 8); return r; }
+static inline uint32_t ld_stream4(const void* p) { uint32_t r; memcpy(&r, p, 4); return r; }
+static inline int bfe_i32(uint32_t v, int off, int width) { return (int)(v << (32 - off - width)) >> (32 - width); }
+static inline uint32_t pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return (a & 0xFFu) | ((b & 0xFFu) << 8) | ((c & 0xFFu) << 16) | (d << 24);
+}
+#else
+template <int K, class T> DEV T quad_bcast(T v) { return dpp_any<T, K * 0x55>(v); }
+DEV float wave_read_lane(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+DEV u32x2 ld_stream8(const void* p) { return __builtin_nontemporal_load((const u32x2*)p); }
+DEV uint32_t ld_stream4(const void* p) { return __builtin_nontemporal_load((const uint32_t*)p); }
+DEV int bfe_i32(uint32_t v, int off, int width) { return __builtin_amdgcn_sbfe((int)v, off, width); }
+// the low bytes of four words as one word (three v_perm_b32)
+DEV uint32_t pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0C0C0400u);   // byte 0 of a, byte 0 of b, 0, 0
+    const uint32_t cd = __builtin_amdgcn_perm(d, c, 0x04000C0Cu);   // 0, 0, byte 0 of c, byte 0 of d
+    return ab | cd;
+}
+#endif
+
+// The reference's four chain steps of one record, acc = fma(d_c, s_c, acc) for c = 0..3 in order, operands from the quad's lanes
+// c = 0..3 (every lane of the quad runs the same chain): v_mov_b32_dpp broadcasts d_c, v_fmac_f32_dpp takes s_c through its own
+// quad_perm — 8 instructions instead of the 10 of separate broadcasts (the compiler SLP-packs those into v_pk_fma_f32 + 16 moves
+// when two chains run side by side).  v_fmac_f32 is the fused multiply-add (one rounding), like fmaf.  The leading s_nop covers
+// the VALU-write -> DPP-read hazard for d and s (hipcc does not look into the statement).
+#ifdef CT_EMU
+static inline float quad_chain4(float acc, float d, float s) {
+    acc = fmaf(quad_bcast<0>(d), quad_bcast<0>(s), acc);
+    acc = fmaf(quad_bcast<1>(d), quad_bcast<1>(s), acc);
+    acc = fmaf(quad_bcast<2>(d), quad_bcast<2>(s), acc);
+    acc = fmaf(quad_bcast<3>(d), quad_bcast<3>(s), acc);
+    return acc;
+}
+#else
+DEV float quad_chain4(float acc, float d, float s) {
+    float t;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %1 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %1 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+        : "+v"(acc), "=&v"(t) : "v"(d), "v"(s));
+    return acc;
+}
+#endif
+
 template <class T> DEV T wave_sum_fast(T v) {
     v += lane_xor1(v); v += lane_xor2(v); v += lane_xor4(v); v += lane_xor8(v); v += lane_xor16(v); v += lane_xor32(v);
     return v;
@@ -321,6 +398,13 @@ DEV int sload_i32(const int* p) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+#endif
+
+// opaque_int: the value, but the compiler cannot see where it came from — what is derived from it is recomputed, not kept in registers.
+#ifdef CT_EMU
+static inline int opaque_int(int v) { return v; }
+#else
+DEV int opaque_int(int v) { asm volatile("" : "+v"(v)); return v; }
 #endif
 
 // sched_fence: nothing is moved across this point by the instruction scheduler.  sgpr_const: a constant the compiler keeps in a scalar

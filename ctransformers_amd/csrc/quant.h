@@ -17,6 +17,21 @@
 //   Q5_K record 1408 B: hdr[8][16] | qh[8][32] | qs[8][128]
 //   Q6_K record 1680 B: d[8] f16 (16 B) | sc[8][16] | qh[8][64] | ql[8][128]
 // Record sizes are 8 x the file block size (the repack moves bytes, engine.cc:place_kblock / repack_r2c4_kernel).
+//
+// LAYOUT_L9 (K-quants; kernels_v9.h decode mat-vec): the same records (2 rows x 4 consecutive K-blocks, same sizes, same unit
+// spaces and arenas), bytes arranged per LANE of the wave that consumes a record: lane = 32 * row + 4 * l + c holds what AVX lane l
+// of the reference touches in block slot (row, c) — so the lane that computes the integer lane sum sumi[l] also owns chain l.
+//   Q4_K record 1152 B: qs[64 lanes][16] | hdr[8 slots][16]
+//       lane dword j (0..3) = file qs bytes 32j + 4l .. +3 (low nibbles: vector 2j, high nibbles: vector 2j + 1, elements 4l .. 4l+3)
+//       hdr = f16 d | f16 dmin | W1 | W2 | W3: the sixteen 6-bit scales / mins re-encoded so that no field any lane extracts with
+//       one bit-field instruction straddles a word (the file's 12 bytes, losslessly):
+//         W1 = sc0 | sc1<<6 | sc2<<12 | sc3<<18 | sc4<<24 | (m7 & 3)<<30
+//         W2 = ((m7>>2) & 3) | sc5<<2 | sc6<<8 | sc7<<14 | m5<<20 | m6<<26
+//         W3 = ((m7>>4) & 3) | m0<<2 | m1<<8 | m2<<14 | m3<<20 | m4<<26
+//   Q5_K record 1408 B: qs[64][16] | qh[64][4] | hdr[8][16]      lane qh word = file qh bytes 4l .. 4l+3 (bit v = vector v)
+//   Q6_K record 1680 B: ql[64][16] | qh[64][8] | sc[8][16] | d[8] f16
+//       lane ql dwords (2n, 2n+1) = file ql bytes 64n + 4l.., 64n + 32 + 4l..; qh dword n = file qh bytes 32n + 4l..;
+//       sc of a slot = the even scales (sc[0], sc[2], .. sc[14]) then the odd ones: lane l reads the 8 bytes of parity l >> 2
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -48,8 +63,9 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
-enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4 };
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
+CT_HD static inline int l9_record_bytes(int t) { return tile8_record_bytes(t); }   // same bytes, arranged per lane
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
 struct DevMat {
@@ -58,7 +74,8 @@ struct DevMat {
     int nb = 0;                 // blocks per row (K/256 for K-quants, K/32 for Q4_0/Q8_0)
     const uint8_t* p[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
-    const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (inside an arena several matrices may share)
+    const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (inside an arena several matrices may share): prompt-chunk kernels
+    const uint8_t* r9 = nullptr;   // LAYOUT_L9 records, same arena geometry: decode mat-vec (kernels_v9.h)
     int layout = 0;                // LAYOUT_R2C4 (records in r2) / LAYOUT_G4 (records in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };
