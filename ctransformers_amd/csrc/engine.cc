@@ -14,6 +14,7 @@
 #include "gguf_reader.h"
 #include "kernels_v7.h"
 #include "kernels_v9.h"
+#include "kernels_attn9.h"
 #include "kernels_q32.h"
 #include "kernels_pf.h"
 #include "kernels_pg.h"
@@ -1236,6 +1237,24 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         // all channels of a head in one workgroup (ALLCH)
         const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)nt);
         if (hd == 128) ATTN(256, 128, true, ag1); else ATTN(256, 64, true, ag1);
+        return;
+    }
+    static const int attn_gen = env_int("CT_AMD_ATTN_GEN", 9);   // 7: attn_fused_exact_kernel (A/B partner)
+    if (nt == 0 && attn_gen != 7 && (hd == 128 || hd == 64)) {
+        // decode, generation 9 (kernels_attn9.h): a workgroup per (head, group of output channels); the groups per head are what
+        // makes the grid about one workgroup per CU — every group recomputes the head's score row, so no more of them than that
+        int ng = hd / 16;
+        while (ng > hd / 64 && hp_.n_head * ng > chip_cus()) ng >>= 1;   // at most four V*P waves beside the seven score waves: the kernel is built for <= 768 threads
+        const int pv_waves = hd / ng / 16;
+        const dim3 g9((unsigned)(hp_.n_head * ng)), b9((unsigned)(448 + 64 * pv_waves));
+#define ATTN9(HDV, PBV, VBV) do { \
+        auto kfn = attn_decode9_kernel<HDV, PBV, VBV>; \
+        CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
+        CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax, ng); } while (0)
+        const bool deep = n_ctx_ > 1024;   // ring depth of the K / V requests
+        if (hd == 128) { if (deep) ATTN9(128, 4, 16); else ATTN9(128, 2, 4); }
+        else { if (deep) ATTN9(64, 4, 16); else ATTN9(64, 2, 4); }
+#undef ATTN9
         return;
     }
     if (hd == 128) ATTN(512, 128, false, ag);

@@ -392,7 +392,15 @@ template <class T> DEV T wave_sum_fast(T v) {
 // which hipcc otherwise fetches with a vector load followed by `s_waitcnt vmcnt(0)` — draining every weight load in flight.
 #ifdef CT_EMU
 static inline int sload_i32(const int* p) { return *p; }
+static inline void sload_i32x4(const int* p, int (&v)[4]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
 #else
+// four consecutive dwords, one scalar load
+DEV void sload_i32x4(const int* p, int (&v)[4]) {
+    typedef int i32x4s __attribute__((ext_vector_type(4)));
+    i32x4s r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+}
 DEV int sload_i32(const int* p) {
     int v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");

@@ -1,0 +1,214 @@
+// Decode attention, generation 9: one launch per layer on EVERY CU, written for its latency chain.
+//
+// attn_fused_exact_kernel (kernels_exact.h) runs a token's attention as n_head x head_dim/64 workgroups — 64 of 256 CUs for a 7B —
+// and as a serial chain: position (vector load) -> K rows -> scores -> max -> exp table -> sum -> V*P -> leftovers, each link one
+// memory latency: 9200 cycles at 140 positions (profiles/r03_v9_inkernel_trace_7b_q4km.txt), bandwidth-bound on a quarter of the
+// chip at 2000 (31 us).  Here:
+//   * grid = n_head x ng workgroups, ng = head_dim / (channels per workgroup) chosen by the host so that the grid is about one
+//     workgroup per CU (7B: 32 heads x 8 groups of 16 channels; 70B: 64 heads x 4 groups of 32): a workgroup owns a group of output
+//     channels of one head and recomputes the head's score row — cheap at short contexts, and at long ones the redundancy (ng) is
+//     what the host bounds.  The groups of a head sit on one XCD (blockIdx % 8 is the XCD: for speed only), so its K rows come out of
+//     that XCD's L2 after the first fetch and HBM sees K and V once.
+//   * seven score waves (a quad of lanes per position, 112 positions per pass and slot) + one V*P wave per 16 channels — the V*P
+//     waves are the last of the workgroup, which start up to a microsecond after the first (wave launch rate): they are not on the
+//     critical path before the probabilities exist.  Nothing waits for
+//     the cursor: the query, the K rows of the first 256 positions (clamped to the cache) and the first V chunks are requested at
+//     kernel entry, the cursor {step, pos, n_total, batch} arrives as ONE scalar load beside them; the V*P waves' rows landed long
+//     before the probabilities exist, the leftover positions' V values are requested as soon as the cursor is known.
+// The arithmetic per position / channel and its order are attn_fused_exact_kernel's (reference ggml_vec_dot_f16, ggml.c:2392-2425:
+// a quad of lanes owns the four AVX accumulator vectors of a dot product; softmax through the fp16 exp table with an order-free
+// double sum, ggml.c:12009-12078; V*P in steps of 32 positions in order, leftovers sequentially in double).
+#pragma once
+#include "kernels_exact.h"
+
+// PB / VB: K-row slots per quad / V chunk slots per V*P lane — the depth of the request rings.  The host picks (2, 4) for contexts up
+// to 1024 (the requests of a deeper ring only delay the short chain) and (4, 16) above.
+template <int HD, int PB, int VB>
+__global__ void __launch_bounds__(768) attn_decode9_kernel(const AttnArgsX a, int ng) {
+    constexpr int NT = 448, NWV = 7, NQ = NT / 4;   // score waves / threads (with one V*P wave: a 512-thread workgroup); NQ quads: positions per pass and slot
+    constexpr int NC = HD / 32;                     // 16-byte chunks of a K row per quad lane
+    constexpr int PSPEC = 2, VSPEC = 4;             // slots requested before the cursor is known (a slot is re-requested for the next pass right after its use)
+    CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats
+    float* prob = reinterpret_cast<float*>(smem_raw);
+    __shared__ double red[NWV];
+    __shared__ float redf[NWV];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = tid & 3, quad = tid >> 2;
+    // workgroup -> (head, channel group): the workgroups that read the same K / V rows (the query heads of one KV head, all their
+    // channel groups) take consecutive positions on ONE XCD (blockIdx % 8) where the head counts allow it — for speed only
+    int h, grp;
+    {
+        const int b = (int)blockIdx.x, rep = a.n_head / a.n_head_kv;
+        if ((a.n_head_kv & 7) == 0) {
+            const int i = b >> 3, per = rep * ng;
+            const int hkv = (b & 7) + 8 * (i / per), r = (i / ng) % rep;
+            h = hkv * rep + r; grp = i % ng;
+        } else { h = b / ng; grp = b - h * ng; }
+    }
+    const bool trace = a.trace && blockIdx.x == 0 && lane == 0;
+    unsigned long long* tr = a.trace + 16 * (wv < 16 ? wv : 15);
+    if (trace) tr[0] = clock64_dev();
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const bool pv_wave = wv >= NWV;                 // V*P: 16 channels x 4 lanes per wave, HD / ng / 16 such waves
+    // ---- requests that do not depend on the cursor ----
+    const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
+    // One register set for both kinds of waves (they are the same kernel: separate arrays would be allocated side by side and spill):
+    // score waves: buf = K-row slots [PB][NC], aux = this lane's slices of the query (fp16 pairs, read through v_fma_mix_f32);
+    // V*P waves: buf = V chunk slots [VB], aux = the leftover positions' values
+    constexpr int NBUF = PB * NC > VB ? PB * NC : VB;
+    static_assert(NC <= 4, "register set");
+    u32x4 buf[NBUF], aux[4];
+    const int d = grp * (HD / ng) + (pv_wave ? wv - NWV : 0) * 16 + (lane >> 2);
+    const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
+    if (pv_wave) {
+#pragma unroll
+        for (int u = 0; u < VSPEC; ++u) {
+            const int off = 32 * u + 32 <= a.v_stride ? 32 * u : a.v_stride - 32;
+            buf[u] = ld16(vrow + off + 8 * j);
+        }
+    } else {
+        const uint16_t* qrow = a.q_f16 + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aux[c] = ld16(qrow + 32 * c + 8 * j);
+#pragma unroll
+        for (int u = 0; u < PSPEC; ++u) {
+            int p = u * NQ + quad;
+            p = p < a.n_ctx ? p : a.n_ctx - 1;
+            const uint16_t* krow = kbase + (size_t)p * HD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
+        }
+    }
+    // ---- the cursor: {step, pos, n_past + n, batch} (kernels.h), one scalar load ----
+    int cur[4];
+    sload_i32x4(a.pos - 1, cur);
+    const int n_kv = cur[1] + 1;
+    // The length of the value dot product is that of the reference batch this token belongs to (attn_fused_exact_kernel).
+    int n_tot = cur[2];
+    if (cur[3] > 0) {
+        const int idx = cur[0], base = cur[1] - cur[0];
+        const int end = (idx / cur[3] + 1) * cur[3], n_eval = n_tot - base;
+        n_tot = base + (end < n_eval ? end : n_eval);
+    }
+    const int np = n_tot & ~31;
+    const int nl = n_kv - np;   // leftover positions (< 32), wave-uniform
+    if (pv_wave) {   // the rest of the first V chunks, the leftover positions' values
+#pragma unroll
+        for (int u = VSPEC; u < VB; ++u)
+            if (32 * u < np) buf[u] = ld16(vrow + 32 * u + 8 * j);
+        if (nl > 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) aux[c] = ld16(vrow + np + 8 * c);
+        }
+    } else {         // the K rows of the first pass beyond the speculative slots
+#pragma unroll
+        for (int u = PSPEC; u < PB; ++u) {
+            const int p = u * NQ + quad;
+            if (u * NQ < n_kv && p < n_kv) {   // first condition: wave-uniform (a scalar branch skips the requests of a short context)
+                const uint16_t* krow = kbase + (size_t)p * HD;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
+            }
+        }
+    }
+    if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
+    // ---- scores: a pass = PB x 128 positions; a slot's K row of the NEXT pass is requested right after its dot product ----
+    float mx = -INFINITY;
+    if (!pv_wave) {
+        for (int base = 0; base < n_kv; base += NQ * PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int p = base + u * NQ + quad;
+                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float kf[8], qf[8];
+                    unpack8_f16(buf[u * NC + c], kf);
+                    unpack8_f16(aux[c], qf);
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
+                }
+                const int pn = p + NQ * PB;
+                if (base + u * NQ + NQ * PB < n_kv && pn < n_kv) {
+                    const uint16_t* krow = kbase + (size_t)pn * HD;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
+                }
+                const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+                if (p < n_kv) {
+                    mx = fmaxf(mx, sc);
+                    if (j == 0) prob[p] = sc;
+                }
+            }
+        }
+    }
+    if (trace) tr[2] = clock64_dev();
+    mx = fmaxf(mx, lane_xor4(mx)); mx = fmaxf(mx, lane_xor8(mx)); mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
+    if (lane == 0 && !pv_wave) redf[wv] = mx;
+    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+    if (trace) tr[3] = clock64_dev();
+    // ---- softmax: fp16 exp table, order-free double sum (the addends are multiples of 2^-24 in (0, 1]) ----
+    double sum = 0.0;
+    constexpr int SB = 4;   // exp-table lookups of 4 elements per thread in flight together
+    for (int i0 = 0; !pv_wave && i0 < n_kv; i0 += NT * SB) {
+        uint16_t e16[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { const int i = i0 + u * NT + tid; e16[u] = i < n_kv ? a.exp_tab[f32_to_f16_bits(prob[i] - mx)] : (uint16_t)0; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * NT + tid;
+            if (i < n_kv) { const float e = f16_bits_to_f32(e16[u]); prob[i] = e; sum += (double)e; }
+        }
+    }
+    if (!pv_wave) {
+        sum = wave_sum_fast(sum);
+        if (lane == 0) red[wv] = sum;
+    }
+    __syncthreads();
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) tot += red[w];
+    const float inv = (float)(1.0 / tot);
+    if (!pv_wave) {
+        for (int i = tid; i < n_kv; i += NT) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+        for (int i = n_kv + tid; i < np; i += NT) prob[i] = 0.0f;  // masked columns of this batch
+    }
+    __syncthreads();
+    if (trace) tr[4] = clock64_dev();
+    if (!pv_wave) return;
+    // ---- V*P of this wave's 16 channels: a quad per channel; a chunk slot is re-requested right after its fmas ----
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i0 = 0; i0 < np; i0 += 32 * VB) {
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            const int i = i0 + 32 * u;
+            if (i < np) {
+                float vf[8];
+                unpack8_f16(buf[u], vf);
+                const float* pr = &prob[i + 8 * j];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+                if (i + 32 * VB < np) buf[u] = ld16(vrow + i + 32 * VB + 8 * j);
+            }
+        }
+    }
+    const float res = f16dot_reduce_exact(acc, j);
+    double sumf = (double)res;
+    if (trace) tr[5] = clock64_dev();
+    // leftover positions np .. n_kv - 1: ggml_vec_dot_f16's scalar tail, sumf += (double)(x[i] * y[i]) in order
+    if (nl > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float lf[8];
+            unpack8_f16(aux[c], lf);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
+            }
+        }
+    }
+    if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
+    if (trace) tr[6] = clock64_dev();
+}
