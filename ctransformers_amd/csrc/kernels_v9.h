@@ -424,10 +424,11 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             }
         }
     };
-    // Records requested before the prologue: about 32 KB per CU over the 16 waves — what the CU's memory pipeline keeps in flight.
+    // Records requested before the prologue: about 50 KB per CU over the 16 waves — what the CU's memory pipeline takes without
+    // blocking the waves in the issue of their requests (four per wave: the last wave reaches the prologue thousands of cycles late).
     // A wave without units requests nothing (wave-uniform branch; it only takes part in the prologue).
 #ifndef V9_PRE
-#define V9_PRE (TYPE == GT_Q6_K ? 1 : 2)
+#define V9_PRE (TYPE == GT_Q6_K ? 2 : 3)   // measured on the 7B: 1 -> 687, 2 -> 715, 3 -> 737, 4 -> 730 tok/s
 #endif
     constexpr int PRE = V9_PRE;
     if (nu == 0) {   // its own copy of the prologue: the path with requests below stays free of conditional loads
@@ -494,7 +495,9 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             issue(R, G);
         }
         acc = quad_chain4(acc, dv, sv);
+#ifndef V9_SKIP_MINS   // measurement only (wrong results)
         if constexpr (mins) accm = quad_chain4(accm, mv, pv);
+#endif
         if (s + 1 < spu) { ++s; return; }
         const float t4 = acc + lane_xor16(acc);
         const float t2 = t4 + lane_xor8(t4);
