@@ -85,7 +85,16 @@ const char* ctransformers_llm_detokenize(ctransformers_llm* llm, int token) {
     return llm->piece.c_str();
 }
 
-bool ctransformers_llm_is_eos_token(ctransformers_llm* llm, int token) { return token == llm->engine().vocab().eos_id; }
+bool ctransformers_llm_is_eos_token(ctransformers_llm* llm, int token) {
+    const auto& v = llm->engine().vocab();
+    if (token == v.eos_id) return true;
+    // StarChat / Dolly end markers of legacy files with special pieces (reference models/llm.h:78-89 LLM::IsEosToken)
+    if (!v.special.empty()) {
+        const std::string text = v.piece(token);
+        return text == "<|end|>" || text == "### End";
+    }
+    return false;
+}
 int ctransformers_llm_eos_token_id(ctransformers_llm* llm) { return llm->engine().vocab().eos_id; }
 int ctransformers_llm_bos_token_id(ctransformers_llm* llm) { return llm->engine().vocab().bos_id; }
 int ctransformers_llm_vocab_size(ctransformers_llm* llm) { return llm->engine().hparams().n_vocab; }
@@ -205,7 +214,7 @@ int ctamd_stage_eval_batched(ctransformers_llm* llm, const int* tokens, int n_to
 int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine().hparams().n_layer; }
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine().hparams().n_embd; }
 long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine().chunk_tokens(); }
-long long ctamd_v7_launches(void) { return ctamd::v7_launches(); }
+long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {

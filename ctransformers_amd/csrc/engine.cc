@@ -12,7 +12,6 @@
 #include <unistd.h>
 
 #include "gguf_reader.h"
-#include "kernels_v7.h"
 #include "kernels_v9.h"
 #include "kernels_attn9.h"
 #include "kernels_q32.h"
@@ -254,7 +253,7 @@ void Engine::release_staged() {
     if (dev_file_) { hipFree(dev_file_); dev_file_ = nullptr; }
 }
 
-// LAYOUT_R2C4 copies for the decode mat-vec (kernels_v7.h).  The matrices of `parts` are placed back to back in ONE device
+// LAYOUT_L9 (decode mat-vec, kernels_v9.h) and LAYOUT_R2C4 (prompt chunks, kernels_pg.h) copies.  The matrices of `parts` are placed back to back in ONE device
 // allocation, in order: a launch walks the row pairs of all its jobs of one weight type as a single contiguous unit space
 // (attn_q | attn_k | attn_v).  `fuse` (two parts of the same type and shape): ONE fused gate/up matrix, unit u = (row u of
 // parts[0], row u of parts[1]), described by parts[0].second; else unit u of a part = its rows (2u, 2u + 1).
@@ -905,37 +904,28 @@ static int chip_cus() {   // CUs of the current device (cached per device)
     return n_cu[d];
 }
 
-// Generation 7 (kernels_v7.h): every job a K-quant matrix with a LAYOUT_R2C4 copy (gate/up: ONE job, the fused matrix).
+// K-quant decode mat-vec (kernels_v9.h): every job a K-quant matrix with a LAYOUT_L9 arena (gate/up: ONE job, the fused matrix).
 // Units are row pairs; the jobs' units are concatenated, type group A first.
-static bool v7_can(const MatvecArgs& a) {
+static bool kq_can(const MatvecArgs& a) {
     if (a.njobs < 1 || a.njobs > 3 || a.K > 32768) return false;
-    if (a.gateup) return a.njobs == 1 && a.job[0].w.layout == LAYOUT_R2C4 && a.job[0].w.r2;
+    if (a.gateup) return a.njobs == 1 && a.job[0].w.layout == LAYOUT_R2C4 && a.job[0].w.r9;
     for (int j = 0; j < a.njobs; ++j) {
         const int e = a.job[j].epi;
-        if (!a.job[j].w.r2 || !is_kquant(a.job[j].w.type)) return false;
+        if (!a.job[j].w.r9 || !is_kquant(a.job[j].w.type)) return false;
         if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_GELU || e == EPI_ADD2)) return false;
     }
     return true;
 }
 
-static long long g_v7_launches = 0;   // test hook (ctamd_v7_launches): which generation produced the logits a test compared
-long long v7_launches() { return g_v7_launches; }
+static long long g_kq_launches = 0;   // test hook (ctamd_kq_launches): K-quant decode mat-vec launches (kernels_v9.h) of this process
+long long kq_launches() { return g_kq_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
 long long pg_launches() { return g_pg_launches; }
 
-// CT_AMD_MATVEC_GEN=7: the previous generation on the LAYOUT_R2C4 arena (A/B partner); default: generation 9 on LAYOUT_L9.
-static int matvec_gen() {
-    static const int g = env_int("CT_AMD_MATVEC_GEN", 9);
-    return g;
-}
-
-static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
-    ++g_v7_launches;
-    const bool g9 = matvec_gen() != 7;
-    if (g9) {
-        for (int j = 0; j < a.njobs; ++j) {
-            if (!a.job[j].w.r9) { err = "mat-vec: K-quant matrix without a LAYOUT_L9 arena"; return false; }
-        }
+static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
+    ++g_kq_launches;
+    for (int j = 0; j < a.njobs; ++j) {
+        if (!a.job[j].w.r9) { err = "mat-vec: K-quant matrix without a LAYOUT_L9 arena"; return false; }
     }
     const int ta = a.job[0].w.type;
     int tb = 0, item0 = 0, na = 0;
@@ -946,7 +936,7 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
         const int units = a.gateup ? a.job[j].w.M : (a.job[j].w.M + 1) / 2;
         a.job[j].pair0 = item0;
         item0 += units;
-        const double bytes = (double)units * spu * tile8_record_bytes(tj);
+        const double bytes = (double)units * spu * l9_record_bytes(tj);
         if (tj == ta && tb == 0) { na += units; bytes_a += bytes; }
         else if ((tb == 0 && tj == GT_Q6_K) || tj == tb) { tb = tj; bytes_b += bytes; }
         else { err = "unsupported weight-type mix in one launch"; return false; }
@@ -954,17 +944,14 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     a.n_pairs = item0;
     a.n_groupA = na;
     // the units of a type group are one contiguous stream: job j + 1 of a group starts where job j ends (upload_r2c4 arenas)
-    a.baseA = g9 ? a.job[0].w.r9 : a.job[0].w.r2;
+    a.baseA = a.job[0].w.r9;
     a.baseB = nullptr;
     for (int j = 0; j < a.njobs; ++j) {
         const bool first_b = tb != 0 && a.job[j].pair0 == na;
-        if (first_b) { a.baseB = g9 ? a.job[j].w.r9 : a.job[j].w.r2; continue; }
+        if (first_b) { a.baseB = a.job[j].w.r9; continue; }
         if (j == 0) continue;
         const int uj = a.job[j].pair0 - a.job[j - 1].pair0;
-        const uint8_t* here = g9 ? a.job[j].w.r9 : a.job[j].w.r2;
-        const uint8_t* prev = g9 ? a.job[j - 1].w.r9 : a.job[j - 1].w.r2;
-        const int recb = g9 ? l9_record_bytes(a.job[j - 1].w.type) : tile8_record_bytes(a.job[j - 1].w.type);
-        if (here != prev + (size_t)uj * spu * recb) {
+        if (a.job[j].w.r9 != a.job[j - 1].w.r9 + (size_t)uj * spu * l9_record_bytes(a.job[j - 1].w.type)) {
             err = "mat-vec jobs of one weight type are not contiguous in memory";
             return false;
         }
@@ -976,16 +963,16 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
     }
     const bool ln = a.pro == PRO_LAYERNORM;
     if (ln && tb != 0) { err = "LayerNorm prologue with a mixed-type launch"; return false; }
-    // one workgroup per CU; more only where a wave would otherwise own more than kV7MaxUnits units (its results wait in LDS
+    // one workgroup per CU; more only where a wave would otherwise own more than kV9MaxUnits units (its results wait in LDS
     // for its epilogue pass) — no real model shape gets there on 256 CUs, the 4-CU emulated chip of the tests does
     int gx = std::max(1, std::min(chip_cus(), a.n_pairs));
     {
         const int nb_units = a.n_pairs - na, nwb = 16 - a.nwA;
-        if (a.nwA > 0) gx = std::max(gx, (na + a.nwA * kV7MaxUnits - 1) / (a.nwA * kV7MaxUnits));
-        if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV7MaxUnits - 1) / (nwb * kV7MaxUnits));
+        if (a.nwA > 0) gx = std::max(gx, (na + a.nwA * kV9MaxUnits - 1) / (a.nwA * kV9MaxUnits));
+        if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV9MaxUnits - 1) / (nwb * kV9MaxUnits));
     }
     const dim3 grid((unsigned)gx), block(1024);
-    if (g9) {
+    {
         if (a.emb_out && (tb != 0 || a.K > 16384)) { err = "emb_out on a mixed-type or wide launch"; return false; }
         if (tb != 0 && a.K > 16384) { err = "mixed-type launch with K > 16384"; return false; }
 #define V9L(MK, TAV, TBV, LNV, EMBV) do { \
@@ -1008,56 +995,16 @@ static bool launch_matvec_v7(MatvecArgs& a, hipStream_t s, std::string& err) {
 #undef V9
 #undef V9T
 #undef V9L
-        return true;
     }
-    if (a.emb_out) {   // lm_head: the instantiation that also stores the normalised vector (one launch per token)
-        if (tb != 0 || a.K > 16384) { err = "emb_out on a mixed-type or wide launch"; return false; }
-#define V7E(TAV) do { \
-            auto kfn = matvec_v7_kernel<16384, TAV, 0, false, true>; \
-            auto kfl = matvec_v7_kernel<16384, TAV, 0, true, true>; \
-            constexpr size_t smem = sizeof(SmemV7<16384>); \
-            CT_OPTIN_ONCE(kfn, smem); \
-            CT_OPTIN_ONCE(kfl, smem); \
-            if (ln) CT_LAUNCH_DYN(kfl, grid, block, smem, s, a); else CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
-        if (ta == GT_Q4_K) V7E(GT_Q4_K); else if (ta == GT_Q5_K) V7E(GT_Q5_K); else V7E(GT_Q6_K);
-#undef V7E
-        return true;
-    }
-#define V7L(MK, TAV, TBV, LNV) do { \
-        auto kfn = matvec_v7_kernel<MK, TAV, TBV, LNV>; \
-        constexpr size_t smem = sizeof(SmemV7<MK>); \
-        CT_OPTIN_ONCE(kfn, smem); \
-        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
-#define V7T(MK, TAV) do { \
-        if (ln) V7L(MK, TAV, 0, true); \
-        else if (tb != 0) V7L(MK, TAV, GT_Q6_K, false); \
-        else V7L(MK, TAV, 0, false); } while (0)
-#define V7(MK) do { \
-        if (ta == GT_Q4_K) V7T(MK, GT_Q4_K); \
-        else if (ta == GT_Q5_K) V7T(MK, GT_Q5_K); \
-        else if (ln) V7L(MK, GT_Q6_K, 0, true); \
-        else V7L(MK, GT_Q6_K, 0, false); } while (0)
-    if (a.K <= 16384) {
-        V7(16384);
-    } else {   // wide rows (ffn_down of the 70B / Falcon-40B class): single-matrix launches only
-        if (tb != 0) { err = "mixed-type launch with K > 16384"; return false; }
-        tb = 0;
-        if (ta == GT_Q4_K) { if (ln) V7L(32768, GT_Q4_K, 0, true); else V7L(32768, GT_Q4_K, 0, false); }
-        else if (ta == GT_Q5_K) { if (ln) V7L(32768, GT_Q5_K, 0, true); else V7L(32768, GT_Q5_K, 0, false); }
-        else { if (ln) V7L(32768, GT_Q6_K, 0, true); else V7L(32768, GT_Q6_K, 0, false); }
-    }
-#undef V7
-#undef V7T
-#undef V7L
     return true;
 }
 
 // One mat-vec launch.
-//   K-quant jobs (LAYOUT_R2C4 arenas)  -> generation 7 (kernels_v7.h), work items are row pairs
+//   K-quant jobs (LAYOUT_L9 arenas)    -> generation 9 (kernels_v9.h), work items are row pairs
 //   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h), work items are 8-row tiles
 static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
-    if (v7_can(a)) return launch_matvec_v7(a, s, err);
-    if (a.job[0].w.layout != LAYOUT_G4) { err = "mat-vec: this launch shape has no kernel (K-quant launch outside generation 7)"; return false; }
+    if (kq_can(a)) return launch_matvec_kq(a, s, err);
+    if (a.job[0].w.layout != LAYOUT_G4) { err = "mat-vec: this launch shape has no kernel (K-quant launch without LAYOUT_L9 arenas)"; return false; }
     a.emb_out = nullptr;
     int item0 = 0;
     for (int j = 0; j < a.njobs; ++j) {   // set_jobs counted row pairs; the kernels count tiles
@@ -1458,7 +1405,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = xl; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (kq_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
         else CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
     }
@@ -1789,7 +1736,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (v7_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (kq_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
         else if (!only_site_)
             CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
                       hp_.rms_eps);

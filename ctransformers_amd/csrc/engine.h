@@ -32,7 +32,7 @@ struct Layer {
     float* attn_norm = nullptr;
     float* ffn_norm = nullptr;
     DevMat wq, wk, wv, wo, w_gate, w_up, w_down;
-    DevMat w_gu;   // fused gate/up matrix in LAYOUT_R2C4 (decode, kernels_v7.h): pair u = (gate row u, up row u)
+    DevMat w_gu;   // fused gate/up matrix in LAYOUT_R2C4 (decode: LAYOUT_L9 arena, kernels_v9.h; prompt chunks: LAYOUT_R2C4): pair u = (gate row u, up row u)
     // falcon (llm_build_falcon, llama.cpp:2493-2798): LayerNorm biases, optional second norm (40B), fused QKV
     float* attn_norm_b = nullptr;
     float* attn_norm2 = nullptr;
@@ -44,7 +44,7 @@ struct Layer {
 };
 
 long long pg_launches();   // test hook: prompt-chunk launches of kernels_pg.h issued by this process
-long long v7_launches();   // test hook: decode mat-vec launches of generation 7 issued by this process
+long long kq_launches();   // test hook: K-quant decode mat-vec launches (kernels_v9.h) issued by this process
 
 class Engine {
    public:

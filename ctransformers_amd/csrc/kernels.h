@@ -1,7 +1,7 @@
 // Hand-written CDNA4 (gfx950, wave64) kernels of the decode hot path that replaces ggml_compute_forward's ops
 // (reference models/ggml/ggml.c) for the llama / falcon / gpt2 graphs.  This header: shared argument structures and the
 // small kernels (embedding row, norms, falcon RoPE + KV store, gpt2 F32 attention, pipeline hand-off, cursor, greedy pick).  The
-// decode mat-vec lives in kernels_v7.h (K-quants; shared block math in kernels_kq.h) and kernels_q32.h (Q8_0 / Q4_0), the prompt-chunk
+// decode mat-vec lives in kernels_v9.h (K-quants), the decode attention in kernels_attn9.h, and kernels_q32.h (Q8_0 / Q4_0), the prompt-chunk
 // kernels in kernels_pg.h / kernels_pf.h, the fp16 attention kernels and the Q8_K prologues in kernels_exact.h.
 //
 // Numerics contract: not only the reference's quantization points but the f32

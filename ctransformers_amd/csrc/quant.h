@@ -9,7 +9,7 @@
 //   Q6_K 210 B / 256 w: 128 B low nibbles | 64 B high 2-bits | 16 x int8 scales | f16 d
 // (a Q6_K row of K=11008 is 9030 B in the file: rows are only 2-byte aligned — the repack is what makes 16-byte loads legal)
 //
-// LAYOUT_R2C4 (K-quants; kernels_v7.h decode, kernels_pg.h prompt chunks): a record holds 2 rows x 4 consecutive K-blocks = 8 block
+// LAYOUT_R2C4 (K-quants; kernels_pg.h prompt chunks): a record holds 2 rows x 4 consecutive K-blocks = 8 block
 // slots (slot p = 4 * row + c), fields grouped so that a wavefront reads each field with 16-byte-per-lane loads; a row pair
 // ("unit") = ceil(nb / 4) consecutive records, blocks past nb are zero slots.  The matrices of a launch site (attn_q | attn_k |
 // attn_v; the fused gate/up matrix: unit u = gate row u, up row u) share one arena, so a launch walks one contiguous unit space.

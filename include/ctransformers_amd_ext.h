@@ -42,8 +42,8 @@ int ctamd_n_embd(ctransformers_llm* llm);
 /* Tokens this handle has evaluated through the prompt-chunk kernels (kernels_pf.h) rather than token by token; lets a
    test assert which path produced the logits it compared. */
 long long ctamd_chunk_tokens(ctransformers_llm* llm);
-/* Decode mat-vec launches of generation 7 (kernels_v7.h) issued by this process so far (eager launches and graph captures). */
-long long ctamd_v7_launches(void);
+/* K-quant decode mat-vec launches (kernels_v9.h) issued by this process so far (eager launches and graph captures). */
+long long ctamd_kq_launches(void);
 /* prompt-chunk launches on the f16 matrix cores (kernels_pg.h) issued by this process so far */
 long long ctamd_pg_launches(void);
 /* In-process pipeline (CT_AMD_DEVICES, csrc/pipeline.h): number of stages of this handle (1 = single GPU) and the layer range of a

@@ -72,7 +72,7 @@ def ref():
 
 # The emulator-heavy tests go to the xdist workers first: `--dist load` hands tests out in collection order, and a three-minute
 # test that starts last is three minutes of one busy worker and seven idle ones.
-_HEAVY_FIRST = ("test_edge_requests_match_reference_build", "test_v7_ragged_and_wide_rows", "test_chunk_attention_across_position_tiles",
+_HEAVY_FIRST = ("test_edge_requests_match_reference_build", "test_matvec9_ragged_and_wide_rows", "test_chunk_attention_across_position_tiles",
                 "test_mpt_on_emulator_build", "test_reference_package_drives_this_library", "test_reference_hf_transformers_shim",
                 "test_wide_rows_on_emulator_build", "test_starcoder_on_emulator_build", "test_wide_k_rows", "test_inprocess_pipeline_equals_reference",
                 "test_gloo_pipeline", "test_stage_chain_micro_batches")

@@ -1,4 +1,4 @@
-"""Generation-7 decode mat-vec (kernels_v7.h: row-pair units, wave-private chain exchange, LAYOUT_R2C4) through the CPU
+"""Generation-9 decode mat-vec (kernels_v9.h: row-pair units, lane-major LAYOUT_L9 records, quad-DPP chain) through the CPU
 emulation of the HIP sources: token-by-token evaluation (CT_AMD_PF=0 keeps prompts off the chunk kernels) against the
 golden vectors of the reference build and, for shapes the goldens do not have, against the oracle restatement."""
 import ctypes
@@ -12,26 +12,26 @@ from ctransformers_amd import synth
 from ctransformers_amd.llm import LLM, Config
 
 
-def v7_launches(lib_handle):
-    f = lib_handle.ctamd_v7_launches
+def kq_launches(lib_handle):
+    f = lib_handle.ctamd_kq_launches
     f.restype, f.argtypes = ctypes.c_longlong, []
     return int(f())
 
 
 @pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "falcon-tiny-q4km", "falcon-tiny7-q4km"])
-def test_v7_token_by_token_equals_reference(emu_lib, monkeypatch, name):
-    """Every mat-vec of the prompt and of the greedy steps runs on generation 7 (two-type launches: attn_v / ffn_down are
+def test_matvec9_token_by_token_equals_reference(emu_lib, monkeypatch, name):
+    """Every mat-vec of the prompt and of the greedy steps runs on the K-quant decode kernel (two-type launches: attn_v / ffn_down are
     Q6_K in these files; falcon: LayerNorm prologue, GELU and double-residual epilogues)."""
     monkeypatch.setenv("CT_AMD_PF", "0")
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
-    n0 = v7_launches(m._lib)
+    n0 = kq_launches(m._lib)
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
     assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
     per_layer = 4
     heads = 0 if name.startswith("falcon") else 2         # one lm_head launch per reference batch (8 + 3 tokens); falcon's Q8_0 head is not a K-quant
-    assert v7_launches(m._lib) - n0 == len(g["prompt"]) * 2 * per_layer + heads
+    assert kq_launches(m._lib) - n0 == len(g["prompt"]) * 2 * per_layer + heads
     t = m.sample(top_k=1, repetition_penalty=1.0)
     assert t == int(g["greedy"][0])
     m.eval([t])
@@ -39,7 +39,7 @@ def test_v7_token_by_token_equals_reference(emu_lib, monkeypatch, name):
 
 
 @pytest.mark.parametrize("ftype,n_ff,n_embd", [("Q4_K_M", 2816, 256), ("Q5_K_M", 13312, 256), ("Q4_K_M", 1280, 768)])
-def test_v7_ragged_and_wide_rows(emu_lib, mirror, monkeypatch, tmp_path, ftype, n_ff, n_embd):
+def test_matvec9_ragged_and_wide_rows(emu_lib, mirror, monkeypatch, tmp_path, ftype, n_ff, n_embd):
     """Rows whose block count is not a multiple of the 4 blocks of a record (11, 52 = 13 records, 3 blocks), rows wider than
     one prologue round, odd unit counts per wave: against the oracle restatement, token by token and over a decode step."""
     monkeypatch.setenv("CT_AMD_PF", "0")
@@ -48,9 +48,9 @@ def test_v7_ragged_and_wide_rows(emu_lib, mirror, monkeypatch, tmp_path, ftype, 
     m = LLM(p, config=Config(context_length=32, batch_size=8, threads=1), lib=emu_lib)
     o = mirror.MirrorLlama(p, 32)
     toks = synth.prompt_tokens(3, hp["n_vocab"])
-    n0 = v7_launches(m._lib)
+    n0 = kq_launches(m._lib)
     m.eval(toks)
-    assert v7_launches(m._lib) > n0
+    assert kq_launches(m._lib) > n0
     lg = o.eval(toks, 0)
     assert np.array_equal(m.logits.to_numpy(), lg)
     t = int(lg.argmax())

@@ -28,6 +28,12 @@ def _check(lib, greedy_steps, light=False):
         assert m.model_type == host[mt]["model_type"] and m.eos_token_id == host[mt]["eos"] == 500 and m.context_length == 96
         for text, ids in host[mt]["tokenize"].items():
             assert m.tokenize(text) == ids, (mt, text)
+    # StarChat end marker: an end-of-sequence token wherever special pieces are registered (reference models/llm.h:78-89
+    # LLM::IsEosToken; `<|end|>` is token 507 of this vocabulary), not under the plain gpt2 type
+    for mt, expect in (("starcoder", True), ("gpt_bigcode", True), ("gpt2", False)):
+        m = _open(lib, mt)
+        assert m.is_eos_token(500) and not m.is_eos_token(505)
+        assert m.is_eos_token(507) is expect, mt
     # the markers really are single tokens under starcoder and are spelled out piece by piece under gpt2
     assert host["starcoder"]["tokenize"]["<|user|>"] == [505] and len(host["gpt2"]["tokenize"]["<|user|>"]) > 1
     assert host["gpt_bigcode"] == dict(host["starcoder"], model_type=host["gpt_bigcode"]["model_type"])
@@ -58,6 +64,14 @@ def test_starcoder_file_through_the_c_restatement(mirror):
         assert int(np.argmax(logits)) == int(t)
         logits = m.eval([int(t)], len(g["prompt"]) + i)
         assert np.array_equal(logits, g["logits"][i + 1])
+
+
+def test_end_marker_is_eos_like_the_reference_build(emu_lib, ref):
+    """ctransformers_llm_is_eos_token over the whole vocabulary, against the reference build itself."""
+    for mt in ("starcoder", "gpt2"):
+        m = _open(emu_lib, mt)
+        r = ref.open_llm(PATH, model_type=mt, context_length=96, batch_size=8, threads=1)
+        assert [m.is_eos_token(t) for t in range(512)] == [r.is_eos_token(t) for t in range(512)], mt
 
 
 def test_unknown_legacy_types_are_refused(emu_lib):
