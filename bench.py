@@ -26,6 +26,7 @@ Extra objects on the JSON line:
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
   prefill       the 128-token prompt through the prompt-chunk kernels (third pass = steady state; the cold first pass beside it)
+  other_configs config 3 (always) and configs 4 / 5 (CTAMD_BENCH_BIG=1) as child runs: decode tok/s, per-token roofline fraction, prefill
 """
 import argparse
 import hashlib
@@ -162,6 +163,30 @@ def cpu_baseline(n_vocab):
                 sample="scalar C restatement (oracle/mirror.c), 1 thread, same synthetic file, 2-token prefill then ONE decode step")
 
 
+def other_configs():
+    """The other single-GPU-capable BASELINE configs, each as a child `bench.py --config N` run (own process, own model file):
+    config 3 (Llama-2-7B Q8_0, 7 GB: seconds to synthesise) always, configs 4 / 5 (Falcon-40B Q4_K_M 25 GB, Llama-2-70B Q5_K_M 49 GB on
+    ONE GPU) when CTAMD_BENCH_BIG=1.  Reported, not the headline."""
+    import subprocess
+    todo = [(3, 240)] + ([(4, 900), (5, 1500)] if os.environ.get("CTAMD_BENCH_BIG") == "1" else [])
+    res = []
+    for cfg, limit in todo:
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--no-cpu-baseline", "--no-other-configs", "--steps", "64"],
+                               capture_output=True, text=True, timeout=limit)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(lines[-1]) if lines else None
+        except subprocess.TimeoutExpired:
+            d = None
+        if d is None:
+            res.append(dict(config=cfg, note="did not finish within %d s" % limit))
+            continue
+        res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
+                        prefill_tok_s=d["prefill_tok_s"], load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
+                        bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
+    return res
+
+
 def stage_ranges(llm):
     import ctypes
     L = llm._lib
@@ -192,6 +217,7 @@ def main():
     ap.add_argument("--steps", type=int, default=N_DECODE)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 3 (and 4 / 5 with CTAMD_BENCH_BIG=1)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2: the headline)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
@@ -255,8 +281,10 @@ def main():
         llm.eval([tok])
         tok = llm.sample(top_k=1, repetition_penalty=1.0)
     steps = min(a.steps, N_CTX - N_PROMPT - a.warmup - 1)
-    # llm.eval() returns only after the library synchronised its stream(s) and copied the logits to the host, so the
-    # wall clock below brackets exactly `steps` complete decode steps (device sync on both sides).
+    # llm.eval() returns only after the library synchronised its stream(s); the logits stay in HBM (lazy outputs: they cross the
+    # bus when ctransformers_llm_logits_data is called) and a greedy sample() returns the device-side first-maximum — 4 bytes per
+    # step.  That is the reference's generate() loop (eval + sample, ctransformers/llm.py:503-540); the wall clock below brackets
+    # exactly `steps` complete decode steps (device sync on both sides).
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -274,11 +302,15 @@ def main():
     par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hipMemcpyPeerAsync hand-off)" % n_stages
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,
                ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
-               dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)", data="synthetic",
+               dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)",
+               data="synthetic (random-init weights at the real shapes and tensor-type mix; quantized blocks drawn from a pool of 8192 per type "
+                    "produced by this repo's numpy quantizer, ctransformers_amd/synth.py — not ggml_quantize_chunk; synthetic prompt tokens)",
                config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + 256-tok greedy decode, ctx 512" % n_gpus
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d-tok greedy decode, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
-                           devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached),
+                           devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached,
+                           handoff="none (one stage)" if n_stages == 1 else "hipMemcpyPeerAsync of the [tokens][n_embd] f32 rows, stage to stage "
+                                   "(in-process pipeline: ranks other than 0 only join the barriers — no RCCL traffic on this path)"),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
                token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4),
                                    note="one sequence: the stages of a pipeline are serial, the denominator is ONE GPU's HBM"),
@@ -292,8 +324,13 @@ def main():
                                   else "matvec_pfm_kernel<GU> (lane sums on v_mfma_i32_4x4x4_16b_i8 with the 1.5*2^23 addend, packed f32 chain, Q8_0 activation images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
-    if not a.no_cpu_baseline and n_gpus == 1:
+    if n_gpus == 1 and a.config == 2 and not a.no_other_configs:
         del llm
+        llm = None
+        out["other_configs"] = other_configs()
+    if not a.no_cpu_baseline and n_gpus == 1:
+        if llm is not None:
+            del llm
         out["cpu_baseline"] = cpu_baseline(n_vocab)
     barrier()
     print(json.dumps(out), flush=True)

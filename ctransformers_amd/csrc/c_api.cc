@@ -52,9 +52,10 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     try {   // nothing may propagate across the C boundary: a malformed file makes create return NULL (as the reference does)
     llm = new ctransformers_llm;
     std::string err;
-    // CT_AMD_DEVICES ("4" or "0,1,2,3"): the GPUs whose HBM the layers are spread over, as one in-process pipeline (the Config
-    // struct of the ABI cannot grow; gpu_layers keeps its meaning "offload": every layer lives on a GPU here).
-    const bool ok = gguf ? llm->pipe.load(model_path, config.context_length, config.gpu_layers, ctamd::parse_devices(getenv("CT_AMD_DEVICES")), err)
+    // The GPUs whose HBM the layers are spread over, as one in-process pipeline: CT_AMD_DEVICES ("4" or "0,1,2,3") when set, else
+    // gpu_layers layers per GPU over the visible devices (pipeline.cc:plan_devices; the Config struct of the ABI cannot grow).
+    const bool ok = gguf ? llm->pipe.load(model_path, config.context_length, config.gpu_layers,
+                                          ctamd::plan_devices(model_path, config.gpu_layers, getenv("CT_AMD_DEVICES")), err)
                          : mpt ? llm->pipe.load_mpt(model_path, config.context_length, err)
                          : llm->pipe.load_gpt2(model_path, err, starcoder);
     if (!ok) {

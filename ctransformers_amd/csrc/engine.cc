@@ -203,24 +203,36 @@ bool Engine::stage_file(const GgufFile& f, const std::vector<const GgufTensor*>&
     const size_t total = (size_t)(file_hi_ - file_lo_);
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void**)&dev_file_, total + 256);
-    if (e != hipSuccess) { dev_file_ = nullptr; err = "hipMalloc for the staged model file failed"; return false; }
+    if (e != hipSuccess) {
+        // no room for the file-layout copy beside the repacked arenas: the host repack path (pageable reads of the mapping, host-side
+        // placement, one copy per arena) takes over — slower to load, same result
+        (void)hipGetLastError();
+        dev_file_ = nullptr;
+        return true;
+    }
 #ifdef CT_EMU
     memcpy(dev_file_, file_lo_, total);
 #else
     constexpr int NSLOT = 4;
     constexpr size_t SLOT = (size_t)64 << 20;
     uint8_t* pin[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[NSLOT];
-    hipStream_t cs;
-    HIP_OK(hipStreamCreate(&cs));
-    for (int k = 0; k < NSLOT; ++k) { HIP_OK(hipHostMalloc((void**)&pin[k], SLOT)); HIP_OK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cs = nullptr;
+    bool ok = true;
+    std::string why;
+    auto fail = [&](const char* what, hipError_t code) { ok = false; why = std::string(what) + " failed: " + hipGetErrorString(code); };
+    hipError_t rc = hipStreamCreate(&cs);
+    if (rc != hipSuccess) fail("hipStreamCreate", rc);
+    for (int k = 0; k < NSLOT && ok; ++k) {
+        if ((rc = hipHostMalloc((void**)&pin[k], SLOT)) != hipSuccess) fail("hipHostMalloc", rc);
+        else if ((rc = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreateWithFlags", rc);
+    }
     const off_t base = (off_t)(file_lo_ - f.map_base());
     const int fd = f.fd();
-    bool ok = true;
     int k = 0;
     for (size_t off = 0; off < total && ok; off += SLOT, k = (k + 1) % NSLOT) {
         const size_t len = std::min(SLOT, total - off);
-        if (off >= NSLOT * SLOT) HIP_OK(hipEventSynchronize(ev[k]));   // the copy that last used this slot
+        if (off >= NSLOT * SLOT && (rc = hipEventSynchronize(ev[k])) != hipSuccess) { fail("hipEventSynchronize", rc); break; }   // the copy that last used this slot
         uint8_t* dstp = pin[k];
         std::atomic<bool> good(true);
         parallel_rows((int)((len + (1 << 20) - 1) >> 20), [&](int m0, int m1) {   // 1 MB pieces
@@ -234,14 +246,20 @@ bool Engine::stage_file(const GgufFile& f, const std::vector<const GgufTensor*>&
                 }
             }
         });
-        if (!good) { ok = false; break; }
-        HIP_OK(hipMemcpyAsync(dev_file_ + off, dstp, len, hipMemcpyHostToDevice, cs));
-        HIP_OK(hipEventRecord(ev[k], cs));
+        if (!good) { ok = false; why = "reading the model file failed"; break; }
+        if ((rc = hipMemcpyAsync(dev_file_ + off, dstp, len, hipMemcpyHostToDevice, cs)) != hipSuccess) { fail("hipMemcpyAsync", rc); break; }
+        if ((rc = hipEventRecord(ev[k], cs)) != hipSuccess) { fail("hipEventRecord", rc); break; }
     }
-    HIP_OK(hipStreamSynchronize(cs));
-    for (int q = 0; q < NSLOT; ++q) { hipHostFree(pin[q]); hipEventDestroy(ev[q]); }
-    hipStreamDestroy(cs);
-    if (!ok) { err = "reading the model file failed"; return false; }
+    if (cs) {
+        rc = hipStreamSynchronize(cs);
+        if (ok && rc != hipSuccess) fail("hipStreamSynchronize", rc);
+    }
+    for (int q = 0; q < NSLOT; ++q) {   // every exit path releases the pinned slots, the events and the copy stream
+        if (pin[q]) (void)hipHostFree(pin[q]);
+        if (ev[q]) (void)hipEventDestroy(ev[q]);
+    }
+    if (cs) (void)hipStreamDestroy(cs);
+    if (!ok) { err = why; return false; }
 #endif
     load_stage_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
@@ -1610,8 +1628,11 @@ bool Engine::chunk_step_mpt(int nt, bool want_logits, std::string& err) {
 bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
     chunk_below_128_ = req_past_ + c0 + nt <= 128;   // positions of this chunk: [n_past + c0, n_past + c0 + nt)
 #ifndef CT_EMU
-    if (use_graph_ && l0_ == 0 && l1_ == hp_.n_layer && !prof_ && !only_site_) {
-        const int key = 4 * nt + 2 * (chunk_below_128_ ? 1 : 0) + (want_logits ? 1 : 0);   // the attention kernel depends on the flag
+    if (use_graph_ && !prof_ && !only_site_) {
+        // the attention kernel depends on the flag; a pipeline stage (not the whole model) copies its rows from / to the hand-off
+        // buffer at offset c0, so its graphs are per (c0, shape) — a request's micro-batches start at the same offsets every time
+        const bool whole = l0_ == 0 && l1_ == hp_.n_layer;
+        const long long key = ((long long)(whole ? 0 : c0 + 1) << 24) | (long long)(4 * nt + 2 * (chunk_below_128_ ? 1 : 0) + (want_logits ? 1 : 0));
         auto it = chunk_graphs_.find(key);
         if (it == chunk_graphs_.end() && chunk_seen_[key]++ >= 1) {
             hipGraph_t g = nullptr;

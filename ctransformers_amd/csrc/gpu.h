@@ -15,6 +15,7 @@
 #define CT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define CT_SMEM_OPTIN(fn, bytes) \
     (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) == hipSuccess)
+constexpr bool kConcurrentLaunches = true;   // host threads may launch on different devices at the same time (pipeline.cc: stages load concurrently)
 #endif
 
 #define DEV __device__ __forceinline__

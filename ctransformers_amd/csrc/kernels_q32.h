@@ -27,21 +27,33 @@ template <int MAXK> struct ActLdsQ32 {
 constexpr int kRecQ8_0 = 1088, kRecQ4_0 = 576;
 
 // (RMSNorm ->) Q8_0 into LDS.  1024 threads: 8 lanes per 32-block (lane l holds elements 4l..4l+3), 128 blocks per pass.
-template <int MAXK>
+// `after_requests`: called by every thread once the activations (and norm weights) are requested and before anything waits for
+// them — the decode kernels put a workgroup barrier and their first weight requests there (the CU's memory pipeline serves its
+// requests in order: an activation load queued behind other waves' weight records waits for them, kernels_v9.h).
+struct NoHook { DEV void operator()() const {} };
+template <int MAXK, class Hook = NoHook>
 DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps,
-                       const float* __restrict__ nbias = nullptr) {
+                       const float* __restrict__ nbias = nullptr, Hook after_requests = Hook()) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, l = tid & 7;
     const int nblk = K >> 5;
     constexpr int PASSES = (MAXK / 32 + 127) / 128;
-    float4 v[PASSES];
-    double s = 0.0;
+    float4 v[PASSES], wn[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int b = (tid >> 3) + ps * 128;
         v[ps] = float4{0.f, 0.f, 0.f, 0.f};
+        wn[ps] = float4{0.f, 0.f, 0.f, 0.f};
         if (b < nblk) {
             v[ps] = *(const float4*)(x + b * 32 + l * 4);
-            if (pro == PRO_RMSNORM) {
+            if (pro != PRO_PLAIN) wn[ps] = *(const float4*)(nw + b * 32 + l * 4);
+        }
+    }
+    after_requests();
+    double s = 0.0;
+    if (pro == PRO_RMSNORM) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if ((tid >> 3) + ps * 128 < nblk) {
                 s += (double)(v[ps].x * v[ps].x);
                 s += (double)(v[ps].y * v[ps].y);
                 s += (double)(v[ps].z * v[ps].z);
@@ -96,7 +108,7 @@ DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const fl
         const bool live = b < nblk;
         float4 t = v[ps];
         if (live && pro != PRO_PLAIN) {
-            const float4 w4 = *(const float4*)(nw + b * 32 + l * 4);
+            const float4 w4 = wn[ps];
             t.x = (t.x * scale) * w4.x;
             t.y = (t.y * scale) * w4.y;
             t.z = (t.z * scale) * w4.z;
@@ -265,9 +277,6 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
     const int ng = a.K >> 7;
     const int NA = ng < 16 ? ng : 16;                 // waves that own block groups
     if (threadIdx.x < kQ32Slots) SM.ctr[threadIdx.x] = 0u;   // published by the prologue's barrier
-    const int pos = a.pos ? *a.pos : 0;
-    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b);
-    if (wv >= NA) return;
     const int base = ng / NA, rem = ng % NA;
     const int gcnt = base + (wv < rem ? 1 : 0);
     const int gbeg = wv * base + (wv < rem ? wv : rem);
@@ -304,7 +313,16 @@ __global__ void __launch_bounds__(1024) matvec_q32s_kernel(const MatvecArgs a) {
             }
         }
     };
-    if (n_seq > 0) load_tile(0);
+    // the first tile's records are requested behind every wave's activation requests (barrier) and before the prologue waits
+    prologue_q8_0<MAXK>(SM.L, a.x, a.norm_w, a.K, a.pro, a.eps, a.norm_b, [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        if (wv < NA && n_seq > 0) load_tile(0);
+    });
+    if (wv >= NA) return;
+    bool need_pos = false;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) need_pos = need_pos || (jj < a.njobs && (a.job[jj].epi == EPI_ROPE_Q || a.job[jj].epi == EPI_ROPE_K || a.job[jj].epi == EPI_V));
+    const int pos = (need_pos && a.pos) ? sload_i32(a.pos) : 0;
     float gate_res = 0.0f;
     for (int seq = 0; seq < n_seq; ++seq) {
         float dd[MAXG][4], ss[MAXG][4];

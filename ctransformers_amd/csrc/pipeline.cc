@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <thread>
 
 #include "gguf_reader.h"
 
@@ -51,6 +52,24 @@ std::vector<int> parse_devices(const char* spec) {
         p = q + 1;
     }
     if (d.empty()) d.push_back(0);
+    return d;
+}
+
+// The devices of a handle.  CT_AMD_DEVICES, when set, decides.  Otherwise `gpu_layers` and the visible GPUs do (north_star; reference
+// knob models/llms/llama.cc:88-95 -> llama.cpp:1913-1919, where layers beyond n_gpu_layers stay on the CPU): a GPU takes at most
+// gpu_layers layers and the layers beyond go to the NEXT GPU — ceil(n_layer / gpu_layers) stages, at most one per visible device.
+// gpu_layers <= 0 or >= n_layer (the usual "everything": 50, 100, 1000) is one GPU.  This library has no CPU path either way.
+std::vector<int> plan_devices(const std::string& path, int gpu_layers, const char* env) {
+    if (env && *env) return parse_devices(env);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 1 || gpu_layers <= 0) return {0};
+    GgufFile f;
+    std::string arch;
+    uint32_t nl = 0;
+    if (!f.open(path) || !f.get_str("general.architecture", arch) || !f.get_u32(arch + ".block_count", nl) || nl == 0) return {0};
+    const int stages = std::min(ndev, ((int)nl + gpu_layers - 1) / gpu_layers);
+    std::vector<int> d;
+    for (int i = 0; i < std::max(1, stages); ++i) d.push_back(i);
     return d;
 }
 
@@ -122,11 +141,26 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
     }
     for (int d : dev_)
         if (d < 0 || d >= ndev) { err = "CT_AMD_DEVICES names device " + std::to_string(d) + " but " + std::to_string(ndev) + " are visible"; return false; }
+    // the stages load at the same time, one host thread each (its own device, stream, pinned slots and byte range of the file);
+    // stages that share a device (the 1-GPU test form "0,0") load one after the other
+    for (size_t s = 0; s < dev_.size(); ++s) st_.emplace_back(new Engine());
+    std::vector<std::string> errs(dev_.size());
+    std::vector<char> oks(dev_.size(), 0);
+    bool distinct = true;
+    for (size_t s = 0; s < dev_.size(); ++s)
+        for (size_t t = s + 1; t < dev_.size(); ++t) distinct = distinct && dev_[s] != dev_[t];
+    auto load_one = [&](size_t s) { oks[s] = st_[s]->load(path, context_length, gpu_layers, errs[s], ranges_[s].first, ranges_[s].second, dev_[s]) ? 1 : 0; };
+    if (distinct && kConcurrentLaunches) {
+        std::vector<std::thread> th;
+        for (size_t s = 0; s < dev_.size(); ++s) th.emplace_back(load_one, s);
+        for (auto& t : th) t.join();
+    } else {
+        for (size_t s = 0; s < dev_.size(); ++s) load_one(s);
+    }
     for (size_t s = 0; s < dev_.size(); ++s) {
-        st_.emplace_back(new Engine());
-        if (!st_[s]->load(path, context_length, gpu_layers, err, ranges_[s].first, ranges_[s].second, dev_[s])) {
+        if (!oks[s]) {
             err = "stage " + std::to_string(s) + " (layers " + std::to_string(ranges_[s].first) + ".." + std::to_string(ranges_[s].second) + " on device " +
-                  std::to_string(dev_[s]) + "): " + err;
+                  std::to_string(dev_[s]) + "): " + errs[s];
             return false;
         }
     }
@@ -157,6 +191,17 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
 bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
     if (st_.size() == 1) return st_[0]->eval(tokens, n, n_past, err, batch);
     if (n <= 0) return true;
+    if (eval_stages(tokens, n, n_past, err, batch)) return true;
+    // a host-side failure in the middle of a request: the stages already fed keep running and writing into the next stage's hand-off
+    // buffer and KV cache — drain every stream before the caller sees the error, so that a retry does not overlap stale work
+    for (size_t s = 0; s < st_.size(); ++s) {
+        (void)hipSetDevice(dev_[s]);
+        (void)hipStreamSynchronize(st_[s]->stream());
+    }
+    return false;
+}
+
+bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& err, int batch) {
     const int S = (int)st_.size(), E = st_[0]->hparams().n_embd;
     for (int s = 0; s < S; ++s)
         if (!st_[s]->req_begin(tokens, n, n_past, batch, err)) return false;

@@ -22,6 +22,8 @@ std::vector<std::pair<int, int>> partition_layers(const std::vector<double>& lay
 
 // "4" -> {0,1,2,3}; "0,2" -> {0,2}; "0,0" -> two stages on device 0 (the 1-GPU test form).  Empty / unset -> {0}.
 std::vector<int> parse_devices(const char* spec);
+// The devices of a handle: `env` (CT_AMD_DEVICES) when set, else ceil(n_layer / gpu_layers) stages over the visible GPUs (pipeline.cc).
+std::vector<int> plan_devices(const std::string& path, int gpu_layers, const char* env);
 
 class Pipeline {
    public:
@@ -32,6 +34,7 @@ class Pipeline {
     // one explicit stage (ctamd_stage_create: the multi-process pipeline of ctransformers_amd/pipeline.py drives it from outside)
     bool load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err);
     bool eval(const int* tokens, int n, int n_past, std::string& err, int batch = 0);
+    const std::vector<int>& devices() const { return dev_; }
     bool coalesces_batches() const { return st_.front()->coalesces_batches() || st_.size() > 1; }
     Engine& first() { return *st_.front(); }
     Engine& last() { return *st_.back(); }
@@ -40,6 +43,7 @@ class Pipeline {
     ~Pipeline();
 
    private:
+    bool eval_stages(const int* tokens, int n, int n_past, std::string& err, int batch);
     std::vector<std::unique_ptr<Engine>> st_;
     std::vector<int> dev_;
     std::vector<std::pair<int, int>> ranges_;

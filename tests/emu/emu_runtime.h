@@ -104,6 +104,7 @@ template <class P> static inline hipError_t hipHostMalloc(P** p, size_t n, unsig
 #define CT_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
 #define CT_SMEM_OPTIN(fn, bytes) ((void)(fn), (bytes) <= 160 * 1024)
 
+constexpr bool kConcurrentLaunches = false;   // the fiber scheduler is one-launch-at-a-time: host code must not launch from several threads
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 enum { hipDeviceAttributeMultiprocessorCount = 0 };

@@ -253,6 +253,58 @@ def test_pipeline_stages_on_gpu():
         assert np.array_equal(logits.numpy(), g["logits"][i + 1])
 
 
+def _visible_gpus():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.parametrize("shape,ftype", [("llama-7b-2l", "Q4_K_M"), ("llama-70b-2l", "Q5_K_M")])
+def test_inprocess_pipeline_two_real_devices(ref, tmp_path, monkeypatch, shape, ftype):
+    """Row (e) across a REAL device boundary (skipped on a 1-GPU box): two stages on devices 0 and 1 behind ctransformers_llm_create —
+    peer access, per-device LDS opt-ins and CU counts, cross-device event waits, hipMemcpyPeerAsync over xGMI, per-stage chunk graphs —
+    against the reference build: a 40-token prompt (micro-batches of 16) and greedy steps, every logits vector.  Both the
+    gpu_layers-driven default partition (no CT_AMD_DEVICES) and the explicit one."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs two visible MI355X devices")
+    from ctransformers_amd import synth
+    from ctransformers_amd.llm import LLM, Config
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, shape, ftype, seed=21)
+    cfg = dict(context_length=128, batch_size=64, threads=8)
+    r = ref.open_llm(p, **cfg)
+    toks = synth.prompt_tokens(40, hp["n_vocab"])
+    r.eval(toks)
+    want = [np.array(r.logits.to_numpy(), copy=True)]
+    for _ in range(3):
+        t = int(want[-1].argmax())
+        r.eval([t])
+        want.append(np.array(r.logits.to_numpy(), copy=True))
+    monkeypatch.setenv("CT_AMD_PP_MB", "16")
+    for env, gpu_layers in (("0,1", 1000), (None, 1)):
+        if env is None:
+            monkeypatch.delenv("CT_AMD_DEVICES", raising=False)
+        else:
+            monkeypatch.setenv("CT_AMD_DEVICES", env)
+        m = LLM(p, config=Config(gpu_layers=gpu_layers, **cfg))
+        import ctypes
+        m._lib.ctamd_n_stages.restype, m._lib.ctamd_n_stages.argtypes = ctypes.c_int, [ctypes.c_void_p]
+        assert m._lib.ctamd_n_stages(m._llm) == 2
+        for rep in range(3):            # the third pass replays the stages' chunk graphs
+            m._context = []
+            m.eval(toks)
+            assert np.array_equal(m.logits.to_numpy(), want[0]), (env, rep)
+        for i in range(3):
+            t = m.sample(top_k=1, repetition_penalty=1.0)
+            assert t == int(want[i].argmax())
+            m.eval([t])
+            assert np.array_equal(m.logits.to_numpy(), want[i + 1])
+
+
 def test_pipeline_two_processes_one_gpu(tmp_path):
     """The N > 1 driver on the 1-GPU box: two ranks (gloo rendezvous on 127.0.0.1, hand-off staged through the host), each
     with its HIP stage on cuda:0.  Same assertions as the CPU gloo test, against the reference goldens."""

@@ -230,3 +230,46 @@ def test_inprocess_pipeline_long_prompt_batches(emu_lib, monkeypatch):
     m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
     m.eval(list(g["long_prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
+
+
+def test_gpu_layers_give_the_default_partition(emu_lib, monkeypatch):
+    """Without CT_AMD_DEVICES the stages come from `gpu_layers` and the visible GPUs (csrc/pipeline.cc:plan_devices): a GPU takes at
+    most gpu_layers layers, the layers beyond go to the next GPU (the reference leaves them on the CPU, llama.cpp:1913-1919) —
+    gpu_layers=1 on a 2-layer file and 4 visible devices is two stages; "everything" (1000) and 0 are one GPU; CT_AMD_DEVICES, when
+    set, decides.  Logits are the reference build's either way."""
+    from conftest import GOLDEN
+    from ctransformers_amd.llm import LLM, Config
+    monkeypatch.delenv("CT_AMD_DEVICES", raising=False)
+    monkeypatch.setenv("CT_EMU_DEVICES", "4")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    for gpu_layers, want in ((1, 2), (2, 1), (1000, 1), (0, 1)):
+        m = LLM(path, config=Config(context_length=96, batch_size=8, threads=1, gpu_layers=gpu_layers), lib=emu_lib)
+        n, ranges = _stages(m)
+        assert n == want, (gpu_layers, n)
+        if want == 2:
+            assert ranges == [(0, 1), (1, 2)]
+            m.eval(list(g["prompt"]))
+            assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+    monkeypatch.setenv("CT_AMD_DEVICES", "0,1")
+    m = LLM(path, config=Config(context_length=96, batch_size=8, threads=1, gpu_layers=1000), lib=emu_lib)
+    assert _stages(m)[0] == 2
+    monkeypatch.delenv("CT_AMD_DEVICES")
+    monkeypatch.setenv("CT_EMU_DEVICES", "1")
+    m = LLM(path, config=Config(context_length=96, batch_size=8, threads=1, gpu_layers=1), lib=emu_lib)
+    assert _stages(m)[0] == 1   # one visible device: one stage whatever gpu_layers says
+
+
+def test_inprocess_pipeline_without_chunk_kernels(emu_lib, monkeypatch):
+    """A multi-stage handle reports that it coalesces the reference's batches (c_api.cc sends the whole request down at once)
+    also when the prompt-chunk kernels are off (CT_AMD_PF=0): the token-step attention kernel derives each token's reference batch
+    from the cursor, so the 45-token prompt evaluated as one request equals the reference's batch-by-batch result."""
+    from conftest import GOLDEN
+    from ctransformers_amd.llm import LLM, Config
+    monkeypatch.setenv("CT_EMU_DEVICES", "2")
+    monkeypatch.setenv("CT_AMD_DEVICES", "2")
+    monkeypatch.setenv("CT_AMD_PF", "0")
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
+    m.eval(list(g["long_prompt"]))
+    assert np.array_equal(m.logits.to_numpy(), g["long_chunked"])
