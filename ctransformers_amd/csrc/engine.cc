@@ -152,6 +152,33 @@ CT_HD static inline void place_kblock9(int type, uint8_t* rp, int r, const uint8
     }
 }
 
+// One file-layout Q8_0 / Q4_0 block -> its place in a LAYOUT_L9 record (quant.h): row (0 / 1) of the pair, block i (0..15) of the record.
+CT_HD static inline void place_block32_l9(int type, uint8_t* rp, int row, int i, const uint8_t* blk) {
+    const int t = i >> 2, c = i & 3;
+    if (type == GT_Q8_0) {
+        for (int l = 0; l < 8; ++l) memcpy(rp + (size_t)(32 * row + 4 * l + c) * 16 + 4 * t, blk + 2 + 4 * l, 4);
+        memcpy(rp + 1024 + (row * 4 + c) * 8 + 2 * t, blk, 2);
+    } else {
+        for (int l = 0; l < 4; ++l) memcpy(rp + (size_t)((row * 4 + l) * 4 + c) * 16 + 4 * t, blk + 2 + 4 * l, 4);
+        memcpy(rp + 512 + (row * 4 + c) * 8 + 2 * t, blk, 2);
+    }
+}
+
+// GPU placement of the 32-block types: one thread per (unit, record, row, block) slot of the arena (cleared first).
+__global__ void __launch_bounds__(256) repack_l9b_kernel(int type, const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
+                                                         uint8_t* __restrict__ dst, int M, int nb, int n_units) {
+    const int spu = (nb + 15) / 16, bb = ggml_block_bytes(type), rec = l9_record_bytes(type);
+    const long long n = (long long)n_units * spu * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int bi = (int)(i & 15), rr = (int)((i >> 4) & 1);
+        const long long us = i >> 5;
+        const int s = (int)(us % spu), u = (int)(us / spu);
+        const int row = sb ? u : 2 * u + rr, b = 16 * s + bi;
+        if (row >= M || b >= nb) continue;
+        place_block32_l9(type, dst + (size_t)us * rec, rr, bi, ((sb && rr) ? sb : sa) + ((size_t)row * nb + b) * bb);
+    }
+}
+
 // The same placement on the GPU: one thread per block slot of the arena, reading the tensor in FILE layout from the staged copy of
 // the model file (stage_file).  `sb` != null: fused gate/up (unit u = row u of sa and of sb), else unit u = rows 2u, 2u + 1 of sa.
 // L9: place_kblock9 (decode arena) instead of place_kblock (prompt-chunk arena).
@@ -376,6 +403,65 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
     return true;
 }
 
+// LAYOUT_L9 arena of Q8_0 / Q4_0 matrices for the decode mat-vec (kernels_v9.h); same contract as upload_r2c4 (the matrices of
+// `parts` back to back in one allocation; `fuse`: one fused gate/up matrix described by parts[0].second).  The LAYOUT_G4 copy the
+// prompt-chunk kernels read is made by upload_matrix.
+bool Engine::upload_l9b(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err) {
+    struct Plan { const GgufTensor* ta; const GgufTensor* tb; DevMat* m; size_t off; int type, K, M, nb, n_units; };
+    std::vector<Plan> plan;
+    size_t total = 0;
+    for (size_t i = 0; i < parts.size(); i += fuse ? 2 : 1) {
+        const GgufTensor* ta = parts[i].first;
+        const GgufTensor* tb = fuse ? parts[i + 1].first : nullptr;
+        if (!ta || (fuse && !tb)) { err = "missing tensor for the L9 layout"; return false; }
+        if (!is_block32(ta->type)) { err = "tensor " + ta->name + ": not a 32-element block type"; return false; }
+        if (tb && (tb->type != ta->type || tb->ne[0] != ta->ne[0] || tb->ne[1] != ta->ne[1])) { err = "gate/up tensors differ in type or shape"; return false; }
+        Plan p;
+        p.ta = ta; p.tb = tb; p.m = parts[i].second; p.type = ta->type; p.K = (int)ta->ne[0]; p.M = (int)ta->ne[1]; p.nb = p.K / 32;
+        if (p.K % 32 || p.K > 32768) { err = "tensor " + ta->name + ": rows of " + std::to_string(p.K) + " elements are not supported"; return false; }
+        p.n_units = tb ? p.M : (p.M + 1) / 2;
+        p.off = total;
+        total += (size_t)p.n_units * l9_spu(p.type, p.K) * l9_record_bytes(p.type);
+        plan.push_back(p);
+    }
+    uint8_t* d9 = nullptr;
+    if (!dev_alloc(dev_allocs_, &d9, total + 4096, err)) return false;
+    if (dev_file_) {
+        HIP_OK(hipMemsetAsync(d9, 0, total + 4096, stream_));
+        for (const Plan& p : plan) {
+            const long long n = (long long)p.n_units * l9_spu(p.type, p.K) * 32;
+            const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16);
+            CT_LAUNCH(repack_l9b_kernel, dim3(gx), dim3(256), stream_, p.type, staged(p.ta), p.tb ? staged(p.tb) : (const uint8_t*)nullptr, d9 + p.off, p.M, p.nb, p.n_units);
+        }
+    } else {
+        std::vector<uint8_t> st(total, 0);
+        for (const Plan& p : plan) {
+            const int bb = ggml_block_bytes(p.type), rec = l9_record_bytes(p.type), spu = l9_spu(p.type, p.K);
+            const uint8_t* sa = p.ta->data;
+            const uint8_t* sb = p.tb ? p.tb->data : nullptr;
+            uint8_t* dst = st.data() + p.off;
+            const int M = p.M, nb = p.nb, type = p.type;
+            parallel_rows(p.n_units, [&](int u0, int u1) {
+                for (int u = u0; u < u1; ++u)
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int row = sb ? u : 2 * u + rr;
+                        if (row >= M) continue;
+                        const uint8_t* src = (sb && rr) ? sb : sa;
+                        for (int b = 0; b < nb; ++b)
+                            place_block32_l9(type, dst + ((size_t)u * spu + (b >> 4)) * rec, rr, b & 15, src + ((size_t)row * nb + b) * bb);
+                    }
+            });
+        }
+        HIP_OK(hipMemset(d9 + total, 0, 4096));
+        HIP_OK(hipMemcpy(d9, st.data(), total, hipMemcpyHostToDevice));
+    }
+    for (const Plan& p : plan) {
+        p.m->r9 = d9 + p.off;
+        if (p.tb) { p.m->type = p.type; p.m->K = p.K; p.m->M = p.M; p.m->nb = p.nb; p.m->layout = LAYOUT_L9; p.m->bytes = p.ta->nbytes + p.tb->nbytes; }
+    }
+    return true;
+}
+
 bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::string& err) {
     m.type = t->type;
     m.K = (int)t->ne[0];
@@ -545,6 +631,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (!upload_matrix(t, m, raw, err)) return false;
         if (is_kquant(t->type) && r2_auto && !upload_r2c4({{t, &m}}, false, err)) return false;
+        if (is_block32(t->type) && r2_auto && !upload_l9b({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -615,11 +702,24 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         r2_auto = true;
         if (!mat(p + "attn_output.weight", L.wo, E, E) || !mat(p + "ffn_down.weight", L.w_down, E, F)) return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
-        if (is_kquant(L.wq.type) && is_kquant(L.wk.type) && is_kquant(L.wv.type) &&
-            !upload_r2c4({{f.tensor(p + "attn_q.weight"), &L.wq}, {f.tensor(p + "attn_k.weight"), &L.wk}, {f.tensor(p + "attn_v.weight"), &L.wv}}, false, err))
-            return false;
+        if (is_kquant(L.wq.type) && is_kquant(L.wk.type) && is_kquant(L.wv.type)) {
+            if (!upload_r2c4({{f.tensor(p + "attn_q.weight"), &L.wq}, {f.tensor(p + "attn_k.weight"), &L.wk}, {f.tensor(p + "attn_v.weight"), &L.wv}}, false, err))
+                return false;
+        } else if (is_block32(L.wq.type) && L.wk.type == L.wq.type && L.wv.type == L.wq.type) {
+            if (!upload_l9b({{f.tensor(p + "attn_q.weight"), &L.wq}, {f.tensor(p + "attn_k.weight"), &L.wk}, {f.tensor(p + "attn_v.weight"), &L.wv}}, false, err))
+                return false;
+        } else {   // mixed families or 32-block types: every matrix its own arena (the site then takes one launch per group, launch_matvec)
+            const std::pair<const char*, DevMat*> qkv[3] = {{"attn_q.weight", &L.wq}, {"attn_k.weight", &L.wk}, {"attn_v.weight", &L.wv}};
+            for (const auto& it : qkv) {
+                if (is_kquant(it.second->type) && !upload_r2c4({{f.tensor(p + it.first), it.second}}, false, err)) return false;
+                if (is_block32(it.second->type) && !upload_l9b({{f.tensor(p + it.first), it.second}}, false, err)) return false;
+            }
+        }
         if (is_kquant(L.w_gate.type) &&
             !upload_r2c4({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
+            return false;
+        if (is_block32(L.w_gate.type) &&
+            !upload_l9b({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
             return false;
     }
     if (l1_ == hp_.n_layer) {
@@ -673,9 +773,9 @@ bool Engine::alloc_state(std::string& err) {
     d_tokens_ = d_state_ + 4;
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
     pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
-    bool kq_model = false;
+    bool kq_model = false, mixed_model = false;
     {   // every layer matrix a K-quant (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 32768
-        int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1;
+        int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1, n_any32 = 0;
         for (int i = l0_; i < l1_; ++i) {
             const Layer& L = layers_[i];
             const std::initializer_list<const DevMat*> llama_mats = {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down};
@@ -684,9 +784,13 @@ bool Engine::alloc_state(std::string& err) {
                 ++n_all;
                 if (m->layout == LAYOUT_R2C4 && is_kquant(m->type)) ++n_kq;
                 if (m->layout == LAYOUT_G4 && (ty32 < 0 || ty32 == m->type) && m->K <= 32768) { ++n_q32; ty32 = m->type; }
+                if (m->layout == LAYOUT_G4 && m->K <= 32768) ++n_any32;
             }
         }
-        pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || n_q32 == n_all);
+        // a llama file that mixes the families (a Q8_0 tensor beside K-quants): both kinds of activation images, one pass per family
+        // at a site (pf_matvec)
+        mixed_model = !hp_.falcon() && !hp_.legacy() && n_kq > 0 && n_any32 > 0 && n_kq + n_any32 == n_all;
+        pf_ok_ = pf_ok_ && ((n_kq == n_all && !hp_.gpt2()) || n_q32 == n_all || mixed_model);
         kq_model = n_kq == n_all;
     }
     if (pf_ok_) {
@@ -698,7 +802,8 @@ bool Engine::alloc_state(std::string& err) {
         pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
         if (!kq_model) {   // Q8_0 activation images of the Q8_0 / Q4_0 chunk kernel
             if (!dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * pf_act_words_q32(std::max(E, F)), err)) return false;
-        } else {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
+        }
+        if (kq_model || mixed_model) {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
             acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max((kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES) + 4096;
             if (!dev_alloc(dev_allocs_, &acts_h_, 2 * acts_h_half_, err)) return false;
             HIP_OK(hipMemset(acts_h_, 0, 2 * acts_h_half_));   // token slots past the chunk's end are read (and their results dropped)
@@ -759,6 +864,7 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device, bo
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (t->type != GT_Q4_0 && t->type != GT_Q8_0) { err = name + ": only Q4_0 / Q8_0 legacy weights are supported"; return false; }
         if (!upload_matrix(t, m, false, err)) return false;
+        if (!upload_l9b({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -850,6 +956,7 @@ bool Engine::load_mpt(const std::string& path, int context_length, std::string& 
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
         if (t->type != GT_Q4_0 && t->type != GT_Q8_0) { err = name + ": only Q4_0 / Q8_0 legacy weights are supported"; return false; }
         if (!upload_matrix(t, m, false, err)) return false;
+        if (!upload_l9b({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -926,11 +1033,12 @@ static int chip_cus() {   // CUs of the current device (cached per device)
 // Units are row pairs; the jobs' units are concatenated, type group A first.
 static bool kq_can(const MatvecArgs& a) {
     if (a.njobs < 1 || a.njobs > 3 || a.K > 32768) return false;
-    if (a.gateup) return a.njobs == 1 && a.job[0].w.layout == LAYOUT_R2C4 && a.job[0].w.r9;
+    if (a.gateup) return a.njobs == 1 && a.job[0].w.r9 && (a.job[0].w.layout == LAYOUT_R2C4 || a.job[0].w.layout == LAYOUT_L9);
+    const bool b32 = is_block32(a.job[0].w.type);
     for (int j = 0; j < a.njobs; ++j) {
-        const int e = a.job[j].epi;
-        if (!a.job[j].w.r9 || !is_kquant(a.job[j].w.type)) return false;
-        if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_GELU || e == EPI_ADD2)) return false;
+        const int t = a.job[j].w.type;
+        if (!a.job[j].w.r9 || !(is_kquant(t) || is_block32(t))) return false;
+        if (is_block32(t) != b32 || (b32 && t != a.job[0].w.type)) return false;   // the 32-block types: one type per launch
     }
     return true;
 }
@@ -948,7 +1056,7 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
     const int ta = a.job[0].w.type;
     int tb = 0, item0 = 0, na = 0;
     double bytes_a = 0.0, bytes_b = 0.0;
-    const int spu = ((a.K >> 8) + 3) / 4;
+    const int spu = l9_spu(ta, a.K);
     for (int j = 0; j < a.njobs; ++j) {
         const int tj = a.job[j].w.type;
         const int units = a.gateup ? a.job[j].w.M : (a.job[j].w.M + 1) / 2;
@@ -1006,6 +1114,8 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
 #define V9(MK) do { \
         if (ta == GT_Q4_K) V9T(MK, GT_Q4_K); \
         else if (ta == GT_Q5_K) V9T(MK, GT_Q5_K); \
+        else if (ta == GT_Q8_0) { if (a.emb_out) V9L(16384, GT_Q8_0, 0, false, true); else V9L(MK, GT_Q8_0, 0, false, false); } \
+        else if (ta == GT_Q4_0) { if (a.emb_out) V9L(16384, GT_Q4_0, 0, false, true); else V9L(MK, GT_Q4_0, 0, false, false); } \
         else if (a.emb_out) { if (ln) V9L(16384, GT_Q6_K, 0, true, true); else V9L(16384, GT_Q6_K, 0, false, true); } \
         else if (ln) V9L(MK, GT_Q6_K, 0, true, false); \
         else V9L(MK, GT_Q6_K, 0, false, false); } while (0)
@@ -1020,7 +1130,7 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
 // One mat-vec launch.
 //   K-quant jobs (LAYOUT_L9 arenas)    -> generation 9 (kernels_v9.h), work items are row pairs
 //   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h), work items are 8-row tiles
-static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
+static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
     if (kq_can(a)) return launch_matvec_kq(a, s, err);
     if (a.job[0].w.layout != LAYOUT_G4) { err = "mat-vec: this launch shape has no kernel (K-quant launch without LAYOUT_L9 arenas)"; return false; }
     a.emb_out = nullptr;
@@ -1060,6 +1170,48 @@ static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
     if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
     else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
 #undef Q32S
+    return true;
+}
+
+// A launch site with several matrices (QKV) whose weight types one kernel launch cannot take together — reference files mix freely
+// (llama.cpp:4785-4850: Q4_K_S has attn_v in Q5_K beside Q4_K q/k; a Q8_0 tensor may sit beside K-quants) — is issued as one launch
+// per group of jobs that CAN share a launch: K-quant jobs whose arenas are contiguous and whose types are all equal or "X.. then
+// Q6_K.." (the two-type kernel), or Q8_0 / Q4_0 jobs of one type.  Every group recomputes the (cheap) prologue; the jobs' epilogues
+// are independent, so the results are those of the single launch.
+static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
+    if (a.gateup || a.njobs <= 1) return launch_matvec_one(a, s, err);
+    int i = 0;
+    while (i < a.njobs) {
+        int j = i + 1;
+        const DevMat& w0 = a.job[i].w;
+        const bool kq0 = is_kquant(w0.type) && w0.r9;
+        const bool b0 = is_block32(w0.type) && w0.r9;
+        int tb = 0;
+        while (j < a.njobs) {
+            const DevMat& wp = a.job[j - 1].w;
+            const DevMat& wj = a.job[j].w;
+            if (kq0) {
+                if (!(is_kquant(wj.type) && wj.r9)) break;
+                if (wj.r9 != wp.r9 + (size_t)((wp.M + 1) / 2) * l9_spu(wp.type, a.K) * l9_record_bytes(wp.type)) break;   // not the same arena run
+                if (wj.type != wp.type) {
+                    if (tb != 0 || wj.type != GT_Q6_K || wp.type != w0.type || a.K > 16384) break;   // only "X.. then Q6_K.." shares a launch
+                    tb = wj.type;
+                }
+            } else if (b0) {
+                if (wj.type != w0.type || !wj.r9 || wj.r9 != wp.r9 + (size_t)((wp.M + 1) / 2) * l9_spu(wp.type, a.K) * l9_record_bytes(wp.type)) break;
+            } else {
+                if (wj.layout != LAYOUT_G4 || wj.type != w0.type) break;
+            }
+            ++j;
+        }
+        if (i == 0 && j == a.njobs) return launch_matvec_one(a, s, err);
+        MatvecArgs g = a;
+        g.njobs = j - i;
+        for (int k = 0; k < g.njobs; ++k) g.job[k] = a.job[i + k];
+        for (int k = g.njobs; k < 3; ++k) g.job[k] = MatJob();
+        if (!launch_matvec_one(g, s, err)) return false;
+        i = j;
+    }
     return true;
 }
 
@@ -1307,6 +1459,27 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
                        std::string& err) {
     if (!site_on(site)) return true;
+    if (!m.gateup && m.njobs > 1) {   // K-quant and Q8_0 / Q4_0 matrices (or the two 32-block types) at one site: one pass per family
+        auto fam = [&](int j) { return m.job[j].w.layout == LAYOUT_G4 ? m.job[j].w.type : -1; };
+        bool mixed = false;
+        for (int j = 1; j < m.njobs; ++j) mixed = mixed || fam(j) != fam(0);
+        if (mixed) {
+            int i = 0;
+            while (i < m.njobs) {
+                int j = i + 1;
+                while (j < m.njobs && fam(j) == fam(i)) ++j;
+                MatvecArgs g = m;
+                g.njobs = j - i;
+                int pair0 = 0;
+                for (int k = 0; k < g.njobs; ++k) { g.job[k] = m.job[i + k]; g.job[k].pair0 = pair0; pair0 += (g.job[k].w.M + 1) / 2; }
+                for (int k = g.njobs; k < 3; ++k) g.job[k] = MatJob();
+                g.n_pairs = pair0;
+                if (!pf_matvec(g, x, ldx, nt, ld_out, ld_res, site, bytes * (j - i) / m.njobs, err)) return false;
+                i = j;
+            }
+            return true;
+        }
+    }
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 activation images, kernels_pf.h
@@ -1721,7 +1894,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.ffn_norm; a.out = h_;
-            if (L.w_gu.r2) {   // generation 7: one job, the fused matrix
+            if (L.w_gu.r9) {   // one job, the fused matrix (LAYOUT_L9 arena)
                 a.job[0].w = L.w_gu; a.job[0].pair0 = 0; a.job[0].epi = EPI_SILU_MUL;
                 a.njobs = 1; a.gateup = 1; a.n_pairs = F;
             } else {

@@ -123,6 +123,7 @@ class Engine {
    private:
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
     bool upload_r2c4(const std::vector<std::pair<const struct GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err);
+    bool upload_l9b(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err);
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);

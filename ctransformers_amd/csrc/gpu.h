@@ -69,6 +69,13 @@ static inline void dot4x8(int (&d)[8], const int (&w)[8], const int (&a)[8]) {
 static inline void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias) {
     for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], __builtin_amdgcn_sdot4(bias, a[i], 0, false), false);
 }
+// four independent dot4 (kernels_v9.h, 32-block types): d[i] = dot4(w[i], a[i]) [+ c[i]]
+static inline void dot4x4(int (&d)[4], const int (&w)[4], const int (&a)[4]) {
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], 0, false);
+}
+static inline void dot4x4_add(int (&d)[4], const int (&w)[4], const int (&a)[4], const int (&c)[4]) {
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], c[i], false);
+}
 // d[i] = dot4(w[i], a[i]) + c[i]
 static inline void dot4x8_add(int (&d)[8], const int (&w)[8], const int (&a)[8], const int (&c)[8]) {
     for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_sdot4(w[i], a[i], c[i], false);
@@ -95,6 +102,16 @@ DEV void dot4x8_bias(int (&d)[8], const int (&w)[8], const int (&a)[8], int bias
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]),
           "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bias));
+}
+DEV void dot4x4(int (&d)[4], const int (&w)[4], const int (&a)[4]) {
+    asm("v_dot4_i32_i8 %0, %4, %8, 0\n\tv_dot4_i32_i8 %1, %5, %9, 0\n\tv_dot4_i32_i8 %2, %6, %10, 0\n\tv_dot4_i32_i8 %3, %7, %11, 0\n\ts_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+}
+DEV void dot4x4_add(int (&d)[4], const int (&w)[4], const int (&a)[4], const int (&c)[4]) {
+    asm("v_dot4_i32_i8 %0, %4, %8, %12\n\tv_dot4_i32_i8 %1, %5, %9, %13\n\tv_dot4_i32_i8 %2, %6, %10, %14\n\tv_dot4_i32_i8 %3, %7, %11, %15\n\ts_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
 }
 DEV void dot4x8_add(int (&d)[8], const int (&w)[8], const int (&a)[8], const int (&c)[8]) {
     asm("v_dot4_i32_i8 %0, %8, %16, %24\n\tv_dot4_i32_i8 %1, %9, %17, %25\n\tv_dot4_i32_i8 %2, %10, %18, %26\n\tv_dot4_i32_i8 %3, %11, %19, %27\n\t"

@@ -33,10 +33,13 @@
 
 constexpr int kImg9Stride = 144;  // dwords per block image: 64 quant words | 8 sums of 32 | y.d | 7 unused | 64 x -32 * (sum of a word's quants)
 template <int MAXK> struct Img9 {
-    int blk[(MAXK / 256 + 3) * kImg9Stride];
+    int blk[(MAXK / 256 + 3) * kImg9Stride];   // >= (MAXK / 512 + 1) * kImg9bStride: the 32-block image fits too
     double red[2][16];   // per-wave partial sums (second array: LayerNorm's second moment)
     unsigned cnt;        // arrivals of the waves that own blocks: only they meet for the norm's sums
 };
+// 32-element block types (Q8_0 / Q4_0 weights x Q8_0 activations): one image per record step (16 blocks = 512 activations):
+// 128 quant words [c][l][t] | 128 words -8 * (sum of a word's quants) [c][l][t] (Q4_0: (nibble - 8) . a = nibble . a - 8 * sum) | 16 y.d [c][t]
+constexpr int kImg9bStride = 272;
 constexpr int kV9MaxUnits = 32;   // units one wave may own in a launch (its results wait in LDS for the epilogue pass)
 template <int MAXK> struct SmemV9 {
     Img9<MAXK> L;
@@ -46,6 +49,9 @@ template <int MAXK> struct SmemV9 {
 struct Lane9 {
     int c, l, row, slot;
     uint32_t o16, o8, o4, o_hdr, o_hdr5, o_sc6, o_d6;   // byte offsets inside a record
+    uint32_t o_qs40, o_d80, o_d40;                      // Q4_0 quants, Q8_0 / Q4_0 block scales
+    int a_b;        // 32-block types: word offset of the lane's four activation words (blocks 4t + c) inside a step image
+    int sh40;       // Q4_0: 0 (l < 4: low nibbles) or 4 (high nibbles)
     int a_w;        // word offset of this lane's first four activation words inside a block image
     int m_sh;       // bit offset of min m_l inside the word that holds it
     bool m_w2, m_split;
@@ -59,6 +65,11 @@ DEV Lane9 lane9(int lane) {
     G.o_sc6 = 1536u + (uint32_t)G.slot * 16u + (uint32_t)(G.l >> 2) * 8u;
     G.o_d6 = 1664u + (uint32_t)G.slot * 2u;
     G.a_w = 4 * G.l;
+    G.o_qs40 = (uint32_t)((G.row * 4 + (G.l & 3)) * 4 + G.c) * 16u;
+    G.o_d80 = 1024u + (uint32_t)(G.row * 4 + G.c) * 8u;
+    G.o_d40 = 512u + (uint32_t)(G.row * 4 + G.c) * 8u;
+    G.a_b = (G.c * 8 + G.l) * 4;
+    G.sh40 = G.l >= 4 ? 4 : 0;
     G.m_w2 = G.l == 5 || G.l == 6;
     G.m_split = G.l == 7;
     G.m_sh = G.l < 5 ? 2 + 6 * G.l : 20 + 6 * (G.l - 5);
@@ -70,7 +81,12 @@ template <int TYPE> struct Rec9;
 template <> struct Rec9<GT_Q4_K> { u32x4 qs, hdr; };
 template <> struct Rec9<GT_Q5_K> { u32x4 qs, hdr; uint32_t qh; };
 template <> struct Rec9<GT_Q6_K> { u32x4 ql; u32x2 qh, sc; uint32_t d; };
-template <int TYPE> DEV constexpr uint32_t rec9_bytes() { return TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u); }
+template <> struct Rec9<GT_Q8_0> { u32x4 qs; u32x2 d; };
+template <> struct Rec9<GT_Q4_0> { u32x4 qs; u32x2 d; };
+template <int TYPE> DEV constexpr bool is_b32() { return TYPE == GT_Q8_0 || TYPE == GT_Q4_0; }
+template <int TYPE> DEV constexpr uint32_t rec9_bytes() {
+    return TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : (TYPE == GT_Q6_K ? 1680u : (TYPE == GT_Q8_0 ? 1088u : 576u)));
+}
 
 template <int TYPE> DEV Rec9<TYPE> rec9_load(const uint8_t* rec, const Lane9& G);
 template <> DEV Rec9<GT_Q4_K> rec9_load<GT_Q4_K>(const uint8_t* rec, const Lane9& G) {
@@ -92,6 +108,19 @@ template <> DEV Rec9<GT_Q6_K> rec9_load<GT_Q6_K>(const uint8_t* rec, const Lane9
     R.sc = ld_stream8(rec + G.o_sc6);
     R.qh = ld_stream8(rec + G.o8);
     R.ql = ld_stream16(rec + G.o16);
+    return R;
+}
+
+template <> DEV Rec9<GT_Q8_0> rec9_load<GT_Q8_0>(const uint8_t* rec, const Lane9& G) {
+    Rec9<GT_Q8_0> R;
+    R.d = ld_stream8(rec + G.o_d80);
+    R.qs = ld_stream16(rec + G.o16);
+    return R;
+}
+template <> DEV Rec9<GT_Q4_0> rec9_load<GT_Q4_0>(const uint8_t* rec, const Lane9& G) {
+    Rec9<GT_Q4_0> R;
+    R.d = ld_stream8(rec + G.o_d40);
+    R.qs = ld_stream16(rec + G.o_qs40);
     return R;
 }
 
@@ -182,6 +211,150 @@ DEV void step9(const Rec9<TYPE>& R, const int* img, const Lane9& G, float& sv, f
         mv = 0.0f;
         pv = 0.0f;
     }
+}
+
+// 32-element block types: one record = 16 blocks of the lane's row = four chain sub-steps; sub-step t: the quad's lanes c = 0..3 hold
+// blocks 4t + c.  Reference ggml.c:3321 (Q8_0) / :2428 (Q4_0), AVX2: acc[l] = fma(fp16(x.d) * fp16(y.d), (float)sumi[l], acc[l]) block
+// after block, sumi[l] = the four products of elements 4l .. 4l+3 (Q4_0: (nibble - 8) . a).
+template <int TYPE>
+DEV float step9b(const Rec9<TYPE>& R, const int* img, const Lane9& G, float acc) {
+    const u32x4 a4 = *(const u32x4*)(img + G.a_b);
+    const f32x4 yd = *(const f32x4*)(img + 256 + 4 * G.c);
+    int w4[4], av[4], d4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = (int)a4[t];
+    if constexpr (TYPE == GT_Q8_0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w4[t] = (int)R.qs[t];
+        dot4x4(d4, w4, av);
+    } else {
+        const u32x4 b4 = *(const u32x4*)(img + 128 + G.a_b);
+        int bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { w4[t] = (int)((R.qs[t] >> G.sh40) & 0x0F0F0F0Fu); bv[t] = (int)b4[t]; }
+        dot4x4_add(d4, w4, av, bv);
+    }
+    const uint32_t dw[4] = {R.d[0] & 0xFFFFu, R.d[0] >> 16, R.d[1] & 0xFFFFu, R.d[1] >> 16};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = quad_chain4(acc, f16_bits_to_f32((uint16_t)dw[t]) * yd[t], (float)d4[t]);
+    return acc;
+}
+
+// Prologue of the 32-block types: (RMSNorm | LayerNorm | nothing) -> Q8_0 images.  Reference ggml.c:1208-1300 (AVX2 path): per 32
+// elements d = amax / 127 stored as fp16, id = 127 / amax (0 when amax == 0), q = round-half-even(x * id).  8 lanes per block (lane l
+// holds elements 4l .. 4l+3), 128 blocks per pass of the 1024 threads.
+template <int MAXK> struct Pro9b {
+    static constexpr int PASSES = MAXK / 32 / 128;
+    static constexpr bool EARLY_W = MAXK <= 16384;
+    float4 x[PASSES];
+    float4 w[EARLY_W ? PASSES : 1];
+};
+template <int MAXK>
+DEV void pro9b_load(Pro9b<MAXK>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro) {
+    const int tid = (int)threadIdx.x, l = tid & 7, nblk = K >> 5;
+#pragma unroll
+    for (int ps = 0; ps < Pro9b<MAXK>::PASSES; ++ps) {
+        const int b = (tid >> 3) + ps * 128;
+        P.x[ps] = float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (Pro9b<MAXK>::EARLY_W) P.w[ps] = float4{0.f, 0.f, 0.f, 0.f};
+        if (b < nblk) {
+            P.x[ps] = *(const float4*)(x + b * 32 + l * 4);
+            if constexpr (Pro9b<MAXK>::EARLY_W) {
+                if (pro != PRO_PLAIN) P.w[ps] = *(const float4*)(nw + b * 32 + l * 4);
+            }
+        }
+    }
+}
+template <int MAXK, bool Q4BIAS, bool EMB>
+DEV void pro9b_finish(Img9<MAXK>& L, Pro9b<MAXK>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro, float eps,
+                      float* __restrict__ emb_out) {
+    constexpr int PASSES = Pro9b<MAXK>::PASSES;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, l = tid & 7;
+    const int nblk = K >> 5, nimg = ((nblk + 15) >> 4) << 4;
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {   // ggml.c:10700-10716: double sum, f32 mean, 1/sqrtf
+        double s = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if ((tid >> 3) + ps * 128 < nblk) {
+                const float4 q = P.x[ps];
+                s += (double)(q.x * q.x); s += (double)(q.y * q.y); s += (double)(q.z * q.z); s += (double)(q.w * q.w);
+            }
+        }
+        s = wave_sum_fast(s);
+        if (lane == 0) L.red[0][wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += L.red[0][w];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + eps);
+    } else if (pro == PRO_LAYERNORM) {   // ggml.c:10605-10654
+        double s1 = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            if ((tid >> 3) + ps * 128 < nblk) { const float4 q = P.x[ps]; s1 += (double)q.x; s1 += (double)q.y; s1 += (double)q.z; s1 += (double)q.w; }
+        s1 = wave_sum_fast(s1);
+        if (lane == 0) L.red[0][wv] = s1;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += L.red[0][w];
+        const float mean = (float)(tot / (double)K);
+        double s2 = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if ((tid >> 3) + ps * 128 < nblk) {
+                float4& q = P.x[ps];
+                q.x -= mean; q.y -= mean; q.z -= mean; q.w -= mean;
+                s2 += (double)(q.x * q.x); s2 += (double)(q.y * q.y); s2 += (double)(q.z * q.z); s2 += (double)(q.w * q.w);
+            }
+        }
+        s2 = wave_sum_fast(s2);
+        if (lane == 0) L.red[1][wv] = s2;
+        __syncthreads();
+        double tot2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot2 += L.red[1][w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int b = (tid >> 3) + ps * 128;
+        const bool live = b < nblk;
+        float4 t = live ? P.x[ps] : float4{0.f, 0.f, 0.f, 0.f};
+        if (live && pro != PRO_PLAIN) {
+            float4 w4;
+            if constexpr (Pro9b<MAXK>::EARLY_W) w4 = P.w[ps];
+            else w4 = *(const float4*)(nw + b * 32 + l * 4);
+            t.x = (t.x * scale) * w4.x; t.y = (t.y * scale) * w4.y; t.z = (t.z * scale) * w4.z; t.w = (t.w * scale) * w4.w;
+            if (pro == PRO_LAYERNORM) {
+                const float4 b4 = *(const float4*)(nbias + b * 32 + l * 4);
+                t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+            }
+            if constexpr (EMB) {
+                if (emb_out && blockIdx.x == 0) *(float4*)(emb_out + b * 32 + l * 4) = t;
+            }
+        }
+        float amax = fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w)));
+        amax = fmaxf(amax, lane_xor1(amax));
+        amax = fmaxf(amax, lane_xor2(amax));
+        amax = fmaxf(amax, lane_xor4(amax));
+        const float d = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        const int q0 = (int)__builtin_rintf(t.x * id), q1 = (int)__builtin_rintf(t.y * id);
+        const int q2 = (int)__builtin_rintf(t.z * id), q3 = (int)__builtin_rintf(t.w * id);
+        if (b < nimg) {   // blocks past the row's end (the padding of its last record): zero quants, y.d = 0
+            const int packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+            const int i16 = b & 15, tt = i16 >> 2, c = i16 & 3;
+            int* img = &L.blk[(b >> 4) * kImg9bStride];
+            img[(c * 8 + l) * 4 + tt] = packed;
+            if constexpr (Q4BIAS) img[128 + (c * 8 + l) * 4 + tt] = sdot4(packed, (int)0xF8F8F8F8u, 0);   // -8 * (sum of the four quants)
+            if (l == 0) img[256 + c * 4 + tt] = (int)f32_to_bits(f16_bits_to_f32(f32_to_f16_bits(d)));
+        }
+    }
+    __syncthreads();
 }
 
 // ---- prologue -----------------------------------------------------------------------------------------------------------------
@@ -401,9 +574,10 @@ template <bool B> struct V9Req { static constexpr bool value = B; };
 template <int TYPE, int MAXK, bool TWO, class Pro>
 DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int g0, int first, int stride, int end, int lane, int wv,
                 Pro pro) {
-    constexpr bool mins = TYPE != GT_Q6_K;
+    constexpr bool B32 = is_b32<TYPE>();
+    constexpr bool mins = TYPE == GT_Q4_K || TYPE == GT_Q5_K;
     constexpr uint32_t REC = rec9_bytes<TYPE>();
-    const int nb = a.K >> 8, spu = (nb + 3) >> 2;
+    const int spu = B32 ? ((a.K >> 5) + 15) >> 4 : ((a.K >> 8) + 3) >> 2;
     const size_t unit_bytes = (size_t)spu * REC;
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
@@ -428,7 +602,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // blocking the waves in the issue of their requests (four per wave: the last wave reaches the prologue thousands of cycles late).
     // A wave without units requests nothing (wave-uniform branch; it only takes part in the prologue).
 #ifndef V9_PRE
-#define V9_PRE (TYPE == GT_Q6_K ? 2 : 3)   // measured on the 7B: 1 -> 687, 2 -> 715, 3 -> 737, 4 -> 730 tok/s
+#define V9_PRE ((TYPE == GT_Q6_K || B32) ? 2 : 3)   // measured on the 7B: 1 -> 687, 2 -> 715, 3 -> 737, 4 -> 730 tok/s
 #endif
     constexpr int PRE = V9_PRE;
     if (nu == 0) {   // its own copy of the prologue: the path with requests below stays free of conditional loads
@@ -468,13 +642,16 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     const bool e_own = e_valid && e_r < e_M;
     const bool need_res = e_own && (e_epi == EPI_ADD || e_epi == EPI_ADD2), need_res2 = e_own && e_epi == EPI_ADD2;
     const bool need_rope = e_own && (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K);
+    const bool need_bias = e_own && (e_epi == EPI_BIAS_STORE || e_epi == EPI_BIAS_ADD || e_epi == EPI_BIAS_GELU);
+    const bool need_res_b = e_own && e_epi == EPI_BIAS_ADD;
     // the cursor position: only launches that write the KV cache / rotate (QKV) read it; after the barriers, so that this
     // scalar-cache round trip holds up no other wave
     bool need_pos = false;
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) need_pos = need_pos || (jj < a.njobs && (a.job[jj].epi == EPI_ROPE_Q || a.job[jj].epi == EPI_ROPE_K || a.job[jj].epi == EPI_V));
     const int pos = (need_pos && a.pos) ? sload_i32(a.pos) : 0;
-    const float e_res = (need_res ? a.res : a.x)[need_res ? e_r : 0];
+    const float e_res = ((need_res || need_res_b) ? a.res : a.x)[(need_res || need_res_b) ? e_r : 0];
+    const float e_bias = (need_bias ? a.bias : a.x)[need_bias ? e_r : 0];
     const float e_res2 = (need_res2 ? a.res2 : a.x)[need_res2 ? e_r : 0];
     const float2 e_cs = *(const float2*)((need_rope ? a.rope_cs : a.x) +
                                          (need_rope ? ((size_t)pos * (a.head_dim >> 1) + ((e_r % a.head_dim) >> 1)) * 2 : 0));
@@ -488,16 +665,23 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // reference's reduction tree (hsum_float_8: (x_l + x_{l+4}), then l ^ 2, then l ^ 1; l sits in lane bits 2..4) — the row results
     // wait in LDS for the epilogue pass.  A surplus step of the last group re-processes the last record; its result is dropped.
     auto step = [&](Rec9<TYPE>& R, auto REQ) __attribute__((always_inline)) {
-        float sv, dv, mv, pv;
-        step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
-        if constexpr (decltype(REQ)::value) {
-            reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
-            issue(R, G);
+        if constexpr (B32) {   // 16 blocks of the row: four chain sub-steps inside
+            acc = step9b<TYPE>(R, &SM.L.blk[s * kImg9bStride], G, acc);
+            if constexpr (decltype(REQ)::value) {
+                float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+                reg_fence(acc, z0, z1, z2);
+                issue(R, G);
+            }
+        } else {
+            float sv, dv, mv, pv;
+            step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
+            if constexpr (decltype(REQ)::value) {
+                reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
+                issue(R, G);
+            }
+            acc = quad_chain4(acc, dv, sv);
+            if constexpr (mins) accm = quad_chain4(accm, mv, pv);
         }
-        acc = quad_chain4(acc, dv, sv);
-#ifndef V9_SKIP_MINS   // measurement only (wrong results)
-        if constexpr (mins) accm = quad_chain4(accm, mv, pv);
-#endif
         if (s + 1 < spu) { ++s; return; }
         const float t4 = acc + lane_xor16(acc);
         const float t2 = t4 + lane_xor8(t4);
@@ -542,6 +726,12 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
         a.out[e_r] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
     } else if (e_epi == EPI_ADD2) {
         a.out[e_r] = (res + e_res) + e_res2;
+    } else if (e_epi == EPI_BIAS_STORE) {
+        a.out[e_r] = e_bias + res;
+    } else if (e_epi == EPI_BIAS_ADD) {
+        a.out[e_r] = (e_bias + res) + e_res;
+    } else if (e_epi == EPI_BIAS_GELU) {
+        a.out[e_r] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(e_bias + res)]);
     } else {   // EPI_ROPE_Q / EPI_ROPE_K: the pair (2u, 2u + 1) is one rotation (reference ggml.c:12536-12537, fma forms of the build)
         const float o = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
         if (e_epi == EPI_ROPE_Q) a.q_f16[e_r] = f32_to_f16_bits(o);
@@ -556,21 +746,35 @@ __global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
     SmemV9<MAXK>& SM = *reinterpret_cast<SmemV9<MAXK>*>(smem_raw);
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
-    Pro9<MAXK, TB == 0> P;
-    pro9_load<MAXK, TB == 0>(P, a.x, a.norm_w, a.K, a.pro, wv, lane);
+    constexpr bool B32 = is_b32<TA>();
+    static_assert(!B32 || TB == 0, "32-block types: single-type launches");
     // Every wave's activation requests are in the CU's memory pipeline before ANY wave requests weights: the pipeline serves a
     // CU's requests in order, and an activation load queued behind other waves' weight records waits for them to stream in from
     // HBM (measured: with the whole ring requested before the prologue, its end moved from cycle 7200 to 11600).  The barrier also
     // publishes the cleared arrival counter of the prologue.
-    if (threadIdx.x == 0) SM.L.cnt = 0u;
-    __syncthreads();
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
+    const int grid = (int)gridDim.x, bx = (int)blockIdx.x;
+    if constexpr (B32) {
+        Pro9b<MAXK> P;
+        pro9b_load<MAXK>(P, a.x, a.norm_w, a.K, a.pro);
+        __syncthreads();
+        const unsigned long long t0 = trace ? clock64_dev() : 0ull;
+        auto pro = [&]() __attribute__((always_inline)) {
+            pro9b_finish<MAXK, TA == GT_Q4_0, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
+        };
+        v9_run<TA, MAXK, false>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
+        if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
+        return;
+    } else {
+    Pro9<MAXK, TB == 0> P;
+    pro9_load<MAXK, TB == 0>(P, a.x, a.norm_w, a.K, a.pro, wv, lane);
+    if (threadIdx.x == 0) SM.L.cnt = 0u;
+    __syncthreads();
     const unsigned long long t0 = trace ? clock64_dev() : 0ull;
     auto pro = [&]() __attribute__((always_inline)) {
         pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane);
     };
-    const int grid = (int)gridDim.x, bx = (int)blockIdx.x;
     if constexpr (TB != 0) {
         const int nwA = a.nwA;
         if (wv < nwA) v9_run<TA, MAXK, true>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
@@ -579,4 +783,5 @@ __global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
         v9_run<TA, MAXK, false>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
     }
     if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
+    }
 }

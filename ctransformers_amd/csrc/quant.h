@@ -65,7 +65,14 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
 enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
-CT_HD static inline int l9_record_bytes(int t) { return tile8_record_bytes(t); }   // same bytes, arranged per lane
+// LAYOUT_L9 for the 32-element block types (kernels_v9.h): a record holds 2 rows x 16 consecutive blocks; lane (row, l, c) reads the
+// dwords of blocks 4t + c (t = 0..3: the record's four chain sub-steps), elements 4l .. 4l+3, as ONE 16-byte load
+//   Q8_0 record 1088 B: qs[64 lanes][4 t][4 B] | d[2 rows][4 c][4 t] f16          (2 x 16 x 34 B: the file's bytes)
+//   Q4_0 record  576 B: qs[2 rows][4 (l & 3)][4 c][4 t][4 B] | d[2][4][4] f16      (lanes l and l + 4 share a dword: low / high nibbles)
+CT_HD static inline int l9_record_bytes(int t) { return t == GT_Q8_0 ? 1088 : (t == GT_Q4_0 ? 576 : tile8_record_bytes(t)); }
+// records per unit (row pair) of a row of K elements
+CT_HD static inline int l9_spu(int t, int K) { return (t == GT_Q8_0 || t == GT_Q4_0) ? ((K >> 5) + 15) >> 4 : ((K >> 8) + 3) >> 2; }
+CT_HD static inline bool is_block32(int t) { return t == GT_Q8_0 || t == GT_Q4_0; }
 
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
 struct DevMat {

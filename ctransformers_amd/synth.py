@@ -259,6 +259,9 @@ def llama_tensor_types(ftype, n_layer):
             t["blk.%d.%s.weight" % (i, nm)] = base
         t["blk.%d.attn_v.weight" % i] = G.Q6_K if more else base
         t["blk.%d.ffn_down.weight" % i] = G.Q6_K if more else base
+        if ftype == "Q4_K_S" and i < 4:   # llama.cpp:4801 (attn_v) and :4830-4832 (ffn_down): Q5_K in the first four layers
+            t["blk.%d.attn_v.weight" % i] = G.Q5_K
+            t["blk.%d.ffn_down.weight" % i] = G.Q5_K
     return t
 
 
@@ -341,8 +344,9 @@ def make_spm_vocab(n_vocab=512):
 
 
 def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_train=4096, pooled=None,
-                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None):
-    """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict."""
+                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None, type_overrides=None):
+    """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict.
+    type_overrides: {tensor-name suffix: ggml type} applied on top of the ftype's mix (e.g. {"attn_v.weight": G.Q8_0})."""
     hp = dict(LLAMA_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     if overrides:
         hp.update(overrides)
@@ -354,6 +358,10 @@ def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_
         pooled = n_embd >= 2048
     src = _WeightSource(seed, pooled)
     types = llama_tensor_types(ftype, n_layer)
+    for suffix, ty in (type_overrides or {}).items():
+        for name in list(types):
+            if name.endswith(suffix):
+                types[name] = ty
 
     w = G.GGUFWriter(path)
     w.add_str("general.architecture", "llama")

@@ -82,6 +82,8 @@ def test_abi_semantics_on_gpu():
     ("llama-small", "Q8_0", 20, 40),     # config 3: 32-element blocks, Q8_0 activations (kernels_q32.h)
     ("llama-small", "Q4_0", 20, 40),     # Q4_0 layers + Q6_K head
     ("llama-7b-2l", "Q8_0", 33, 8),      # real 7B shapes: K = 4096 / 11008 (86 block groups), 32000-row Q8_0 head
+    ("llama-7b-2l", "Q4_K_S", 33, 8),    # Q4_K_S mix at 7B widths: attn_v / ffn_down in Q5_K beside Q4_K (one launch per type group at the QKV site)
+    ("llama-7b-2l", "Q4_K_M+v_q8_0", 20, 6),   # a Q8_0 attn_v beside K-quant q / k: K-quant and 32-block kernels at one site
     ("falcon-small", "Q4_K_M", 40, 30),  # config 4 graph: LayerNorm x2, fused QKV (Q5_K), neox RoPE, GQA 16/2, GELU, Q8_0 head
     ("falcon-tiny7", "Q8_0", 20, 50),    # 7B-style block (one norm, MQA) on the 32-element-block kernels
     ("falcon-40b-2l", "Q4_K_M", 9, 4),   # config 4 widths: K = 8192 (12288 instantiation) and K = 32768 (wide-K path), Q8_0 head
@@ -101,6 +103,9 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
         hp, mt = synth.write_gpt2_ggml(p, shape, seed=21, ftype={"Q4_0": 2, "Q8_0": 7}[ftype], pieces=synth.STARCODER_PIECES), "starcoder"
     elif shape.startswith("mpt"):
         hp, mt = synth.write_mpt_ggml(p, shape, seed=21, ftype={"Q4_0": 2, "Q8_0": 7}[ftype]), "mpt"
+    elif "+v_q8_0" in ftype:
+        from ctransformers_amd import gguf as G
+        hp = synth.write_llama_gguf(p, shape, ftype.split("+")[0], seed=21, type_overrides={"attn_v.weight": G.Q8_0})
     else:
         hp = (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p, shape, ftype, seed=21)
     ctx = n_prompt + n_decode + 8

@@ -30,7 +30,7 @@ def test_matvec9_token_by_token_equals_reference(emu_lib, monkeypatch, name):
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
     assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
     per_layer = 4
-    heads = 0 if name.startswith("falcon") else 2         # one lm_head launch per reference batch (8 + 3 tokens); falcon's Q8_0 head is not a K-quant
+    heads = 2                                              # one lm_head launch per reference batch (8 + 3 tokens); falcon's Q8_0 head takes the same kernel
     assert kq_launches(m._lib) - n0 == len(g["prompt"]) * 2 * per_layer + heads
     t = m.sample(top_k=1, repetition_penalty=1.0)
     assert t == int(g["greedy"][0])
@@ -56,3 +56,34 @@ def test_matvec9_ragged_and_wide_rows(emu_lib, mirror, monkeypatch, tmp_path, ft
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 3))
+
+
+@pytest.mark.parametrize("case", ["Q4_K_S", "v_q8_0", "k_q4_0_v_q5_k"])
+def test_matvec9_type_mixes_at_one_site(emu_lib, mirror, monkeypatch, tmp_path, case):
+    """Weight-type mixes one kernel launch cannot take together are issued as one launch per group (engine.cc:launch_matvec; reference
+    files mix freely, llama.cpp:4785-4850): a Q4_K_S file (attn_v and ffn_down in Q5_K beside Q4_K), a Q8_0 attn_v beside K-quant
+    q / k, a Q4_0 attn_k and a Q5_K attn_v beside a Q4_K attn_q.  Token by token and through the prompt-chunk kernels, against the
+    oracle restatement."""
+    from ctransformers_amd import gguf as G
+    p = str(tmp_path / "m.gguf")
+    kw = dict(overrides=dict(n_layer=2))
+    if case == "Q4_K_S":
+        hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_S", seed=11, **kw)
+    elif case == "v_q8_0":
+        hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=12, type_overrides={"attn_v.weight": G.Q8_0}, **kw)
+    else:
+        hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=13, type_overrides={"attn_k.weight": G.Q4_0, "attn_v.weight": G.Q5_K}, **kw)
+    o = mirror.MirrorLlama(p, 32)
+    toks = synth.prompt_tokens(9, hp["n_vocab"])
+    o.eval(toks[:8], 0)
+    want = np.array(o.eval(toks[8:], 8), copy=True)   # the restatement returns a view of its live logits buffer
+    for pf in ("0", "1"):
+        monkeypatch.setenv("CT_AMD_PF", pf)
+        m = LLM(p, config=Config(context_length=32, batch_size=8, threads=1), lib=emu_lib)
+        m.eval(toks)
+        assert np.array_equal(m.logits.to_numpy(), want), (case, pf)
+        t = int(want.argmax())
+        m.eval([t])
+        if pf == "0":
+            nxt = np.array(o.eval([t], 9), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), nxt), (case, pf)
