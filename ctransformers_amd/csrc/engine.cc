@@ -1132,45 +1132,8 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
 //   LAYOUT_G4 (Q8_0 / Q4_0)            -> systolic 32-block kernel (kernels_q32.h), work items are 8-row tiles
 static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
     if (kq_can(a)) return launch_matvec_kq(a, s, err);
-    if (a.job[0].w.layout != LAYOUT_G4) { err = "mat-vec: this launch shape has no kernel (K-quant launch without LAYOUT_L9 arenas)"; return false; }
-    a.emb_out = nullptr;
-    int item0 = 0;
-    for (int j = 0; j < a.njobs; ++j) {   // set_jobs counted row pairs; the kernels count tiles
-        a.job[j].pair0 = a.gateup ? 0 : item0;
-        item0 += (a.job[j].w.M + 7) / 8;
-    }
-    a.n_pairs = a.gateup ? (a.job[0].w.M + 7) / 8 : item0;
-    const int ty = a.job[0].w.type;
-    const dim3 grid((unsigned)std::max(1, std::min(chip_cus(), a.n_pairs))), block(1024);
-    for (int j = 1; j < a.njobs; ++j)
-        if (a.job[j].w.type != ty || a.job[j].w.layout != LAYOUT_G4) { err = "mixed weight types in a Q8_0/Q4_0 launch"; return false; }
-    if (a.K > 12288) {   // wide rows (K = 4 d_model of the MPT / StarCoder down projections): sub-batched systolic form
-        if (a.K > 32768 || a.gateup) { err = "Q8_0/Q4_0 mat-vec with K > 32768 (or a gate/up launch with K > 12288) not supported"; return false; }
-        for (int j = 0; j < a.njobs; ++j)
-            if (a.job[j].epi == EPI_ROPE_Q || a.job[j].epi == EPI_ROPE_K) { err = "rotary epilogue on a wide Q8_0/Q4_0 launch"; return false; }
-        if (ty == GT_Q8_0) CT_LAUNCH((matvec_q32w_kernel<GT_Q8_0, 32768, 6>), grid, block, s, a);
-        else CT_LAUNCH((matvec_q32w_kernel<GT_Q4_0, 32768, 6>), grid, block, s, a);
-        return true;
-    }
-    static const int systolic = env_int("CT_AMD_Q32_SYSTOLIC", 1);
-    if (!systolic) {   // A/B: wave-per-tile form
-        const dim3 g((unsigned)std::max(1, std::min(chip_cus(), (a.n_pairs + 15) / 16)));
-        if (ty == GT_Q8_0) {
-            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, true>), g, block, s, a);
-            else CT_LAUNCH((matvec_q32_kernel<GT_Q8_0, 12288, false>), g, block, s, a);
-        } else {
-            if (a.gateup) CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, true>), g, block, s, a);
-            else CT_LAUNCH((matvec_q32_kernel<GT_Q4_0, 12288, false>), g, block, s, a);
-        }
-        return true;
-    }
-#define Q32S(TY, MG) do { if (a.gateup) CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, true>), grid, block, s, a); \
-                          else CT_LAUNCH((matvec_q32s_kernel<TY, 12288, MG, false>), grid, block, s, a); } while (0)
-    const int per_wave = ((a.K >> 7) + 15) / 16;
-    if (ty == GT_Q8_0) { if (per_wave <= 2) Q32S(GT_Q8_0, 2); else Q32S(GT_Q8_0, 6); }
-    else { if (per_wave <= 2) Q32S(GT_Q4_0, 2); else Q32S(GT_Q4_0, 6); }
-#undef Q32S
-    return true;
+    err = "mat-vec: this launch shape has no kernel (a matrix without a LAYOUT_L9 arena, or weight types that cannot share a launch)";
+    return false;
 }
 
 // A launch site with several matrices (QKV) whose weight types one kernel launch cannot take together — reference files mix freely
@@ -1200,7 +1163,7 @@ static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
             } else if (b0) {
                 if (wj.type != w0.type || !wj.r9 || wj.r9 != wp.r9 + (size_t)((wp.M + 1) / 2) * l9_spu(wp.type, a.K) * l9_record_bytes(wp.type)) break;
             } else {
-                if (wj.layout != LAYOUT_G4 || wj.type != w0.type) break;
+                break;
             }
             ++j;
         }

@@ -433,6 +433,25 @@ static inline int opaque_int(int v) { return v; }
 DEV int opaque_int(int v) { asm volatile("" : "+v"(v)); return v; }
 #endif
 
+// ---- LDS arrival counters: waves of one workgroup meet without a workgroup barrier (kernels_v9.h prologue) ------------------------
+#ifdef CT_EMU
+DEV void lds_signal(unsigned* ctr, int lane, unsigned inc) {
+    if (lane == 0) *ctr += inc;
+}
+DEV void lds_wait_ge(const unsigned* ctr, unsigned target) {
+    while (*(const volatile unsigned*)ctr < target) emu::spin_yield();
+}
+#else
+DEV void lds_signal(unsigned* ctr, int lane, unsigned inc) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS writes are visible before the count moves
+    if (lane == 0) __hip_atomic_fetch_add(ctr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DEV void lds_wait_ge(const unsigned* ctr, unsigned target) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
+
 // sched_fence: nothing is moved across this point by the instruction scheduler.  sgpr_const: a constant the compiler keeps in a scalar
 // register instead of re-materialising it as a literal operand.
 #ifdef CT_EMU

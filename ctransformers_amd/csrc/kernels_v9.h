@@ -29,7 +29,7 @@
 // Arithmetic and its order are generation 7's (= the reference build's, kernels_exact.h header): integer lane sums exact, one fma
 // per block and lane in block order, hsum_float_8's tree at the end of the row.
 #pragma once
-#include "kernels_kq.h"   // lds_signal / lds_wait_ge
+#include "kernels_exact.h"
 
 constexpr int kImg9Stride = 144;  // dwords per block image: 64 quant words | 8 sums of 32 | y.d | 7 unused | 64 x -32 * (sum of a word's quants)
 template <int MAXK> struct Img9 {

@@ -26,7 +26,7 @@ def test_product_build_has_no_register_spills():
         m = re.search(r"remark:\s+(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
         if m and cur is not None:
             cur[m.group(1)] = int(m.group(2))
-    names = [k for k in kernels if "matvec_v7" in k or "matmul_pg" in k or "attn_fused" in k or "q32" in k or "quantize" in k]
+    names = [k for k in kernels if "matvec_v9" in k or "attn_decode9" in k or "matmul_pg" in k or "attn_fused" in k or "matvec_pf" in k or "quantize" in k]
     assert len(names) > 40, "the resource remarks of the hot kernels are in the log (%d found)" % len(names)
     # vector-register spills and scratch memory are what costs; scalar registers parked in vector lanes (v_writelane) touch no memory
     bad = {k: v for k, v in kernels.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}

@@ -1,5 +1,5 @@
 """Q8_0 / Q4_0 rows longer than 12288 elements (the K = 4 d_model down projections of MPT-7B, StarCoder-7B / -15B): the
-sub-batched systolic decode kernel (kernels_q32.h matvec_q32w_kernel) and the chunk kernel with 8 (K <= 16384) or 4 (K <= 32768)
+MAXK = 32768 instantiation of the decode mat-vec (kernels_v9.h, 32-block records) and the chunk kernel with 8 (K <= 16384) or 4 (K <= 32768)
 token images per workgroup, against the reference build on the same file.  The llama graph lets n_ff be wide while everything
 else stays small, so the cases run in seconds on the emulator build; the full MPT-7B / StarCoder widths run on the GPU
 (tests/test_gpu_parity.py)."""
