@@ -650,8 +650,10 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) need_pos = need_pos || (jj < a.njobs && (a.job[jj].epi == EPI_ROPE_Q || a.job[jj].epi == EPI_ROPE_K || a.job[jj].epi == EPI_V));
     const int pos = (need_pos && a.pos) ? sload_i32(a.pos) : 0;
-    const float e_res = ((need_res || need_res_b) ? a.res : a.x)[(need_res || need_res_b) ? e_r : 0];
-    const float e_bias = (need_bias ? a.bias : a.x)[need_bias ? e_r : 0];
+    const bool want_res = need_res || (B32 && need_res_b);
+    const float e_res = (want_res ? a.res : a.x)[want_res ? e_r : 0];
+    float e_bias = 0.0f;   // the bias epilogues exist for the legacy (gpt2 / starcoder / mpt) graphs only: 32-block weight types
+    if constexpr (B32) e_bias = (need_bias ? a.bias : a.x)[need_bias ? e_r : 0];
     const float e_res2 = (need_res2 ? a.res2 : a.x)[need_res2 ? e_r : 0];
     const float2 e_cs = *(const float2*)((need_rope ? a.rope_cs : a.x) +
                                          (need_rope ? ((size_t)pos * (a.head_dim >> 1) + ((e_r % a.head_dim) >> 1)) * 2 : 0));
