@@ -483,9 +483,17 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
         // the 32-block kernels (kernels_q32.h) take rows in groups of four blocks and at most 12288 elements: real Falcon-7B
         // (n_embd 4544) and the ffn_down rows of Llama-13B/70B Q4_0/Q8_0 files (13824, 28672) are outside that — said here, at
         // load, not by a failing launch later
-        if (m.K % 128 || m.K > 32768) {
-            err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 128, at most 32768)";
+        if (m.K % 32 || m.K > 32768) {
+            err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 32, at most 32768)";
             return false;
+        }
+        if (m.K % 128) {
+            // Rows that are not whole groups of four blocks (real Falcon-7B: n_embd 4544 = 142 blocks): the decode arena (LAYOUT_L9,
+            // upload_l9b: a row's last record is padded with zero blocks, the prologue writes zero images with y.d = 0 for them) serves
+            // them; the prompt-chunk kernels' LAYOUT_G4 copy does not exist, so such a handle evaluates prompts token by token
+            // (alloc_state: pf_ok_ stays false) — the reference's results either way.
+            m.layout = LAYOUT_L9;
+            return true;
         }
         m.layout = LAYOUT_G4;
         const bool q8 = t->type == GT_Q8_0;

@@ -442,6 +442,9 @@ FALCON_SHAPES = {
     "falcon-tiny": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=2, n_layer=2, n_ff=1024, norm2=True),
     "falcon-tiny7": dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=1, n_layer=2, n_ff=1024, norm2=False),
     "falcon-small": dict(n_vocab=1024, n_embd=1024, n_head=16, n_head_kv=2, n_layer=3, n_ff=4096, norm2=True),
+    # two layers at the real Falcon-7B widths (4544 = 71 heads of 64: rows of 142 32-blocks; K-quant files of this model fall back to
+    # the 32-block types for every tensor with such rows, llama.cpp:4850-4870)
+    "falcon-7b-2l": dict(n_vocab=65024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=2, n_ff=18176, norm2=False),
     # two layers at the real Falcon-40B widths (K = 8192 / 32768, 65024 x 8192 Q8_0 head)
     "falcon-40b-2l": dict(n_vocab=65024, n_embd=8192, n_head=128, n_head_kv=8, n_layer=2, n_ff=32768, norm2=True),
 }
