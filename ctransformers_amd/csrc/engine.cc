@@ -952,7 +952,7 @@ bool Engine::load_mpt(const std::string& path, int context_length, std::string& 
     clip_qkv_ = f.clip_qkv;
     if (n_ctx_ > kMaxCtxFused) { err = "context length above " + std::to_string(kMaxCtxFused) + " not supported yet"; return false; }
     if (hp_.n_embd % 128) { err = "mpt: d_model must be a multiple of 128 for the 32-block mat-vec kernels"; return false; }
-    if (hp_.head_dim() != 64 && hp_.head_dim() != 128) { err = "mpt: head sizes other than 64 / 128 are not supported"; return false; }
+    if (hp_.head_dim() != 64 && hp_.head_dim() != 112 && hp_.head_dim() != 128) { err = "mpt: head sizes other than 64 / 112 / 128 are not supported"; return false; }
     vocab_.load_legacy(f.vocab);
     l0_ = 0;
     l1_ = hp_.n_layer;
@@ -1259,7 +1259,9 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
         CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
         const dim3 ag1((unsigned)hp_.n_head, 1u, (unsigned)std::max(1, nt));
-        if (nt > 0) { if (hd == 128) ATTN_ALIBI(256, 128, true, ag1); else ATTN_ALIBI(256, 64, true, ag1); }
+        if (hd == 112) {   // MPT-30B heads: three 32-element steps + the scalar tail of 16; all channels of a head in one workgroup
+            if (nt > 0) ATTN_ALIBI(256, 112, true, ag1); else ATTN_ALIBI(512, 112, true, ag1);
+        } else if (nt > 0) { if (hd == 128) ATTN_ALIBI(256, 128, true, ag1); else ATTN_ALIBI(256, 64, true, ag1); }
         else { if (hd == 128) ATTN_ALIBI(512, 128, false, ag); else ATTN_ALIBI(512, 64, false, ag); }
 #undef ATTN_ALIBI
         return;

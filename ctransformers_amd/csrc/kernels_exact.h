@@ -92,10 +92,15 @@ struct AttnArgsX {
 // ALLCH (prompt chunks): one workgroup per (head, token) runs ALL head_dim channels of V*P, 64 at a time, instead of one workgroup
 // per 64 channels each recomputing the score row — half the workgroups for the latency-bound chunk launch.
 // ALIBI (MPT): ggml_alibi between the scale and the mask — the reference build contracts `i * m_k + src` into one fma.
+// Head sizes that are not whole 32-element steps (MPT-30B: 112 = 3 steps + 16): the K.Q dot takes ggml_vec_dot_f16's scalar tail too —
+// after the tree reduce, sumf += (double)(k[i] * q[i]) for i = HD & ~31 .. HD - 1 in order (every lane of the quad runs it on the
+// same values) — and the V*P part walks the head's channels 64 at a time with the last group partly idle (ALLCH instantiations only).
 template <int NT, int HD, bool ALLCH = false, bool ALIBI = false>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
     constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
+    constexpr int TAIL = HD - 32 * NC;          // elements of the scalar tail of the K.Q dot (0 or 16)
+    static_assert(TAIL == 0 || (TAIL == 16 && ALLCH), "head_dim: a multiple of 32, or of 16 with all channels in one workgroup");
     constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
     constexpr int VB = 8;                       // V chunks (32 positions each) in flight together
     CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats (dynamic: 2 KB at the default context, 128 KB at 32768)
@@ -136,9 +141,15 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     float qf[NC][8];   // this lane's slices of the query, converted once
 #pragma unroll
     for (int c = 0; c < NC; ++c) unpack8_f16(ld16(qrow + 32 * c + 8 * j), qf[c]);
+    float qt[TAIL ? TAIL : 1];   // the tail elements of the query
+    if constexpr (TAIL > 0) {
+#pragma unroll
+        for (int c = 0; c < TAIL / 8; ++c) unpack8_f16(ld16(qrow + 32 * NC + 8 * c), qt + 8 * c);
+    }
     float mx = -INFINITY;
     for (int base = 0; base < n_kv; base += NQ * PB) {
         u32x4 kv[PB][NC];
+        u32x4 kt[PB][TAIL ? TAIL / 8 : 1];
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             const int p = base + u * NQ + (tid >> 2);
@@ -146,10 +157,15 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
 #pragma unroll
             for (int c = 0; c < NC; ++c)   // no clamping: hundreds of idle quads re-reading one row serialise in the L1
                 kv[u][c] = (p < n_kv) ? ld16(krow + 32 * c) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (TAIL > 0) {
+#pragma unroll
+                for (int c = 0; c < TAIL / 8; ++c)   // kbase carries the quad lane's 8 * j: the tail is read from the row's start
+                    kt[u][c] = (p < n_kv) ? ld16(krow - 8 * j + 32 * NC + 8 * c) : u32x4{0u, 0u, 0u, 0u};
+            }
         }
         if (base == 0) {   // after the K requests (the critical path), before anything waits on them
 #pragma unroll
-            for (int u = 0; u < VB; ++u) vv[u] = (pv_thread && 32 * u < np) ? ld16(vrow + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};
+            for (int u = 0; u < VB; ++u) vv[u] = (pv_thread && 32 * u < np) ? ld16(vrow + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};   // (HD >= 64: the first 64 channels exist)
         }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
@@ -162,7 +178,19 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
 #pragma unroll
                 for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[c][l], acc[l]);
             }
-            float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            float dot = f16dot_reduce_exact(acc, j);
+            if constexpr (TAIL > 0) {   // ggml.c:2420-2423
+                double sumf = (double)dot;
+#pragma unroll
+                for (int c = 0; c < TAIL / 8; ++c) {
+                    float kf[8];
+                    unpack8_f16(kt[u][c], kf);
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) sumf += (double)(kf[l] * qt[8 * c + l]);
+                }
+                dot = (float)sumf;
+            }
+            float sc = dot * a.kq_scale;
             if (ALIBI) sc = fmaf((float)p, slope, sc);
             if (p < n_kv) {
                 mx = fmaxf(mx, sc);
@@ -203,9 +231,10 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     if (trace) tr[4] = clock64_dev();
     if (!pv_thread) return;
 #pragma unroll 1
-    for (int half = 0; half < (ALLCH ? HD / 64 : 1); ++half) {
+    for (int half = 0; half < (ALLCH ? (HD + 63) / 64 : 1); ++half) {
     if (half > 0) {   // the next 64 channels of this head
         d += 64;
+        if (HD % 64 != 0 && d >= HD) return;   // quad-uniform (ALLCH: blockIdx.y == 0): the last group of a head of 112 has 48 channels
         vrow += (size_t)64 * a.v_stride;
 #pragma unroll
         for (int u = 0; u < VB; ++u) vv[u] = (32 * u < np) ? ld16(vrow + 32 * u + 8 * j) : u32x4{0u, 0u, 0u, 0u};

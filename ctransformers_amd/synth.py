@@ -648,6 +648,9 @@ MPT_SHAPES = {
     "mpt-tiny": dict(n_vocab=512, max_seq_len=96, n_embd=384, n_head=6, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.75),
     "mpt-tiny128": dict(n_vocab=512, max_seq_len=2048, n_embd=512, n_head=4, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
     "mpt-7b-2l": dict(n_vocab=50432, max_seq_len=2048, n_embd=4096, n_head=32, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
+    # heads of 112 (MPT-30B: d_model 7168, 64 heads): the K.Q dot is three 32-element steps + ggml_vec_dot_f16's scalar tail of 16
+    "mpt-tiny112": dict(n_vocab=512, max_seq_len=96, n_embd=896, n_head=8, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
+    "mpt-30b-2l": dict(n_vocab=50432, max_seq_len=2048, n_embd=7168, n_head=64, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0),
 }
 
 

@@ -95,6 +95,7 @@ def test_abi_semantics_on_gpu():
     ("starcoder-7b-2l", "Q4_0", 33, 8),   # StarCoderBase-7B widths: rows of 16384 (wide-row kernels, bias epilogues)
     ("mpt-7b-2l", "Q4_0", 33, 12),        # MPT-7B widths: ALiBi over 32 heads of 128, 50432-row tied head, rows of 16384
     ("mpt-7b-2l", "Q8_0", 12, 6),
+    ("mpt-30b-2l", "Q4_0", 40, 8),        # MPT-30B widths: 64 heads of 112 (the f16 dot's scalar tail), d_model 7168, rows of 28672
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
     p = str(tmp_path / "m.gguf")

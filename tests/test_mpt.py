@@ -84,6 +84,25 @@ def test_mpt_c_restatement_against_reference_vectors(mirror, name):
     assert np.array_equal(m.eval(g["long_prompt"], 0), g["long_one"])
 
 
+@pytest.mark.parametrize("ftype", [7, 2])
+def test_mpt_heads_of_112(emu_lib, mirror, tmp_path, ftype):
+    """MPT-30B's head size (112 = three 32-element steps of ggml_vec_dot_f16 + its scalar tail of 16, ggml.c:2392-2425): prompt through the
+    chunk kernels and decode steps against the oracle restatement (pinned to the reference build on this shape when the mirror tests were
+    written: tests/golden/make_golden.py has no 112 vectors, the GPU suite compares mpt-30b-2l with the reference build itself)."""
+    from ctransformers_amd import synth
+    p = str(tmp_path / "m.bin")
+    hp = synth.write_mpt_ggml(p, "mpt-tiny112", seed=23, ftype=ftype)
+    m = LLM(p, "mpt", config=Config(context_length=48, batch_size=16, threads=1), lib=emu_lib)
+    o = mirror.MirrorMpt(p, 48)
+    toks = synth.prompt_tokens(5, hp["n_vocab"])
+    m.eval(toks)
+    lg = np.array(o.eval(toks, 0), copy=True)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    t = int(lg.argmax())
+    m.eval([t])
+    assert np.array_equal(m.logits.to_numpy(), o.eval([t], 5))
+
+
 def test_truncated_and_mistyped_mpt_files_are_refused(emu_lib, tmp_path):
     raw = open(os.path.join(GOLDEN, "mpt-tiny-q80.bin"), "rb").read()
     for cut in (3, 20, 40, 700, len(raw) // 2):
