@@ -1244,7 +1244,11 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     ax.q_stride = hp_.n_embd; ax.out_stride = hp_.n_embd;
     ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
     ax.n_embd_gqa = hp_.n_embd_gqa(); ax.n_ctx = n_ctx_; ax.v_stride = v_stride_;
-    ax.kq_scale = 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
+    // llama.cpp:2263 / :2596 write 1.0f / sqrtf(float(n_embd) / n_head); the legacy loaders (mpt.cc:460-462, gpt2.cc:540-543) write
+    // 1.0f / sqrt(float(n_embd) / n_head): ::sqrt is the double function there, the double quotient is rounded to float once by
+    // ggml_new_f32 — an ulp apart from the sqrtf form at head sizes such as 96 or 112 (equal at 64 and 128)
+    ax.kq_scale = hp_.legacy() ? (float)(1.0 / sqrt((double)((float)hp_.n_embd / (float)hp_.n_head)))
+                               : 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
     ax.alibi = alibi_;
     if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
@@ -1666,7 +1670,7 @@ bool Engine::chunk_step_gpt2(int nt, bool want_logits, std::string& err) {
     base.silu_tab = silu_tab_;
     base.gelu_tab = gelu_tab_;
     base.eps = hp_.rms_eps;
-    const float kq_scale = 1.0f / (float)sqrt((double)((float)E / (float)hp_.n_head));   // gpt2.cc:540
+    const float kq_scale = (float)(1.0 / sqrt((double)((float)E / (float)hp_.n_head)));   // gpt2.cc:540-543 (see launch_attention)
     for (int il = 0; il < hp_.n_layer; ++il) {
         const Layer& L = layers_[il];
         float* km = kmem_ + (size_t)il * n_ctx_ * E;
@@ -2049,7 +2053,7 @@ bool Engine::token_step_gpt2(bool want_logits, std::string& err) {
     base.gelu_tab = gelu_tab_;
     base.eps = hp_.rms_eps;
     base.dbg_sink = scores_;
-    const float kq_scale = 1.0f / (float)sqrt((double)((float)E / (float)hp_.n_head));   // gpt2.cc:540
+    const float kq_scale = (float)(1.0 / sqrt((double)((float)E / (float)hp_.n_head)));   // gpt2.cc:540-543 (see launch_attention)
     for (int il = 0; il < hp_.n_layer; ++il) {
         const Layer& L = layers_[il];
         {
