@@ -1345,7 +1345,9 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         auto kfn = attn_decode9_kernel<HDV, PBV, VBV>; \
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
         CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax, ng); } while (0)
-        const bool deep = n_ctx_ > 1024;   // ring depth of the K / V requests
+        // ring depth of the K / V requests; seven score waves with two K-row slots each measured best at contexts <= 1024 (3 / 4 / 5 score
+        // waves, four slots: 0-4 % slower per token on the 7B, profiles/r03_attn9_score_waves_ab.txt)
+        const bool deep = n_ctx_ > 1024;
         if (hd == 128) { if (deep) ATTN9(128, 4, 16); else ATTN9(128, 2, 4); }
         else { if (deep) ATTN9(64, 4, 16); else ATTN9(64, 2, 4); }
 #undef ATTN9
@@ -1367,7 +1369,7 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     if (tg == 32) {
         int items = 0;
         for (int j = 0; j < m.njobs; ++j) items += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;
-        if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus()) tg = 16;
+        if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus() * (8 / kPgWaves)) tg = 16;
     }
     if (pg_force_tg_ == 16 || pg_force_tg_ == 32) tg = pg_force_tg_;
     const int groups = (nt + tg - 1) / tg, nb = m.K / 256;
@@ -1383,7 +1385,7 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
     else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
     else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
-    constexpr int NW = 8;
+    constexpr int NW = kPgWaves;
     for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
         PgArgs a;
         a.m = m;

@@ -31,7 +31,10 @@
 // hold 16 different tokens -> conflict-free.  Sums [kg][tok] x 8 B with the kg stride = 128 mod 256 (kg 0 / 1 on different banks).
 // The kPgWaves waves of a workgroup copy a stage by LDS-DMA without a branch: the values as whole 1 KB pieces (16 B per lane),
 // TG / 16 per wave; the tail (sums, y.d; padded) as 256 B pieces (4 B per lane), TAILP per wave.
-constexpr int kPgWaves = 8;
+#ifndef PG_WAVES
+#define PG_WAVES 8   // waves (= 16-row items) per workgroup; 4: two workgroups per CU, their per-step barriers independent (A/B switch)
+#endif
+constexpr int kPgWaves = PG_WAVES;
 template <int TG> struct PgStage {
     static constexpr int VALS = 0;
     static constexpr int SUMS = 512 * TG;
@@ -174,7 +177,8 @@ struct PgFeed { const uint8_t* src; uint8_t* dst; const uint8_t* rec0; int wv, l
 template <int TYPE, int TG, int RD, int CB>
 DEV void pg_feed(int l, const PgFeed& F, const PgLane& LN, PgRec<TYPE>& ring) {
     using ST = PgStage<TG>;
-    constexpr int G = TG / 16, NW = kPgWaves;
+    constexpr int NW = kPgWaves, G = TG / 2 / NW;   // 1 KB value pieces per wave (TG x 512 bytes over NW waves)
+    static_assert(G + ST::TAILP <= 8, "the step issues at most eight DMA pieces per wave");
     // The refill goes first: hipcc does not see the DMA and counts its own loads only, so its `s_waitcnt vmcnt(N)` for an older ring
     // slot lets exactly its N youngest loads stay in flight — with the DMA pieces younger than the refill they stay in flight too,
     // issued before it they would have to land first.
@@ -351,7 +355,7 @@ DEV void pg_block(const PgRec<TYPE>& R, PgRec<TYPE>& ring, const PgFeed& F, cons
 // groups): the workgroups of one row range differ by a multiple of 8 in their linear id, i.e. run on the same XCD, whose L2
 // then serves the re-reads of the range's weights by the other token groups.
 template <int TYPE, int TG, int NW, bool GU, bool TRACE = false>
-__global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
+__global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const PgArgs a) {
     CT_DYN_SMEM(smem);
     using ST = PgStage<TG>;
     constexpr int G = TG / 16, SB = ST::BYTES;
@@ -400,9 +404,10 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
     static_assert(NW == kPgWaves, "the stage layout is cut for kPgWaves waves");
     constexpr int NRING = TYPE == GT_Q4_K ? 3 : (TYPE == GT_Q5_K ? 5 : 6);   // loads of one pg_load
     const int lane16 = lane * 16, lane4 = lane * 4;
+    constexpr int VP = TG / 2 / NW;   // 1 KB value pieces of a stage per wave
 #define PG_STAGE(SRC, DST) do { \
         _Pragma("unroll") \
-        for (int c = 0; c < G; ++c) glds16((SRC) + (size_t)(c * NW + wv) * 1024 + lane16, (DST) + (size_t)(c * NW + wv) * 1024); \
+        for (int c = 0; c < VP; ++c) glds16((SRC) + (size_t)(c * NW + wv) * 1024 + lane16, (DST) + (size_t)(c * NW + wv) * 1024); \
         _Pragma("unroll") \
         for (int c = 0; c < ST::TAILP; ++c) glds4((SRC) + ST::SUMS + (size_t)(c * NW + wv) * 256 + lane4, (DST) + ST::SUMS + (size_t)(c * NW + wv) * 256); } while (0)
     // Three LDS buffers (rotating byte offsets; all below 64 KB, the reach of the DMA's M0 base) and ONE barrier per step, in its
@@ -415,7 +420,6 @@ __global__ void __launch_bounds__(NW * 64) matmul_pg_kernel(const PgArgs a) {
     //   WAR      the copy overwrites the buffer of stage b - 1; it is issued behind the barrier of step b, which a wave reaches only after
     //            it has finished step b - 1.
     // The wait leaves the younger requests in flight: this step's ring refill (NRING; memory operations retire in order).
-    constexpr int NDMA = G + ST::TAILP;   // DMA instructions per stage and wave
     unsigned long long* tr = nullptr;
     if constexpr (TRACE) { if ((m.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && wv == 0 && lane == 0) tr = (unsigned long long*)(smem + 3 * SB); }
     pg_stamp<TRACE>(tr, 0);
