@@ -107,11 +107,22 @@ CT_HD static inline void place_kblock(int type, uint8_t* rp, int r, const uint8_
         memcpy(rp + r * 16, hdr, 16);
         memcpy(rp + 128 + r * 32, blk + 16, 32);
         memcpy(rp + 384 + r * 128, blk + 48, 128);
-    } else {  // GT_Q6_K
+    } else {  // GT_Q6_K: scales and d as in the file, the quants unpacked-ready (quant.h:r2c4_record_bytes)
         memcpy(rp + r * 2, blk + 208, 2);
         memcpy(rp + 16 + r * 16, blk + 192, 16);
-        memcpy(rp + 144 + r * 64, blk + 128, 64);
-        memcpy(rp + 656 + r * 128, blk, 128);
+        uint8_t* q = rp + 144 + r * 256;
+        for (int p = 0; p < 4; ++p)
+            for (int l = 0; l < 8; ++l) {
+                uint32_t W, H;
+                memcpy(&W, blk + 4 * (8 * p + l), 4);                    // ql bytes 32p + 4l ..: low nibbles vector va, high nibbles vb
+                memcpy(&H, blk + 128 + 4 * (8 * (p >> 1) + l), 4);       // qh bytes 32(p >> 1) + 4l ..
+                H >>= 2 * (p & 1);
+                auto q6 = [&](int wsh, int hsh) { return ((W >> wsh) & 0xFu) | (((H >> hsh) & 3u) << 4); };
+                const uint32_t A = (q6(0, 0) << 3) | (q6(16, 16) << 19) | (q6(8, 8) << 9) | (q6(24, 24) << 25);
+                const uint32_t B = (q6(4, 4) << 3) | (q6(20, 20) << 19) | (q6(12, 12) << 9) | (q6(28, 28) << 25);
+                memcpy(q + (p * 8 + l) * 8, &A, 4);
+                memcpy(q + (p * 8 + l) * 8 + 4, &B, 4);
+            }
     }
 }
 
@@ -186,7 +197,7 @@ template <int TYPE, bool L9 = false>
 __global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
                                                           uint8_t* __restrict__ dst, int M, int nb, int n_units) {
     constexpr int type = TYPE;
-    const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = L9 ? l9_record_bytes(type) : tile8_record_bytes(type);
+    const int spu = (nb + 3) / 4, bb = ggml_block_bytes(type), rec = L9 ? l9_record_bytes(type) : r2c4_record_bytes(type);
     const long long n = (long long)n_units * spu * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int slot = (int)(i & 7), rr = slot >> 2, cc = slot & 3;
@@ -317,7 +328,7 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
         if (p.K > 32768) { err = "tensor " + ta->name + ": rows longer than 32768 are not supported yet"; return false; }
         p.n_units = tb ? p.M : (p.M + 1) / 2;
         p.off = total;
-        p.bytes = (size_t)p.n_units * ((p.nb + 3) / 4) * tile8_record_bytes(p.type);
+        p.bytes = (size_t)p.n_units * ((p.nb + 3) / 4) * r2c4_record_bytes(p.type);
         total += p.bytes;
         p.off9 = total9;
         total9 += (size_t)p.n_units * ((p.nb + 3) / 4) * l9_record_bytes(p.type);
@@ -357,7 +368,7 @@ bool Engine::upload_r2c4(const std::vector<std::pair<const GgufTensor*, DevMat*>
     }
     std::vector<uint8_t> st(total, 0), st9(total9, 0);
     for (const Plan& p : plan) {
-        const int type = p.type, nb = p.nb, M = p.M, bb = ggml_block_bytes(type), rec = tile8_record_bytes(type), spu = (nb + 3) / 4;
+        const int type = p.type, nb = p.nb, M = p.M, bb = ggml_block_bytes(type), rec = r2c4_record_bytes(type), spu = (nb + 3) / 4;
         const uint8_t* sa = p.ta->data;
         const uint8_t* sb = p.tb ? p.tb->data : nullptr;
         uint8_t* dst = st.data() + p.off;

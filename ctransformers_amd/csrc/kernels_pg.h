@@ -119,7 +119,7 @@ DEV PgConst pg_consts(int p) {
 template <int TYPE> struct PgRec;
 template <> struct PgRec<GT_Q4_K> { u32x4 h, qa, qb; };
 template <> struct PgRec<GT_Q5_K> { u32x4 h, qa, qb, ha, hb; };
-template <> struct PgRec<GT_Q6_K> { u32x4 sc, qa, qb, ha, hb; uint32_t d; };
+template <> struct PgRec<GT_Q6_K> { u32x4 sc, q[4]; uint32_t d; };   // q[l >> 1] = {A(l), B(l), A(l + 1), B(l + 1)} (quant.h:r2c4_record_bytes)
 
 // Block 4 * RD + CB of the lane's row, counted from the record `rec0` points at: record +RD, slot 4 * (row & 1) + CB (quant.h
 // LAYOUT_R2C4).  RD and CB are compile-time, the lane-dependent parts sit in three 32-bit offsets: every load is (advancing
@@ -129,12 +129,12 @@ template <int TYPE> DEV PgLane pg_lane(int rr, int p) {
     PgLane L;
     if constexpr (TYPE == GT_Q4_K) { L.h = (uint32_t)rr * 64u; L.x = 0u; L.q = (uint32_t)rr * 512u + (uint32_t)p * 32u; }
     else if constexpr (TYPE == GT_Q5_K) { L.h = (uint32_t)rr * 64u; L.x = (uint32_t)rr * 128u; L.q = (uint32_t)rr * 512u + (uint32_t)p * 32u; }
-    else { L.h = (uint32_t)rr * 64u; L.x = (uint32_t)rr * 256u + (uint32_t)(p >> 1) * 32u; L.q = (uint32_t)rr * 512u + (uint32_t)p * 32u; }
+    else { L.h = (uint32_t)rr * 64u; L.x = 0u; L.q = (uint32_t)rr * 1024u + (uint32_t)p * 64u; }
     return L;
 }
 template <int TYPE, int RD, int CB>
 DEV PgRec<TYPE> pg_load(const uint8_t* __restrict__ rec0, const PgLane& L) {
-    constexpr uint32_t REC = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
+    constexpr uint32_t REC = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 2192u);   // r2c4_record_bytes(TYPE)
     const uint8_t* rec = rec0 + RD * REC;
     PgRec<TYPE> R;
     if constexpr (TYPE == GT_Q4_K) {
@@ -150,10 +150,8 @@ DEV PgRec<TYPE> pg_load(const uint8_t* __restrict__ rec0, const PgLane& L) {
     } else {
         R.d = *(const uint16_t*)(rec + (L.h >> 3) + CB * 2);
         R.sc = ld16(rec + L.h + 16 + CB * 16);
-        R.ha = ld16(rec + L.x + 144 + CB * 64);
-        R.hb = ld16(rec + L.x + 144 + CB * 64 + 16);
-        R.qa = ld16(rec + L.q + 656 + CB * 128);
-        R.qb = ld16(rec + L.q + 656 + CB * 128 + 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.q[k] = ld16(rec + L.q + 144 + CB * 256 + k * 16);
     }
     return R;
 }
@@ -318,11 +316,10 @@ DEV void pg_block(const PgRec<TYPE>& R, PgRec<TYPE>& ring, const PgFeed& F, cons
                     Ac[g] = An[g];
                     if (l < 7) An[g] = *(const u32x4*)(buf + ST::VALS + (((l + 1) * 4 + p) * TG + g * 16 + r16) * 16);
                 }
-                const uint32_t ql = l < 4 ? R.qa[k] : R.qb[k];
-                const uint32_t qh = (l < 4 ? R.ha[k] : R.hb[k]) >> (2 * kq);
-                constexpr uint32_t NIB = 0x00780078u, HB = 0x01800180u;   // C.one6 = 0x58005800: 0x5800 | (q6 << 3) = 128 + q6
-                const uint32_t v0 = ((ql << 3) & NIB) | (((qh << 7) & HB) | C.one6), v1 = ((ql >> 5) & NIB) | (((qh >> 1) & HB) | C.one6);
-                const uint32_t v2 = ((ql >> 1) & NIB) | (((qh << 3) & HB) | C.one6), v3 = ((ql >> 9) & NIB) | (((qh >> 5) & HB) | C.one6);
+                const uint32_t A = R.q[l >> 1][2 * (l & 1)], B = R.q[l >> 1][2 * (l & 1) + 1];   // the record keeps the 6-bit values operand-ready
+                constexpr uint32_t Q6M = 0x01F801F8u;   // C.one6 = 0x58005800: 0x5800 | (q6 << 3) = 128 + q6
+                const uint32_t v0 = (A & Q6M) | C.one6, v1 = ((A >> 6) & Q6M) | C.one6;   // vector va: elements (0, 2), (1, 3)
+                const uint32_t v2 = (B & Q6M) | C.one6, v3 = ((B >> 6) & Q6M) | C.one6;   // vector vb
                 // (128 + q6) * s - 160 * s = (q6 - 32) * s
                 const u32x4 WE = {pk_fma_f16(v0, ea, cea), pk_fma_f16(v1, ea, cea), pk_fma_f16(v2, eb, ceb), pk_fma_f16(v3, eb, ceb)};
                 const u32x4 WB = {pk_fma_f16(v0, ba, cba), pk_fma_f16(v1, ba, cba), pk_fma_f16(v2, bb, cbb), pk_fma_f16(v3, bb, cbb)};
@@ -359,15 +356,20 @@ __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const PgArgs a) {
     CT_DYN_SMEM(smem);
     using ST = PgStage<TG>;
     constexpr int G = TG / 16, SB = ST::BYTES;
-    constexpr uint32_t REC = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 1680u);   // tile8_record_bytes(TYPE)
+    constexpr uint32_t REC = TYPE == GT_Q4_K ? 1152u : (TYPE == GT_Q5_K ? 1408u : 2192u);   // r2c4_record_bytes(TYPE)
     const MatvecArgs& m = a.m;
-    if ((int)blockIdx.x * NW >= a.n_items) return;   // padding workgroups (whole workgroups: no barrier is left waiting)
+    // (row block, token group) = (blockIdx.x, blockIdx.y).  Measured in round 3: a remapping that makes the token groups of one row
+    // block neighbours in dispatch order on one XCD (so that they run together and share the XCD's L2) changes nothing (15 377 vs
+    // 15 345 tok/s): the re-reads of a matrix by the later token groups are served by the 256 MB infinity cache, the step is bound by
+    // instruction issue (in-kernel stamps: 2 x (181 VALU x 4 + 24 MFMA x 16) cycles per pair of waves and step).
+    const int bx = (int)blockIdx.x, grp = (int)blockIdx.y;
+    if (bx * NW >= a.n_items) return;   // padding workgroups (whole workgroups: no barrier is left waiting)
     const int tid = (int)threadIdx.x, lane = lane_id();
     const int wv = uniform_int(wave_id());
     const int r16 = lane & 15, p = lane >> 4, rr = r16 & 1;
-    const int grp = (int)blockIdx.y, t0 = grp * TG;
+    const int t0 = grp * TG;
     const int nb = m.K >> 8, nrec = (nb + 3) >> 2;
-    int item = (int)blockIdx.x * NW + wv;
+    int item = bx * NW + wv;
     const bool item_ok = item < a.n_items;   // a surplus wave of the last workgroup walks the last item again (it takes part in the
     item = item_ok ? item : a.n_items - 1;   // copies and barriers) and stores nothing
     // job of this item (explicit selects: indexing the kernel argument with a run-time value goes through scratch)
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const PgArgs a) {
     //            it has finished step b - 1.
     // The wait leaves the younger requests in flight: this step's ring refill (NRING; memory operations retire in order).
     unsigned long long* tr = nullptr;
-    if constexpr (TRACE) { if ((m.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && wv == 0 && lane == 0) tr = (unsigned long long*)(smem + 3 * SB); }
+    if constexpr (TRACE) { if ((m.dbg & 32) && bx == 0 && grp == 0 && wv == 0 && lane == 0) tr = (unsigned long long*)(smem + 3 * SB); }
     pg_stamp<TRACE>(tr, 0);
     PG_STAGE(src, smem);
     PG_STAGE(src + (size_t)(1 < nb ? 1 : nb - 1) * SB, smem + (size_t)SB);

@@ -65,6 +65,12 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
 enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5 };
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
+// LAYOUT_R2C4 record of the prompt-chunk copy.  Q4_K / Q5_K: 8 x the file block.  Q6_K: the quants are stored UNPACKED-READY for the
+// f16 matrix-core operand (kernels_pg.h): per (slot, p, l) two dwords A, B with the four 6-bit values of vector va(p) / vb(p),
+// elements 4l .. 4l+3, at bits 3..8 | 19..24 (elements 0, 2) and 9..14 | 25..30 (elements 1, 3) — `(A & 0x01F801F8) | 0x58005800`
+// and `((A >> 6) & 0x01F801F8) | 0x58005800` are the halves 128 + q6 of the operand, six instructions per AVX lane instead of
+// twenty.  256 bytes per block instead of the file's 192 (ql + qh): d[8] | sc[8][16] | q[8 slots][4 p][8 l][A, B] = 2192 B.
+CT_HD static inline int r2c4_record_bytes(int t) { return t == GT_Q6_K ? 2192 : tile8_record_bytes(t); }
 // LAYOUT_L9 for the 32-element block types (kernels_v9.h): a record holds 2 rows x 16 consecutive blocks; lane (row, l, c) reads the
 // dwords of blocks 4t + c (t = 0..3: the record's four chain sub-steps), elements 4l .. 4l+3, as ONE 16-byte load
 //   Q8_0 record 1088 B: qs[64 lanes][4 t][4 B] | d[2 rows][4 c][4 t] f16          (2 x 16 x 34 B: the file's bytes)
