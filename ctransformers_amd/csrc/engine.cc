@@ -1040,6 +1040,9 @@ static int current_device() {
 static int chip_cus() {   // CUs of the current device (cached per device)
     static int n_cu[16] = {};
     const int d = current_device();
+#ifdef CT_EMU
+    n_cu[d] = 0;   // the emulated chip's CU count may change between tests of one process (CT_EMU_CUS)
+#endif
     if (n_cu[d] == 0) {
         int n = 0;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
@@ -1359,8 +1362,18 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         // ring depth of the K / V requests; seven score waves with two K-row slots each measured best at contexts <= 1024 (3 / 4 / 5 score
         // waves, four slots: 0-4 % slower per token on the 7B, profiles/r03_attn9_score_waves_ab.txt)
         const bool deep = n_ctx_ > 1024;
-        if (hd == 128) { if (deep) ATTN9(128, 4, 16); else ATTN9(128, 2, 4); }
-        else { if (deep) ATTN9(64, 4, 16); else ATTN9(64, 2, 4); }
+        if (deep) {   // 512 threads: 8 - pv_waves score waves (kernels_attn9.h)
+            const dim3 b9d(512);
+#define ATTN9D(HDV, NWVV) do { \
+            auto kfn = attn_decode9_kernel<HDV, 4, 16, NWVV, 512>; \
+            CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
+            CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax, ng); } while (0)
+            if (hd == 128) { if (pv_waves == 1) ATTN9D(128, 7); else if (pv_waves == 2) ATTN9D(128, 6); else ATTN9D(128, 4); }
+            else { if (pv_waves == 1) ATTN9D(64, 7); else if (pv_waves == 2) ATTN9D(64, 6); else ATTN9D(64, 4); }
+#undef ATTN9D
+            return;
+        }
+        if (hd == 128) ATTN9(128, 2, 4); else ATTN9(64, 2, 4);
 #undef ATTN9
         return;
     }

@@ -23,9 +23,13 @@
 
 // PB / VB: K-row slots per quad / V chunk slots per V*P lane — the depth of the request rings.  The host picks (2, 4) for contexts up
 // to 1024 (the requests of a deeper ring only delay the short chain) and (4, 16) above.
-template <int HD, int PB, int VB>
-__global__ void __launch_bounds__(768) attn_decode9_kernel(const AttnArgsX a, int ng) {
-    constexpr int NT = 448, NWV = 7, NQ = NT / 4;   // score waves / threads (with one V*P wave: a 512-thread workgroup); NQ quads: positions per pass and slot
+template <bool B> struct A9Req { static constexpr bool value = B; };
+
+// NWV score waves.  Short contexts: seven, beside up to four V*P waves (<= 768 threads, three waves on a SIMD: 170 registers).  The deep
+// rings of the long-context form need more registers than that: it runs 8 - (V*P waves) score waves, 512 threads, two waves per SIMD.
+template <int HD, int PB, int VB, int NWV = 7, int MAXT = 768>
+__global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, int ng) {
+    constexpr int NT = 64 * NWV, NQ = NT / 4;   // score threads; NQ quads: positions per pass and slot
     constexpr int NC = HD / 32;                     // 16-byte chunks of a K row per quad lane
     constexpr int PSPEC = 2, VSPEC = 4;             // slots requested before the cursor is known (a slot is re-requested for the next pass right after its use)
     CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats
@@ -91,55 +95,61 @@ __global__ void __launch_bounds__(768) attn_decode9_kernel(const AttnArgsX a, in
     }
     const int np = n_tot & ~31;
     const int nl = n_kv - np;   // leftover positions (< 32), wave-uniform
-    if (pv_wave) {   // the rest of the first V chunks, the leftover positions' values
+    // Every request below is UNCONDITIONAL (an address clamped into the cache instead of a branch around the load).  With a branch
+    // around a load anywhere in a loop hipcc cannot count the loads in flight and waits `vmcnt(0)` before every use of a slot — the
+    // rings then hold one request at a time, each step costs a whole memory latency (the kernel had 43 such waits: 370 cycles per
+    // 32-position V step, 23 000 of 48 900 cycles at 2000 positions).  The loops are peeled instead: all rounds but the last re-request
+    // every slot, the last requests nothing (kernels_v9.h has the same rule for the weight ring).
+    const int last_c = np >= 32 ? np - 32 : 0;   // first position of the last 32-position V chunk of the fma part
+    const int last_p = n_kv - 1;
+    if (pv_wave) {   // the rest of the first V chunks, the leftover positions' values (the row is padded: np + 31 stays inside the cache)
 #pragma unroll
-        for (int u = VSPEC; u < VB; ++u)
-            if (32 * u < np) buf[u] = ld16(vrow + 32 * u + 8 * j);
-        if (nl > 0) {
+        for (int u = VSPEC; u < VB; ++u) buf[u] = ld16(vrow + (32 * u < last_c ? 32 * u : last_c) + 8 * j);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) aux[c] = ld16(vrow + np + 8 * c);
-        }
+        for (int c = 0; c < 4; ++c) aux[c] = ld16(vrow + np + 8 * c);
     } else {         // the K rows of the first pass beyond the speculative slots
 #pragma unroll
         for (int u = PSPEC; u < PB; ++u) {
             const int p = u * NQ + quad;
-            if (u * NQ < n_kv && p < n_kv) {   // first condition: wave-uniform (a scalar branch skips the requests of a short context)
-                const uint16_t* krow = kbase + (size_t)p * HD;
+            const uint16_t* krow = kbase + (size_t)(p < last_p ? p : last_p) * HD;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
-            }
+            for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
         }
     }
     if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
     // ---- scores: a pass = PB x 128 positions; a slot's K row of the NEXT pass is requested right after its dot product ----
     float mx = -INFINITY;
     if (!pv_wave) {
-        for (int base = 0; base < n_kv; base += NQ * PB) {
+        auto slot = [&](int u, int base, auto REQ) __attribute__((always_inline)) {
+            const int p = base + u * NQ + quad;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int p = base + u * NQ + quad;
-                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < NC; ++c) {
+                float kf[8], qf[8];
+                unpack8_f16(buf[u * NC + c], kf);
+                unpack8_f16(aux[c], qf);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    float kf[8], qf[8];
-                    unpack8_f16(buf[u * NC + c], kf);
-                    unpack8_f16(aux[c], qf);
-#pragma unroll
-                    for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
-                }
-                const int pn = p + NQ * PB;
-                if (base + u * NQ + NQ * PB < n_kv && pn < n_kv) {
-                    const uint16_t* krow = kbase + (size_t)pn * HD;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
-                }
-                const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
-                if (p < n_kv) {
-                    mx = fmaxf(mx, sc);
-                    if (j == 0) prob[p] = sc;
-                }
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
             }
+            if constexpr (decltype(REQ)::value) {   // the slot's K row of the NEXT pass
+                const int pn = p + NQ * PB;
+                const uint16_t* krow = kbase + (size_t)(pn < last_p ? pn : last_p) * HD;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
+            }
+            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if (p < n_kv) {
+                mx = fmaxf(mx, sc);
+                if (j == 0) prob[p] = sc;
+            }
+        };
+        int base = 0;
+        for (; base + NQ * PB < n_kv; base += NQ * PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) slot(u, base, A9Req<true>{});
         }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) slot(u, base, A9Req<false>{});
     }
     if (trace) tr[2] = clock64_dev();
     mx = fmaxf(mx, lane_xor4(mx)); mx = fmaxf(mx, lane_xor8(mx)); mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
@@ -180,18 +190,29 @@ __global__ void __launch_bounds__(768) attn_decode9_kernel(const AttnArgsX a, in
     if (!pv_wave) return;
     // ---- V*P of this wave's 16 channels: a quad per channel; a chunk slot is re-requested right after its fmas ----
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i0 = 0; i0 < np; i0 += 32 * VB) {
+    int i0 = 0;
+    for (; i0 + 32 * VB < np; i0 += 32 * VB) {   // every chunk of this round exists; each slot is re-requested (clamped to the last chunk)
 #pragma unroll
         for (int u = 0; u < VB; ++u) {
             const int i = i0 + 32 * u;
-            if (i < np) {
-                float vf[8];
-                unpack8_f16(buf[u], vf);
-                const float* pr = &prob[i + 8 * j];
+            float vf[8];
+            unpack8_f16(buf[u], vf);
+            const float* pr = &prob[i + 8 * j];
 #pragma unroll
-                for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
-                if (i + 32 * VB < np) buf[u] = ld16(vrow + i + 32 * VB + 8 * j);
-            }
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            const int in = i + 32 * VB;
+            buf[u] = ld16(vrow + (in < last_c ? in : last_c) + 8 * j);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {   // the last round requests nothing
+        const int i = i0 + 32 * u;
+        if (i < np) {
+            float vf[8];
+            unpack8_f16(buf[u], vf);
+            const float* pr = &prob[i + 8 * j];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
         }
     }
     const float res = f16dot_reduce_exact(acc, j);

@@ -82,6 +82,7 @@ struct AttnArgsX {
     unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
     int q_stride, out_stride;    // prompt chunks (kernels_pf.h): token blockIdx.z has position *pos + z, query row z, output row z
     const float* alibi;          // MPT: per-head slope m_k; the scaled score of key position i becomes fma(m_k, i, score) (ggml.c:12193-12254)
+    int vt_off, vt_row;          // attn_decode9_kernel<.., VLDS>: byte offset of the V tile in dynamic LDS, halves per channel row of it
 };
 
 // Fused form of the two kernels above (one launch per layer instead of two): grid (n_head, head_dim/64), 1024 threads.

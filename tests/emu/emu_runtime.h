@@ -108,4 +108,8 @@ constexpr bool kConcurrentLaunches = false;   // the fiber scheduler is one-laun
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 enum { hipDeviceAttributeMultiprocessorCount = 0 };
-static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 4; return hipSuccess; }  // emulate a 4-CU chip
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) {   // emulate a 4-CU chip (CT_EMU_CUS: another count, for launch shapes that depend on it)
+    const char* e = getenv("CT_EMU_CUS");
+    *v = (e && atoi(e) > 0) ? atoi(e) : 4;
+    return hipSuccess;
+}

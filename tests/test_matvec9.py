@@ -113,3 +113,25 @@ def test_block32_rows_not_a_multiple_of_128(emu_lib, mirror, tmp_path, arch, fty
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 5))
+
+
+@pytest.mark.parametrize("heads,n_embd,cus", [((4, 2), 256, 4), ((2, 1), 256, 64), ((4, 2), 512, 16)])
+def test_decode_attention_long_context_form(emu_lib, mirror, monkeypatch, tmp_path, heads, n_embd, cus):
+    """Contexts above 1024 take the deep-ring form of the decode attention (kernels_attn9.h: four K-row slots, sixteen V chunks, every
+    request unconditional, peeled last rounds; 8 - (V*P waves) score waves): head sizes 64 and 128, one / two / four V*P waves per
+    workgroup (the emulated chip's CU count decides, CT_EMU_CUS), decode steps at positions 70.. (two 32-position fma steps +
+    leftovers) against the oracle restatement."""
+    monkeypatch.setenv("CT_EMU_CUS", str(cus))
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=29, overrides=dict(n_embd=n_embd, n_head=heads[0], n_head_kv=heads[1], n_layer=1))
+    m = LLM(p, config=Config(context_length=1088, batch_size=128, threads=1), lib=emu_lib)
+    o = mirror.MirrorLlama(p, 1088)
+    toks = synth.prompt_tokens(70, hp["n_vocab"])
+    m.eval(toks)
+    lg = np.array(o.eval(toks, 0), copy=True)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 70 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (70 + i)
