@@ -1361,7 +1361,8 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax, ng); } while (0)
         // ring depth of the K / V requests; seven score waves with two K-row slots each measured best at contexts <= 1024 (3 / 4 / 5 score
         // waves, four slots: 0-4 % slower per token on the 7B, profiles/r03_attn9_score_waves_ab.txt)
-        const bool deep = n_ctx_ > 1024;
+        static const int deep_min = env_int("CT_AMD_ATTN_DEEP_CTX", 1024);   // measurement switch: contexts above this take the deep-ring form
+        const bool deep = n_ctx_ > deep_min;
         if (deep) {   // 512 threads: 8 - pv_waves score waves (kernels_attn9.h)
             const dim3 b9d(512);
 #define ATTN9D(HDV, NWVV) do { \
