@@ -413,13 +413,16 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         static const int deep_min = env_int("CT_AMD_ATTN_DEEP_CTX", 1024);   // measurement switch: contexts above this take the deep-ring form
         const bool deep = n_ctx_ > deep_min;
         if (deep) {   // 512 threads: 8 - pv_waves score waves (kernels_attn9.h)
-            const dim3 b9d(512);
+            static const int nwv4_sw = env_int("CT_AMD_ATTN_NWV4", 0);
+            const dim3 b9d((unsigned)(64 * ((nwv4_sw ? 4 : 8 - pv_waves) + pv_waves)));
 #define ATTN9D(HDV, NWVV) do { \
             auto kfn = attn_decode9_kernel<HDV, 4, 16, NWVV, 512>; \
             CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
             CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax, ng); } while (0)
-            if (hd == 128) { if (pv_waves == 1) ATTN9D(128, 7); else if (pv_waves == 2) ATTN9D(128, 6); else ATTN9D(128, 4); }
-            else { if (pv_waves == 1) ATTN9D(64, 7); else if (pv_waves == 2) ATTN9D(64, 6); else ATTN9D(64, 4); }
+            static const int deep_nwv4 = env_int("CT_AMD_ATTN_NWV4", 0);   // measurement switch: four score waves (one per SIMD) whatever the V*P wave count
+            const int pvw = deep_nwv4 ? 4 : pv_waves;
+            if (hd == 128) { if (pvw == 1) ATTN9D(128, 7); else if (pvw == 2) ATTN9D(128, 6); else ATTN9D(128, 4); }
+            else { if (pvw == 1) ATTN9D(64, 7); else if (pvw == 2) ATTN9D(64, 6); else ATTN9D(64, 4); }
 #undef ATTN9D
             return;
         }

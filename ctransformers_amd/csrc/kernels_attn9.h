@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     if (trace) tr[3] = clock64_dev();
     // ---- softmax: fp16 exp table, order-free double sum (the addends are multiples of 2^-24 in (0, 1]) ----
     double sum = 0.0;
-    constexpr int SB = 4;   // exp-table lookups of 4 elements per thread in flight together
+    constexpr int SB = VB >= 16 ? 8 : 4;   // exp-table lookups per thread in flight together (long-context form: one round for 2000+ positions)
     for (int i0 = 0; !pv_wave && i0 < n_kv; i0 += NT * SB) {
         uint16_t e16[SB];
 #pragma unroll
@@ -191,15 +191,27 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     // ---- V*P of this wave's 16 channels: a quad per channel; a chunk slot is re-requested right after its fmas ----
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i0 = 0;
+    float pn[8];   // the probabilities of the NEXT step, read one step ahead (an LDS round trip per step otherwise: 150 cycles per step at 2000 positions)
+    {
+        const float* p0 = &prob[8 * j];   // position 0 .. 7 + 8j: inside the row whatever np is
+#pragma unroll
+        for (int l = 0; l < 8; ++l) pn[l] = p0[l];
+    }
     for (; i0 + 32 * VB < np; i0 += 32 * VB) {   // every chunk of this round exists; each slot is re-requested (clamped to the last chunk)
 #pragma unroll
         for (int u = 0; u < VB; ++u) {
             const int i = i0 + 32 * u;
-            float vf[8];
+            float vf[8], pc[8];
             unpack8_f16(buf[u], vf);
-            const float* pr = &prob[i + 8 * j];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            for (int l = 0; l < 8; ++l) pc[l] = pn[l];
+            {
+                const float* pr = &prob[i + 32 + 8 * j];   // i + 32 <= i0 + 32 * VB < np
+#pragma unroll
+                for (int l = 0; l < 8; ++l) pn[l] = pr[l];
+            }
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pc[l], acc[l]);
             const int in = i + 32 * VB;
             buf[u] = ld16(vrow + (in < last_c ? in : last_c) + 8 * j);
         }
@@ -208,11 +220,18 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     for (int u = 0; u < VB; ++u) {   // the last round requests nothing
         const int i = i0 + 32 * u;
         if (i < np) {
-            float vf[8];
+            float vf[8], pc[8];
             unpack8_f16(buf[u], vf);
-            const float* pr = &prob[i + 8 * j];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pr[l], acc[l]);
+            for (int l = 0; l < 8; ++l) pc[l] = pn[l];
+            {
+                const int inx = i + 32 < last_c ? i + 32 : last_c;   // the step after the last re-reads the last chunk's probabilities (unused)
+                const float* pr = &prob[inx + 8 * j];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) pn[l] = pr[l];
+            }
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pc[l], acc[l]);
         }
     }
     const float res = f16dot_reduce_exact(acc, j);
