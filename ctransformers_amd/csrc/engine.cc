@@ -410,19 +410,18 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax, ng); } while (0)
         // ring depth of the K / V requests; seven score waves with two K-row slots each measured best at contexts <= 1024 (3 / 4 / 5 score
         // waves, four slots: 0-4 % slower per token on the 7B, profiles/r03_attn9_score_waves_ab.txt)
-        static const int deep_min = env_int("CT_AMD_ATTN_DEEP_CTX", 1024);   // measurement switch: contexts above this take the deep-ring form
-        const bool deep = n_ctx_ > deep_min;
-        if (deep) {   // 512 threads: 8 - pv_waves score waves (kernels_attn9.h)
-            static const int nwv4_sw = env_int("CT_AMD_ATTN_NWV4", 0);
-            const dim3 b9d((unsigned)(64 * ((nwv4_sw ? 4 : 8 - pv_waves) + pv_waves)));
-#define ATTN9D(HDV, NWVV) do { \
-            auto kfn = attn_decode9_kernel<HDV, 4, 16, NWVV, 512>; \
+        const bool deep = n_ctx_ > 1024;
+        if (deep) {
+            // Long-context form (kernels_attn9.h): four K-row slots, sixteen V chunks, FOUR score waves — one per SIMD, beside the V*P
+            // waves: with seven, six of them share three SIMDs and finish late (the score phase is VALU work); measured at 2001 positions
+            // 16.2 against 16.7 us (7B) and 16.4 against 17.4 us (70B widths), profiles/r03_attn9_ring_fix.txt.  At contexts <= 1024
+            // the forms measure the same per token (717-727 tok/s); the shallow one stays there.
+            const dim3 b9d((unsigned)(64 * (4 + pv_waves)));
+#define ATTN9D(HDV) do { \
+            auto kfn = attn_decode9_kernel<HDV, 4, 16, 4, 512>; \
             CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
             CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax, ng); } while (0)
-            static const int deep_nwv4 = env_int("CT_AMD_ATTN_NWV4", 0);   // measurement switch: four score waves (one per SIMD) whatever the V*P wave count
-            const int pvw = deep_nwv4 ? 4 : pv_waves;
-            if (hd == 128) { if (pvw == 1) ATTN9D(128, 7); else if (pvw == 2) ATTN9D(128, 6); else ATTN9D(128, 4); }
-            else { if (pvw == 1) ATTN9D(64, 7); else if (pvw == 2) ATTN9D(64, 6); else ATTN9D(64, 4); }
+            if (hd == 128) ATTN9D(128); else ATTN9D(64);
 #undef ATTN9D
             return;
         }

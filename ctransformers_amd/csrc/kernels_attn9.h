@@ -26,7 +26,8 @@
 template <bool B> struct A9Req { static constexpr bool value = B; };
 
 // NWV score waves.  Short contexts: seven, beside up to four V*P waves (<= 768 threads, three waves on a SIMD: 170 registers).  The deep
-// rings of the long-context form need more registers than that: it runs 8 - (V*P waves) score waves, 512 threads, two waves per SIMD.
+// rings of the long-context form need more registers than that: it runs four score waves (one per SIMD) beside the V*P waves, at most
+// 512 threads, two waves per SIMD.
 template <int HD, int PB, int VB, int NWV = 7, int MAXT = 768>
 __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, int ng) {
     constexpr int NT = 64 * NWV, NQ = NT / 4;   // score threads; NQ quads: positions per pass and slot

@@ -21,6 +21,6 @@ for target in [t for t in (128, 512, 2000) if t < int(os.environ.get("ATTN_CTX",
     rows = [[buf[16 * w + k] for k in range(8)] for w in range(16)]
     t0 = min(r[0] for r in rows if r[0])
     print("n_kv", rows[0][7])
-    for w in (0, 3, 7, 8, 9):
+    for w in (0, 3, 4, 5, 7):
         r = rows[w]
         print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "cursor", "scores", "max", "softmax", "pv_fma", "exit"))))
