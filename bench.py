@@ -324,6 +324,29 @@ def main():
                                   else "matvec_pfm_kernel<GU> (lane sums on v_mfma_i32_4x4x4_16b_i8 with the 1.5*2^23 addend, packed f32 chain, Q8_0 activation images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
+    if n_stages > 1:
+        # A pipeline evaluates a prompt in micro-batches (CT_AMD_PP_MB; default 64 tokens up to four stages, 32 beyond: stage s works on micro-batch c while stage
+        # s - 1 works on c + 1).  Larger micro-batches mean fewer passes over the weights and less overlap: the best size depends on
+        # the stage count, so the prompt rate is reported per size (a fresh handle each: the size is read at load).
+        out["prefill"]["micro_batch_tokens"] = int(os.environ.get("CT_AMD_PP_MB", "64" if n_stages <= 4 else "32"))   # pipeline.cc's default
+        by_mb = {str(out["prefill"]["micro_batch_tokens"]): out["prefill_tok_s"]}
+        del llm
+        llm = None
+        for mb in (32, 64, 128):
+            if str(mb) in by_mb:
+                continue
+            os.environ["CT_AMD_PP_MB"] = str(mb)
+            h = LLM(MODEL, config=Config(context_length=N_CTX, batch_size=N_PROMPT, gpu_layers=1000))
+            for _ in range(2):
+                h._context = []
+                h.eval(prompt)
+            h._context = []
+            t0 = time.perf_counter()
+            h.eval(prompt)
+            by_mb[str(mb)] = round(N_PROMPT / (time.perf_counter() - t0), 1)
+            del h
+        os.environ["CT_AMD_PP_MB"] = str(out["prefill"]["micro_batch_tokens"])
+        out["prefill"]["tok_s_by_micro_batch"] = by_mb
     if n_gpus == 1 and a.config == 2 and not a.no_other_configs:
         del llm
         llm = None

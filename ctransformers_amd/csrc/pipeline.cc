@@ -174,6 +174,10 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
         }
     }
     ev_.assign(dev_.size(), {});
+    // Tokens per micro-batch of a prompt.  A (stage, micro-batch) unit of a 7B costs 1.96 / 2.6 / 4.0 ms x 2 / stages at 32 / 64 / 128
+    // tokens (bench.py --gpus 2 on one GPU, `tok_s_by_micro_batch`: fewer passes over the weights with larger ones), a 128-token
+    // prompt takes (micro-batches + stages - 1) units: 64 tokens win up to four stages, 32 beyond.  CT_AMD_PP_MB overrides.
+    micro_batch_ = st_.size() <= 4 ? 64 : 32;
     const char* mb = getenv("CT_AMD_PP_MB");
     if (mb && atoi(mb) > 0) micro_batch_ = atoi(mb);
     return true;
