@@ -320,6 +320,16 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV>; \
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
         CT_LAUNCH_DYN(kfn, GRID, dim3(NTV), smem, stream_, ax); } while (0)
+    if (n_ctx_ > kMaxCtxFused) {   // llama / falcon contexts whose probability row exceeds LDS: the row in global memory, one workgroup per head
+        ax.scores = scores_;
+        const dim3 agp((unsigned)hp_.n_head, 1u, 1u);
+#define ATTN_GP(HDV) do { \
+        auto kfn = attn_fused_exact_kernel<512, HDV, true, false, true>; \
+        CT_LAUNCH_DYN(kfn, agp, dim3(512), (size_t)64, stream_, ax); } while (0)
+        if (hd == 128) ATTN_GP(128); else if (hd == 64) ATTN_GP(64); else if (hd == 192) ATTN_GP(192); else ATTN_GP(256);
+#undef ATTN_GP
+        return;
+    }
     if (alibi_) {   // MPT: the fused kernel with the ALiBi term (one workgroup per (head, token) for chunks); head sizes checked at load
 #define ATTN_ALIBI(NTV, HDV, ALLV, GRID) do { \
         auto kfn = attn_fused_exact_kernel<NTV, HDV, ALLV, true>; \

@@ -571,7 +571,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     hp_.n_vocab = vocab_.size();
     // reference default n_ctx = 512 unless context_length is passed (llama.cpp:5281, llama.cc:90-92)
     n_ctx_ = context_length > 0 ? context_length : 512;
-    if (n_ctx_ > kMaxCtxFused) { err = "context_length above " + std::to_string(kMaxCtxFused) + " not supported yet"; return false; }
+    // the reference takes any context_length (llama.cc:90-92).  Up to kMaxCtxFused the attention kernels keep a token's probability row
+    // in LDS; above it the row lives in global memory, prompts run token by token and nothing is tuned (kernels_exact.h GPROB)
+    if (n_ctx_ > (1 << 20)) { err = "context_length above 1048576 is not supported"; return false; }
 
     HIP_OK(hipStreamCreate(&stream_));
     bool r2_auto = true;   // mat() also makes the matrix's own R2C4 copy (false: the caller places several matrices in one arena)
@@ -723,7 +725,7 @@ bool Engine::alloc_state(std::string& err) {
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
-    pf_ok_ = E <= 12288 && F <= 32768 && env_int("CT_AMD_PF", 1) != 0;
+    pf_ok_ = E <= 12288 && F <= 32768 && n_ctx_ <= kMaxCtxFused && env_int("CT_AMD_PF", 1) != 0;
     bool kq_model = false, mixed_model = false;
     {   // every layer matrix a K-quant (llama, falcon), or every one Q8_0 / Q4_0 of one type with K <= 32768
         int n_kq = 0, n_q32 = 0, n_all = 0, ty32 = -1, n_any32 = 0;

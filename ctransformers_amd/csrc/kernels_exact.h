@@ -96,8 +96,12 @@ struct AttnArgsX {
 // Head sizes that are not whole 32-element steps (MPT-30B: 112 = 3 steps + 16): the K.Q dot takes ggml_vec_dot_f16's scalar tail too —
 // after the tree reduce, sumf += (double)(k[i] * q[i]) for i = HD & ~31 .. HD - 1 in order (every lane of the quad runs it on the
 // same values) — and the V*P part walks the head's channels 64 at a time with the last group partly idle (ALLCH instantiations only).
-template <int NT, int HD, bool ALLCH = false, bool ALIBI = false>
+// GPROB (contexts above kMaxCtxFused, whose probability row does not fit LDS): the row lives in global memory, a.scores[head][n_ctx]
+// (one workgroup per head: ALLCH), written and read by this workgroup only, between workgroup barriers.  The reference takes any
+// context length (llama.cc:90-92); this form is the slow path that keeps such handles loadable.
+template <int NT, int HD, bool ALLCH = false, bool ALIBI = false, bool GPROB = false>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
+    static_assert(!GPROB || ALLCH, "the global probability row has one writer: all channels of a head in one workgroup");
     constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
     constexpr int TAIL = HD - 32 * NC;          // elements of the scalar tail of the K.Q dot (0 or 16)
@@ -105,10 +109,10 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
     constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
     constexpr int VB = 8;                       // V chunks (32 positions each) in flight together
     CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats (dynamic: 2 KB at the default context, 128 KB at 32768)
-    float* prob = reinterpret_cast<float*>(smem_raw);
     __shared__ double red[NWV];
     __shared__ float redf[NWV];
     const int h = (int)blockIdx.x;
+    float* prob = GPROB ? a.scores + ((size_t)blockIdx.z * a.n_head + h) * a.n_ctx : reinterpret_cast<float*>(smem_raw);
     const bool trace = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0;
     unsigned long long* tr = a.trace + 16 * (threadIdx.x >> 6);
     if (trace) tr[0] = clock64_dev();

@@ -403,7 +403,8 @@ def test_long_context(ref, tmp_path):
 
 def test_context_above_8192(ref, tmp_path):
     """context_length 10240 (the probability row of the attention kernel lives in dynamic LDS, up to 32768 positions): a 9000-token
-    prompt, then greedy steps past position 9000, bit-identical to the reference CPU build."""
+    prompt, then greedy steps past position 9000, bit-identical to the reference CPU build; then a handle at context 40000 (the row
+    in global memory)."""
     p = str(tmp_path / "c.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=43)
     toks = synth.prompt_tokens(9000, hp["n_vocab"])
@@ -417,8 +418,18 @@ def test_context_above_8192(ref, tmp_path):
         t = int(a.argmax())
         r.eval([t])
         m.eval([t])
-    with pytest.raises(RuntimeError):
-        open_hip(p, context_length=40000)   # above the 32768 the kernel's LDS row can hold: refused at load
+    # above the 32768 positions the kernels' LDS row can hold: the probability row in global memory, prompts token by token
+    r = ref.open_llm(p, context_length=40000, batch_size=64, threads=16)
+    m = open_hip(p, context_length=40000, batch_size=64)
+    short = synth.prompt_tokens(70, hp["n_vocab"])
+    r.eval(short)
+    m.eval(short)
+    for i in range(3):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "context 40000, position %d" % (70 + i)
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
 
 
 def test_context_2048_gqa_64_8(ref, tmp_path):

@@ -135,3 +135,23 @@ def test_decode_attention_long_context_form(emu_lib, mirror, monkeypatch, tmp_pa
         m.eval([t])
         lg = np.array(o.eval([t], 70 + i), copy=True)
         assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (70 + i)
+
+
+def test_context_above_32768(emu_lib, mirror, tmp_path):
+    """The reference takes any context_length (models/llms/llama.cc:90-92).  Above 32768 positions a token's probability row no longer
+    fits LDS: it lives in global memory (kernels_exact.h GPROB, one workgroup per head), prompts run token by token — against the
+    oracle restatement at context 40000 (positions 0..36: the fma steps and the leftovers of the value dot product)."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=37, overrides=dict(n_layer=1))
+    m = LLM(p, config=Config(context_length=40000, batch_size=64, threads=1), lib=emu_lib)
+    assert m.context_length == 40000
+    o = mirror.MirrorLlama(p, 40000)
+    toks = synth.prompt_tokens(35, hp["n_vocab"])
+    m.eval(toks)
+    lg = np.array(o.eval(toks, 0), copy=True)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 35 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (35 + i)
