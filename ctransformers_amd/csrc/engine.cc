@@ -17,6 +17,7 @@
 #include "kernels_q32.h"
 #include "kernels_pf.h"
 #include "kernels_pg.h"
+#include "kernels_f16.h"
 
 namespace ctamd {
 
@@ -212,7 +213,30 @@ static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
 // per group of jobs that CAN share a launch: K-quant jobs whose arenas are contiguous and whose types are all equal or "X.. then
 // Q6_K.." (the two-type kernel), or Q8_0 / Q4_0 jobs of one type.  Every group recomputes the (cheap) prologue; the jobs' epilogues
 // are independent, so the results are those of the single launch.
+// A site whose matrices are F16 (kernels_f16.h): one dot-product launch per matrix into the site's scratch rows, then the epilogue launch.
+static bool launch_matvec_f16(MatvecArgs& a, hipStream_t s, std::string& err) {
+    if (!a.f16_tmp) { err = "F16 mat-vec without its scratch rows"; return false; }
+    if (a.pro == PRO_LAYERNORM) { err = "F16 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
+    if (a.K % 32 || a.K > 32768) { err = "F16 rows must be whole 32-element steps, at most 32768 elements"; return false; }
+    int off = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const DevMat& w = a.job[j].w;
+        if (w.type != GT_F16 || !w.raw) { err = "a launch site mixes F16 matrices with other weight types"; return false; }
+        // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
+        const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
+        auto kfn = matvec_f16_kernel<256>;
+        CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
+        CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
+        off += w.M;
+    }
+    const int n_rows = a.gateup ? a.job[0].w.M : off;
+    CT_LAUNCH(f16_epilogue_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), s, a, (const float*)a.f16_tmp, n_rows);
+    return true;
+}
+
 static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
+    for (int j = 0; j < a.njobs; ++j)
+        if (a.job[j].w.type == GT_F16) return launch_matvec_f16(a, s, err);
     if (a.gateup || a.njobs <= 1) return launch_matvec_one(a, s, err);
     int i = 0;
     while (i < a.njobs) {

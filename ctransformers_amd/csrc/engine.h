@@ -168,6 +168,8 @@ class Engine {
     uint16_t* kcache_ = nullptr;
     uint16_t* vcache_ = nullptr;
     float *x_ = nullptr, *attn_out_ = nullptr, *h_ = nullptr, *scores_ = nullptr, *d_logits_ = nullptr, *d_emb_ = nullptr;
+    float* f16_tmp_ = nullptr;   // models with F16 weight matrices: raw rows of one mat-vec site (kernels_f16.h)
+    bool has_f16_ = false;
     uint16_t* q_f16_ = nullptr;
     // prompt-chunk scratch (rows of kPfChunk tokens): residual stream, attention output, FFN hidden, fp16 queries, Q8_K images
     float *xb_ = nullptr, *attn_out_b_ = nullptr, *hb_ = nullptr;

@@ -136,7 +136,7 @@ bool Engine::token_step_gpt2(bool want_logits, std::string& err) {
     base.silu_tab = silu_tab_;
     base.gelu_tab = gelu_tab_;
     base.eps = hp_.rms_eps;
-    base.dbg_sink = scores_;
+    base.dbg_sink = scores_; base.f16_tmp = f16_tmp_;
     const float kq_scale = (float)(1.0 / sqrt((double)((float)E / (float)hp_.n_head)));   // gpt2.cc:540-543 (see launch_attention)
     for (int il = 0; il < hp_.n_layer; ++il) {
         const Layer& L = layers_[il];
@@ -197,7 +197,7 @@ bool Engine::token_step_mpt(bool want_logits, std::string& err) {
     base.silu_tab = silu_tab_;
     base.gelu_tab = gelu_tab_;
     base.eps = hp_.rms_eps;
-    base.dbg_sink = scores_;
+    base.dbg_sink = scores_; base.f16_tmp = f16_tmp_;
     for (int il = 0; il < hp_.n_layer; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)il * n_ctx_ * E;

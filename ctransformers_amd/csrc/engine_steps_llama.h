@@ -105,7 +105,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     base.silu_tab = silu_tab_;
     base.eps = hp_.rms_eps;
     base.dbg = env_int("CT_AMD_DBG", 0);
-    base.dbg_sink = scores_;
+    base.dbg_sink = scores_; base.f16_tmp = f16_tmp_;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;

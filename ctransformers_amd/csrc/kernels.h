@@ -83,6 +83,7 @@ struct MatvecArgs {
     const int* pos;         // device scalar: position of this token
     int n_ctx, head_dim, n_embd_gqa, v_stride;
     const uint16_t* silu_tab;  // 65536-entry fp16->fp16 table (reference ggml.c:4328-4332)
+    float* f16_tmp;            // F16 weight matrices (kernels_f16.h): raw results of the launch's rows, between the dot kernel and the epilogue kernel
     float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
     int dbg;                   // measurement only (CT_AMD_DBG / ctamd_trace_site): bit 32 = write in-kernel s_memtime stamps to dbg_sink
 };

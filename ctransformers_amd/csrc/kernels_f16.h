@@ -1,0 +1,114 @@
+// F16 weight matrices (llama GGUF files of ftype F16; the F16 output.weight the reference's quantizer falls back to for rows that are
+// not whole 256-blocks, llama.cpp:4866-4869): token steps only, bit-identical to the reference CPU build.
+//
+// Reference: ggml_compute_forward_mul_mat with an F16 src0 (ggml.c:11031-11245): vec_dot_type is F16, so the activation row is
+// converted with ggml_fp32_to_fp16_row (round to nearest even, F16C) and every output is ggml_vec_dot_f16 (ggml.c:2392-2425) of the
+// weight row and that fp16 vector — the dot product of the attention kernels (kernels_exact.h header): 4 accumulator vectors x 8
+// lanes, one fma per element in 32-element steps, the AVX reduce tree.  Rows here are whole 32-element steps (checked at load): no
+// scalar tail.
+//   matvec_f16_kernel    prologue per workgroup: (RMSNorm * w ->) fp16 activation vector in LDS; a quad of lanes per output row
+//                        (lane j = accumulator vector j: the 16-byte chunks j, j + 4, ... of the row), eight requests in flight per
+//                        lane, every request unconditional (a clamped row instead of a branch: kernels_attn9.h); raw f32 results
+//   f16_epilogue_kernel  the decode kernels' epilogues (kernels_v9.h) on those results: store / + residual / RoPE -> fp16 Q /
+//                        RoPE -> K cache / V cache / SiLU(gate) * up
+// Two launches per site instead of one fused kernel: F16 files are not on any BASELINE config; what matters here is that they load
+// and give the reference's bits (13.5 GB per 7B token: bandwidth-bound at a few hundred tokens/s either way).
+#pragma once
+#include "kernels_exact.h"
+
+template <int NT>
+__global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps,
+                                                        const uint16_t* __restrict__ W, int M, float* __restrict__ out) {
+    CT_DYN_SMEM(smem_raw);   // the fp16 activation vector: K halves
+    uint16_t* xh = reinterpret_cast<uint16_t*>(smem_raw);
+    __shared__ double red[NT / 64];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3, quad = tid >> 2;
+    // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf), ggml_mul with the norm weight, then fp16 ----
+    float scale = 1.0f;
+    if (pro == PRO_RMSNORM) {
+        double s = 0.0;
+        for (int i = tid; i < K; i += NT) { const float v = x[i]; s += (double)(v * v); }
+        s = wave_sum(s);
+        if (lane == 0) red[wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += red[w];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + eps);
+    }
+    for (int i = tid; i < K; i += NT) {
+        float v = x[i];
+        if (pro == PRO_RMSNORM) v = (v * scale) * nw[i];
+        xh[i] = f32_to_f16_bits(v);
+    }
+    __syncthreads();
+    // ---- rows: a quad per row, NT / 4 rows per pass of the workgroup ----
+    constexpr int PB = 8;   // 32-element steps in flight per lane
+    const int steps = K >> 5;
+    for (int row0 = (int)blockIdx.x * (NT / 4); row0 < M; row0 += (int)gridDim.x * (NT / 4)) {
+        const int row = row0 + quad;
+        const uint16_t* wrow = W + (size_t)(row < M ? row : M - 1) * K + 8 * j;   // a quad past the last row re-reads it (nothing stored)
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32x4 buf[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) buf[u] = ld16(wrow + 32 * (u < steps ? u : steps - 1));
+        int s0 = 0;
+        for (; s0 + PB < steps; s0 += PB) {   // every step of this round exists; each slot is re-requested (clamped to the last step)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                float wf[8], xf[8];
+                unpack8_f16(buf[u], wf);
+                unpack8_f16(*(const u32x4*)(xh + 32 * (s0 + u) + 8 * j), xf);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
+                const int sn = s0 + u + PB;
+                buf[u] = ld16(wrow + 32 * (sn < steps ? sn : steps - 1));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {   // the last round requests nothing
+            if (s0 + u < steps) {
+                float wf[8], xf[8];
+                unpack8_f16(buf[u], wf);
+                unpack8_f16(*(const u32x4*)(xh + 32 * (s0 + u) + 8 * j), xf);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
+            }
+        }
+        const float res = f16dot_reduce_exact(acc, j);
+        if (j == 0 && row < M) out[row] = res;
+    }
+}
+
+// Row r of the launch's concatenated outputs (job 0's rows, then job 1's, ...; gate/up: rows [0, F) = gate, [F, 2F) = up).
+__global__ void __launch_bounds__(256) f16_epilogue_kernel(const MatvecArgs a, const float* __restrict__ tmp, int n_rows) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n_rows) return;
+    if (a.gateup) {   // SiLU(gate) * up through the fp16 table (kernels_v9.h epilogue)
+        const int F = a.job[0].w.M;
+        if (r < F) a.out[r] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(tmp[r])]) * tmp[F + r];
+        return;
+    }
+    int jb = 0, row = r;
+    if (a.njobs > 1 && row >= a.job[0].w.M) { row -= a.job[0].w.M; jb = 1; }
+    if (a.njobs > 2 && jb == 1 && row >= a.job[1].w.M) { row -= a.job[1].w.M; jb = 2; }
+    const int epi = jb == 2 ? a.job[2].epi : (jb == 1 ? a.job[1].epi : a.job[0].epi);
+    const float res = tmp[r];
+    if (epi == EPI_STORE) {
+        a.out[row] = res;
+    } else if (epi == EPI_ADD) {
+        a.out[row] = res + a.res[row];
+    } else if (epi == EPI_V) {
+        a.vcache[(size_t)row * a.v_stride + *a.pos] = f32_to_f16_bits(res);
+    } else if (epi == EPI_ROPE_Q || epi == EPI_ROPE_K) {   // normal-mode RoPE (ggml.c:12522-12539, the build's fma forms): rows 2i, 2i + 1 rotate together
+        const int pos = *a.pos;
+        const float other = tmp[r ^ 1];
+        const int ip = (row % a.head_dim) >> 1;
+        const float cs = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 0];
+        const float sn = a.rope_cs[((size_t)pos * (a.head_dim >> 1) + ip) * 2 + 1];
+        const float o = (row & 1) ? fmaf(res, cs, other * sn) : fmaf(res, cs, -(other * sn));
+        if (epi == EPI_ROPE_Q) a.q_f16[row] = f32_to_f16_bits(o);
+        else a.kcache[kcache_off(pos, row, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
+    }
+}

@@ -63,7 +63,7 @@ CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K 
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
-enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5 };
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5, LAYOUT_F16 = 6 };   // LAYOUT_F16: fp16 rows as in the file (DevMat::raw; kernels_f16.h)
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 // LAYOUT_R2C4 record of the prompt-chunk copy.  Q4_K / Q5_K: 8 x the file block.  Q6_K: the quants are stored UNPACKED-READY for the
 // f16 matrix-core operand (kernels_pg.h): per (slot, p, l) two dwords A, B with the four 6-bit values of vector va(p) / vb(p),

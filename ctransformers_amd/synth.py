@@ -249,7 +249,7 @@ def use_more_bits(i, n):
 
 def llama_tensor_types(ftype, n_layer):
     """name -> ggml type for every 2-D tensor of a llama GGUF under an ftype (reference llama.cpp:4785-4850)."""
-    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K}[ftype]
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K, "F16": G.F16}[ftype]
     t = {"token_embd.weight": base, "output.weight": G.Q6_K if ftype in ("Q4_K_M", "Q5_K_M", "Q4_K_S", "Q6_K") else base}
     if ftype == "Q4_0":
         t["output.weight"] = G.Q6_K  # reference llama.cpp:4787-4790 (non-falcon: output is always Q6_K when k-quants on)

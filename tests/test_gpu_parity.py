@@ -84,6 +84,7 @@ def test_abi_semantics_on_gpu():
     ("llama-7b-2l", "Q8_0", 33, 8),      # real 7B shapes: K = 4096 / 11008 (86 block groups), 32000-row Q8_0 head
     ("llama-7b-2l", "Q4_K_S", 33, 8),    # Q4_K_S mix at 7B widths: attn_v / ffn_down in Q5_K beside Q4_K (one launch per type group at the QKV site)
     ("llama-7b-2l", "Q4_K_M+v_q8_0", 20, 6),   # a Q8_0 attn_v beside K-quant q / k: K-quant and 32-block kernels at one site
+    ("llama-7b-2l", "F16", 12, 6),       # fp16 weight matrices at the 7B widths (kernels_f16.h: token steps, the prompt too)
     ("falcon-small", "Q4_K_M", 40, 30),  # config 4 graph: LayerNorm x2, fused QKV (Q5_K), neox RoPE, GQA 16/2, GELU, Q8_0 head
     ("falcon-tiny7", "Q8_0", 20, 50),    # 7B-style block (one norm, MQA) on the 32-element-block kernels
     ("falcon-7b-2l", "Q8_0", 9, 6),      # real Falcon-7B widths: n_embd 4544 = 142 blocks of 32 (not whole groups of four), 71 heads on ONE KV head
@@ -118,8 +119,8 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     r.eval(toks)
     m.eval(toks)
     # every model family / weight type evaluates prompts through the chunk kernels — except 32-block rows that are not whole groups of
-    # four blocks (Falcon-7B's 4544): token by token on the decode kernels
-    assert chunk_tokens(m) == (0 if shape == "falcon-7b-2l" else n_prompt)
+    # four blocks (Falcon-7B's 4544) and fp16 matrices: token by token on the decode kernels
+    assert chunk_tokens(m) == (0 if shape == "falcon-7b-2l" or ftype == "F16" else n_prompt)
     for i in range(n_decode):
         a, b = r.logits.to_numpy(), m.logits.to_numpy()
         assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())

@@ -155,3 +155,24 @@ def test_context_above_32768(emu_lib, mirror, tmp_path):
         m.eval([t])
         lg = np.array(o.eval([t], 35 + i), copy=True)
         assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (35 + i)
+
+
+def test_f16_weight_matrices(emu_lib, mirror, tmp_path):
+    """A llama GGUF of ftype F16 (every 2-D tensor fp16; reference: vec_dot_type F16 — the activation row through ggml_fp32_to_fp16_row,
+    ggml_vec_dot_f16 per output row, ggml.c:11031-11245 / :2392-2425): kernels_f16.h, token steps for the prompt too — against the oracle
+    restatement (which the GPU suite and tests/test_oracle.py compare with the reference build on such a file)."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "F16", seed=41)
+    m = LLM(p, config=Config(context_length=64, batch_size=8, threads=1), lib=emu_lib)
+    o = mirror.MirrorLlama(p, 64)
+    toks = synth.prompt_tokens(9, hp["n_vocab"])
+    o.eval(toks[:8], 0)
+    lg = np.array(o.eval(toks[8:], 8), copy=True)   # the reference's batches of 8: 8 + 1
+    m.eval(toks)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    assert np.array_equal(m.embeddings.to_numpy(), o.embeddings)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 9 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (9 + i)
