@@ -96,3 +96,29 @@ def test_reference_build_reproduces_golden(ref):
     r = ref.open_llm(os.path.join(GOLDEN, "tiny-q4km.gguf"), context_length=96, batch_size=8, threads=2)
     r.eval(list(g["prompt"]))
     assert np.array_equal(r.logits.to_numpy(), g["logits"][0])
+
+
+def test_restatement_follows_reference_build_on_shapes_without_goldens(mirror, ref, tmp_path):
+    """Shapes and types added after the golden vectors were generated, pinned on the reference build itself (needs oracle/_ref): fp16
+    weight matrices (ftype F16: vec_dot_type F16), Q8_0 rows that are not whole groups of four blocks with an odd head count on one KV
+    head (Falcon-7B's geometry), MPT heads of 112 (the f16 dot's scalar tail; the double-sqrt scale of the legacy graphs is pinned
+    by tests/test_mpt.py)."""
+    cases = []
+    p = str(tmp_path / "f16.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "F16", seed=41)
+    cases.append((p, None, mirror.MirrorLlama(p, 64), hp))
+    p = str(tmp_path / "f7.gguf")
+    hp = synth.write_falcon_gguf(p, "falcon-tiny7", "Q8_0", seed=17, overrides=dict(n_embd=192, n_head=3, n_head_kv=1, n_ff=768, n_layer=2))
+    cases.append((p, None, mirror.MirrorFalcon(p, 64), hp))
+    p = str(tmp_path / "m112.bin")
+    hp = synth.write_mpt_ggml(p, "mpt-tiny112", seed=23, ftype=2)
+    cases.append((p, "mpt", mirror.MirrorMpt(p, 64), hp))
+    for path, mt, o, hp in cases:
+        r = ref.open_llm(path, model_type=mt, context_length=64, batch_size=64, threads=2)
+        toks = synth.prompt_tokens(37, hp["n_vocab"])
+        r.eval(toks)
+        a = np.array(r.logits.to_numpy(), copy=True)
+        assert np.array_equal(a, o.eval(toks, 0)), path
+        t = int(a.argmax())
+        r.eval([t])
+        assert np.array_equal(r.logits.to_numpy(), o.eval([t], 37)), path
