@@ -572,7 +572,8 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 activation images, kernels_pf.h
-        const int aw32 = pf_act_words_q32(m.K);
+        const int Kp = (m.K + 127) & ~127;   // rows in whole groups of four blocks (zero blocks behind a row's end: kernels_pf.h)
+        const int aw32 = pf_act_words_q32(Kp);
         // 8 tokens per workgroup on the matrix-core form while their images fit the CU's LDS (K <= 16384: 144 KB); wider rows take
         // the dot4 form with 4.  (Measured on config 3, profiles/r02_q80_chunk_sites.txt: 16 / 32 tokens per workgroup change
         // nothing — the kernel is bound by instruction issue, not by the weight traffic — and the dot4 form at 8 tokens is 6 % slower.)
@@ -583,6 +584,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         else CT_LAUNCH((pf_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b, paired);
         PfArgs a;
         a.m = m;
+        a.m.K = Kp;
         a.acts = acts_; a.act_words = aw32; a.n_tok = nt;
         a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
         int item0 = 0;

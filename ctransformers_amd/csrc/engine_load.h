@@ -145,13 +145,13 @@ __global__ void __launch_bounds__(256) repack_r2c4_kernel(const uint8_t* __restr
 
 // LAYOUT_G4 (Q8_0 / Q4_0, quant.h) from the staged file copy: one thread per (tile, group of four blocks, row, block).
 __global__ void __launch_bounds__(256) repack_g4_kernel(int q8, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int M, int nb) {
-    const int ng = nb / 4, bb = q8 ? 34 : 18, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512, nl = q8 ? 8 : 4;
+    const int ng = (nb + 3) / 4, bb = q8 ? 34 : 18, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512, nl = q8 ? 8 : 4;
     const long long n = (long long)((M + 7) / 8) * ng * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int bi = (int)(i & 3), r = (int)((i >> 2) & 7);
         const long long tg = i >> 5;
         const int g = (int)(tg % ng), tl = (int)(tg / ng), row = tl * 8 + r;
-        if (row >= M) continue;   // zero rows (the buffer is cleared first)
+        if (row >= M || g * 4 + bi >= nb) continue;   // zero rows / zero blocks behind a row's end (the buffer is cleared first)
         const uint8_t* blk = src + ((size_t)row * nb + (size_t)g * 4 + bi) * bb;
         uint8_t* rp = dst + (size_t)tg * rec;
         memcpy(rp + dbase + r * 8 + bi * 2, blk, 2);
@@ -442,17 +442,11 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
             err = "tensor " + t->name + ": Q8_0/Q4_0 rows of " + std::to_string(m.K) + " elements are not supported (need a multiple of 32, at most 32768)";
             return false;
         }
-        if (m.K % 128) {
-            // Rows that are not whole groups of four blocks (real Falcon-7B: n_embd 4544 = 142 blocks): the decode arena (LAYOUT_L9,
-            // upload_l9b: a row's last record is padded with zero blocks, the prologue writes zero images with y.d = 0 for them) serves
-            // them; the prompt-chunk kernels' LAYOUT_G4 copy does not exist, so such a handle evaluates prompts token by token
-            // (alloc_state: pf_ok_ stays false) — the reference's results either way.
-            m.layout = LAYOUT_L9;
-            return true;
-        }
+        // Rows that are not whole groups of four blocks (real Falcon-7B: n_embd 4544 = 142 blocks): the last group of a row is padded
+        // with zero blocks (d = 0) here, the activation images likewise (kernels_pf.h), the decode arena's last record too (upload_l9b)
         m.layout = LAYOUT_G4;
         const bool q8 = t->type == GT_Q8_0;
-        const int n_tiles = (M + 7) / 8, ng = nb / 4, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512;
+        const int n_tiles = (M + 7) / 8, ng = (nb + 3) / 4, rec = q8 ? 1088 : 576, dbase = q8 ? 1024 : 512;
         if (dev_file_) {   // the tensor is already on the device in file layout (stage_file): repack there
             const size_t bytes = (size_t)n_tiles * ng * rec;
             uint8_t* d = nullptr;
@@ -473,6 +467,7 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
                         const int row = tl * 8 + r;
                         if (row >= M) continue;
                         for (int i = 0; i < 4; ++i) {
+                            if (g * 4 + i >= nb) continue;   // zero block behind the row's end
                             const uint8_t* blk = src + ((size_t)row * nb + (size_t)g * 4 + i) * bb;
                             memcpy(rp + dbase + r * 8 + i * 2, blk, 2);
                             if (q8) {
@@ -767,7 +762,7 @@ bool Engine::alloc_state(std::string& err) {
             return false;
         pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
         if (!kq_model) {   // Q8_0 activation images of the Q8_0 / Q4_0 chunk kernel
-            if (!dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * pf_act_words_q32(std::max(E, F)), err)) return false;
+            if (!dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * pf_act_words_q32((std::max(E, F) + 127) & ~127), err)) return false;
         }
         if (kq_model || mixed_model) {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
             acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max((kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES) + 4096;

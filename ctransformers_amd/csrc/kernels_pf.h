@@ -42,16 +42,19 @@ __global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __re
     __shared__ ActLdsQ32<MAXK> L;
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
     prologue_q8_0<MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);   // nb_: LayerNorm bias (gpt2)
-    if (!paired) {   // one image per token, q8[K/4] | yd[K/32]: the matrix-core form (matvec_pfm_kernel) reads a token per lane
+    // the images cover whole groups of four blocks: a row whose last group is incomplete (K % 128 != 0) gets zero blocks there, as the
+    // weight records do (engine_load.h:upload_matrix) — the kernels then see a row of Kp elements whose tail contributes fma(0, 0, acc)
+    const int Kp = (K + 127) & ~127;
+    if (!paired) {   // one image per token, q8[Kp/4] | yd[Kp/32]: the matrix-core form (matvec_pfm_kernel) reads a token per lane
         int* o1 = acts + (size_t)t * act_words;
-        for (int i = tid; i < (K >> 2); i += 1024) o1[i] = L.q8[i];
-        for (int i = tid; i < (K >> 5); i += 1024) o1[(K >> 2) + i] = (int)f32_to_bits(L.yd[i]);
+        for (int i = tid; i < (Kp >> 2); i += 1024) o1[i] = L.q8[i];
+        for (int i = tid; i < (Kp >> 5); i += 1024) o1[(Kp >> 2) + i] = (int)f32_to_bits(L.yd[i]);
         return;
     }
     // tokens are stored in pairs (the chunk kernel's two-wide float steps): q8 of the even token | q8 of the odd token | block scales
     // interleaved {even, odd} per block — 2 * act_words words per pair
     int* o = acts + (size_t)(t >> 1) * 2 * act_words;
-    const int nq = K >> 2, nb = K >> 5, odd = t & 1;
+    const int nq = Kp >> 2, nb = Kp >> 5, odd = t & 1;
     for (int i = tid; i < nq; i += 1024) o[odd * nq + i] = L.q8[i];
     for (int i = tid; i < nb; i += 1024) o[2 * nq + 2 * i + odd] = (int)f32_to_bits(L.yd[i]);
 }

@@ -120,7 +120,7 @@ DEV void prologue_q8_0(ActLdsQ32<MAXK>& L, const float* __restrict__ x, const fl
         const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
         const int q0 = (int)__builtin_rintf(t.x * id), q1 = (int)__builtin_rintf(t.y * id);
         const int q2 = (int)__builtin_rintf(t.z * id), q3 = (int)__builtin_rintf(t.w * id);
-        if (live) {
+        if (b < ((nblk + 3) & ~3)) {   // blocks past the row's end inside its last group of four: zero quants, y.d = 0 (rows of Falcon-7B: 142 blocks)
             L.q8[((b >> 2) * 8 + l) * 4 + (b & 3)] = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
             if (l == 0) L.yd[b] = f16_bits_to_f32(f32_to_f16_bits(d));
         }

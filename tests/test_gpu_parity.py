@@ -118,9 +118,9 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     toks = synth.prompt_tokens(n_prompt, hp["n_vocab"])
     r.eval(toks)
     m.eval(toks)
-    # every model family / weight type evaluates prompts through the chunk kernels — except 32-block rows that are not whole groups of
-    # four blocks (Falcon-7B's 4544) and fp16 matrices: token by token on the decode kernels
-    assert chunk_tokens(m) == (0 if shape == "falcon-7b-2l" or ftype == "F16" else n_prompt)
+    # every model family / weight type evaluates prompts through the chunk kernels (32-block rows that are not whole groups of four
+    # blocks — Falcon-7B's 4544 — with zero blocks behind the row's end) — except fp16 matrices: token by token
+    assert chunk_tokens(m) == (0 if ftype == "F16" else n_prompt)
     for i in range(n_decode):
         a, b = r.logits.to_numpy(), m.logits.to_numpy()
         assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())

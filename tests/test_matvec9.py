@@ -92,9 +92,10 @@ def test_matvec9_type_mixes_at_one_site(emu_lib, mirror, monkeypatch, tmp_path, 
 @pytest.mark.parametrize("arch,ftype", [("falcon", "Q8_0"), ("falcon", "Q4_0"), ("llama", "Q8_0"), ("llama", "Q4_0")])
 def test_block32_rows_not_a_multiple_of_128(emu_lib, mirror, tmp_path, arch, ftype):
     """Q8_0 / Q4_0 rows that are whole 32-blocks but not whole groups of four (real Falcon-7B: n_embd 4544 = 142 blocks; here 192 =
-    6 blocks, llama ffn_down 480 = 15 blocks): the file loads, the decode arena's padded last record serves the rows, prompts go
-    token by token (no LAYOUT_G4 copy for the chunk kernels) — against the oracle restatement, an odd head count (3) with one KV
-    head included.  Reference: every type has a vec_dot and no row-length rule beyond the block size (ggml.c:1676-1795)."""
+    6 blocks, llama ffn_down 480 = 15 blocks): the decode arena's last record and the chunk kernels' last group of four blocks are
+    padded with zero blocks, the activation images likewise — prompt through the chunk kernels, decode steps, against the oracle
+    restatement, an odd head count (3) with one KV head included.  Reference: every type has a vec_dot and no row-length rule
+    beyond the block size (ggml.c:1676-1795)."""
     p = str(tmp_path / "m.gguf")
     if arch == "falcon":
         hp = synth.write_falcon_gguf(p, "falcon-tiny7", ftype, seed=17, overrides=dict(n_embd=192, n_head=3, n_head_kv=1, n_ff=768, n_layer=2))
@@ -110,6 +111,11 @@ def test_block32_rows_not_a_multiple_of_128(emu_lib, mirror, tmp_path, arch, fty
     lg = np.array(o.eval(toks, 0), copy=True)
     assert np.array_equal(m.logits.to_numpy(), lg)
     assert np.array_equal(m.embeddings.to_numpy(), o.embeddings)
+    f = m._lib.ctamd_chunk_tokens
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    # the prompt went through the chunk kernels — except in the llama Q4_0 case, whose `output.weight` override also matches
+    # attn_output.weight: Q4_0 and Q8_0 matrices in one layer have no chunk form (token by token, same results)
+    assert int(f(m._llm)) == (0 if (arch, ftype) == ("llama", "Q4_0") else 5)
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 5))
