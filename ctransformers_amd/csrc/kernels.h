@@ -281,6 +281,31 @@ __global__ void gpt2_kv_append_kernel(const float* __restrict__ qkv, float* __re
         vmem[(size_t)pos * E + i] = row[2 * E + i];
     }
 }
+// The scalar tail of ggml_vec_dot_f32 (`for (i = np; i < n; ++i) sumf += x[i]*y[i]`, ggml.c:2355-2389) as the reference BUILD runs it:
+// gcc -O3 vectorises the in-order reduction — groups of 8 products by vmulps (not fused) added in order, one group of 4 the same way if
+// at least 4 are left, then at most 3 fused scalar steps (disassembly of oracle/_ref; every length 3..31 checked against the exported
+// function).  Round 3: the pure-fma tail this replaces differed by an ulp in ~40 % of the dots with 4 or more leftovers, which the
+// Q8_0 quantization of the attention output absorbed on every model of the suite — and did not at GPT-2 XL's width.
+DEV float dot_f32_tail(const float* __restrict__ x, size_t sx, const float* __restrict__ y, int i, int n, float sumf) {
+    for (; n - i >= 8; i += 8) {
+        float p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = x[(size_t)(i + k) * sx] * y[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sumf = sumf + p[k];
+    }
+    if (n - i >= 4) {
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = x[(size_t)(i + k) * sx] * y[i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sumf = sumf + p[k];
+        i += 4;
+    }
+    for (; i < n; ++i) sumf = fmaf(x[(size_t)i * sx], y[i], sumf);
+    return sumf;
+}
+
 __global__ void __launch_bounds__(256) attn_f32_exact_kernel(const float* __restrict__ qkv, float* __restrict__ kmem,
                                                              float* __restrict__ vmem, float* __restrict__ out,
                                                              const uint16_t* __restrict__ exp_tab, const int* __restrict__ pos_p,
@@ -320,8 +345,7 @@ __global__ void __launch_bounds__(256) attn_f32_exact_kernel(const float* __rest
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int l = 0; l < 8; ++l) s[j][l] = fmaf(k[i + 8 * j + l], q[i + 8 * j + l], s[j][l]);
-        float sumf = dot_f32_reduce(s);
-        for (int i = np; i < hd; ++i) sumf = fmaf(k[i], q[i], sumf);
+        const float sumf = dot_f32_tail(k, 1, q, np, hd, dot_f32_reduce(s));
         const float sc = sumf * kq_scale;
         prob[p] = sc;
         mx = fmaxf(mx, sc);
@@ -353,9 +377,7 @@ __global__ void __launch_bounds__(256) attn_f32_exact_kernel(const float* __rest
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int l = 0; l < 8; ++l) s[j][l] = fmaf(v[(size_t)(i + 8 * j + l) * E], prob[i + 8 * j + l], s[j][l]);
-        float sumf = dot_f32_reduce(s);
-        for (int i = np; i < n_tot; ++i) sumf = fmaf(v[(size_t)i * E], prob[i], sumf);
-        out[h * hd + d] = sumf;
+        out[h * hd + d] = dot_f32_tail(v, (size_t)E, prob, np, n_tot, dot_f32_reduce(s));
     }
 }
 

@@ -559,6 +559,7 @@ def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ct
 GPT2_SHAPES = {
     "gpt2-117m": dict(n_vocab=50257, n_ctx=1024, n_embd=768, n_head=12, n_layer=12),
     "gpt2-tiny": dict(n_vocab=512, n_ctx=96, n_embd=256, n_head=4, n_layer=2),
+    "gpt2-xl-2l": dict(n_vocab=50257, n_ctx=1024, n_embd=1600, n_head=25, n_layer=2),   # GPT-2 XL widths: rows of 50 / 200 blocks (not whole groups of four), 25 heads
     # the reference's starcoder / gptbigcode loader reads the same container (models/llms/starcoder.cc); heads of 64 like the real ones
     "starcoder-tiny": dict(n_vocab=512, n_ctx=96, n_embd=384, n_head=6, n_layer=2),
     "starcoder-1b": dict(n_vocab=49152, n_ctx=8192, n_embd=2048, n_head=16, n_layer=24),

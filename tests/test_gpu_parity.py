@@ -92,6 +92,7 @@ def test_abi_semantics_on_gpu():
     ("falcon-40b-2l", "Q4_K_M", 9, 4),   # config 4 widths: K = 8192 (12288 instantiation) and K = 32768 (wide-K path), Q8_0 head
     ("llama-70b-2l", "Q5_K_M", 9, 4),    # config 5 widths: GQA 64/8, K = 8192 / 28672, Q5_K + Q6_K
     ("gpt2-117m", "Q4_0", 40, 24),       # config 1: GPT-2 117M shapes, legacy GGML container, F32 KV cache, tied lm_head
+    ("gpt2-xl-2l", "Q4_0", 20, 24),       # GPT-2 XL widths: n_embd 1600 (50 blocks per row), 25 heads; the F32 dot tails of 4+ leftovers
     ("starcoder-1b-4l", "Q8_0", 40, 16),  # StarCoderBase-1B widths through the reference's starcoder loader: heads of 128, 49152 rows
     ("starcoder-7b-2l", "Q4_0", 33, 8),   # StarCoderBase-7B widths: rows of 16384 (wide-row kernels, bias epilogues)
     ("mpt-7b-2l", "Q4_0", 33, 12),        # MPT-7B widths: ALiBi over 32 heads of 128, 50432-row tied head, rows of 16384

@@ -182,3 +182,27 @@ def test_f16_weight_matrices(emu_lib, mirror, tmp_path):
         m.eval([t])
         lg = np.array(o.eval([t], 9 + i), copy=True)
         assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (9 + i)
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "mpt"])
+def test_legacy_graphs_at_widths_that_are_not_multiples_of_128(emu_lib, mirror, tmp_path, arch):
+    """GPT-2 XL has n_embd 1600 (50 blocks of 32 per row); here 192 with three heads, for the gpt2 and the mpt graph: prompt through the
+    chunk kernels (zero blocks behind a row's end), decode steps (the F32 attention's dot tails of 4 and more leftovers: dot_f32_tail)
+    — against the oracle restatement."""
+    p = str(tmp_path / "m.bin")
+    if arch == "gpt2":
+        synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=96, n_embd=192, n_head=3, n_layer=2), seed=5)
+        o = mirror.MirrorGpt2(p)
+    else:
+        synth.write_mpt_ggml(p, dict(n_vocab=512, max_seq_len=96, n_embd=192, n_head=3, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0), seed=6, ftype=7)
+        o = mirror.MirrorMpt(p, 96)
+    m = LLM(p, arch, config=Config(context_length=96, batch_size=64, threads=1), lib=emu_lib)
+    toks = synth.prompt_tokens(13, 512)
+    m.eval(toks)
+    lg = np.array(o.eval(toks, 0), copy=True)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 13 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg)

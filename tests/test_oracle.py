@@ -122,3 +122,23 @@ def test_restatement_follows_reference_build_on_shapes_without_goldens(mirror, r
         t = int(a.argmax())
         r.eval([t])
         assert np.array_equal(r.logits.to_numpy(), o.eval([t], 37)), path
+
+
+def test_f32_dot_tail_follows_the_reference_build(mirror, ref):
+    """ggml_vec_dot_f32 (GPT-2 / StarCoder attention over the F32 KV cache): the reference BUILD runs the scalar tail `sumf += x[i]*y[i]`
+    as groups of 8 and 4 UNFUSED products added in order and at most 3 fused steps (gcc's in-order vectorised reduction).  Every length
+    1..70 against the exported function of oracle/_ref (a pure-fma tail differs in ~40 % of the dots with 4 or more leftovers)."""
+    import ctypes
+    from oracle import mirror as mm
+    L = mm.lib()
+    L.mir_vec_dot_f32.restype = ctypes.c_float
+    L.mir_vec_dot_f32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    vd = ref._VEC_DOT(ref.traits(G.F32).vec_dot)
+    rng = np.random.default_rng(5)
+    for n in range(1, 71):
+        for _ in range(20):
+            x = rng.standard_normal(n).astype(np.float32)
+            y = rng.random(n).astype(np.float32)
+            s = ctypes.c_float(0)
+            vd(n, ctypes.byref(s), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p))
+            assert np.float32(s.value) == np.float32(L.mir_vec_dot_f32(n, x.ctypes.data, y.ctypes.data)), n
