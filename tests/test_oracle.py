@@ -142,3 +142,22 @@ def test_f32_dot_tail_follows_the_reference_build(mirror, ref):
             s = ctypes.c_float(0)
             vd(n, ctypes.byref(s), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p))
             assert np.float32(s.value) == np.float32(L.mir_vec_dot_f32(n, x.ctypes.data, y.ctypes.data)), n
+
+
+def test_f16_dot_follows_the_reference_build_at_every_length(mirror, ref):
+    """ggml_vec_dot_f16 (llama / falcon / mpt attention; F16 weight matrices): 32-element steps, the AVX reduce tree, and the scalar tail
+    `sumf += (double)(x[i]*y[i])` — every length 1..70 against the exported function of oracle/_ref."""
+    import ctypes
+    from oracle import mirror as mm
+    L = mm.lib()
+    L.mir_vec_dot_f16.restype = ctypes.c_float
+    L.mir_vec_dot_f16.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    vd = ref._VEC_DOT(ref.traits(G.F16).vec_dot)
+    rng = np.random.default_rng(6)
+    for n in range(1, 71):
+        for _ in range(20):
+            x = (rng.standard_normal(n) * rng.choice([0.05, 1.0, 30.0])).astype(np.float16)
+            y = rng.random(n).astype(np.float16)
+            s = ctypes.c_float(0)
+            vd(n, ctypes.byref(s), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p))
+            assert np.float32(s.value) == np.float32(L.mir_vec_dot_f16(n, x.ctypes.data, y.ctypes.data)), n
