@@ -157,13 +157,72 @@ def quantize_q4_0(x):
     return out.reshape(lead + (-1,))
 
 
+def _pack5(q, nb):
+    """q uint8 [nb, 32] in 0..31 -> (qh [nb, 4] bit e = bit 4 of element e, qs [nb, 16] nibbles: element e | element e + 16 << 4)."""
+    hb = (q >> 4).astype(np.uint32)
+    qh = (hb << np.arange(32, dtype=np.uint32)[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+    lo = q & 0xF
+    return qh.view(np.uint8).reshape(nb, 4), (lo[:, 0:16] | (lo[:, 16:32] << 4)).astype(np.uint8)
+
+
+def quantize_q4_1(x):
+    """block_q4_1 (reference ggml.c:895-900): d, m fp16; q = round((x - min) / d) in 0..15 (quantize_row_q4_1_reference ggml.c:1001-1040)."""
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 32)
+    nb = xb.shape[0]
+    mn, mx = xb.min(axis=-1), xb.max(axis=-1)
+    d = ((mx - mn) / 15.0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(d[:, None] != 0, np.floor((xb - mn[:, None]) / d[:, None] + 0.5), 0).clip(0, 15).astype(np.uint8)
+    out = np.zeros((nb, 20), dtype=np.uint8)
+    out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = _f16(mn).view(np.uint8).reshape(nb, 2)
+    out[:, 4:20] = q[:, 0:16] | (q[:, 16:32] << 4)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q5_0(x):
+    """block_q5_0 (reference ggml.c:903-908): d fp16 | qh | 16 nibble bytes; q = x / d + 16.5 in 0..31 (ggml.c:1042-1085)."""
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 32)
+    nb = xb.shape[0]
+    idx = np.abs(xb).argmax(axis=-1)
+    mx = xb[np.arange(nb), idx]
+    d = (mx / -16.0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(d[:, None] != 0, np.floor(xb / d[:, None] + 16.5), 16).clip(0, 31).astype(np.uint8)
+    out = np.zeros((nb, 22), dtype=np.uint8)
+    out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
+    out[:, 2:6], out[:, 6:22] = _pack5(q, nb)
+    return out.reshape(lead + (-1,))
+
+
+def quantize_q5_1(x):
+    """block_q5_1 (reference ggml.c:911-917): d, m fp16 | qh | 16 nibble bytes; q = round((x - min) / d) in 0..31 (ggml.c:1087-1130)."""
+    x = np.asarray(x, dtype=np.float32)
+    lead = x.shape[:-1]
+    xb = x.reshape(-1, 32)
+    nb = xb.shape[0]
+    mn, mx = xb.min(axis=-1), xb.max(axis=-1)
+    d = ((mx - mn) / 31.0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(d[:, None] != 0, np.floor((xb - mn[:, None]) / d[:, None] + 0.5), 0).clip(0, 31).astype(np.uint8)
+    out = np.zeros((nb, 24), dtype=np.uint8)
+    out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = _f16(mn).view(np.uint8).reshape(nb, 2)
+    out[:, 4:8], out[:, 8:24] = _pack5(q, nb)
+    return out.reshape(lead + (-1,))
+
+
 def quantize(x, ggml_type):
     if ggml_type == G.F32:
         return np.ascontiguousarray(x, dtype=np.float32).view(np.uint8).reshape(x.shape[:-1] + (-1,))
     if ggml_type == G.F16:
         return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).view(np.uint8).reshape(x.shape[:-1] + (-1,))
     return {G.Q4_K: quantize_q4_K, G.Q5_K: quantize_q5_K, G.Q6_K: quantize_q6_K, G.Q8_0: quantize_q8_0,
-            G.Q4_0: quantize_q4_0}[ggml_type](x)
+            G.Q4_0: quantize_q4_0, G.Q4_1: quantize_q4_1, G.Q5_0: quantize_q5_0, G.Q5_1: quantize_q5_1}[ggml_type](x)
 
 
 def dequantize(raw, ggml_type, K):
@@ -221,6 +280,18 @@ def dequantize(raw, ggml_type, K):
         qs = b[:, 2:18]
         q = np.concatenate([(qs & 0xF).astype(np.int32) - 8, (qs >> 4).astype(np.int32) - 8], axis=1).astype(f32)
         return (q * d[:, None]).astype(f32).reshape(lead + (K,))
+    if ggml_type in (G.Q4_1, G.Q5_0, G.Q5_1):   # reference ggml.c:1538-1610: x0*d + m is one fused multiply-add in the reference build
+        hdr = 2 if ggml_type == G.Q5_0 else 4
+        d = b[:, 0:2].copy().view(np.float16).astype(np.float64).reshape(nb)
+        m = b[:, 2:4].copy().view(np.float16).astype(np.float64).reshape(nb) if ggml_type != G.Q5_0 else np.zeros(nb)
+        qs = b[:, hdr + (0 if ggml_type == G.Q4_1 else 4):]
+        q = np.concatenate([qs & 0xF, qs >> 4], axis=1).astype(np.int32)
+        if ggml_type != G.Q4_1:
+            qh = b[:, hdr:hdr + 4].copy().view(np.uint32).reshape(nb, 1)
+            q |= (((qh >> np.arange(32, dtype=np.uint32)[None, :]) & 1) << 4).astype(np.int32)
+        if ggml_type == G.Q5_0:
+            q -= 16
+        return (q.astype(np.float64) * d[:, None] + m[:, None]).astype(f32).reshape(lead + (K,))   # exact in f64, rounded once = fma
     raise ValueError(ggml_type)
 
 
@@ -249,9 +320,10 @@ def use_more_bits(i, n):
 
 def llama_tensor_types(ftype, n_layer):
     """name -> ggml type for every 2-D tensor of a llama GGUF under an ftype (reference llama.cpp:4785-4850)."""
-    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K, "F16": G.F16}[ftype]
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K, "F16": G.F16, "Q4_1": G.Q4_1,
+            "Q5_0": G.Q5_0, "Q5_1": G.Q5_1}[ftype]
     t = {"token_embd.weight": base, "output.weight": G.Q6_K if ftype in ("Q4_K_M", "Q5_K_M", "Q4_K_S", "Q6_K") else base}
-    if ftype == "Q4_0":
+    if ftype in ("Q4_0", "Q4_1", "Q5_0", "Q5_1"):
         t["output.weight"] = G.Q6_K  # reference llama.cpp:4787-4790 (non-falcon: output is always Q6_K when k-quants on)
     for i in range(n_layer):
         more = ftype in ("Q4_K_M", "Q5_K_M") and use_more_bits(i, n_layer)
