@@ -17,7 +17,7 @@
 #include "kernels_q32.h"
 #include "kernels_pf.h"
 #include "kernels_pg.h"
-#include "kernels_f16.h"
+#include "kernels_raw32.h"
 
 namespace ctamd {
 
@@ -213,20 +213,36 @@ static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
 // per group of jobs that CAN share a launch: K-quant jobs whose arenas are contiguous and whose types are all equal or "X.. then
 // Q6_K.." (the two-type kernel), or Q8_0 / Q4_0 jobs of one type.  Every group recomputes the (cheap) prologue; the jobs' epilogues
 // are independent, so the results are those of the single launch.
-// A site whose matrices are F16 (kernels_f16.h): one dot-product launch per matrix into the site's scratch rows, then the epilogue launch.
-static bool launch_matvec_f16(MatvecArgs& a, hipStream_t s, std::string& err) {
-    if (!a.f16_tmp) { err = "F16 mat-vec without its scratch rows"; return false; }
-    if (a.pro == PRO_LAYERNORM) { err = "F16 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
-    if (a.K % 32 || a.K > 32768) { err = "F16 rows must be whole 32-element steps, at most 32768 elements"; return false; }
+// A site whose matrices stay in file layout (F16: kernels_f16.h; Q4_1 / Q5_0 / Q5_1: kernels_raw32.h): one dot-product launch per
+// matrix into the site's scratch rows, then the epilogue launch.
+static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
+    if (!a.f16_tmp) { err = "file-layout mat-vec without its scratch rows"; return false; }
+    if (a.pro == PRO_LAYERNORM) { err = "F16 / Q4_1 / Q5_0 / Q5_1 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
+    if (a.K % 32 || a.K > 32768) { err = "file-layout rows must be whole 32-element steps, at most 32768 elements"; return false; }
     int off = 0;
     for (int j = 0; j < a.njobs; ++j) {
         const DevMat& w = a.job[j].w;
-        if (w.type != GT_F16 || !w.raw) { err = "a launch site mixes F16 matrices with other weight types"; return false; }
-        // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
-        const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
-        auto kfn = matvec_f16_kernel<256>;
-        CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
-        CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
+        if (!(w.type == GT_F16 || is_raw32(w.type)) || !w.raw) { err = "a launch site mixes file-layout matrices (F16, Q4_1, Q5_0, Q5_1) with other weight types"; return false; }
+        if (w.type == GT_F16) {
+            // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
+            const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
+            auto kfn = matvec_f16_kernel<256>;
+            CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
+            CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
+        } else {   // 32 rows per pass of a 256-thread workgroup; LDS: K quant bytes + 8 bytes per block
+            const int gx = std::max(1, std::min((w.M + 31) / 32, 8 * chip_cus()));
+            const size_t lds = (size_t)a.K + (size_t)(a.K / 32) * 8;
+#define CT_RAW32(T)                                                                                                                        \
+    {                                                                                                                                      \
+        auto kfn = matvec_raw32_kernel<T, 256>;                                                                                            \
+        CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);                                                                                             \
+        CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), lds, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint8_t*)w.raw, w.M, a.f16_tmp + off); \
+    }
+            if (w.type == GT_Q4_1) CT_RAW32(GT_Q4_1)
+            else if (w.type == GT_Q5_0) CT_RAW32(GT_Q5_0)
+            else CT_RAW32(GT_Q5_1)
+#undef CT_RAW32
+        }
         off += w.M;
     }
     const int n_rows = a.gateup ? a.job[0].w.M : off;
@@ -236,7 +252,7 @@ static bool launch_matvec_f16(MatvecArgs& a, hipStream_t s, std::string& err) {
 
 static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
     for (int j = 0; j < a.njobs; ++j)
-        if (a.job[j].w.type == GT_F16) return launch_matvec_f16(a, s, err);
+        if (a.job[j].w.type == GT_F16 || is_raw32(a.job[j].w.type)) return launch_matvec_raw(a, s, err);
     if (a.gateup || a.njobs <= 1) return launch_matvec_one(a, s, err);
     int i = 0;
     while (i < a.njobs) {

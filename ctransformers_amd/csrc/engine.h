@@ -169,7 +169,7 @@ class Engine {
     uint16_t* vcache_ = nullptr;
     float *x_ = nullptr, *attn_out_ = nullptr, *h_ = nullptr, *scores_ = nullptr, *d_logits_ = nullptr, *d_emb_ = nullptr;
     float* f16_tmp_ = nullptr;   // models with F16 weight matrices: raw rows of one mat-vec site (kernels_f16.h)
-    bool has_f16_ = false;
+    bool has_raw_ = false;   // some matrix stays in file layout (F16, Q4_1, Q5_0, Q5_1): two-launch sites, token steps only
     uint16_t* q_f16_ = nullptr;
     // prompt-chunk scratch (rows of kPfChunk tokens): residual stream, attention output, FFN hidden, fp16 queries, Q8_K images
     float *xb_ = nullptr, *attn_out_b_ = nullptr, *hb_ = nullptr;

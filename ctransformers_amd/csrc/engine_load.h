@@ -410,16 +410,17 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     m.K = (int)t->ne[0];
     m.M = (int)t->ne[1];
     const int be = ggml_block_elems(t->type), bb = ggml_block_bytes(t->type);
-    if (t->type == GT_F16) {   // fp16 rows stay in file layout (kernels_f16.h); token steps only — prompts of such a handle run token by token
-        if (hp_.falcon() || hp_.legacy()) { err = "tensor " + t->name + ": F16 weight matrices are supported for llama graphs only"; return false; }
-        if (m.K % 32 || m.K > 32768) { err = "tensor " + t->name + ": F16 rows of " + std::to_string(m.K) + " elements are not supported"; return false; }
-        m.nb = m.K; m.bytes = t->nbytes; m.layout = LAYOUT_F16;
+    if (t->type == GT_F16 || is_raw32(t->type)) {   // rows stay in file layout (kernels_f16.h, kernels_raw32.h); token steps only — prompts of such a handle run token by token
+        const std::string tn = t->type == GT_F16 ? "F16" : (t->type == GT_Q4_1 ? "Q4_1" : (t->type == GT_Q5_0 ? "Q5_0" : "Q5_1"));
+        if (hp_.falcon() || hp_.legacy()) { err = "tensor " + t->name + ": " + tn + " weight matrices are supported for llama graphs only"; return false; }
+        if (m.K % 32 || m.K > 32768) { err = "tensor " + t->name + ": " + tn + " rows of " + std::to_string(m.K) + " elements are not supported"; return false; }
+        m.nb = t->type == GT_F16 ? m.K : m.K / 32; m.bytes = t->nbytes; m.layout = t->type == GT_F16 ? LAYOUT_F16 : LAYOUT_RAW32;
         uint8_t* d = nullptr;
         if (!dev_alloc(dev_allocs_, &d, t->nbytes + 64, err)) return false;
         if (dev_file_) HIP_OK(hipMemcpyAsync(d, staged(t), t->nbytes, hipMemcpyDeviceToDevice, stream_));
         else HIP_OK(hipMemcpy(d, t->data, t->nbytes, hipMemcpyHostToDevice));
         m.raw = d;
-        has_f16_ = true;
+        has_raw_ = true;
         return true;
     }
     if (!(is_kquant(t->type) || t->type == GT_Q8_0 || t->type == GT_Q4_0)) {
@@ -731,7 +732,7 @@ bool Engine::alloc_state(std::string& err) {
         return false;
     d_emb_ = d_logits_ + V;
     d_tokens_ = d_state_ + 4;
-    if (has_f16_ && !dev_alloc(dev_allocs_, &f16_tmp_, (size_t)std::max(std::max(V, 2 * F), E + 2 * G) + 64, err)) return false;
+    if (has_raw_ && !dev_alloc(dev_allocs_, &f16_tmp_, (size_t)std::max(std::max(V, 2 * F), E + 2 * G) + 64, err)) return false;
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
     pf_ok_ = E <= 12288 && F <= 32768 && n_ctx_ <= kMaxCtxFused && env_int("CT_AMD_PF", 1) != 0;
     bool kq_model = false, mixed_model = false;

@@ -113,6 +113,16 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
             const int j = e & 31;
             const int q = (j < 16) ? (b[2 + j] & 0xF) : (b[2 + j - 16] >> 4);
             y = (float)(q - 8) * d;
+        } else if (type == GT_Q4_1 || type == GT_Q5_0 || type == GT_Q5_1) {   // ggml.c:1538-1610; q * d is exact (5 x 11 bits): x0*d + m rounds once, fused or not
+            const int bbk = type == GT_Q4_1 ? 20 : (type == GT_Q5_0 ? 22 : 24), hdr = type == GT_Q5_0 ? 2 : 4;
+            const uint8_t* b = row + (size_t)(e >> 5) * bbk;
+            const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
+            const float m = type == GT_Q5_0 ? 0.0f : f16_bits_to_f32((uint16_t)(b[2] | (b[3] << 8)));
+            const int j = e & 31;
+            const uint8_t* qs = b + hdr + (type == GT_Q4_1 ? 0 : 4);
+            int q = (j < 16) ? (qs[j] & 0xF) : (qs[j - 16] >> 4);
+            if (type != GT_Q4_1) q |= ((b[hdr + (j >> 3)] >> (j & 7)) & 1) << 4;
+            y = type == GT_Q5_0 ? (float)(q - 16) * d : fmaf((float)q, d, m);
         } else if (type == GT_Q4_K || type == GT_Q5_K) {
             const int bb = (type == GT_Q4_K) ? 144 : 176;
             const uint8_t* b = row + (size_t)(e >> 8) * bb;

@@ -48,22 +48,24 @@ enum GgmlType : int {
 };
 
 CT_HD static inline int ggml_block_elems(int t) {
-    switch (t) { case GT_F32: case GT_F16: return 1; case GT_Q4_0: case GT_Q8_0: return 32;
+    switch (t) { case GT_F32: case GT_F16: return 1; case GT_Q4_0: case GT_Q8_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: return 32;
                  case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return 256; default: return 0; }
 }
 CT_HD static inline int ggml_block_bytes(int t) {
     switch (t) { case GT_F32: return 4; case GT_F16: return 2; case GT_Q4_0: return 18; case GT_Q8_0: return 34;
+                 case GT_Q4_1: return 20; case GT_Q5_0: return 22; case GT_Q5_1: return 24;
                  case GT_Q4_K: return 144; case GT_Q5_K: return 176; case GT_Q6_K: return 210; default: return 0; }
 }
 CT_HD static inline size_t ggml_row_bytes(int t, int64_t k) { return (size_t)(k / ggml_block_elems(t)) * ggml_block_bytes(t); }
 CT_HD static inline bool is_kquant(int t) { return t == GT_Q4_K || t == GT_Q5_K || t == GT_Q6_K; }
+CT_HD static inline bool is_raw32(int t) { return t == GT_Q4_1 || t == GT_Q5_0 || t == GT_Q5_1; }   // kernels_raw32.h: file layout, token steps
 
 // The 12-byte 6-bit scale/min field of Q4_K / Q5_K headers is re-encoded (losslessly, same size) as four 24-bit groups
 // g_c = sc[2c] | sc[2c+1]<<6 | m[2c]<<12 | m[2c+1]<<18 (c = 0..3), little-endian bit order.
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
-enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5, LAYOUT_F16 = 6 };   // LAYOUT_F16: fp16 rows as in the file (DevMat::raw; kernels_f16.h)
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5, LAYOUT_F16 = 6, LAYOUT_RAW32 = 7 };   // LAYOUT_F16 / LAYOUT_RAW32: rows as in the file (DevMat::raw; kernels_f16.h, kernels_raw32.h)
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 // LAYOUT_R2C4 record of the prompt-chunk copy.  Q4_K / Q5_K: 8 x the file block.  Q6_K: the quants are stored UNPACKED-READY for the
 // f16 matrix-core operand (kernels_pg.h): per (slot, p, l) two dwords A, B with the four 6-bit values of vector va(p) / vb(p),

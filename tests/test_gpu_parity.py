@@ -85,6 +85,9 @@ def test_abi_semantics_on_gpu():
     ("llama-7b-2l", "Q4_K_S", 33, 8),    # Q4_K_S mix at 7B widths: attn_v / ffn_down in Q5_K beside Q4_K (one launch per type group at the QKV site)
     ("llama-7b-2l", "Q4_K_M+v_q8_0", 20, 6),   # a Q8_0 attn_v beside K-quant q / k: K-quant and 32-block kernels at one site
     ("llama-7b-2l", "F16", 12, 6),       # fp16 weight matrices at the 7B widths (kernels_f16.h: token steps, the prompt too)
+    ("llama-7b-2l", "Q4_1", 12, 6),      # ftypes Q4_1 / Q5_0 / Q5_1 at the 7B widths (kernels_raw32.h on the file layout: Q8_1 / Q8_0 activation
+    ("llama-7b-2l", "Q5_0", 12, 6),      # blocks, token steps for the prompt too; rows of 11008 = 344 blocks)
+    ("llama-7b-2l", "Q5_1", 12, 6),
     ("falcon-small", "Q4_K_M", 40, 30),  # config 4 graph: LayerNorm x2, fused QKV (Q5_K), neox RoPE, GQA 16/2, GELU, Q8_0 head
     ("falcon-tiny7", "Q8_0", 20, 50),    # 7B-style block (one norm, MQA) on the 32-element-block kernels
     ("falcon-7b-2l", "Q8_0", 9, 6),      # real Falcon-7B widths: n_embd 4544 = 142 blocks of 32 (not whole groups of four), 71 heads on ONE KV head
@@ -120,8 +123,8 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     r.eval(toks)
     m.eval(toks)
     # every model family / weight type evaluates prompts through the chunk kernels (32-block rows that are not whole groups of four
-    # blocks — Falcon-7B's 4544 — with zero blocks behind the row's end) — except fp16 matrices: token by token
-    assert chunk_tokens(m) == (0 if ftype == "F16" else n_prompt)
+    # blocks — Falcon-7B's 4544 — with zero blocks behind the row's end) — except file-layout matrices (F16, Q4_1, Q5_0, Q5_1): token by token
+    assert chunk_tokens(m) == (0 if ftype in ("F16", "Q4_1", "Q5_0", "Q5_1") else n_prompt)
     for i in range(n_decode):
         a, b = r.logits.to_numpy(), m.logits.to_numpy()
         assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())

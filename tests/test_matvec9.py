@@ -184,6 +184,29 @@ def test_f16_weight_matrices(emu_lib, mirror, tmp_path):
         assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (9 + i)
 
 
+@pytest.mark.parametrize("ftype", ["Q4_1", "Q5_0", "Q5_1"])
+def test_q4_1_q5_0_q5_1_weight_matrices(emu_lib, mirror, tmp_path, ftype):
+    """A llama GGUF of ftype Q4_1 / Q5_0 / Q5_1 (every 2-D tensor of the base type, output.weight Q6_K, token_embd rows dequantized by
+    get_rows; reference: vec_dot_type Q8_1 / Q8_0 / Q8_1, ggml.c:2699 / :2825 / :3065 AVX2 forms): kernels_raw32.h on the file layout,
+    token steps for the prompt too — against the oracle restatement (tests/test_oracle.py compares it with the reference build on the
+    same kind of file and op by op)."""
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", ftype, seed=43, overrides=dict(n_ff=608))   # ffn_down rows of 19 blocks: not whole rounds of four
+    m = LLM(p, config=Config(context_length=64, batch_size=8, threads=1), lib=emu_lib)
+    o = mirror.MirrorLlama(p, 64)
+    toks = synth.prompt_tokens(9, hp["n_vocab"])
+    o.eval(toks[:8], 0)
+    lg = np.array(o.eval(toks[8:], 8), copy=True)   # the reference's batches of 8: 8 + 1
+    m.eval(toks)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    assert np.array_equal(m.embeddings.to_numpy(), o.embeddings)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 9 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (9 + i)
+
+
 @pytest.mark.parametrize("arch", ["gpt2", "mpt"])
 def test_legacy_graphs_at_widths_that_are_not_multiples_of_128(emu_lib, mirror, tmp_path, arch):
     """GPT-2 XL has n_embd 1600 (50 blocks of 32 per row); here 192 with three heads, for the gpt2 and the mpt graph: prompt through the

@@ -100,13 +100,17 @@ def test_reference_build_reproduces_golden(ref):
 
 def test_restatement_follows_reference_build_on_shapes_without_goldens(mirror, ref, tmp_path):
     """Shapes and types added after the golden vectors were generated, pinned on the reference build itself (needs oracle/_ref): fp16
-    weight matrices (ftype F16: vec_dot_type F16), Q8_0 rows that are not whole groups of four blocks with an odd head count on one KV
+    weight matrices (ftype F16: vec_dot_type F16), ftypes Q4_1 / Q5_0 / Q5_1, Q8_0 rows that are not whole groups of four blocks with an odd head count on one KV
     head (Falcon-7B's geometry), MPT heads of 112 (the f16 dot's scalar tail; the double-sqrt scale of the legacy graphs is pinned
     by tests/test_mpt.py)."""
     cases = []
     p = str(tmp_path / "f16.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", "F16", seed=41)
     cases.append((p, None, mirror.MirrorLlama(p, 64), hp))
+    for ft in ("Q4_1", "Q5_0", "Q5_1"):   # vec_dot_type Q8_1 / Q8_0 / Q8_1; token_embd rows through dequantize_row_q4_1 / q5_0 / q5_1
+        p = str(tmp_path / (ft + ".gguf"))
+        hp = synth.write_llama_gguf(p, "llama-tiny", ft, seed=43, overrides=dict(n_ff=608))
+        cases.append((p, None, mirror.MirrorLlama(p, 64), hp))
     p = str(tmp_path / "f7.gguf")
     hp = synth.write_falcon_gguf(p, "falcon-tiny7", "Q8_0", seed=17, overrides=dict(n_embd=192, n_head=3, n_head_kv=1, n_ff=768, n_layer=2))
     cases.append((p, None, mirror.MirrorFalcon(p, 64), hp))
@@ -161,3 +165,32 @@ def test_f16_dot_follows_the_reference_build_at_every_length(mirror, ref):
             s = ctypes.c_float(0)
             vd(n, ctypes.byref(s), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p))
             assert np.float32(s.value) == np.float32(L.mir_vec_dot_f16(n, x.ctypes.data, y.ctypes.data)), n
+
+
+@pytest.mark.parametrize("t", [G.Q4_1, G.Q5_0, G.Q5_1])
+def test_q4_1_q5_0_q5_1_follow_the_reference_build(mirror, ref, t):
+    """Q8_1 activation blocks (d f32, s = d * sum), the three AVX2 dot products — `summs += m * s` is ONE fused multiply-add per block in
+    the reference build (an unfused sum differs in two rows of three) — and the dequantize rows (numpy and C restatement), op by op
+    against oracle/_ref: scales 1e-3 .. 300, all-zero blocks, rows of 1 .. 142 blocks."""
+    import ctypes
+    from oracle import mirror as mm
+    L = mm.lib()
+    rng = np.random.default_rng(3 + t)
+    for trial in range(40):
+        sc = float(rng.choice([1e-3, 0.1, 1, 10, 300]))
+        K = int(rng.choice([32, 96, 512, 2816, 4544]))
+        w = (rng.standard_normal((5, K)) * 0.1 + rng.choice([0, 0.05])).astype(np.float32)
+        wraw = synth.quantize(w, t).reshape(5, -1)
+        x = (rng.standard_normal(K) * sc).astype(np.float32)
+        if trial % 7 == 0:
+            x[:32] = 0
+        a, _ = ref.quantize_activation(x, t)
+        if t != G.Q5_0:
+            out = np.zeros(K // 32 * 40, dtype=np.uint8)
+            L.mir_quantize_row_q8_1(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), K)
+            assert np.array_equal(out, np.asarray(a).view(np.uint8).ravel())
+        assert np.array_equal(mirror.matvec(t, wraw, x, K), ref.matvec(t, wraw, x, K))
+        d = ref.dequantize(wraw, t, K)
+        assert np.array_equal(mirror.dequantize(wraw, t, K), d)
+        assert np.array_equal(synth.dequantize(wraw, t, K), d)
+        assert np.abs(d - w).max() < 0.05   # the numpy quantizers (synthetic files) produce legal, close blocks
