@@ -217,13 +217,13 @@ static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
 // matrix into the site's scratch rows, then the epilogue launch.
 static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
     if (!a.f16_tmp) { err = "file-layout mat-vec without its scratch rows"; return false; }
-    if (a.pro == PRO_LAYERNORM) { err = "F16 / Q4_1 / Q5_0 / Q5_1 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
     if (a.K % 32 || a.K > 32768) { err = "file-layout rows must be whole 32-element steps, at most 32768 elements"; return false; }
     int off = 0;
     for (int j = 0; j < a.njobs; ++j) {
         const DevMat& w = a.job[j].w;
         if (!(w.type == GT_F16 || is_raw32(w.type)) || !w.raw) { err = "a launch site mixes file-layout matrices (F16, Q4_1, Q5_0, Q5_1) with other weight types"; return false; }
         if (w.type == GT_F16) {
+            if (a.pro == PRO_LAYERNORM) { err = "F16 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
             // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
             const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
             auto kfn = matvec_f16_kernel<256>;
@@ -236,7 +236,7 @@ static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
     {                                                                                                                                      \
         auto kfn = matvec_raw32_kernel<T, 256>;                                                                                            \
         CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);                                                                                             \
-        CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), lds, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint8_t*)w.raw, w.M, a.f16_tmp + off); \
+        CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), lds, s, a.x, a.norm_w, a.norm_b, a.K, a.pro, a.eps, (const uint8_t*)w.raw, w.M, a.f16_tmp + off); \
     }
             if (w.type == GT_Q4_1) CT_RAW32(GT_Q4_1)
             else if (w.type == GT_Q5_0) CT_RAW32(GT_Q5_0)

@@ -10,7 +10,7 @@
 //                        (lane j = accumulator vector j: the 16-byte chunks j, j + 4, ... of the row), eight requests in flight per
 //                        lane, every request unconditional (a clamped row instead of a branch: kernels_attn9.h); raw f32 results
 //   f16_epilogue_kernel  the decode kernels' epilogues (kernels_v9.h) on those results: store / + residual / RoPE -> fp16 Q /
-//                        RoPE -> K cache / V cache / SiLU(gate) * up
+//                        RoPE -> K cache / V cache / SiLU(gate) * up / GELU / + two residuals / row bias forms
 // Two launches per site instead of one fused kernel: F16 files are not on any BASELINE config; what matters here is that they load
 // and give the reference's bits (13.5 GB per 7B token: bandwidth-bound at a few hundred tokens/s either way).
 #pragma once
@@ -99,6 +99,16 @@ __global__ void __launch_bounds__(256) f16_epilogue_kernel(const MatvecArgs a, c
         a.out[row] = res;
     } else if (epi == EPI_ADD) {
         a.out[row] = res + a.res[row];
+    } else if (epi == EPI_GELU) {   // the single-job epilogues of the falcon / gpt2 / mpt graphs, as kernels_v9.h writes them
+        a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(res)]);
+    } else if (epi == EPI_ADD2) {
+        a.out[row] = (res + a.res[row]) + a.res2[row];
+    } else if (epi == EPI_BIAS_STORE) {
+        a.out[row] = a.bias[row] + res;
+    } else if (epi == EPI_BIAS_ADD) {
+        a.out[row] = (a.bias[row] + res) + a.res[row];
+    } else if (epi == EPI_BIAS_GELU) {
+        a.out[row] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(a.bias[row] + res)]);
     } else if (epi == EPI_V) {
         a.vcache[(size_t)row * a.v_stride + *a.pos] = f32_to_f16_bits(res);
     } else if (epi == EPI_ROPE_Q || epi == EPI_ROPE_K) {   // normal-mode RoPE (ggml.c:12522-12539, the build's fma forms): rows 2i, 2i + 1 rotate together

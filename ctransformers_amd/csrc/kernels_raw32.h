@@ -1,5 +1,5 @@
-// Q4_1 / Q5_0 / Q5_1 weight matrices (llama GGUF files of those ftypes: llama.cpp:4785-4790 quantizes every 2-D tensor but output.weight
-// to the base type): token steps only, on the FILE layout (DevMat::raw, LAYOUT_RAW32), bit-identical to the reference CPU build.
+// Q4_1 / Q5_0 / Q5_1 weight matrices (llama / falcon GGUF files of those ftypes: llama.cpp:4785-4790 quantizes every 2-D tensor but
+// output.weight to the base type; legacy GGML files of gpt2 / starcoder / mpt with ftype 3 / 8 / 9): token steps only, on the FILE layout (DevMat::raw, LAYOUT_RAW32), bit-identical to the reference CPU build.
 //
 // Reference: ggml_compute_forward_mul_mat (ggml.c:11031-11245) quantizes the activation row to the weight type's vec_dot_type —
 // Q8_0 for Q5_0, Q8_1 for Q4_1 / Q5_1 (type traits ggml.c:1700-1745) — and every output is one of
@@ -12,7 +12,7 @@
 // Activation blocks (AVX2 quantizers ggml.c:1208-1300, :1420-1476): d = amax / 127 (Q8_0: stored as fp16; Q8_1: f32), id = 127 / amax
 // (0 for an all-zero block), q = round-half-even(x * id), Q8_1 s = d * (float)(sum of the quants).
 //
-//   matvec_raw32_kernel  prologue per workgroup: (RMSNorm * w ->) activation blocks in LDS; eight lanes per output row (lane l = AVX
+//   matvec_raw32_kernel  prologue per workgroup: (RMSNorm * w | LayerNorm * w + b ->) activation blocks in LDS; eight lanes per output row (lane l = AVX
 //                        lane l), four blocks requested per round, every request unconditional (clamped block index); raw f32 results
 //   f16_epilogue_kernel  (kernels_f16.h) the decode epilogues on those results
 // These ftypes are on no BASELINE config: the point is that such files load and give the reference's bits; the layout-specific
@@ -45,8 +45,8 @@ template <int TYPE> DEV Raw32Blk raw32_load(const uint8_t* b, int l) {
 }
 
 template <int TYPE, int NT>
-__global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps,
-                                                          const uint8_t* __restrict__ W, int M, float* __restrict__ out) {
+__global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restrict__ x, const float* __restrict__ nw, const float* __restrict__ nbias,
+                                                          int K, int pro, float eps, const uint8_t* __restrict__ W, int M, float* __restrict__ out) {
     constexpr bool Q81 = TYPE != GT_Q5_0;   // activation blocks are Q8_1
     constexpr int BB = raw32_block_bytes<TYPE>();
     CT_DYN_SMEM(smem_raw);   // K / 4 quant words | K / 32 block scales d | K / 32 block sums s
@@ -54,29 +54,55 @@ __global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restric
     const int nb = K >> 5;
     float* ad = reinterpret_cast<float*>(aq + (K >> 2));
     float* as = ad + nb;
-    __shared__ double red[NT / 64];
+    __shared__ double red[2][NT / 64];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), l = tid & 7;
-    // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf), ggml_mul with the norm weight, then the activation blocks ----
-    float scale = 1.0f;
-    if (pro == PRO_RMSNORM) {
-        double s = 0.0;
-        for (int i = tid; i < K; i += NT) { const float v = x[i]; s += (double)(v * v); }
-        s = wave_sum(s);
-        if (lane == 0) red[wv] = s;
+    // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf) or ggml.c:10605-10654 (norm: f32 mean of a double sum, the
+    // centred values' squares summed in double, f32 variance), ggml_mul with the norm weight (ggml_add with its bias), then the activation blocks ----
+    float scale = 1.0f, mean = 0.0f;
+    if (pro == PRO_LAYERNORM) {
+        double s1 = 0.0;
+        for (int i = tid; i < K; i += NT) s1 += (double)x[i];
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wv] = s1;
         __syncthreads();
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) tot += red[w];
-        const float mean = (float)(tot / (double)K);
-        scale = 1.0f / sqrtf(mean + eps);
+        for (int w = 0; w < NT / 64; ++w) tot += red[0][w];
+        mean = (float)(tot / (double)K);
+        double s2 = 0.0;
+        for (int i = tid; i < K; i += NT) { const float v = x[i] - mean; s2 += (double)(v * v); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wv] = s2;
+        __syncthreads();
+        double tot2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot2 += red[1][w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
+    } else if (pro == PRO_RMSNORM) {
+        double s = 0.0;
+        for (int i = tid; i < K; i += NT) { const float v = x[i]; s += (double)(v * v); }
+        s = wave_sum(s);
+        if (lane == 0) red[0][wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += red[0][w];
+        const float ms = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(ms + eps);
     }
     for (int b0 = 0; b0 < nb; b0 += NT / 8) {   // eight lanes per block (lane l: elements 4l .. 4l+3); whole groups of eight lanes stay together
         const int b = b0 + (tid >> 3);
         const int bc = b < nb ? b : nb - 1;
         float4 t = *(const float4*)(x + bc * 32 + l * 4);
-        if (pro == PRO_RMSNORM) {
+        if (pro != PRO_PLAIN) {
             const float4 w4 = *(const float4*)(nw + bc * 32 + l * 4);
+            if (pro == PRO_LAYERNORM) { t.x -= mean; t.y -= mean; t.z -= mean; t.w -= mean; }
             t.x = (t.x * scale) * w4.x; t.y = (t.y * scale) * w4.y; t.z = (t.z * scale) * w4.z; t.w = (t.w * scale) * w4.w;
+            if (pro == PRO_LAYERNORM && nbias) {
+                const float4 b4 = *(const float4*)(nbias + bc * 32 + l * 4);
+                t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+            }
         }
         float amax = fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w)));
         amax = fmaxf(amax, lane_xor1(amax));

@@ -75,6 +75,9 @@ def test_abi_semantics_on_gpu():
     # sampler / tokenizer parity of the HIP binary: tests/test_tokenizers.py::test_tokenizers_and_samplers_match_reference_hip_build
 
 
+LEGACY_FTYPE = {"Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum ggml_ftype (reference ggml.h:322-336)
+
+
 @pytest.mark.parametrize("shape,ftype,n_prompt,n_decode", [
     ("llama-small", "Q4_K_M", 20, 60),   # MHA 8/8, head_dim 64, K = 512 / 1280 (odd block counts)
     ("llama-tiny", "Q5_K_M", 5, 80),     # GQA 4/2, runs past 64 positions (fp16 dot leftovers + full 32-steps)
@@ -100,17 +103,21 @@ def test_abi_semantics_on_gpu():
     ("starcoder-7b-2l", "Q4_0", 33, 8),   # StarCoderBase-7B widths: rows of 16384 (wide-row kernels, bias epilogues)
     ("mpt-7b-2l", "Q4_0", 33, 12),        # MPT-7B widths: ALiBi over 32 heads of 128, 50432-row tied head, rows of 16384
     ("mpt-7b-2l", "Q8_0", 12, 6),
+    ("gpt2-xl-2l", "Q5_1", 9, 6),         # legacy ftypes 3 / 8 / 9 and falcon GGUF in Q4_1 / Q5_0 / Q5_1: kernels_raw32.h behind LayerNorms, row-bias /
+    ("starcoder-1b-4l", "Q4_1", 9, 4),    # GELU / two-residual epilogues, tied lm_head in the same type
+    ("mpt-7b-2l", "Q5_0", 9, 4),
+    ("falcon-7b-2l", "Q5_1", 9, 4),
     ("mpt-30b-2l", "Q4_0", 40, 8),        # MPT-30B widths: 64 heads of 112 (the f16 dot's scalar tail), d_model 7168, rows of 28672
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
     p = str(tmp_path / "m.gguf")
     mt = None
     if shape.startswith("gpt2"):
-        hp, mt = synth.write_gpt2_ggml(p, shape, seed=21), "gpt2"
+        hp, mt = synth.write_gpt2_ggml(p, shape, seed=21, ftype=LEGACY_FTYPE[ftype]), "gpt2"
     elif shape.startswith("starcoder"):
-        hp, mt = synth.write_gpt2_ggml(p, shape, seed=21, ftype={"Q4_0": 2, "Q8_0": 7}[ftype], pieces=synth.STARCODER_PIECES), "starcoder"
+        hp, mt = synth.write_gpt2_ggml(p, shape, seed=21, ftype=LEGACY_FTYPE[ftype], pieces=synth.STARCODER_PIECES), "starcoder"
     elif shape.startswith("mpt"):
-        hp, mt = synth.write_mpt_ggml(p, shape, seed=21, ftype={"Q4_0": 2, "Q8_0": 7}[ftype]), "mpt"
+        hp, mt = synth.write_mpt_ggml(p, shape, seed=21, ftype=LEGACY_FTYPE[ftype]), "mpt"
     elif "+v_q8_0" in ftype:
         from ctransformers_amd import gguf as G
         hp = synth.write_llama_gguf(p, shape, ftype.split("+")[0], seed=21, type_overrides={"attn_v.weight": G.Q8_0})

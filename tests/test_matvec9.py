@@ -229,3 +229,31 @@ def test_legacy_graphs_at_widths_that_are_not_multiples_of_128(emu_lib, mirror, 
         m.eval([t])
         lg = np.array(o.eval([t], 13 + i), copy=True)
         assert np.array_equal(m.logits.to_numpy(), lg)
+
+
+@pytest.mark.parametrize("arch,ftype", [("gpt2", "Q5_1"), ("gpt2", "Q5_0"), ("mpt", "Q4_1"), ("mpt", "Q5_0"), ("falcon", "Q5_1"), ("falcon", "Q4_1")])
+def test_q4_1_q5_0_q5_1_in_the_layernorm_graphs(emu_lib, mirror, tmp_path, arch, ftype):
+    """Legacy GGML files of ftype 3 / 8 / 9 (gpt2, mpt) and falcon GGUF files of ftype Q4_1 / Q5_0 / Q5_1: kernels_raw32.h behind a LayerNorm
+    (with and without bias), the row-bias / GELU / two-residual epilogues, the tied Q5_x lm_head of gpt2 — against the oracle restatement
+    (tests/test_oracle.py compares it with the reference build on the same kinds of file)."""
+    ft = {"Q4_1": 3, "Q5_0": 8, "Q5_1": 9}[ftype]
+    p = str(tmp_path / ("m.gguf" if arch == "falcon" else "m.bin"))
+    if arch == "gpt2":
+        synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=96, n_embd=192, n_head=3, n_layer=2), seed=5, ftype=ft)
+        o = mirror.MirrorGpt2(p)
+    elif arch == "mpt":
+        synth.write_mpt_ggml(p, dict(n_vocab=512, max_seq_len=96, n_embd=192, n_head=3, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0), seed=6, ftype=ft)
+        o = mirror.MirrorMpt(p, 96)
+    else:
+        synth.write_falcon_gguf(p, "falcon-tiny7", ftype, seed=17)
+        o = mirror.MirrorFalcon(p, 96)
+    m = LLM(p, None if arch == "falcon" else arch, config=Config(context_length=96, batch_size=64, threads=1), lib=emu_lib)
+    toks = synth.prompt_tokens(7, 512)
+    m.eval(toks)
+    lg = np.array(o.eval(toks, 0), copy=True)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    for i in range(2):
+        t = int(lg.argmax())
+        m.eval([t])
+        lg = np.array(o.eval([t], 7 + i), copy=True)
+        assert np.array_equal(m.logits.to_numpy(), lg)
