@@ -229,8 +229,9 @@ static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
             auto kfn = matvec_f16_kernel<256>;
             CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
             CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
-        } else {   // 8 rows per pass of a 256-thread workgroup; LDS: K quant bytes + 8 bytes per block
-            const int gx = std::max(1, std::min((w.M + 7) / 8, 8 * chip_cus()));
+        } else {   // 16 rows per pass of a 256-thread workgroup (128 / 512 threads measured 170 / 218 against 225 tok/s on the 7B Q4_1 file:
+                   // profiles/r03_raw32_q41_q50_q51.txt); LDS: K quant bytes + 8 bytes per block
+            const int gx = std::max(1, std::min((w.M + 15) / 16, 8 * chip_cus()));
             const size_t lds = (size_t)a.K + (size_t)(a.K / 32) * 8;
 #define CT_RAW32(T)                                                                                                                        \
     {                                                                                                                                      \

@@ -12,8 +12,8 @@
 // Activation blocks (AVX2 quantizers ggml.c:1208-1300, :1420-1476): d = amax / 127 (Q8_0: stored as fp16; Q8_1: f32), id = 127 / amax
 // (0 for an all-zero block), q = round-half-even(x * id), Q8_1 s = d * (float)(sum of the quants).
 //
-//   matvec_raw32_kernel  prologue per workgroup: (RMSNorm * w | LayerNorm * w + b ->) activation blocks in LDS; 32 lanes per output row (AVX lane x
-//                        block column: four blocks per round, chained through the quad), 16 blocks requested ahead, every request
+//   matvec_raw32_kernel  prologue per workgroup: (RMSNorm * w | LayerNorm * w + b ->) activation blocks in LDS; 16 lanes per output row (AVX lane pair x
+//                        block column: four blocks per round, chained through the quad), a ring of 32 blocks in flight per lane, every request
 //                        unconditional (clamped block index); raw f32 results
 //   f16_epilogue_kernel  (kernels_f16.h) the decode epilogues on those results
 // These ftypes are on no BASELINE config: the point is that such files load and give the reference's bits; the layout-specific
@@ -126,56 +126,57 @@ __global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restric
         }
     }
     __syncthreads();
-    // ---- rows: 32 lanes per row — lane = (row of the wave's pair, AVX lane lq, block column c): a round is four consecutive blocks, one
-    // per column; the quad's lanes c = 0..3 run the reference's chain over them in order (quad_chain4: gpu.h).  Two rows per wave put
-    // M / 2 waves on the chip (eight lanes per row left a 4096-row site at two waves per CU: 0.45 TB/s).  A column past the row's end
-    // contributes fma(0, 0, acc) = acc (acc is never -0: it starts at +0). ----
-    constexpr int PB = 4;   // rounds (of four blocks) requested ahead
-    const int c = lane & 3, lq = (lane >> 2) & 7, sh = lq >= 4 ? 4 : 0;
-    constexpr int RPW = NT / 32;   // rows per pass of the workgroup
+    // ---- rows: 16 lanes per row — lane = (row of the wave's four, AVX lane pair lq | lq + 4, block column c): a round is four consecutive
+    // blocks, one per column; a lane's nibble word serves both AVX lanes of its pair (low / high nibbles: elements 4 lq .. and 16 + 4 lq ..);
+    // the quad's lanes c = 0..3 run the reference's chains over the round in order (quad_chain4: gpu.h).  A column past the row's end
+    // contributes fma(0, 0, acc) = acc (acc is never -0: it starts at +0).  Eight lanes per row (no columns) left a 4096-row site at two
+    // waves per CU: 0.45 TB/s; 32 lanes per row (one AVX lane per lane) twice the load instructions per byte: 0.9 TB/s. ----
+    constexpr int PB = 8;   // rounds (of four blocks) in flight per lane: a register ring, every slot re-requested as soon as it is consumed
+    const int c = lane & 3, lq = (lane >> 2) & 3;
+    constexpr int RPW = NT / 16;   // rows per pass of the workgroup
     for (int row0 = (int)blockIdx.x * RPW; row0 < M; row0 += (int)gridDim.x * RPW) {
-        const int row = row0 + (tid >> 5);
-        const uint8_t* wrow = W + (size_t)(row < M ? row : M - 1) * nb * BB;   // a wave half past the last row re-reads it (nothing stored)
-        float acc = 0.0f, summs = 0.0f;
-        Raw32Blk R[PB], N[PB];
+        const int row = row0 + (tid >> 4);
+        const uint8_t* wrow = W + (size_t)(row < M ? row : M - 1) * nb * BB;   // lanes past the last row re-read it (nothing stored)
+        float accl = 0.0f, acch = 0.0f, summs = 0.0f;
+        Raw32Blk R[PB];
 #pragma unroll
         for (int u = 0; u < PB; ++u) { const int b = 4 * u + c; R[u] = raw32_load<TYPE>(wrow + (size_t)(b < nb ? b : nb - 1) * BB, lq); }
-        for (int b0 = 0; b0 < nb; b0 += 4 * PB) {
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {   // the next 16 blocks: every request unconditional (clamped to the row's last block)
-                const int b = b0 + 4 * PB + 4 * u + c;
-                N[u] = raw32_load<TYPE>(wrow + (size_t)(b < nb ? b : nb - 1) * BB, lq);
-            }
+        for (int b0 = 0; b0 < nb; b0 += 4 * PB) {   // no branch inside: hipcc counts the requests in flight (s_waitcnt vmcnt(N), kernels_attn9.h)
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                if (b0 + 4 * u < nb) {   // wave-uniform
-                    const int b = b0 + 4 * u + c;
-                    const bool live = b < nb;
-                    const int bc = live ? b : nb - 1;
-                    const int a = aq[bc * 8 + lq];
-                    int w = (int)((R[u].qs >> sh) & 0x0F0F0F0Fu);
-                    int isum;
-                    if constexpr (TYPE == GT_Q4_1) {
-                        isum = sdot4(w, a, 0);
-                    } else {
-                        const uint32_t h4 = (R[u].qh >> (4 * lq)) & 0xFu;
-                        w |= (int)(((h4 * 0x00204081u) & 0x01010101u) << 4);   // bit k of h4 -> bit 4 of byte k
-                        if constexpr (TYPE == GT_Q5_1) isum = sdot4(w, a, 0);
-                        else isum = sdot4(w, a, sdot4((int)0xF0F0F0F0u, a, 0));   // (q5 - 16) . a = q5 . a - 16 * (sum of a)
+                const int b = b0 + 4 * u + c;
+                const bool live = b < nb;
+                const int bc = live ? b : nb - 1;
+                const int al = aq[bc * 8 + lq], ah = aq[bc * 8 + 4 + lq];
+                int wl = (int)(R[u].qs & 0x0F0F0F0Fu), wh = (int)((R[u].qs >> 4) & 0x0F0F0F0Fu);
+                int il, ih;
+                if constexpr (TYPE == GT_Q4_1) {
+                    il = sdot4(wl, al, 0); ih = sdot4(wh, ah, 0);
+                } else {
+                    const uint32_t hl = (R[u].qh >> (4 * lq)) & 0xFu, hh = (R[u].qh >> (16 + 4 * lq)) & 0xFu;
+                    wl |= (int)(((hl * 0x00204081u) & 0x01010101u) << 4);   // bit k of the four -> bit 4 of byte k
+                    wh |= (int)(((hh * 0x00204081u) & 0x01010101u) << 4);
+                    if constexpr (TYPE == GT_Q5_1) { il = sdot4(wl, al, 0); ih = sdot4(wh, ah, 0); }
+                    else {   // (q5 - 16) . a = q5 . a - 16 * (sum of a)
+                        il = sdot4(wl, al, sdot4((int)0xF0F0F0F0u, al, 0));
+                        ih = sdot4(wh, ah, sdot4((int)0xF0F0F0F0u, ah, 0));
                     }
-                    const float dx = f16_bits_to_f32((uint16_t)(R[u].dm & 0xFFFFu));
-                    acc = quad_chain4(acc, live ? dx * ad[bc] : 0.0f, live ? (float)isum : 0.0f);
-                    if constexpr (Q81) summs = quad_chain4(summs, live ? f16_bits_to_f32((uint16_t)(R[u].dm >> 16)) : 0.0f, live ? as[bc] : 0.0f);
                 }
+                const float dx = f16_bits_to_f32((uint16_t)(R[u].dm & 0xFFFFu));
+                const float mx = f16_bits_to_f32((uint16_t)(R[u].dm >> 16));
+                const int bn = b + 4 * PB;
+                R[u] = raw32_load<TYPE>(wrow + (size_t)(bn < nb ? bn : nb - 1) * BB, lq);
+                const float dv = live ? dx * ad[bc] : 0.0f;
+                accl = quad_chain4(accl, dv, live ? (float)il : 0.0f);
+                acch = quad_chain4(acch, dv, live ? (float)ih : 0.0f);
+                if constexpr (Q81) summs = quad_chain4(summs, live ? mx : 0.0f, live ? as[bc] : 0.0f);
             }
-#pragma unroll
-            for (int u = 0; u < PB; ++u) R[u] = N[u];
         }
-        // hsum_float_8 (ggml.c:609-615): ((x0 + x4) + (x2 + x6)) + ((x1 + x5) + (x3 + x7)); AVX lane lq sits at lane bits 2..4
-        float r = acc + lane_xor16(acc);
+        // hsum_float_8 (ggml.c:609-615): ((x0 + x4) + (x2 + x6)) + ((x1 + x5) + (x3 + x7)); the pair (lq, lq + 4) is in this lane, lq at lane bits 2..3
+        float r = acch + accl;
         r = r + lane_xor8(r);
         r = r + lane_xor4(r);
         if constexpr (Q81) r = r + summs;
-        if ((lane & 31) == 0 && row < M) out[row] = r;
+        if ((lane & 15) == 0 && row < M) out[row] = r;
     }
 }
