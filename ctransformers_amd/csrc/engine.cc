@@ -223,12 +223,11 @@ static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
         const DevMat& w = a.job[j].w;
         if (!(w.type == GT_F16 || is_raw32(w.type)) || !w.raw) { err = "a launch site mixes file-layout matrices (F16, Q4_1, Q5_0, Q5_1) with other weight types"; return false; }
         if (w.type == GT_F16) {
-            if (a.pro == PRO_LAYERNORM) { err = "F16 weight matrices behind a LayerNorm are not supported (llama graphs only)"; return false; }
             // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
             const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
             auto kfn = matvec_f16_kernel<256>;
             CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
-            CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
+            CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.norm_b, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
         } else {   // 16 rows per pass of a 256-thread workgroup (128 / 512 threads measured 170 / 218 against 225 tok/s on the 7B Q4_1 file:
                    // profiles/r03_raw32_q41_q50_q51.txt); LDS: K quant bytes + 8 bytes per block
             const int gx = std::max(1, std::min((w.M + 15) / 16, 8 * chip_cus()));

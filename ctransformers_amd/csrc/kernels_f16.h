@@ -1,12 +1,12 @@
-// F16 weight matrices (llama GGUF files of ftype F16; the F16 output.weight the reference's quantizer falls back to for rows that are
-// not whole 256-blocks, llama.cpp:4866-4869): token steps only, bit-identical to the reference CPU build.
+// F16 weight matrices (GGUF files of ftype F16 — llama, falcon; legacy gpt2 / starcoder / mpt files of ftype 1, what the reference's convert
+// scripts write; the F16 output.weight the reference's quantizer falls back to for rows that are not whole 256-blocks, llama.cpp:4866-4869): token steps only, bit-identical to the reference CPU build.
 //
 // Reference: ggml_compute_forward_mul_mat with an F16 src0 (ggml.c:11031-11245): vec_dot_type is F16, so the activation row is
 // converted with ggml_fp32_to_fp16_row (round to nearest even, F16C) and every output is ggml_vec_dot_f16 (ggml.c:2392-2425) of the
 // weight row and that fp16 vector — the dot product of the attention kernels (kernels_exact.h header): 4 accumulator vectors x 8
 // lanes, one fma per element in 32-element steps, the AVX reduce tree.  Rows here are whole 32-element steps (checked at load): no
 // scalar tail.
-//   matvec_f16_kernel    prologue per workgroup: (RMSNorm * w ->) fp16 activation vector in LDS; a quad of lanes per output row
+//   matvec_f16_kernel    prologue per workgroup: (RMSNorm * w | LayerNorm * w + b ->) fp16 activation vector in LDS; a quad of lanes per output row
 //                        (lane j = accumulator vector j: the 16-byte chunks j, j + 4, ... of the row), eight requests in flight per
 //                        lane, every request unconditional (a clamped row instead of a branch: kernels_attn9.h); raw f32 results
 //   f16_epilogue_kernel  the decode kernels' epilogues (kernels_v9.h) on those results: store / + residual / RoPE -> fp16 Q /
@@ -17,29 +17,51 @@
 #include "kernels_exact.h"
 
 template <int NT>
-__global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, float eps,
-                                                        const uint16_t* __restrict__ W, int M, float* __restrict__ out) {
+__global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict__ x, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
+                                                        float eps, const uint16_t* __restrict__ W, int M, float* __restrict__ out) {
     CT_DYN_SMEM(smem_raw);   // the fp16 activation vector: K halves
     uint16_t* xh = reinterpret_cast<uint16_t*>(smem_raw);
-    __shared__ double red[NT / 64];
+    __shared__ double red[2][NT / 64];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3, quad = tid >> 2;
-    // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf), ggml_mul with the norm weight, then fp16 ----
-    float scale = 1.0f;
-    if (pro == PRO_RMSNORM) {
-        double s = 0.0;
-        for (int i = tid; i < K; i += NT) { const float v = x[i]; s += (double)(v * v); }
-        s = wave_sum(s);
-        if (lane == 0) red[wv] = s;
+    // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf) or ggml.c:10605-10654 (norm: f32 mean of a double sum, the centred
+    // values' squares summed in double, f32 variance), ggml_mul with the norm weight (ggml_add with its bias), then fp16 ----
+    float scale = 1.0f, mean = 0.0f;
+    if (pro == PRO_LAYERNORM) {
+        double s1 = 0.0;
+        for (int i = tid; i < K; i += NT) s1 += (double)x[i];
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wv] = s1;
         __syncthreads();
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) tot += red[w];
-        const float mean = (float)(tot / (double)K);
-        scale = 1.0f / sqrtf(mean + eps);
+        for (int w = 0; w < NT / 64; ++w) tot += red[0][w];
+        mean = (float)(tot / (double)K);
+        double s2 = 0.0;
+        for (int i = tid; i < K; i += NT) { const float v = x[i] - mean; s2 += (double)(v * v); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wv] = s2;
+        __syncthreads();
+        double tot2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot2 += red[1][w];
+        const float variance = (float)(tot2 / (double)K);
+        scale = 1.0f / sqrtf(variance + eps);
+    } else if (pro == PRO_RMSNORM) {
+        double s = 0.0;
+        for (int i = tid; i < K; i += NT) { const float v = x[i]; s += (double)(v * v); }
+        s = wave_sum(s);
+        if (lane == 0) red[0][wv] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += red[0][w];
+        const float ms = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(ms + eps);
     }
     for (int i = tid; i < K; i += NT) {
         float v = x[i];
-        if (pro == PRO_RMSNORM) v = (v * scale) * nw[i];
+        if (pro == PRO_LAYERNORM) { v = ((v - mean) * scale) * nw[i]; if (nbias) v += nbias[i]; }
+        else if (pro == PRO_RMSNORM) v = (v * scale) * nw[i];
         xh[i] = f32_to_f16_bits(v);
     }
     __syncthreads();

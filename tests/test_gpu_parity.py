@@ -75,7 +75,7 @@ def test_abi_semantics_on_gpu():
     # sampler / tokenizer parity of the HIP binary: tests/test_tokenizers.py::test_tokenizers_and_samplers_match_reference_hip_build
 
 
-LEGACY_FTYPE = {"Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum ggml_ftype (reference ggml.h:322-336)
+LEGACY_FTYPE = {"F16": 1, "Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum ggml_ftype (reference ggml.h:322-336)
 
 
 @pytest.mark.parametrize("shape,ftype,n_prompt,n_decode", [
@@ -107,6 +107,9 @@ LEGACY_FTYPE = {"Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum 
     ("starcoder-1b-4l", "Q4_1", 9, 4),    # GELU / two-residual epilogues, tied lm_head in the same type
     ("mpt-7b-2l", "Q5_0", 9, 4),
     ("falcon-7b-2l", "Q5_1", 9, 4),
+    ("gpt2-xl-2l", "F16", 9, 4),          # fp16 matrices behind LayerNorms (legacy ftype 1: what the reference's convert scripts write; falcon GGUF F16)
+    ("mpt-7b-2l", "F16", 9, 4),
+    ("falcon-7b-2l", "F16", 9, 4),
     ("mpt-30b-2l", "Q4_0", 40, 8),        # MPT-30B widths: 64 heads of 112 (the f16 dot's scalar tail), d_model 7168, rows of 28672
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):

@@ -231,12 +231,14 @@ def test_legacy_graphs_at_widths_that_are_not_multiples_of_128(emu_lib, mirror, 
         assert np.array_equal(m.logits.to_numpy(), lg)
 
 
-@pytest.mark.parametrize("arch,ftype", [("gpt2", "Q5_1"), ("gpt2", "Q5_0"), ("mpt", "Q4_1"), ("mpt", "Q5_0"), ("falcon", "Q5_1"), ("falcon", "Q4_1")])
+@pytest.mark.parametrize("arch,ftype", [("gpt2", "Q5_1"), ("gpt2", "Q5_0"), ("mpt", "Q4_1"), ("mpt", "Q5_0"), ("falcon", "Q5_1"), ("falcon", "Q4_1"),
+                                        ("gpt2", "F16"), ("mpt", "F16"), ("falcon", "F16")])
 def test_q4_1_q5_0_q5_1_in_the_layernorm_graphs(emu_lib, mirror, tmp_path, arch, ftype):
-    """Legacy GGML files of ftype 3 / 8 / 9 (gpt2, mpt) and falcon GGUF files of ftype Q4_1 / Q5_0 / Q5_1: kernels_raw32.h behind a LayerNorm
+    """Legacy GGML files of ftype 3 / 8 / 9 (gpt2, mpt) and falcon GGUF files of ftype Q4_1 / Q5_0 / Q5_1: kernels_raw32.h — and of ftype 1 / F16
+    (what the reference's convert scripts write): kernels_f16.h — behind a LayerNorm
     (with and without bias), the row-bias / GELU / two-residual epilogues, the tied Q5_x lm_head of gpt2 — against the oracle restatement
     (tests/test_oracle.py compares it with the reference build on the same kinds of file)."""
-    ft = {"Q4_1": 3, "Q5_0": 8, "Q5_1": 9}[ftype]
+    ft = {"F16": 1, "Q4_1": 3, "Q5_0": 8, "Q5_1": 9}[ftype]
     p = str(tmp_path / ("m.gguf" if arch == "falcon" else "m.bin"))
     if arch == "gpt2":
         synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=96, n_embd=192, n_head=3, n_layer=2), seed=5, ftype=ft)

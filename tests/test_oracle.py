@@ -127,6 +127,16 @@ def test_restatement_follows_reference_build_on_shapes_without_goldens(mirror, r
     p = str(tmp_path / "f50.gguf")
     hp = synth.write_falcon_gguf(p, "falcon-tiny7", "Q5_0", seed=17)
     cases.append((p, None, mirror.MirrorFalcon(p, 64), hp))
+    # fp16 matrices behind LayerNorms: legacy ftype 1 (what the reference's convert scripts write), falcon GGUF of ftype F16
+    p = str(tmp_path / "g16.bin")
+    hp = synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=64, n_embd=192, n_head=3, n_layer=2), seed=5, ftype=1)
+    cases.append((p, "gpt2", mirror.MirrorGpt2(p), hp))
+    p = str(tmp_path / "m16.bin")
+    hp = synth.write_mpt_ggml(p, dict(n_vocab=512, max_seq_len=64, n_embd=192, n_head=3, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0), seed=6, ftype=1)
+    cases.append((p, "mpt", mirror.MirrorMpt(p, 64), hp))
+    p = str(tmp_path / "f16f.gguf")
+    hp = synth.write_falcon_gguf(p, "falcon-tiny7", "F16", seed=17)
+    cases.append((p, None, mirror.MirrorFalcon(p, 64), hp))
     for path, mt, o, hp in cases:
         r = ref.open_llm(path, model_type=mt, context_length=64, batch_size=64, threads=2)
         toks = synth.prompt_tokens(37, hp["n_vocab"])
