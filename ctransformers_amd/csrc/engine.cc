@@ -213,7 +213,7 @@ static bool launch_matvec_one(MatvecArgs& a, hipStream_t s, std::string& err) {
 // per group of jobs that CAN share a launch: K-quant jobs whose arenas are contiguous and whose types are all equal or "X.. then
 // Q6_K.." (the two-type kernel), or Q8_0 / Q4_0 jobs of one type.  Every group recomputes the (cheap) prologue; the jobs' epilogues
 // are independent, so the results are those of the single launch.
-// A site whose matrices stay in file layout (F16: kernels_f16.h; Q4_1 / Q5_0 / Q5_1: kernels_raw32.h): one dot-product launch per
+// A site whose matrices stay in file layout (F16 / F32: kernels_f16.h; Q4_1 / Q5_0 / Q5_1: kernels_raw32.h): one dot-product launch per
 // matrix into the site's scratch rows, then the epilogue launch.
 static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
     if (!a.f16_tmp) { err = "file-layout mat-vec without its scratch rows"; return false; }
@@ -221,13 +221,20 @@ static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
     int off = 0;
     for (int j = 0; j < a.njobs; ++j) {
         const DevMat& w = a.job[j].w;
-        if (!(w.type == GT_F16 || is_raw32(w.type)) || !w.raw) { err = "a launch site mixes file-layout matrices (F16, Q4_1, Q5_0, Q5_1) with other weight types"; return false; }
-        if (w.type == GT_F16) {
+        if (!(w.type == GT_F16 || w.type == GT_F32 || is_raw32(w.type)) || !w.raw) { err = "a launch site mixes file-layout matrices (F32, F16, Q4_1, Q5_0, Q5_1) with other weight types"; return false; }
+        if (w.type == GT_F16 || w.type == GT_F32) {
             // 256-thread workgroups, 64 rows per pass: 1024-thread ones measured 75 against 125 tok/s on the 7B F16 file
             const int gx = std::max(1, std::min((w.M + 63) / 64, 8 * chip_cus()));
-            auto kfn = matvec_f16_kernel<256>;
-            CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
-            CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.norm_b, a.K, a.pro, a.eps, (const uint16_t*)w.raw, w.M, a.f16_tmp + off);
+            if (w.type == GT_F16) {
+                auto kfn = matvec_f16_kernel<256, false>;
+                CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
+                CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 2, s, a.x, a.norm_w, a.norm_b, a.K, a.pro, a.eps, (const void*)w.raw, w.M, a.f16_tmp + off);
+            } else {
+                if (a.K > 16384) { err = "F32 rows of more than 16384 elements are not supported"; return false; }
+                auto kfn = matvec_f16_kernel<256, true>;
+                CT_OPTIN_ONCE(kfn, (size_t)64 * 1024);
+                CT_LAUNCH_DYN(kfn, dim3((unsigned)gx), dim3(256), (size_t)a.K * 4, s, a.x, a.norm_w, a.norm_b, a.K, a.pro, a.eps, (const void*)w.raw, w.M, a.f16_tmp + off);
+            }
         } else {   // 16 rows per pass of a 256-thread workgroup (128 / 512 threads measured 170 / 218 against 225 tok/s on the 7B Q4_1 file:
                    // profiles/r03_raw32_q41_q50_q51.txt); LDS: K quant bytes + 8 bytes per block
             const int gx = std::max(1, std::min((w.M + 15) / 16, 8 * chip_cus()));
@@ -252,7 +259,7 @@ static bool launch_matvec_raw(MatvecArgs& a, hipStream_t s, std::string& err) {
 
 static bool launch_matvec(MatvecArgs& a, hipStream_t s, std::string& err) {
     for (int j = 0; j < a.njobs; ++j)
-        if (a.job[j].w.type == GT_F16 || is_raw32(a.job[j].w.type)) return launch_matvec_raw(a, s, err);
+        if (a.job[j].w.type == GT_F16 || a.job[j].w.type == GT_F32 || is_raw32(a.job[j].w.type)) return launch_matvec_raw(a, s, err);
     if (a.gateup || a.njobs <= 1) return launch_matvec_one(a, s, err);
     int i = 0;
     while (i < a.njobs) {

@@ -410,10 +410,10 @@ bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::s
     m.K = (int)t->ne[0];
     m.M = (int)t->ne[1];
     const int be = ggml_block_elems(t->type), bb = ggml_block_bytes(t->type);
-    if (t->type == GT_F16 || is_raw32(t->type)) {   // rows stay in file layout (kernels_f16.h, kernels_raw32.h); token steps only — prompts of such a handle run token by token
-        const std::string tn = t->type == GT_F16 ? "F16" : (t->type == GT_Q4_1 ? "Q4_1" : (t->type == GT_Q5_0 ? "Q5_0" : "Q5_1"));
-        if (m.K % 32 || m.K > 32768) { err = "tensor " + t->name + ": " + tn + " rows of " + std::to_string(m.K) + " elements are not supported"; return false; }
-        m.nb = t->type == GT_F16 ? m.K : m.K / 32; m.bytes = t->nbytes; m.layout = t->type == GT_F16 ? LAYOUT_F16 : LAYOUT_RAW32;
+    if (t->type == GT_F16 || t->type == GT_F32 || is_raw32(t->type)) {   // rows stay in file layout (kernels_f16.h, kernels_raw32.h); token steps only — prompts of such a handle run token by token
+        const std::string tn = t->type == GT_F16 ? "F16" : t->type == GT_F32 ? "F32" : (t->type == GT_Q4_1 ? "Q4_1" : (t->type == GT_Q5_0 ? "Q5_0" : "Q5_1"));
+        if (m.K % 32 || m.K > (t->type == GT_F32 ? 16384 : 32768)) { err = "tensor " + t->name + ": " + tn + " rows of " + std::to_string(m.K) + " elements are not supported"; return false; }
+        m.nb = is_raw32(t->type) ? m.K / 32 : m.K; m.bytes = t->nbytes; m.layout = is_raw32(t->type) ? LAYOUT_RAW32 : LAYOUT_F16;
         uint8_t* d = nullptr;
         if (!dev_alloc(dev_allocs_, &d, t->nbytes + 64, err)) return false;
         if (dev_file_) HIP_OK(hipMemcpyAsync(d, staged(t), t->nbytes, hipMemcpyDeviceToDevice, stream_));
@@ -823,7 +823,7 @@ bool Engine::load_gpt2(const std::string& path, std::string& err, int device, bo
         const GgufTensor* t = f.tensor(name);
         if (!t) { err = "missing tensor " + name; return false; }
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
-        if (!is_block32(t->type) && !is_raw32(t->type) && t->type != GT_F16) { err = name + ": only F16 / Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 legacy weights are supported"; return false; }
+        if (!is_block32(t->type) && !is_raw32(t->type) && t->type != GT_F16 && t->type != GT_F32) { err = name + ": only F32 / F16 / Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 legacy weights are supported"; return false; }
         if (!upload_matrix(t, m, false, err)) return false;
         if (is_block32(t->type) && !upload_l9b({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
@@ -915,7 +915,7 @@ bool Engine::load_mpt(const std::string& path, int context_length, std::string& 
         const GgufTensor* t = f.tensor(name);
         if (!t) { err = "missing tensor " + name; return false; }
         if (t->ne[0] != K || t->ne[1] != M) { err = "bad shape for " + name; return false; }
-        if (!is_block32(t->type) && !is_raw32(t->type) && t->type != GT_F16) { err = name + ": only F16 / Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 legacy weights are supported"; return false; }
+        if (!is_block32(t->type) && !is_raw32(t->type) && t->type != GT_F16 && t->type != GT_F32) { err = name + ": only F32 / F16 / Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 legacy weights are supported"; return false; }
         if (!upload_matrix(t, m, false, err)) return false;
         if (is_block32(t->type) && !upload_l9b({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;

@@ -16,11 +16,15 @@
 #pragma once
 #include "kernels_exact.h"
 
-template <int NT>
+// F32W: the matrix is F32 (vec_dot_type F32: the activation row stays f32, ggml_vec_dot_f32 ggml.c:2355-2389 — the same 32-element steps,
+// four accumulator vectors and reduce tree on f32 operands); otherwise F16.
+template <int NT, bool F32W>
 __global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict__ x, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
-                                                        float eps, const uint16_t* __restrict__ W, int M, float* __restrict__ out) {
-    CT_DYN_SMEM(smem_raw);   // the fp16 activation vector: K halves
-    uint16_t* xh = reinterpret_cast<uint16_t*>(smem_raw);
+                                                        float eps, const void* __restrict__ Wv, int M, float* __restrict__ out) {
+    using WT = typename std::conditional<F32W, float, uint16_t>::type;
+    const WT* __restrict__ W = reinterpret_cast<const WT*>(Wv);
+    CT_DYN_SMEM(smem_raw);   // the activation vector: K halves (F32 matrices: K floats)
+    WT* xh = reinterpret_cast<WT*>(smem_raw);
     __shared__ double red[2][NT / 64];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id(), j = tid & 3, quad = tid >> 2;
     // ---- prologue: ggml.c:10700-10716 (rms_norm: double sum, f32 mean, 1 / sqrtf) or ggml.c:10605-10654 (norm: f32 mean of a double sum, the centred
@@ -62,41 +66,53 @@ __global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict_
         float v = x[i];
         if (pro == PRO_LAYERNORM) { v = ((v - mean) * scale) * nw[i]; if (nbias) v += nbias[i]; }
         else if (pro == PRO_RMSNORM) v = (v * scale) * nw[i];
-        xh[i] = f32_to_f16_bits(v);
+        if constexpr (F32W) xh[i] = v;
+        else xh[i] = f32_to_f16_bits(v);
     }
     __syncthreads();
     // ---- rows: a quad per row, NT / 4 rows per pass of the workgroup ----
     constexpr int PB = 8;   // 32-element steps in flight per lane
+    constexpr int NV = F32W ? 2 : 1;   // 16-byte requests per step and lane (eight elements)
     const int steps = K >> 5;
     for (int row0 = (int)blockIdx.x * (NT / 4); row0 < M; row0 += (int)gridDim.x * (NT / 4)) {
         const int row = row0 + quad;
-        const uint16_t* wrow = W + (size_t)(row < M ? row : M - 1) * K + 8 * j;   // a quad past the last row re-reads it (nothing stored)
+        const WT* wrow = W + (size_t)(row < M ? row : M - 1) * K + 8 * j;   // a quad past the last row re-reads it (nothing stored)
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        u32x4 buf[PB];
+        u32x4 buf[PB][NV];
+        auto request = [&](int u, int st) {
+            const WT* p = wrow + 32 * (st < steps ? st : steps - 1);
 #pragma unroll
-        for (int u = 0; u < PB; ++u) buf[u] = ld16(wrow + 32 * (u < steps ? u : steps - 1));
+            for (int v = 0; v < NV; ++v) buf[u][v] = ld16(p + 4 * v * (F32W ? 1 : 2));
+        };
+        auto consume = [&](int u, int st) {
+            float wf[8], xf[8];
+            if constexpr (F32W) {
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const u32x4 xv = *(const u32x4*)(xh + 32 * st + 8 * j + 4 * v);
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { wf[4 * v + l] = bits_to_f32(buf[u][v][l]); xf[4 * v + l] = bits_to_f32(xv[l]); }
+                }
+            } else {
+                unpack8_f16(buf[u][0], wf);
+                unpack8_f16(*(const u32x4*)(xh + 32 * st + 8 * j), xf);
+            }
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
+        };
+#pragma unroll
+        for (int u = 0; u < PB; ++u) request(u, u);
         int s0 = 0;
         for (; s0 + PB < steps; s0 += PB) {   // every step of this round exists; each slot is re-requested (clamped to the last step)
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                float wf[8], xf[8];
-                unpack8_f16(buf[u], wf);
-                unpack8_f16(*(const u32x4*)(xh + 32 * (s0 + u) + 8 * j), xf);
-#pragma unroll
-                for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
-                const int sn = s0 + u + PB;
-                buf[u] = ld16(wrow + 32 * (sn < steps ? sn : steps - 1));
+                consume(u, s0 + u);
+                request(u, s0 + u + PB);
             }
         }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {   // the last round requests nothing
-            if (s0 + u < steps) {
-                float wf[8], xf[8];
-                unpack8_f16(buf[u], wf);
-                unpack8_f16(*(const u32x4*)(xh + 32 * (s0 + u) + 8 * j), xf);
-#pragma unroll
-                for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
-            }
+            if (s0 + u < steps) consume(u, s0 + u);
         }
         const float res = f16dot_reduce_exact(acc, j);
         if (j == 0 && row < M) out[row] = res;

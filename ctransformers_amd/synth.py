@@ -320,7 +320,7 @@ def use_more_bits(i, n):
 
 def llama_tensor_types(ftype, n_layer):
     """name -> ggml type for every 2-D tensor of a llama GGUF under an ftype (reference llama.cpp:4785-4850)."""
-    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K, "F16": G.F16, "Q4_1": G.Q4_1,
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_K_S": G.Q4_K, "Q6_K": G.Q6_K, "F16": G.F16, "F32": G.F32, "Q4_1": G.Q4_1,
             "Q5_0": G.Q5_0, "Q5_1": G.Q5_1}[ftype]
     t = {"token_embd.weight": base, "output.weight": G.Q6_K if ftype in ("Q4_K_M", "Q5_K_M", "Q4_K_S", "Q6_K") else base}
     if ftype in ("Q4_0", "Q4_1", "Q5_0", "Q5_1"):
@@ -524,8 +524,8 @@ FALCON_SHAPES = {
 
 def falcon_tensor_types(ftype, n_layer):
     """name -> ggml type of the 2-D tensors of a falcon GGUF (reference llama.cpp:4785-4850, arch == FALCON rules)."""
-    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_1": G.Q4_1, "Q5_0": G.Q5_0, "Q5_1": G.Q5_1, "F16": G.F16}[ftype]
-    t = {"token_embd.weight": base, "output.weight": G.F16 if ftype == "F16" else G.Q8_0}   # :4787-4788: a quantized falcon output is always Q8_0
+    base = {"Q4_K_M": G.Q4_K, "Q5_K_M": G.Q5_K, "Q8_0": G.Q8_0, "Q4_0": G.Q4_0, "Q4_1": G.Q4_1, "Q5_0": G.Q5_0, "Q5_1": G.Q5_1, "F16": G.F16, "F32": G.F32}[ftype]
+    t = {"token_embd.weight": base, "output.weight": base if ftype in ("F16", "F32") else G.Q8_0}   # :4787-4788: a quantized falcon output is always Q8_0
     for i in range(n_layer):
         qkv, down = base, base
         if ftype == "Q4_K_M":
@@ -667,7 +667,7 @@ def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm
     if pooled is None:
         pooled = E >= 2048
     src = _WeightSource(seed, pooled)
-    wtype = {1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
+    wtype = {0: G.F32, 1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
     rng = np.random.default_rng(seed + 17)
     with open(path, "wb") as f:
         f.write(struct.pack("<I", 0x67676d6c))
@@ -737,7 +737,7 @@ def write_mpt_ggml(path, shape="mpt-tiny", seed=1234, ftype=2, pooled=None, piec
     if pooled is None:
         pooled = E >= 2048
     src = _WeightSource(seed, pooled)
-    wtype = {1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
+    wtype = {0: G.F32, 1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
     with open(path, "wb") as f:
         f.write(struct.pack("<I", 0x67676d6c))
         f.write(struct.pack("<5i2fi", E, C, H, NL, V, hp["alibi_bias_max"], hp["clip_qkv"], ftype + 1000 * 2))

@@ -75,7 +75,7 @@ def test_abi_semantics_on_gpu():
     # sampler / tokenizer parity of the HIP binary: tests/test_tokenizers.py::test_tokenizers_and_samplers_match_reference_hip_build
 
 
-LEGACY_FTYPE = {"F16": 1, "Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum ggml_ftype (reference ggml.h:322-336)
+LEGACY_FTYPE = {"F32": 0, "F16": 1, "Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}   # enum ggml_ftype (reference ggml.h:322-336)
 
 
 @pytest.mark.parametrize("shape,ftype,n_prompt,n_decode", [
@@ -110,6 +110,8 @@ LEGACY_FTYPE = {"F16": 1, "Q4_0": 2, "Q4_1": 3, "Q8_0": 7, "Q5_0": 8, "Q5_1": 9}
     ("gpt2-xl-2l", "F16", 9, 4),          # fp16 matrices behind LayerNorms (legacy ftype 1: what the reference's convert scripts write; falcon GGUF F16)
     ("mpt-7b-2l", "F16", 9, 4),
     ("falcon-7b-2l", "F16", 9, 4),
+    ("llama-7b-2l", "F32", 9, 4),         # F32 matrices (vec_dot_type F32): the fp16 kernels' structure on f32 operands
+    ("gpt2-xl-2l", "F32", 9, 4),
     ("mpt-30b-2l", "Q4_0", 40, 8),        # MPT-30B widths: 64 heads of 112 (the f16 dot's scalar tail), d_model 7168, rows of 28672
 ])
 def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt, n_decode):
@@ -133,8 +135,8 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     r.eval(toks)
     m.eval(toks)
     # every model family / weight type evaluates prompts through the chunk kernels (32-block rows that are not whole groups of four
-    # blocks — Falcon-7B's 4544 — with zero blocks behind the row's end) — except file-layout matrices (F16, Q4_1, Q5_0, Q5_1): token by token
-    assert chunk_tokens(m) == (0 if ftype in ("F16", "Q4_1", "Q5_0", "Q5_1") else n_prompt)
+    # blocks — Falcon-7B's 4544 — with zero blocks behind the row's end) — except file-layout matrices (F32, F16, Q4_1, Q5_0, Q5_1): token by token
+    assert chunk_tokens(m) == (0 if ftype in ("F32", "F16", "Q4_1", "Q5_0", "Q5_1") else n_prompt)
     for i in range(n_decode):
         a, b = r.logits.to_numpy(), m.logits.to_numpy()
         assert np.array_equal(a, b), "step %d: max rel %.3g" % (i, np.abs(a - b).max() / np.abs(a).max())

@@ -163,12 +163,13 @@ def test_context_above_32768(emu_lib, mirror, tmp_path):
         assert np.array_equal(m.logits.to_numpy(), lg), "position %d" % (35 + i)
 
 
-def test_f16_weight_matrices(emu_lib, mirror, tmp_path):
-    """A llama GGUF of ftype F16 (every 2-D tensor fp16; reference: vec_dot_type F16 — the activation row through ggml_fp32_to_fp16_row,
+@pytest.mark.parametrize("ftype", ["F16", "F32"])
+def test_f16_weight_matrices(emu_lib, mirror, tmp_path, ftype):
+    """A llama GGUF of ftype F32 (vec_dot_type F32: ggml_vec_dot_f32 of the weight row and the f32 activation row, ggml.c:2355-2389) or F16 (every 2-D tensor fp16; reference: vec_dot_type F16 — the activation row through ggml_fp32_to_fp16_row,
     ggml_vec_dot_f16 per output row, ggml.c:11031-11245 / :2392-2425): kernels_f16.h, token steps for the prompt too — against the oracle
     restatement (which the GPU suite and tests/test_oracle.py compare with the reference build on such a file)."""
     p = str(tmp_path / "m.gguf")
-    hp = synth.write_llama_gguf(p, "llama-tiny", "F16", seed=41)
+    hp = synth.write_llama_gguf(p, "llama-tiny", ftype, seed=41)
     m = LLM(p, config=Config(context_length=64, batch_size=8, threads=1), lib=emu_lib)
     o = mirror.MirrorLlama(p, 64)
     toks = synth.prompt_tokens(9, hp["n_vocab"])
@@ -232,13 +233,13 @@ def test_legacy_graphs_at_widths_that_are_not_multiples_of_128(emu_lib, mirror, 
 
 
 @pytest.mark.parametrize("arch,ftype", [("gpt2", "Q5_1"), ("gpt2", "Q5_0"), ("mpt", "Q4_1"), ("mpt", "Q5_0"), ("falcon", "Q5_1"), ("falcon", "Q4_1"),
-                                        ("gpt2", "F16"), ("mpt", "F16"), ("falcon", "F16")])
+                                        ("gpt2", "F16"), ("mpt", "F16"), ("falcon", "F16"), ("gpt2", "F32"), ("falcon", "F32")])
 def test_q4_1_q5_0_q5_1_in_the_layernorm_graphs(emu_lib, mirror, tmp_path, arch, ftype):
     """Legacy GGML files of ftype 3 / 8 / 9 (gpt2, mpt) and falcon GGUF files of ftype Q4_1 / Q5_0 / Q5_1: kernels_raw32.h — and of ftype 1 / F16
     (what the reference's convert scripts write): kernels_f16.h — behind a LayerNorm
     (with and without bias), the row-bias / GELU / two-residual epilogues, the tied Q5_x lm_head of gpt2 — against the oracle restatement
     (tests/test_oracle.py compares it with the reference build on the same kinds of file)."""
-    ft = {"F16": 1, "Q4_1": 3, "Q5_0": 8, "Q5_1": 9}[ftype]
+    ft = {"F32": 0, "F16": 1, "Q4_1": 3, "Q5_0": 8, "Q5_1": 9}[ftype]
     p = str(tmp_path / ("m.gguf" if arch == "falcon" else "m.bin"))
     if arch == "gpt2":
         synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=96, n_embd=192, n_head=3, n_layer=2), seed=5, ftype=ft)

@@ -137,6 +137,13 @@ def test_restatement_follows_reference_build_on_shapes_without_goldens(mirror, r
     p = str(tmp_path / "f16f.gguf")
     hp = synth.write_falcon_gguf(p, "falcon-tiny7", "F16", seed=17)
     cases.append((p, None, mirror.MirrorFalcon(p, 64), hp))
+    # F32 matrices (vec_dot_type F32: ggml_vec_dot_f32 on the f32 activation row)
+    p = str(tmp_path / "l32.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "F32", seed=41)
+    cases.append((p, None, mirror.MirrorLlama(p, 64), hp))
+    p = str(tmp_path / "g32.bin")
+    hp = synth.write_gpt2_ggml(p, dict(n_vocab=512, n_ctx=64, n_embd=192, n_head=3, n_layer=2), seed=5, ftype=0)
+    cases.append((p, "gpt2", mirror.MirrorGpt2(p), hp))
     for path, mt, o, hp in cases:
         r = ref.open_llm(path, model_type=mt, context_length=64, batch_size=64, threads=2)
         toks = synth.prompt_tokens(37, hp["n_vocab"])
