@@ -260,3 +260,23 @@ def test_q4_1_q5_0_q5_1_in_the_layernorm_graphs(emu_lib, mirror, tmp_path, arch,
         m.eval([t])
         lg = np.array(o.eval([t], 7 + i), copy=True)
         assert np.array_equal(m.logits.to_numpy(), lg)
+
+
+@pytest.mark.parametrize("head_type", ["F16", "Q5_0"])
+def test_file_layout_lm_head_behind_prompt_chunks(emu_lib, mirror, tmp_path, head_type):
+    """A K-quant file whose output.weight stays in a file-layout type (the F16 fallback of the reference's quantizer for rows that are not whole
+    256-blocks, llama.cpp:4866-4869; a requantized head): the layers keep their prompt-chunk kernels, the chunk's last token goes through the
+    file-layout mat-vec for the logits."""
+    from ctransformers_amd import gguf as G
+    p = str(tmp_path / "m.gguf")
+    hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=47, type_overrides={"output.weight": {"F16": G.F16, "Q5_0": G.Q5_0}[head_type]})
+    m = LLM(p, config=Config(context_length=64, batch_size=8, threads=1), lib=emu_lib)
+    o = mirror.MirrorLlama(p, 64)
+    toks = synth.prompt_tokens(13, hp["n_vocab"])
+    o.eval(toks[:8], 0)
+    lg = np.array(o.eval(toks[8:], 8), copy=True)
+    m.eval(toks)
+    assert np.array_equal(m.logits.to_numpy(), lg)
+    t = int(lg.argmax())
+    m.eval([t])
+    assert np.array_equal(m.logits.to_numpy(), o.eval([t], 13))
