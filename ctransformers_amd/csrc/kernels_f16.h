@@ -101,13 +101,14 @@ __global__ void __launch_bounds__(NT) matvec_f16_kernel(const float* __restrict_
             for (int l = 0; l < 8; ++l) acc[l] = fmaf(wf[l], xf[l], acc[l]);
         };
 #pragma unroll
-        for (int u = 0; u < PB; ++u) request(u, u);
+        for (int u = 0; u < PB; ++u) { request(u, u); sched_fence(); }   // issued in slot order: the loop's waits are counted against this order too
         int s0 = 0;
         for (; s0 + PB < steps; s0 += PB) {   // every step of this round exists; each slot is re-requested (clamped to the last step)
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 consume(u, s0 + u);
                 request(u, s0 + u + PB);
+                sched_fence();   // slot by slot: without it the scheduler gathers the round's waits at its top and the re-requests at its end
             }
         }
 #pragma unroll

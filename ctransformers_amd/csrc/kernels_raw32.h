@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restric
         float accl = 0.0f, acch = 0.0f, summs = 0.0f;
         Raw32Blk R[PB];
 #pragma unroll
-        for (int u = 0; u < PB; ++u) { const int b = 4 * u + c; R[u] = raw32_load<TYPE>(wrow + (size_t)(b < nb ? b : nb - 1) * BB, lq); }
+        for (int u = 0; u < PB; ++u) {   // issued in slot order (the fence): the loop's waits are counted against this order too
+            const int b = 4 * u + c;
+            R[u] = raw32_load<TYPE>(wrow + (size_t)(b < nb ? b : nb - 1) * BB, lq);
+            sched_fence();
+        }
         for (int b0 = 0; b0 < nb; b0 += 4 * PB) {   // no branch inside: hipcc counts the requests in flight (s_waitcnt vmcnt(N), kernels_attn9.h)
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -148,6 +152,7 @@ __global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restric
                 const bool live = b < nb;
                 const int bc = live ? b : nb - 1;
                 const int al = aq[bc * 8 + lq], ah = aq[bc * 8 + 4 + lq];
+                const float adv = ad[bc], asv = Q81 ? as[bc] : 0.0f;   // unconditional (clamped index): a `live ? ad[bc] : 0` becomes a branch around the read
                 int wl = (int)(R[u].qs & 0x0F0F0F0Fu), wh = (int)((R[u].qs >> 4) & 0x0F0F0F0Fu);
                 int il, ih;
                 if constexpr (TYPE == GT_Q4_1) {
@@ -166,10 +171,11 @@ __global__ void __launch_bounds__(NT) matvec_raw32_kernel(const float* __restric
                 const float mx = f16_bits_to_f32((uint16_t)(R[u].dm >> 16));
                 const int bn = b + 4 * PB;
                 R[u] = raw32_load<TYPE>(wrow + (size_t)(bn < nb ? bn : nb - 1) * BB, lq);
-                const float dv = live ? dx * ad[bc] : 0.0f;
+                const float dv = live ? dx * adv : 0.0f;
                 accl = quad_chain4(accl, dv, live ? (float)il : 0.0f);
                 acch = quad_chain4(acch, dv, live ? (float)ih : 0.0f);
-                if constexpr (Q81) summs = quad_chain4(summs, live ? mx : 0.0f, live ? as[bc] : 0.0f);
+                if constexpr (Q81) summs = quad_chain4(summs, live ? mx : 0.0f, live ? asv : 0.0f);
+                sched_fence();   // slot by slot: without it the scheduler hoists every slot's first use to the top of the round (one wait for all eight)
             }
         }
         // hsum_float_8 (ggml.c:609-615): ((x0 + x4) + (x2 + x6)) + ((x1 + x5) + (x3 + x7)); the pair (lq, lq + 4) is in this lane, lq at lane bits 2..3
