@@ -14,7 +14,7 @@ in-process pipeline of the library (ctransformers_amd/csrc/pipeline.cc, CT_AMD_D
 hand-off by hipMemcpyPeerAsync over xGMI.  `python bench.py --gpus N` therefore brings the N stages up itself.  When the
 driver launches N ranks with torch.distributed.run, rank 0 drives the N stages and the other ranks take part in the barriers
 and the MAX reduction only (backend gloo: they own no GPU work); where a rank cannot see N devices the one-process-per-GPU
-RCCL pipeline of ctransformers_amd/pipeline.py runs instead.  Decode of one sequence is serial over the stages (strong
+RCCL pipeline of tools/rccl_pipeline.py runs instead.  Decode of one sequence is serial over the stages (strong
 scaling: the model is fixed), so the roofline denominator stays ONE GPU's HBM.
 
 `--config 3|4|5` runs the other single-GPU-capable BASELINE configs instead (3: Llama-2-7B Q8_0; 4: Falcon-40B Q4_K_M, 25 GB; 5:
@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from ctransformers_amd import measure, synth  # noqa: E402
+from ctransformers_amd import measure
+from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
@@ -237,7 +238,7 @@ def main():
     group = None
     if world > 1:
         if os.environ.get("CTAMD_FORCE_RCCL_PIPELINE") == "1" or (n_gpus > 1 and not os.environ.get("CTAMD_BENCH_DEVICES") and visible_gpus() < n_gpus):
-            from ctransformers_amd import pipeline   # one process per GPU, RCCL point-to-point hand-off
+            from tools import rccl_pipeline as pipeline   # one process per GPU, RCCL point-to-point hand-off
             return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -304,7 +305,7 @@ def main():
                ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
                dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)",
                data="synthetic (random-init weights at the real shapes and tensor-type mix; quantized blocks drawn from a pool of 8192 per type "
-                    "produced by this repo's numpy quantizer, ctransformers_amd/synth.py — not ggml_quantize_chunk; synthetic prompt tokens)",
+                    "produced by this repo's numpy quantizer, tools/synth.py — not ggml_quantize_chunk; synthetic prompt tokens)",
                config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + 256-tok greedy decode, ctx 512" % n_gpus
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d-tok greedy decode, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,

@@ -344,7 +344,10 @@ void Engine::apply_trace(MatvecArgs& a, const char* site) {
     }
 }
 
-bool Engine::run_matvec(MatvecArgs& a, std::string& err) { return launch_matvec(a, stream_, err); }
+bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
+    if (!a.f16_tmp) a.f16_tmp = f16_tmp_;   // file-layout matrices (F16 / Q4_1 / Q5_x head behind chunked K-quant layers): every step function gets them
+    return launch_matvec(a, stream_, err);
+}
 
 // One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
 void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
@@ -663,11 +666,20 @@ bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
             HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
             const bool ok = chunk_step(c0, nt, want_logits, err);
             const hipError_t e = hipStreamEndCapture(stream_, &g);
-            if (!ok) return false;
+            if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
             if (e != hipSuccess) { err = std::string("hipStreamEndCapture (chunk) failed: ") + hipGetErrorString(e); return false; }
             hipGraphExec_t ex = nullptr;
-            HIP_OK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-            HIP_OK(hipGraphDestroy(g));
+            const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) { err = std::string("hipGraphInstantiate (chunk) failed: ") + hipGetErrorString(ei); return false; }
+            // a pipeline stage keys its graphs by micro-batch offset too (n_ctx / micro-batch offsets x shapes): bound what stays
+            // instantiated — past the cap the oldest-keyed graph goes (a later use of its shape captures again)
+            if (chunk_graphs_.size() >= kMaxChunkGraphs) {
+                auto old = chunk_graphs_.begin();
+                (void)hipGraphExecDestroy(old->second);
+                chunk_seen_.erase(old->first);
+                chunk_graphs_.erase(old);
+            }
             it = chunk_graphs_.emplace(key, ex).first;
         }
         if (it != chunk_graphs_.end()) {
@@ -689,7 +701,7 @@ bool Engine::ensure_graphs(std::string& err) {
         HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
         const bool ok = token_step(head == 1, err);
         hipError_t e = hipStreamEndCapture(stream_, &g);
-        if (!ok) return false;
+        if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
         if (e != hipSuccess) { err = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e); return false; }
         hipGraphExec_t ex = nullptr;
         HIP_OK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));

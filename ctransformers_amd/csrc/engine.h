@@ -203,6 +203,7 @@ class Engine {
     bool chunk_below_128_ = false;   // every position of the chunk being launched is < 128 (attn_chunk_tile_kernel applies)
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
+    static constexpr size_t kMaxChunkGraphs = 64;
     std::map<long long, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by (stage: row offset + 1) << 24 | 4 * n_tokens + 2 * below-128 + want_logits; captured on second use
     std::map<long long, int> chunk_seen_;
 #endif

@@ -1,6 +1,6 @@
 // Mat-vec, generation 9 (K-quants, every K): the lane that computes sumi[l] owns chain l.
 //
-// Generation 7 (kernels_v7.h) kept a record's nibble bytes in file order, so a lane's 16 bytes were four AVX lanes of ONE
+// Generation 7 (deleted in round 3 after the A/B; git history) kept a record's nibble bytes in file order, so a lane's 16 bytes were four AVX lanes of ONE
 // 32-element vector pair: every step paid a transpose-reduce over four lanes, a round trip through a wave-private LDS buffer to
 // hand the chain operands to the lanes that replay the reference's f32 chain, and a prologue that 4 of 16 waves computed for all
 // 256 workgroups (profiles/r02_v7_*: 133 VALU instructions per 1152-byte record, a third of every launch spent before the first
@@ -587,7 +587,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     const uint8_t* pf_ptr = base + (size_t)((nu > 0 ? first : g0) - g0) * unit_bytes;
     Rec9<TYPE> ring[4];
     auto issue = [&](Rec9<TYPE>& slot, const Lane9& GG) __attribute__((always_inline)) {
-        slot = rec9_load<TYPE>(pf_ptr, GG);   // unconditional, same instruction count every step (kernels_v7.h header)
+        slot = rec9_load<TYPE>(pf_ptr, GG);   // unconditional, same instruction count every step: a conditional load in the loop makes hipcc wait vmcnt(0) per step
         if (pf_left > 1) {
             --pf_left;
             pf_ptr += REC;
@@ -701,7 +701,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
         s = 0;
     };
     // All groups but the last: every step requests the record its slot holds four steps later — the loop contains no other vector
-    // memory instruction and no conditional one, so hipcc counts the ring with `s_waitcnt vmcnt(N)` (kernels_v7.h header).  A request
+    // memory instruction and no conditional one, so hipcc counts the ring with `s_waitcnt vmcnt(N)`.  A request
     // past the wave's last record (at most three, and none when a unit is a multiple of four records) reads that record again.
     // The last group requests nothing: the memory pipeline of the CU belongs to the waves that still have records to fetch.
     for (int g = 0; g + 1 < groups; ++g) {

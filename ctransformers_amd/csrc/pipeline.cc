@@ -56,9 +56,12 @@ std::vector<int> parse_devices(const char* spec) {
 }
 
 // The devices of a handle.  CT_AMD_DEVICES, when set, decides.  Otherwise `gpu_layers` and the visible GPUs do (north_star; reference
-// knob models/llms/llama.cc:88-95 -> llama.cpp:1913-1919, where layers beyond n_gpu_layers stay on the CPU): a GPU takes at most
-// gpu_layers layers and the layers beyond go to the NEXT GPU — ceil(n_layer / gpu_layers) stages, at most one per visible device.
-// gpu_layers <= 0 or >= n_layer (the usual "everything": 50, 100, 1000) is one GPU.  This library has no CPU path either way.
+// knob models/llms/llama.cc:88-95 -> llama.cpp:1913-1919, where layers beyond n_gpu_layers stay on the CPU): gpu_layers sets the STAGE
+// COUNT — ceil(n_layer / gpu_layers), at most one stage per visible device — and partition_layers then balances the stages by weight
+// bytes (a stage may hold a layer more or less than gpu_layers; the last one also streams the head).  NOTE the consequence on a multi-GPU
+// host: any 0 < gpu_layers < n_layer spreads the model (gpu_layers = 1 takes every visible GPU); gpu_layers <= 0 or >= n_layer (the usual
+// "everything": 50, 100, 1000) is one GPU.  CT_AMD_DEVICES=0 pins a handle to one device regardless.  This library has no CPU path
+// either way.  (include/ctransformers_llm.h documents the same.)
 std::vector<int> plan_devices(const std::string& path, int gpu_layers, const char* env) {
     if (env && *env) return parse_devices(env);
     int ndev = 0;
@@ -149,7 +152,17 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
     bool distinct = true;
     for (size_t s = 0; s < dev_.size(); ++s)
         for (size_t t = s + 1; t < dev_.size(); ++t) distinct = distinct && dev_[s] != dev_[t];
-    auto load_one = [&](size_t s) { oks[s] = st_[s]->load(path, context_length, gpu_layers, errs[s], ranges_[s].first, ranges_[s].second, dev_[s]) ? 1 : 0; };
+    auto load_one = [&](size_t s) {   // runs on its own thread: nothing may escape it (an exception there would be std::terminate, not a NULL handle)
+        try {
+            oks[s] = st_[s]->load(path, context_length, gpu_layers, errs[s], ranges_[s].first, ranges_[s].second, dev_[s]) ? 1 : 0;
+        } catch (const std::exception& e) {
+            errs[s] = std::string("exception while loading: ") + e.what();
+            oks[s] = 0;
+        } catch (...) {
+            errs[s] = "unknown exception while loading";
+            oks[s] = 0;
+        }
+    };
     if (distinct && kConcurrentLaunches) {
         std::vector<std::thread> th;
         for (size_t s = 0; s < dev_.size(); ++s) th.emplace_back(load_one, s);
@@ -157,13 +170,14 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
     } else {
         for (size_t s = 0; s < dev_.size(); ++s) load_one(s);
     }
-    for (size_t s = 0; s < dev_.size(); ++s) {
+    for (size_t s = 0; s < dev_.size(); ++s) {   // every failed stage is named (the stages that did load are released with the handle)
         if (!oks[s]) {
-            err = "stage " + std::to_string(s) + " (layers " + std::to_string(ranges_[s].first) + ".." + std::to_string(ranges_[s].second) + " on device " +
-                  std::to_string(dev_[s]) + "): " + errs[s];
-            return false;
+            if (!err.empty()) err += "; ";
+            err += "stage " + std::to_string(s) + " (layers " + std::to_string(ranges_[s].first) + ".." + std::to_string(ranges_[s].second) + " on device " +
+                   std::to_string(dev_[s]) + "): " + errs[s];
         }
     }
+    if (!err.empty()) return false;
     for (size_t s = 0; s + 1 < dev_.size(); ++s) {   // direct peer copies where the link allows them (hipMemcpyPeerAsync works either way)
         if (dev_[s] == dev_[s + 1]) continue;
         int can = 0;

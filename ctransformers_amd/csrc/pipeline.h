@@ -31,7 +31,7 @@ class Pipeline {
     bool load(const std::string& path, int context_length, int gpu_layers, const std::vector<int>& devices, std::string& err);
     bool load_gpt2(const std::string& path, std::string& err, bool starcoder = false);
     bool load_mpt(const std::string& path, int context_length, std::string& err);
-    // one explicit stage (ctamd_stage_create: the multi-process pipeline of ctransformers_amd/pipeline.py drives it from outside)
+    // one explicit stage (ctamd_stage_create: the multi-process pipeline of tools/rccl_pipeline.py drives it from outside)
     bool load_stage(const std::string& path, int context_length, int layer_begin, int layer_end, int device, std::string& err);
     bool eval(const int* tokens, int n, int n_past, std::string& err, int batch = 0);
     const std::vector<int>& devices() const { return dev_; }

@@ -24,7 +24,7 @@ int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long lon
 /* ---- multi-GPU layer pipeline (DESIGN.md row e): one process per GPU, each owning a contiguous layer range ------------
  * The reference has no multi-GPU path in this ABI (its cuBLAS offload splits tensors inside one process,
  * models/ggml/llama.cpp:1938-2070 `tensor_split`); the MI355X design shards LAYERS across ranks instead and hands the
- * [n_tokens][n_embd] f32 residual stream from stage to stage (RCCL send/recv, ctransformers_amd/pipeline.py).
+ * [n_tokens][n_embd] f32 residual stream from stage to stage (RCCL send/recv, tools/rccl_pipeline.py).
  * A stage handle is a normal ctransformers_llm*: on the last stage logits_data / sample / embeddings work as usual. */
 ctransformers_llm* ctamd_stage_create(const char* model_path, int context_length, int layer_begin, int layer_end,
                                       int device);

@@ -18,7 +18,10 @@ extern "C" {
 /* reference models/llm.h:6-11 — passed BY VALUE to ctransformers_llm_create. */
 struct ctransformers_config {
     int context_length; /* <=0: library default (512 for GGUF, reference llama.cpp:5281) */
-    int gpu_layers;     /* here: all layers are GPU-resident; value kept for ABI compatibility */
+    int gpu_layers;     /* reference models/llms/llama.cc:88-95 (layers offloaded to the GPU).  Here every layer is GPU-resident; on a host
+                           with several visible MI355X the value sets the pipeline STAGE COUNT: 0 < gpu_layers < n_layer spreads the
+                           layers over ceil(n_layer / gpu_layers) GPUs (at most the visible ones; stages balanced by weight bytes),
+                           <= 0 or >= n_layer keeps the model on one GPU.  CT_AMD_DEVICES overrides (csrc/pipeline.cc:plan_devices). */
     bool mmap;
     bool mlock;
 };

@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_void_p
 
 import numpy as np
 
-from ctransformers_amd import gguf as G
+from tools import gguf as G
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "libmirror.so")

@@ -79,13 +79,38 @@ def dequantize(raw, ggml_type, K):
 def quantize_activation(x, weight_type):
     """f32 [K] -> raw bytes of the weight type's vec_dot_type (Q8_K for K-quants, Q8_0 for Q4_0/Q8_0), exactly as
     ggml_compute_forward_mul_mat's INIT phase does (reference ggml.c:11141-11154)."""
-    from ctransformers_amd import gguf as G
+    from tools import gguf as G
     x = np.ascontiguousarray(x, dtype=np.float32)
     vt = traits(weight_type).vec_dot_type
     be, bb = G.TYPE_BLOCK[vt]
     out = np.zeros(x.size // be * bb, dtype=np.uint8)
     _FROM_FLOAT(traits(vt).from_float)(_fptr(x), out.ctypes.data_as(c_void_p), x.size)
     return out, vt
+
+
+def quantize_chunk(x, ggml_type):
+    """f32 [..., K] -> uint8 [..., row_bytes] through the reference's OWN quantizer, `ggml_quantize_chunk` (reference
+    models/ggml/ggml.c:19319; K-quants: models/ggml/k_quants.c:600-1115 — make_qkx1_quants / make_qx_quants scale searches,
+    Q6_K with its `iscale = -128.f/max_scale`, which gives negative block scales and negative d).  This is what the files the
+    reference reads in the field were produced by (llama.cpp's quantize tool calls it per tensor chunk)."""
+    from tools import gguf as G
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    lead, K = x.shape[:-1], x.shape[-1]
+    be, bb = G.TYPE_BLOCK[int(ggml_type)]
+    assert K % be == 0
+    n = x.size
+    out = np.zeros(n // be * bb, dtype=np.uint8)
+    hist = (ctypes.c_int64 * 16)()
+    L = lib()
+    L.ggml_quantize_chunk.argtypes = [c_int, POINTER(c_float), c_void_p, c_int, c_int, POINTER(ctypes.c_int64)]
+    L.ggml_quantize_chunk.restype = c_size_t
+    step = max(be, (1 << 24) // be * be)     # int-sized chunks, as the quantize tool feeds it
+    flat = x.reshape(-1)
+    for start in range(0, n, step):
+        cnt = min(step, n - start)
+        got = L.ggml_quantize_chunk(int(ggml_type), _fptr(flat), out.ctypes.data_as(c_void_p), start, cnt, hist)
+        assert got == cnt // be * bb, (got, cnt)
+    return out.reshape(lead + (K // be * bb,))
 
 
 def vec_dot(weight_type, wrow, act_raw, K):

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import gguf as G, synth  # noqa: E402
+from tools import gguf as G, synth  # noqa: E402
 from oracle import ref  # noqa: E402
 
 

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from ctransformers_amd import pipeline  # noqa: E402
+from tools import rccl_pipeline as pipeline  # noqa: E402
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
     if os.path.exists(npz):
         prompt = [int(t) for t in np.load(npz)["long_prompt"]]
     else:   # ad-hoc model: a fixed pseudo-random prompt
-        from ctransformers_amd import synth
+        from tools import synth
         prompt = synth.prompt_tokens(13, dims["n_vocab"])
     pre = pipe.prefill(prompt, 0, micro_batch=micro)
     logits, toks, pos = pre, [], len(prompt)

@@ -145,10 +145,10 @@ def test_bpe_tokenizer_matches_reference(emu_lib):
 
 
 def test_wide_k_rows(emu_lib, mirror, tmp_path):
-    """ffn_down with K > 12288 (70B / Falcon-40B class rows; the MAXK = 32768 instantiation of kernels_v7.h): here a
+    """ffn_down with K > 12288 (70B / Falcon-40B class rows; the MAXK = 32768 instantiation of kernels_v9.h): here a
     Q6_K matrix (layer 0 is a use_more_bits layer) with 52 blocks (13 records of four, an uneven split over the waves), checked
     against the oracle.  (Q4_K / Q5_K at K = 28672 / 32768 are covered on hardware: tests/test_gpu_parity.py, 70b-2l / 40b-2l.)"""
-    from ctransformers_amd import synth
+    from tools import synth
     p = str(tmp_path / "wide.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", "Q5_K_M", seed=31, overrides=dict(n_ff=13312, n_layer=1))
     m = LLM(p, config=Config(context_length=32, batch_size=8, threads=1), lib=emu_lib)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 
 pytestmark = pytest.mark.gpu
@@ -124,7 +124,7 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
     elif shape.startswith("mpt"):
         hp, mt = synth.write_mpt_ggml(p, shape, seed=21, ftype=LEGACY_FTYPE[ftype]), "mpt"
     elif "+v_q8_0" in ftype:
-        from ctransformers_amd import gguf as G
+        from tools import gguf as G
         hp = synth.write_llama_gguf(p, shape, ftype.split("+")[0], seed=21, type_overrides={"attn_v.weight": G.Q8_0})
     else:
         hp = (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p, shape, ftype, seed=21)
@@ -281,7 +281,7 @@ def test_pipeline_stages_on_gpu():
     """Row (e) on hardware: two layer stages of the HIP library chained through device-resident hand-off rows are
     bit-identical to the reference goldens (prefill in chunks of 8 + greedy decode)."""
     import torch
-    from ctransformers_amd import pipeline
+    from tools import rccl_pipeline as pipeline
     path = os.path.join(GOLDEN, "tiny-q4km.gguf")
     g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
     s0 = pipeline.HipStage(path, 0, 1, context_length=96, device="cuda:0")
@@ -322,7 +322,7 @@ def test_inprocess_pipeline_two_real_devices(ref, tmp_path, monkeypatch, shape, 
     gpu_layers-driven default partition (no CT_AMD_DEVICES) and the explicit one."""
     if _visible_gpus() < 2:
         pytest.skip("needs two visible MI355X devices")
-    from ctransformers_amd import synth
+    from tools import synth
     from ctransformers_amd.llm import LLM, Config
     p = str(tmp_path / "m.gguf")
     hp = synth.write_llama_gguf(p, shape, ftype, seed=21)

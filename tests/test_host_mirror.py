@@ -3,7 +3,7 @@ own tests/test_llm.py:27-54 with a mock in place of the library), Config default
 import numpy as np
 import pytest
 
-from ctransformers_amd import gguf as G, synth
+from tools import gguf as G, synth
 from ctransformers_amd.llm import LLM, Config, utf8_split_incomplete
 
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 
 
@@ -64,7 +64,7 @@ def test_matvec9_type_mixes_at_one_site(emu_lib, mirror, monkeypatch, tmp_path, 
     files mix freely, llama.cpp:4785-4850): a Q4_K_S file (attn_v and ffn_down in Q5_K beside Q4_K), a Q8_0 attn_v beside K-quant
     q / k, a Q4_0 attn_k and a Q5_K attn_v beside a Q4_K attn_q.  Token by token and through the prompt-chunk kernels, against the
     oracle restatement."""
-    from ctransformers_amd import gguf as G
+    from tools import gguf as G
     p = str(tmp_path / "m.gguf")
     kw = dict(overrides=dict(n_layer=2))
     if case == "Q4_K_S":
@@ -101,7 +101,7 @@ def test_block32_rows_not_a_multiple_of_128(emu_lib, mirror, tmp_path, arch, fty
         hp = synth.write_falcon_gguf(p, "falcon-tiny7", ftype, seed=17, overrides=dict(n_embd=192, n_head=3, n_head_kv=1, n_ff=768, n_layer=2))
         o = mirror.MirrorFalcon(p, 32)
     else:
-        from ctransformers_amd import gguf as G
+        from tools import gguf as G
         hp = synth.write_llama_gguf(p, "llama-tiny", ftype, seed=18, overrides=dict(n_embd=192, n_head=3, n_head_kv=1, n_ff=480, n_layer=2),
                                     type_overrides={"output.weight": G.Q8_0})   # llama.cpp:4787: rows that are not whole 256-blocks -> Q8_0 head
         o = mirror.MirrorLlama(p, 32)
@@ -113,9 +113,7 @@ def test_block32_rows_not_a_multiple_of_128(emu_lib, mirror, tmp_path, arch, fty
     assert np.array_equal(m.embeddings.to_numpy(), o.embeddings)
     f = m._lib.ctamd_chunk_tokens
     f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
-    # the prompt went through the chunk kernels — except in the llama Q4_0 case, whose `output.weight` override also matches
-    # attn_output.weight: Q4_0 and Q8_0 matrices in one layer have no chunk form (token by token, same results)
-    assert int(f(m._llm)) == (0 if (arch, ftype) == ("llama", "Q4_0") else 5)
+    assert int(f(m._llm)) == 5   # the prompt went through the chunk kernels
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 5))
@@ -267,7 +265,7 @@ def test_file_layout_lm_head_behind_prompt_chunks(emu_lib, mirror, tmp_path, hea
     """A K-quant file whose output.weight stays in a file-layout type (the F16 fallback of the reference's quantizer for rows that are not whole
     256-blocks, llama.cpp:4866-4869; a requantized head): the layers keep their prompt-chunk kernels, the chunk's last token goes through the
     file-layout mat-vec for the logits."""
-    from ctransformers_amd import gguf as G
+    from tools import gguf as G
     p = str(tmp_path / "m.gguf")
     hp = synth.write_llama_gguf(p, "llama-tiny", "Q4_K_M", seed=47, type_overrides={"output.weight": {"F16": G.F16, "Q5_0": G.Q5_0}[head_type]})
     m = LLM(p, config=Config(context_length=64, batch_size=8, threads=1), lib=emu_lib)
@@ -277,6 +275,9 @@ def test_file_layout_lm_head_behind_prompt_chunks(emu_lib, mirror, tmp_path, hea
     lg = np.array(o.eval(toks[8:], 8), copy=True)
     m.eval(toks)
     assert np.array_equal(m.logits.to_numpy(), lg)
+    f = m._lib.ctamd_chunk_tokens
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    assert int(f(m._llm)) == len(toks)   # the layers really took the chunk kernels (only the head is in a file-layout type)
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 13))

@@ -89,7 +89,7 @@ def test_mpt_heads_of_112(emu_lib, mirror, tmp_path, ftype):
     """MPT-30B's head size (112 = three 32-element steps of ggml_vec_dot_f16 + its scalar tail of 16, ggml.c:2392-2425): prompt through the
     chunk kernels and decode steps against the oracle restatement (pinned to the reference build on this shape when the mirror tests were
     written: tests/golden/make_golden.py has no 112 vectors, the GPU suite compares mpt-30b-2l with the reference build itself)."""
-    from ctransformers_amd import synth
+    from tools import synth
     p = str(tmp_path / "m.bin")
     hp = synth.write_mpt_ggml(p, "mpt-tiny112", seed=23, ftype=ftype)
     m = LLM(p, "mpt", config=Config(context_length=48, batch_size=16, threads=1), lib=emu_lib)
@@ -107,7 +107,7 @@ def test_mpt_kq_scale_is_the_double_sqrt_form(mirror, ref, tmp_path):
     """mpt.cc:460-462 writes `1.0f / sqrt(float(n_embd) / n_head)`: ::sqrt is the double function, the double quotient becomes a float
     once — one ulp away from 1.0f / sqrtf(.) at a head size of 112 (equal at 64 / 128).  This file (32 heads of 112, two layers, seed 21)
     is one where that ulp moves the logits by 1e-2 relative: the restatement must follow the reference build (needs oracle/_ref)."""
-    from ctransformers_amd import synth
+    from tools import synth
     p = str(tmp_path / "m.bin")
     hp = synth.write_mpt_ggml(p, dict(n_vocab=512, max_seq_len=2048, n_embd=3584, n_head=32, n_layer=2, alibi_bias_max=8.0, clip_qkv=0.0), seed=21, ftype=2)
     r = ref.open_llm(p, model_type="mpt", context_length=28, batch_size=64, threads=4)

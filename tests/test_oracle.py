@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from ctransformers_amd import gguf as G, synth
+from tools import gguf as G, synth
 
 OPS = np.load(os.path.join(GOLDEN, "ops.npz"))
 TYPES = [G.Q4_K, G.Q5_K, G.Q6_K, G.Q8_0, G.Q4_0]

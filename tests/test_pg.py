@@ -71,7 +71,7 @@ def test_chunk_attention_across_position_tiles(emu_lib, ref, monkeypatch, name, 
     """Prompts longer than one chunk and one 64-position tile: the later chunk attends through several K / V tiles with the
     accumulators carried from tile to tile (attn_chunk_long_kernel), ragged reference batch ends included; with the 128-position
     kernel switched off the first chunk takes the tiled kernel as well.  Against the reference build on the same file."""
-    from ctransformers_amd import synth
+    from tools import synth
     monkeypatch.setenv("CT_AMD_ATTN_TILE", tile_first)
     path = os.path.join(GOLDEN, name + ".gguf")
     toks = synth.prompt_tokens(n_prompt, 512)

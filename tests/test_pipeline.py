@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
-from ctransformers_amd import pipeline
+from tools import rccl_pipeline as pipeline
 
 
 def test_partition_layers():
@@ -140,7 +140,7 @@ def test_gloo_pipeline_world2(emu_lib, tmp_path, mirror):
 def test_gloo_pipeline_world3_middle_rank(emu_lib, tmp_path, mirror):
     """Three ranks: the middle rank only receives, runs its layers and sends on (no token ids, no sampling).  A 3-layer
     model, one layer per rank; tokens and final logits equal the oracle's."""
-    from ctransformers_amd import synth
+    from tools import synth
     path = str(tmp_path / "three.gguf")
     synth.write_llama_gguf(path, "llama-tiny", "Q4_K_M", seed=41, overrides=dict(n_layer=3))
     port = _free_port()

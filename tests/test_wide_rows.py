@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 
 CASES = [("Q8_0", 13312), ("Q4_0", 16384), ("Q8_0", 16512), ("Q4_0", 32768)]

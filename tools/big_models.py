@@ -3,7 +3,8 @@ usage: big_models.py falcon-40b|llama-2-70b"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth, measure
+from ctransformers_amd import measure
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 which = sys.argv[1]
 ft = "Q4_K_M" if which.startswith("falcon") else "Q5_K_M"

@@ -2,7 +2,8 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth, measure
+from ctransformers_amd import measure
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 shape = sys.argv[1] if len(sys.argv) > 1 else "llama-70b-2l"
 p = "/tmp/%s.gguf" % shape

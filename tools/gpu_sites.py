@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 for kv in sys.argv[2:]:
     k, v = kv.split("="); os.environ[k] = v
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 
 p = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")

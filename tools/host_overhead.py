@@ -2,7 +2,7 @@
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 p = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
 if not os.path.exists(p):

@@ -8,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
-from ctransformers_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 from oracle import ref  # noqa: E402
 

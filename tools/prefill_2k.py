@@ -6,7 +6,7 @@ Q5_K_M` = config 5's model on one GPU).  Prints a text summary and one JSON line
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/ctamd_llama2_7b_q4km_r2.gguf"

@@ -3,7 +3,7 @@ prompt evaluated in chunks of that size, third pass (steady state).  usage: pref
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 path, shape, ftype = (sys.argv[1].split(":") + ["llama-2-7b", "Q4_K_M"])[:3]

@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import gguf as G
-from .llm import load_library
+from ctransformers_amd.llm import load_library
 
 
 def partition_layers(n_layer, world, head_cost=0.5, embed_cost=0.0):
@@ -252,7 +252,7 @@ def bench_main(args, model_path, shape, ftype, n_prompt=128, n_ctx=512):
         pos += 1
     barrier_sync()
     dt_local = time.perf_counter() - t0
-    from . import measure
+    from ctransformers_amd import measure
     roof = measure.roofline(measure.profile_sites(stage._lib, stage._h, 8)) if rank == 0 else None  # after the timed region
     dt = torch.tensor([dt_local, prefill_s, load_s], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)

@@ -6,7 +6,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ctransformers_amd import synth
+from tools import synth
 from ctransformers_amd.llm import LLM, Config
 from oracle import ref
 

@@ -1,4 +1,5 @@
-"""Synthetic model files at real architecture shapes (no weights are downloadable here).
+"""TEST / BENCH INFRASTRUCTURE (not part of the product package): synthetic model files at real architecture shapes (no weights
+are downloadable here).
 
 * numpy block quantizers producing *valid* GGML blocks (layouts: reference models/ggml/ggml.c:888-925 for
   Q4_0/Q8_0, models/ggml/k_quants.h:76-126 for Q4_K/Q5_K/Q6_K).  They are NOT the reference's quantizers
@@ -216,7 +217,51 @@ def quantize_q5_1(x):
     return out.reshape(lead + (-1,))
 
 
-def quantize(x, ggml_type):
+def fuzz_blocks(n_blocks, ggml_type, sigma, rng):
+    """ARBITRARY block bytes of a quantized type (what a file MAY hold, not what a quantizer would write): every quant / 6-bit scale / min /
+    high-bit pattern uniformly random (Q8_0 quants incl. -128, Q6_K scales over the whole int8 range), block scales d / dmin = finite fp16 values
+    of either sign around the magnitude that keeps a row's dot product near `sigma` x the activation norm, with zeros, fp16 sub-normals
+    and the largest value of the range mixed in.  -> uint8 [n_blocks, block_bytes]"""
+    be, bb = G.TYPE_BLOCK[ggml_type]
+    raw = rng.integers(0, 256, size=(n_blocks, bb), dtype=np.uint8)
+    # typical |weight| of a block with d = 1: Q4_K 63 * 15 / 4, Q5_K 63 * 31 / 4, Q6_K 64 * 16, Q8_0 64, Q4_0 / Q4_1 4, Q5_x 8
+    unit = {G.Q4_K: 240.0, G.Q5_K: 490.0, G.Q6_K: 1024.0, G.Q8_0: 64.0, G.Q4_0: 4.0, G.Q4_1: 8.0, G.Q5_0: 8.0, G.Q5_1: 16.0}[ggml_type]
+
+    def scales(n):
+        mag = np.float32(sigma) / np.float32(unit) * np.exp2(rng.uniform(-3.0, 1.0, size=n)).astype(np.float32)
+        d = (mag * rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=n)).astype(np.float16)
+        kind = rng.integers(0, 16, size=n)
+        d[kind == 0] = np.float16(0.0)
+        d[kind == 1] = np.float16(-0.0)
+        sub = np.frombuffer(rng.integers(1, 0x400, size=n, dtype=np.uint16).tobytes(), dtype=np.float16)   # fp16 sub-normals
+        d = np.where(kind == 2, sub, d)
+        d = np.where(kind == 3, -sub, d)
+        return np.ascontiguousarray(d).view(np.uint8).reshape(n, 2)
+
+    if ggml_type in (G.Q4_K, G.Q5_K):
+        raw[:, 0:2], raw[:, 2:4] = scales(n_blocks), scales(n_blocks)
+    elif ggml_type == G.Q6_K:
+        raw[:, 208:210] = scales(n_blocks)
+    elif ggml_type in (G.Q8_0, G.Q4_0, G.Q5_0):
+        raw[:, 0:2] = scales(n_blocks)
+    else:   # Q4_1 / Q5_1: d, m
+        raw[:, 0:2], raw[:, 2:4] = scales(n_blocks), scales(n_blocks)
+    return raw
+
+
+def quantize(x, ggml_type, quantizer=None):
+    """quantizer=None / "numpy": this file's block quantizers; "reference": the reference's own `ggml_quantize_chunk` through the
+    oracle build (oracle/ref.py:quantize_chunk) — the blocks real model files hold, e.g. Q6_K with negative scales and d; "fuzz":
+    `fuzz_blocks` (the values of x only seed the generator and set the magnitude)."""
+    if quantizer == "reference" and ggml_type not in (G.F32, G.F16):
+        from oracle import ref
+        return ref.quantize_chunk(x, ggml_type)
+    if quantizer == "fuzz" and ggml_type not in (G.F32, G.F16):
+        x = np.asarray(x, dtype=np.float32)
+        be, bb = G.TYPE_BLOCK[ggml_type]
+        rng = np.random.default_rng(int(np.abs(x.reshape(-1)[:64]).view(np.uint32).sum()) & 0x7fffffff)
+        sigma = float(np.sqrt(np.mean(np.square(x.reshape(-1)[:1 << 16], dtype=np.float64)))) or 1.0
+        return fuzz_blocks(x.size // be, ggml_type, sigma, rng).reshape(x.shape[:-1] + (x.shape[-1] // be * bb,))
     if ggml_type == G.F32:
         return np.ascontiguousarray(x, dtype=np.float32).view(np.uint8).reshape(x.shape[:-1] + (-1,))
     if ggml_type == G.F16:
@@ -354,10 +399,10 @@ class BlockPool:
     blocks from the pool (fast path for multi-GB synthetic models; every block is a legal quantization of real
     Gaussian data, every tensor is a different random sequence of them)."""
 
-    def __init__(self, ggml_type, sigma, rng, n_blocks=1 << 13):
+    def __init__(self, ggml_type, sigma, rng, n_blocks=1 << 13, quantizer=None):
         be, bb = G.TYPE_BLOCK[ggml_type]
         x = rng.standard_normal((n_blocks, be), dtype=np.float32) * np.float32(sigma)
-        self.blocks = quantize(x, ggml_type).reshape(n_blocks, bb)
+        self.blocks = quantize(x, ggml_type, quantizer).reshape(n_blocks, bb)
         self.n, self.bb, self.be = n_blocks, bb, be
 
     def draw(self, rng, n_blocks):
@@ -366,19 +411,20 @@ class BlockPool:
 
 
 class _WeightSource:
-    def __init__(self, seed, pooled):
+    def __init__(self, seed, pooled, quantizer=None):
         self.rng = np.random.default_rng(seed)
         self.pooled = pooled
+        self.quantizer = quantizer
         self.pools = {}
 
     def matrix(self, rows, K, ggml_type, sigma):
         """-> uint8 [rows * row_bytes]"""
         if ggml_type in (G.F32, G.F16) or not self.pooled:
             x = self.rng.standard_normal((rows, K), dtype=np.float32) * np.float32(sigma)
-            return quantize(x, ggml_type).reshape(-1)
+            return quantize(x, ggml_type, self.quantizer).reshape(-1)
         key = (ggml_type, round(float(sigma), 9))
         if key not in self.pools:
-            self.pools[key] = BlockPool(ggml_type, sigma, self.rng)
+            self.pools[key] = BlockPool(ggml_type, sigma, self.rng, quantizer=self.quantizer)
         pool = self.pools[key]
         return pool.draw(self.rng, rows * (K // pool.be)).reshape(-1)
 
@@ -416,9 +462,10 @@ def make_spm_vocab(n_vocab=512):
 
 
 def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_train=4096, pooled=None,
-                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None, type_overrides=None):
+                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None, type_overrides=None, quantizer=None):
     """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict.
-    type_overrides: {tensor-name suffix: ggml type} applied on top of the ftype's mix (e.g. {"attn_v.weight": G.Q8_0})."""
+    type_overrides: {tensor name or dotted name suffix: ggml type} applied on top of the ftype's mix (e.g. {"attn_v.weight": G.Q8_0};
+    "output.weight" names the head only, not blk.N.attn_output.weight).  quantizer: see `quantize`."""
     hp = dict(LLAMA_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     if overrides:
         hp.update(overrides)
@@ -428,11 +475,11 @@ def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_
     n_embd_gqa = head_dim * n_head_kv
     if pooled is None:
         pooled = n_embd >= 2048
-    src = _WeightSource(seed, pooled)
+    src = _WeightSource(seed, pooled, quantizer)
     types = llama_tensor_types(ftype, n_layer)
     for suffix, ty in (type_overrides or {}).items():
         for name in list(types):
-            if name.endswith(suffix):
+            if name == suffix or name.endswith("." + suffix):
                 types[name] = ty
 
     w = G.GGUFWriter(path)
@@ -563,7 +610,7 @@ def make_bpe_vocab(n_vocab):
 
 
 def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ctx_train=2048, pooled=None, norm_eps=1e-5,
-                      overrides=None):
+                      overrides=None, quantizer=None):
     """Write a synthetic falcon-architecture GGUF v2 file.  Returns the hparams dict."""
     hp = dict(FALCON_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     if overrides:
@@ -573,7 +620,7 @@ def write_falcon_gguf(path, shape="falcon-tiny", ftype="Q4_K_M", seed=1234, n_ct
     head_dim = n_embd // n_head
     if pooled is None:
         pooled = n_embd >= 2048
-    src = _WeightSource(seed, pooled)
+    src = _WeightSource(seed, pooled, quantizer)
     types = falcon_tensor_types(ftype, n_layer)
     w = G.GGUFWriter(path)
     w.add_str("general.architecture", "falcon")
@@ -658,7 +705,7 @@ def make_gpt2_vocab(n_vocab):
     return toks[:n_vocab]
 
 
-def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm_head=False, pieces=None):
+def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm_head=False, pieces=None, quantizer=None):
     """Synthetic GPT-2 in the legacy GGML container (magic 0x67676d6c, 6 x i32 hparams, vocab, tensors; ftype 2 = Q4_0,
     stored as ftype + 1000*GGML_QNT_VERSION).  Returns the hparams dict."""
     import struct
@@ -666,7 +713,7 @@ def write_gpt2_ggml(path, shape="gpt2-tiny", seed=1234, ftype=2, pooled=None, lm
     V, C, E, H, NL = hp["n_vocab"], hp["n_ctx"], hp["n_embd"], hp["n_head"], hp["n_layer"]
     if pooled is None:
         pooled = E >= 2048
-    src = _WeightSource(seed, pooled)
+    src = _WeightSource(seed, pooled, quantizer)
     wtype = {0: G.F32, 1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
     rng = np.random.default_rng(seed + 17)
     with open(path, "wb") as f:
@@ -727,7 +774,7 @@ MPT_SHAPES = {
 }
 
 
-def write_mpt_ggml(path, shape="mpt-tiny", seed=1234, ftype=2, pooled=None, pieces=None):
+def write_mpt_ggml(path, shape="mpt-tiny", seed=1234, ftype=2, pooled=None, pieces=None, quantizer=None):
     """Synthetic MPT in the legacy GGML container as the reference's mpt loader reads it (models/llms/mpt.cc:50-363): magic,
     d_model, max_seq_len, n_heads, n_layers, n_vocab, alibi_bias_max (f32), clip_qkv (f32), ftype; the vocabulary without a count,
     pieces in UTF-8 (the loader keeps the low byte of every code point); quantized wte, f32 norm gains, four matrices per layer."""
@@ -736,7 +783,7 @@ def write_mpt_ggml(path, shape="mpt-tiny", seed=1234, ftype=2, pooled=None, piec
     V, C, E, H, NL = hp["n_vocab"], hp["max_seq_len"], hp["n_embd"], hp["n_head"], hp["n_layer"]
     if pooled is None:
         pooled = E >= 2048
-    src = _WeightSource(seed, pooled)
+    src = _WeightSource(seed, pooled, quantizer)
     wtype = {0: G.F32, 1: G.F16, 2: G.Q4_0, 3: G.Q4_1, 7: G.Q8_0, 8: G.Q5_0, 9: G.Q5_1}[ftype]   # enum ggml_ftype (ggml.h:322-336)
     with open(path, "wb") as f:
         f.write(struct.pack("<I", 0x67676d6c))
