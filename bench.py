@@ -26,7 +26,8 @@ Extra objects on the JSON line:
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
   prefill       the 128-token prompt through the prompt-chunk kernels (third pass = steady state; the cold first pass beside it)
-  other_configs config 3 (always) and configs 4 / 5 (CTAMD_BENCH_BIG=1) as child runs: decode tok/s, per-token roofline fraction, prefill
+  other_configs config 3 (always) and configs 4 / 5 (when the scratch disk has 58 GB free; CTAMD_BENCH_BIG=0 / 1 forces) as child runs: decode tok/s,
+                per-token roofline fraction, prefill
 """
 import argparse
 import hashlib
@@ -168,8 +169,12 @@ def other_configs():
     """The other single-GPU-capable BASELINE configs, each as a child `bench.py --config N` run (own process, own model file):
     config 3 (Llama-2-7B Q8_0, 7 GB: seconds to synthesise) always, configs 4 / 5 (Falcon-40B Q4_K_M 25 GB, Llama-2-70B Q5_K_M 49 GB on
     ONE GPU) when CTAMD_BENCH_BIG=1.  Reported, not the headline."""
+    import shutil
     import subprocess
-    todo = [(3, 240)] + ([(4, 900), (5, 1500)] if os.environ.get("CTAMD_BENCH_BIG") == "1" else [])
+    big = os.environ.get("CTAMD_BENCH_BIG")
+    if big is None:   # default: on, when the scratch disk takes the 49 GB file (one big file at a time; pooled synthesis: tens of seconds each)
+        big = "1" if shutil.disk_usage(os.path.dirname(CONFIGS[5][2])).free > 58e9 else "0"
+    todo = [(3, 240)] + ([(4, 600), (5, 900)] if big == "1" else [])
     res = []
     for cfg, limit in todo:
         try:
@@ -185,6 +190,12 @@ def other_configs():
         res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
                         prefill_tok_s=d["prefill_tok_s"], load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
                         bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
+        if cfg in (4, 5) and os.environ.get("CTAMD_BENCH_KEEP_BIG") != "1":   # 25 / 49 GB of scratch disk: not left behind
+            for f in (CONFIGS[cfg][2], CONFIGS[cfg][2] + ".stamp.json"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
     return res
 
 
@@ -218,7 +229,7 @@ def main():
     ap.add_argument("--steps", type=int, default=N_DECODE)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 3 (and 4 / 5 with CTAMD_BENCH_BIG=1)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 3, 4 and 5")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2: the headline)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
@@ -295,6 +306,16 @@ def main():
     barrier()
     tok_s = steps / dt
 
+    issue = None
+    if n_stages > 1:   # host time of the one issuing thread per stage and decode step (csrc/pipeline.cc:eval_stages) against the step itself
+        import ctypes
+        f = llm._lib.ctamd_stage_issue_us
+        f.restype, f.argtypes = ctypes.c_double, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
+        ev = ctypes.c_longlong(0)
+        us = [f(llm._llm, s_, ctypes.byref(ev)) for s_ in range(n_stages)]
+        issue = dict(evals=int(ev.value), us_per_eval_by_stage=[round(u / max(1, ev.value), 2) for u in us],
+                     us_per_eval_total=round(sum(us) / max(1, ev.value), 2), step_us=round(dt / steps * 1e6, 1),
+                     note="averaged over every eval of the handle (three prompt passes + decode steps); the issuing thread binds when its total approaches step_us")
     sites = measure.profile_sites(llm._lib, llm._llm, 8)
     roof = measure.roofline(sites)
     wbytes = synth.weight_bytes_per_token(MODEL)
@@ -306,8 +327,9 @@ def main():
                dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)",
                data="synthetic (random-init weights at the real shapes and tensor-type mix; quantized blocks drawn from a pool of 8192 per type "
                     "produced by this repo's numpy quantizer, tools/synth.py — not ggml_quantize_chunk; synthetic prompt tokens)",
-               config=dict(workload="Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + 256-tok greedy decode, ctx 512" % n_gpus
-                           if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d-tok greedy decode, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, steps),
+               config=dict(workload=("Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps (positions %d..%d; BASELINE "
+                                     "configs[1] decodes 256: --steps 256 --warmup 0), ctx 512" % (n_gpus, a.warmup, steps, N_PROMPT + a.warmup, N_PROMPT + a.warmup + steps - 1))
+                           if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, a.warmup, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
                            devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached,
                            handoff="none (one stage)" if n_stages == 1 else "hipMemcpyPeerAsync of the [tokens][n_embd] f32 rows, stage to stage "
@@ -325,6 +347,8 @@ def main():
                                   else "matvec_pfm_kernel<GU> (lane sums on v_mfma_i32_4x4x4_16b_i8 with the 1.5*2^23 addend, packed f32 chain, Q8_0 activation images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
+    if issue is not None:
+        out["config"]["host_issue"] = issue
     if n_stages > 1:
         # A pipeline evaluates a prompt in micro-batches (CT_AMD_PP_MB; default 64 tokens up to four stages, 32 beyond: stage s works on micro-batch c while stage
         # s - 1 works on c + 1).  Larger micro-batches mean fewer passes over the weights and less overlap: the best size depends on

@@ -225,6 +225,11 @@ int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* 
     return 0;
 }
 
+double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals) {
+    if (evals) *evals = llm->pipe.issue_evals();
+    return llm->pipe.issue_us(stage);
+}
+
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine().weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
     std::string err;

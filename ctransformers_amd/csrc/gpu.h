@@ -147,6 +147,44 @@ DEV int mul24(int a, int b) { return __mul24(a, b); }
 DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// ---- round-4 step primitives (measured issue costs, tools/experiments/gen_valu_rate.py on MI355X, cycles per wave-instruction and SIMD at
+// four waves per SIMD: v_and / v_lshrrev / v_add_u32 / v_mul_f32 / v_fma_f32 / v_fmac_f32 / v_mov 2.0; everything with a DPP or SDWA
+// modifier, every other VOP3 (v_bfe, v_mad_i32_i24, v_add3, v_dot4, v_perm, v_alignbit, v_lshl_add, v_cndmask with an SGPR mask), v_mul_i32_i24, the
+// conversions, v_max_f32 and the 64-bit forms 3.1-3.3; v_rcp 6.1) -------------------------------------------------------------------------------
+// mad24: a * b + c on 24-bit operands as ONE v_mad_i32_i24 (hipcc re-associates mul24 + add chains into v_mul x 2 + v_add3: three
+// instructions of the 3.3-cycle class for two products instead of two).
+// lshr64_lo: low word of ((hi:lo) >> sh), sh = 0..63 per lane: one v_lshrrev_b64 when hi:lo sit in consecutive registers.
+// lane_up4_add: v + (the value of lane + 4 inside its row of 16; lanes 12..15 of a row add zero) — ONE v_add_u32_dpp row_shl:4.
+// mix_mul_f16lo / mix_mulneg_f16hi: fp16(h & 0xFFFF) * f resp. -(fp16(h >> 16) * f) rounded once to f32: v_fma_mix_f32 converts the
+// half operand on the fly (one instruction for conversion + multiply; the addend -0.0 keeps the product's sign of zero).
+#ifdef CT_EMU
+static inline int mad24(int a, int b, int c) { return a * b + c; }
+static inline uint32_t lshr64_lo(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 63)); }
+static inline int lane_up4_add(int v) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int o = __shfl(v, (lane & 15) + 4 < 16 ? lane + 4 : lane);
+    return v + ((lane & 15) + 4 < 16 ? o : 0);
+}
+static inline float mix_mul_f16lo(uint32_t h, float f) { return _cvtsh_ss((uint16_t)(h & 0xFFFFu)) * f; }
+static inline float mix_mulneg_f16hi(uint32_t h, float f) { return -f * _cvtsh_ss((uint16_t)(h >> 16)); }
+#else
+DEV int mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV uint32_t lshr64_lo(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (sh & 63)); }
+DEV int lane_up4_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true); }   // row_shl:4, bound_ctrl
+DEV float mix_mul_f16lo(uint32_t h, float f) {
+    float r;
+    const uint32_t nz = 0x80000000u;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(f), "s"(nz));
+    return r;
+}
+DEV float mix_mulneg_f16hi(uint32_t h, float f) {
+    float r;
+    const uint32_t nz = 0x80000000u;
+    asm("v_fma_mix_f32 %0, %1, -%2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(f), "s"(nz));
+    return r;
+}
+#endif
+
 // ---- 16-byte streaming load (weights are read once per token: non-temporal, `nt-weights` row of the guide) ----------
 #ifdef CT_EMU
 struct u32x4 {

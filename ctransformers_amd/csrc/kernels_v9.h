@@ -31,6 +31,13 @@
 #pragma once
 #include "kernels_exact.h"
 
+// Stamps inside the prologue cost eight registers the 128-register instantiations do not have: a -DV9_PROTRACE build only
+// (make OUT=../lib_trace EXTRA=-DV9_PROTRACE; tools/gpu_trace.py with SITES_LIB).
+#ifdef V9_PROTRACE
+#define V9_STAMP(cond, dst) do { if (cond) (dst) = clock64_dev(); } while (0)
+#else
+#define V9_STAMP(cond, dst) do { } while (0)
+#endif
 constexpr int kImg9Stride = 144;  // dwords per block image: 64 quant words | 8 sums of 32 | y.d | 7 unused | 64 x -32 * (sum of a word's quants)
 template <int MAXK> struct Img9 {
     int blk[(MAXK / 256 + 3) * kImg9Stride];   // >= (MAXK / 512 + 1) * kImg9bStride: the 32-block image fits too
@@ -404,7 +411,7 @@ DEV double row16_sum(double v) { v += lane_xor1(v); v += lane_xor2(v); v += lane
 // normalised vector as f32 — the final-norm "embeddings" output of the ABI, produced by the lm_head launch (EMB instantiation).
 template <int MAXK, bool LN, bool EMB, bool EW, bool Q6IMG>
 DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
-                     float eps, float* __restrict__ emb_out, int wv, int lane) {
+                     float eps, float* __restrict__ emb_out, int wv, int lane, bool trace, unsigned long long (&ts)[4]) {
     constexpr int ROUNDS = Pro9<MAXK, EW>::ROUNDS;
     const int nblk = K >> 8, nimg = ((nblk + 3) >> 2) << 2;
     const int sub = lane & 15;
@@ -429,6 +436,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
                 s += (64 * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
             }
         }
+        V9_STAMP(trace, ts[0]);   // the activations have arrived (their squares are summed)
         s = wave_sum_fast(s);
         if (lane == 0) L.red[0][wv] = s;
         lds_signal(&L.cnt, lane, 1u);
@@ -437,6 +445,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
         for (unsigned w = 0; w < n_live; ++w) tot += L.red[0][w];
         const float mean = (float)(pow2 ? tot * inv_k : tot / (double)K);
         scale = 1.0f / sqrtf(mean + eps);
+        V9_STAMP(trace, ts[1]);   // the norm's scale is known
     }
     if constexpr (LN) {
         if (pro == PRO_LAYERNORM && wave_live) {
@@ -514,6 +523,9 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
             float am = fabsf(t[0]);
 #pragma unroll
             for (int e = 1; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+#ifdef V9_PROTRACE
+            if (trace && rd == 0 && pro == PRO_PLAIN) { reg_fence(am, t[0], t[1], t[2]); ts[0] = clock64_dev(); }   // the activations have arrived
+#endif
             float amax = am;
             amax = fmaxf(amax, lane_xor1(amax));
             amax = fmaxf(amax, lane_xor2(amax));
@@ -550,6 +562,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
                 for (int k = 0; k < 4; ++k) neg32[k] = sdot4((int)packed[k], (int)0xE0E0E0E0u, 0);
             }
             const int s32 = s16 + lane_xor1(s16);
+            V9_STAMP(trace && rd == 0, ts[2]);   // round 0 quantized (in registers)
             if (b < nimg) {
                 const int v = sub >> 1, l0 = 4 * (sub & 1);
                 int* img = &L.blk[b * kImg9Stride];
@@ -564,6 +577,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
             }
         }
     }
+    V9_STAMP(trace, ts[3]);   // images written, at the barrier
     __syncthreads();
 }
 
@@ -606,7 +620,8 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 #endif
     constexpr int PRE = V9_PRE;
     if (nu == 0) {   // its own copy of the prologue: the path with requests below stays free of conditional loads
-        pro();
+        unsigned long long ts0[4];
+        pro(false, ts0);
         return;
     }
     {
@@ -616,7 +631,8 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     }
     // trace stamps are kept in registers until the loop is over (a store before it would be a pending write at its entry)
     const unsigned long long t1 = trace ? clock64_dev() : 0ull;
-    pro();
+    unsigned long long ts[4] = {0ull, 0ull, 0ull, 0ull};
+    pro(trace, ts);
     const unsigned long long t2 = trace ? clock64_dev() : 0ull;
     // the lane constants are recomputed behind the prologue instead of living through it (a dozen registers the two-type
     // instantiations do not have: they spilled)
@@ -708,7 +724,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
         step(ring[0], V9Req<true>{}); step(ring[1], V9Req<true>{}); step(ring[2], V9Req<true>{}); step(ring[3], V9Req<true>{});
     }
     step(ring[0], V9Req<false>{}); step(ring[1], V9Req<false>{}); step(ring[2], V9Req<false>{}); step(ring[3], V9Req<false>{});
-    if (trace) { tr[1] = t1; tr[2] = t2; tr[3] = clock64_dev(); }
+    if (trace) { tr[1] = t1; tr[2] = t2; tr[3] = clock64_dev(); tr[8] = ts[0]; tr[9] = ts[1]; tr[10] = ts[2]; tr[11] = ts[3]; }
     // ---- epilogue pass: lane l finishes row (l & 1) of unit l >> 1 ----
     wave_lds_sync();
     const float res = SM.RES[wv][lane];
@@ -762,7 +778,7 @@ __global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
         pro9b_load<MAXK>(P, a.x, a.norm_w, a.K, a.pro);
         __syncthreads();
         const unsigned long long t0 = trace ? clock64_dev() : 0ull;
-        auto pro = [&]() __attribute__((always_inline)) {
+        auto pro = [&](bool, unsigned long long (&)[4]) __attribute__((always_inline)) {
             pro9b_finish<MAXK, TA == GT_Q4_0, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
         };
         v9_run<TA, MAXK, false>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
@@ -774,8 +790,8 @@ __global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
     if (threadIdx.x == 0) SM.L.cnt = 0u;
     __syncthreads();
     const unsigned long long t0 = trace ? clock64_dev() : 0ull;
-    auto pro = [&]() __attribute__((always_inline)) {
-        pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane);
+    auto pro = [&](bool trc, unsigned long long (&ts)[4]) __attribute__((always_inline)) {
+        pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane, trc, ts);
     };
     if constexpr (TB != 0) {
         const int nwA = a.nwA;

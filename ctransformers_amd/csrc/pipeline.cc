@@ -1,5 +1,7 @@
 #include "pipeline.h"
 
+#include <chrono>
+
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -234,11 +236,15 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
             ev_[s].push_back(e);
         }
     }
+    if ((int)issue_us_.size() != S) issue_us_.assign(S, 0.0);
+    ++issue_evals_;
     for (int k = 0; k < n_mb; ++k) {
         const int c0 = k * mb, nt = std::min(mb, n - c0);
         const bool last_mb = k == n_mb - 1;
         for (int s = 0; s < S; ++s) {
             Engine& st = *st_[s];
+            const auto t_issue = std::chrono::steady_clock::now();
+            struct Acc { double& d; std::chrono::steady_clock::time_point t0; ~Acc() { d += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } acc{issue_us_[s], t_issue};
             PIPE_OK(hipSetDevice(dev_[s]));
             if (s > 0) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));
             if (!st.req_range(c0, nt, last_mb, err)) return false;

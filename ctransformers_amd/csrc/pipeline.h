@@ -40,6 +40,10 @@ class Pipeline {
     Engine& last() { return *st_.back(); }
     int n_stages() const { return (int)st_.size(); }
     const std::vector<std::pair<int, int>>& ranges() const { return ranges_; }
+    // host time (us) the ONE issuing thread has spent queueing stage s's launches, waits and copies so far, and the evals counted
+    // (ctamd_stage_issue_us: bench.py --gpus N prints it — on a real N-GPU node it shows whether that thread binds before the GPUs do)
+    double issue_us(int s) const { return s >= 0 && s < (int)issue_us_.size() ? issue_us_[s] : 0.0; }
+    long long issue_evals() const { return issue_evals_; }
     ~Pipeline();
 
    private:
@@ -49,6 +53,8 @@ class Pipeline {
     std::vector<std::pair<int, int>> ranges_;
     std::vector<std::vector<hipEvent_t>> ev_;   // ev_[s][k]: micro-batch k's rows have left stage s
     int micro_batch_ = 32;
+    std::vector<double> issue_us_;
+    long long issue_evals_ = 0;
 };
 
 }  // namespace ctamd

@@ -50,6 +50,9 @@ long long ctamd_pg_launches(void);
    stage (returns -1 for a single-stage handle). */
 int ctamd_n_stages(ctransformers_llm* llm);
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end);
+/* Host microseconds the one issuing thread of the in-process pipeline has spent queueing stage `stage`'s launches, event waits and peer
+   copies since the handle was created; *evals = the multi-stage evals counted (0.0 for a single-stage handle). */
+double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals);
 #ifdef __cplusplus
 }
 #endif

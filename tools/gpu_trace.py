@@ -18,9 +18,9 @@ for site in ("qkv", "wo", "gate_up", "down", "lm_head"):
     rows = [[buf[16 * w + k] for k in range(16)] for w in range(16)]
     t0 = min(r[0] for r in rows if r[0])
     print(site)
-    for w in (0, 1, 2, 5, 15):
+    for w in (0, 1, 2, 3, 5, 10, 15):
         r = rows[w]
-        print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "loads", "prolog", "math", "barrier", "chain", "exit"))) + "  pro(sum, barrier, quantized):" + " ".join("%d" % (r[k] - t0) for k in range(8, 11) if r[k] > t0))
+        print("  wave %2d: " % w + " ".join("%s=%6d" % (n, r[k] - t0 if r[k] else -1) for k, n in enumerate(("entry", "loads", "prolog", "math", "barrier", "chain", "exit"))) + "  pro(x arrived, scale known, quantized, images written):" + " ".join("%d" % (r[k] - t0) for k in range(8, 12) if r[k] > t0))
 for rep in range(2):
     lib.ctamd_trace_site(m._llm, b"attn", buf, 256)
 rows = [[buf[16 * w + k] for k in range(8)] for w in range(16)]
