@@ -169,6 +169,12 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         if (a.nwA > 0) gx = std::max(gx, (na + a.nwA * kV9MaxUnits - 1) / (a.nwA * kV9MaxUnits));
         if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV9MaxUnits - 1) / (nwb * kV9MaxUnits));
     }
+    // Launches in which a wave would own at most one unit of MANY records (ffn_down of every llama: 2048 row pairs of eleven records on
+    // 4096 waves; the 70B's: 28 records) take the 8-wave form with a 12-slot ring: the whole unit (or three times the records) in
+    // flight per wave instead of four steps per memory latency (kernels_v9.h:matvec_v9_kernel).
+    // (Measured and NOT taken, round 4: an 8-wave workgroup with a ring of 11 / 8 / 7 slots for launches in which a wave owns one unit of many
+    // records — ffn_down, 2048 row pairs of eleven records — so that the whole unit is in flight: 10.8 us against 8.8 us per launch.  A CU
+    // with eight streaming waves is served at about 8.6 B/cycle whatever their requests in flight, with sixteen at 10.7: DESIGN.md 5.)
     const dim3 grid((unsigned)gx), block(1024);
     {
         if (a.emb_out && (tb != 0 || a.K > 16384)) { err = "emb_out on a mixed-type or wide launch"; return false; }

@@ -69,9 +69,11 @@ CT_HD static inline void place_kblock9(int type, uint8_t* rp, int r, const uint8
             if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
             else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
         }
-        const uint32_t W1 = sc[0] | (sc[1] << 6) | (sc[2] << 12) | (sc[3] << 18) | (sc[4] << 24) | ((mn[7] & 3u) << 30);
-        const uint32_t W2 = ((mn[7] >> 2) & 3u) | (sc[5] << 2) | (sc[6] << 8) | (sc[7] << 14) | (mn[5] << 20) | (mn[6] << 26);
-        const uint32_t W3 = ((mn[7] >> 4) & 3u) | (mn[0] << 2) | (mn[1] << 8) | (mn[2] << 14) | (mn[3] << 20) | (mn[4] << 26);
+        // the eight mins as 48 CONTIGUOUS bits of the pair W3:W2 (lane l takes min l with one 64-bit shift by 6 l), scales 0..4 in W1,
+        // 5 and 6 whole in W3, scale 7 split 2 + 4 over the spare bits (every lane pays for the split once, none selects a word)
+        const uint32_t W1 = sc[0] | (sc[1] << 6) | (sc[2] << 12) | (sc[3] << 18) | (sc[4] << 24) | ((sc[7] & 3u) << 30);
+        const uint32_t W2 = mn[0] | (mn[1] << 6) | (mn[2] << 12) | (mn[3] << 18) | (mn[4] << 24) | ((mn[5] & 3u) << 30);
+        const uint32_t W3 = (mn[5] >> 2) | (mn[6] << 4) | (mn[7] << 10) | (sc[5] << 16) | (sc[6] << 22) | ((sc[7] >> 2) << 28);
         uint8_t* hdr = rp + (type == GT_Q4_K ? 1024 : 1280) + r * 16;
         memcpy(hdr, blk, 4);
         memcpy(hdr + 4, &W1, 4); memcpy(hdr + 8, &W2, 4); memcpy(hdr + 12, &W3, 4);

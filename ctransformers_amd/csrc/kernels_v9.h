@@ -60,8 +60,7 @@ struct Lane9 {
     int a_b;        // 32-block types: word offset of the lane's four activation words (blocks 4t + c) inside a step image
     int sh40;       // Q4_0: 0 (l < 4: low nibbles) or 4 (high nibbles)
     int a_w;        // word offset of this lane's first four activation words inside a block image
-    int m_sh;       // bit offset of min m_l inside the word that holds it
-    bool m_w2, m_split;
+    int m_sh;       // bit offset of min m_l inside the pair W3:W2 of the block header
 };
 DEV Lane9 lane9(int lane) {
     Lane9 G;
@@ -77,9 +76,7 @@ DEV Lane9 lane9(int lane) {
     G.o_d40 = 512u + (uint32_t)(G.row * 4 + G.c) * 8u;
     G.a_b = (G.c * 8 + G.l) * 4;
     G.sh40 = G.l >= 4 ? 4 : 0;
-    G.m_w2 = G.l == 5 || G.l == 6;
-    G.m_split = G.l == 7;
-    G.m_sh = G.l < 5 ? 2 + 6 * G.l : 20 + 6 * (G.l - 5);
+    G.m_sh = 6 * G.l;
     return G;
 }
 
@@ -131,25 +128,23 @@ template <> DEV Rec9<GT_Q4_0> rec9_load<GT_Q4_0>(const uint8_t* rec, const Lane9
     return R;
 }
 
-// The scale / min words of a Q4_K / Q5_K block slot (quant.h LAYOUT_L9; engine.cc:place_kblock9): every 6-bit scale sits inside
-// one word (all lanes need all eight), the mins m0..m6 too, m7 is split over the three spare bit pairs.
-DEV int scaled_sum45(uint32_t W1, uint32_t W2, const int (&d)[8]) {
-    int sum = mul24((int)(W1 & 63u), d[0]);
-    sum += mul24((int)bfe32(W1, 6, 6), d[1]);
-    sum += mul24((int)bfe32(W1, 12, 6), d[2]);
-    sum += mul24((int)bfe32(W1, 18, 6), d[3]);
-    sum += mul24((int)bfe32(W1, 24, 6), d[4]);
-    sum += mul24((int)bfe32(W2, 2, 6), d[5]);
-    sum += mul24((int)bfe32(W2, 8, 6), d[6]);
-    sum += mul24((int)bfe32(W2, 14, 6), d[7]);
-    return sum;
+// The scale / min words of a Q4_K / Q5_K block slot (quant.h LAYOUT_L9; engine_load.h:place_kblock9): scales 0..4 in W1, 5 and 6 in W3,
+// scale 7 split over the spare bits; the eight mins are 48 contiguous bits of the pair W3:W2.  Two mad chains of four (hipcc would
+// re-associate mul24 + add into v_mul x 2 + v_add3: eleven instructions of the 3.3-cycle class for the eight products instead of eight).
+DEV int scaled_sum45(uint32_t W1, uint32_t W3, const int (&d)[8]) {
+    int s0 = mul24((int)(W1 & 63u), d[0]);
+    int s1 = mul24((int)bfe32(W1, 24, 6), d[4]);
+    s0 = mad24((int)bfe32(W1, 6, 6), d[1], s0);
+    s1 = mad24((int)bfe32(W3, 16, 6), d[5], s1);
+    s0 = mad24((int)bfe32(W1, 12, 6), d[2], s0);
+    s1 = mad24((int)bfe32(W3, 22, 6), d[6], s1);
+    s0 = mad24((int)bfe32(W1, 18, 6), d[3], s0);
+    const uint32_t sc7 = (W1 >> 30) | ((W3 >> 28) << 2);
+    s1 = mad24((int)sc7, d[7], s1);
+    return s0 + s1;
 }
-DEV int min45(uint32_t W1, uint32_t W2, uint32_t W3, const Lane9& G) {
-    const uint32_t word = G.m_w2 ? W2 : W3;
-    const uint32_t m = bfe32(word, G.m_sh, 6);
-    const uint32_t m7 = (alignbit32(W2, W1, 30u) & 0xFu) | ((W3 & 3u) << 4);
-    return (int)(G.m_split ? m7 : m);
-}
+// min m_l of lane l: bits 6 l .. 6 l + 5 of W3:W2 (G.m_sh = 6 l)
+DEV int min45(uint32_t W2, uint32_t W3, const Lane9& G) { return (int)(lshr64_lo(W3, W2, G.m_sh) & 63u); }
 // Q6_K: sum over the eight vectors of the signed scale byte v (of the two words lo | hi) times d[v]; the byte selects fold into
 // the multiplies (v_mul_i32_i24_sdwa with sext)
 DEV int scaled_sum6(uint32_t lo, uint32_t hi, const int (&d)[8]) {
@@ -167,9 +162,14 @@ DEV int scaled_sum6(uint32_t lo, uint32_t hi, const int (&d)[8]) {
 // mv = -y.d * fp16(dmin).  `img`: the block's image in LDS (Img9).
 template <int TYPE>
 DEV void step9(const Rec9<TYPE>& R, const int* img, const Lane9& G, float& sv, float& dv, float& mv, float& pv) {
+#if defined(V9_EXP) && V9_EXP == 4   // experiment (timing only): the activation words come from registers, not from LDS
+    const u32x4 a_lo = {(uint32_t)G.a_w, (uint32_t)G.c, (uint32_t)G.l, 0x01020304u}, a_hi = {(uint32_t)G.row, 0x7f7f7f7fu, (uint32_t)G.o16, 0x11111111u};
+    const float yd = 0.001f;
+#else
     const u32x4 a_lo = *(const u32x4*)(img + G.a_w);        // vectors 0..3, elements 4l .. 4l+3
     const u32x4 a_hi = *(const u32x4*)(img + 32 + G.a_w);   // vectors 4..7
     const float yd = bits_to_f32((uint32_t)img[72]);
+#endif
     int a8[8], w8[8], d8[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a8[k] = (int)a_lo[k]; a8[4 + k] = (int)a_hi[k]; }
@@ -187,13 +187,19 @@ DEV void step9(const Rec9<TYPE>& R, const int* img, const Lane9& G, float& sv, f
         }
         dot4x8(d8, w8, a8);
         const uint32_t W1 = R.hdr[1], W2 = R.hdr[2], W3 = R.hdr[3];
-        sv = (float)scaled_sum45(W1, W2, d8);
-        int p = mul24(min45(W1, W2, W3, G), img[64 + G.l]);
-        p += lane_xor4(p);                       // l ^ 1: prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1]
-        if constexpr (TYPE == GT_Q5_K) { p += lane_xor8(p); p += lane_xor16(p); }   // the block total
+        sv = (float)scaled_sum45(W1, W3, d8);
+#if defined(V9_EXP) && V9_EXP == 4
+        int p = mul24(min45(W2, W3, G), G.a_w + 77);
+#else
+        int p = mul24(min45(W2, W3, G), img[64 + G.l]);
+#endif
+        // prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1] in the lanes of EVEN l (one DPP add from lane + 4: l + 1); the odd-l lanes keep a
+        // value nobody reads — their copy of chain t never reaches the row result (the end-of-unit sums below read even l only)
+        p = lane_up4_add(p);
+        if constexpr (TYPE == GT_Q5_K) { p += lane_xor8(p); p += lane_xor16(p); }   // the block total (in the lanes of l = 0, 4 | 0: see v9_run)
         pv = (float)p;
-        dv = yd * f16_bits_to_f32((uint16_t)(R.hdr[0] & 0xFFFF));
-        mv = -yd * f16_bits_to_f32((uint16_t)(R.hdr[0] >> 16));
+        dv = mix_mul_f16lo(R.hdr[0], yd);        // y.d * fp16(d): conversion and product in one instruction, one rounding
+        mv = mix_mulneg_f16hi(R.hdr[0], yd);     // -y.d * fp16(dmin)
     } else {
         // Q6_K: half n of the block = ql bytes 64n .. 64n+63 (ql[2n]: bytes 4l.. of the first 32, ql[2n+1]: of the second 32) and
         // qh bytes 32n + 4l ..; vector 4n + g: g&1 picks the ql word, g&2 its nibble, bits 2g of qh (reference k_quants.c:3800-3872)
@@ -369,8 +375,8 @@ DEV void pro9b_finish(Img9<MAXK>& L, Pro9b<MAXK>& P, const float* __restrict__ n
 // 64 blocks per round: K <= 16384 is ONE round.  What every workgroup of a launch recomputes is issue-bound, so it is written for
 // instruction count: the block-scalar work (amax tree, first-maximum, the two divisions) is shared by four blocks per wave, packed
 // f32 multiplies, the quant byte is the low byte of the magic-number sum (clamped as a float), sums of 16 by dot4.
-template <int MAXK, bool EW> struct Pro9 {
-    static constexpr int ROUNDS = MAXK / 256 / 64;
+template <int MAXK, bool EW, int NW = 16> struct Pro9 {
+    static constexpr int ROUNDS = MAXK / 256 / (4 * NW);   // NW waves x 4 blocks per round
     // the norm weights travel with the activations (requested later they would queue behind the weight stream: 3000 cycles) —
     // except in the widest instantiation (K > 16384: ffn_down of the 70B class, no norm in front of it)
     static constexpr bool EARLY_W = MAXK <= 16384;
@@ -381,18 +387,19 @@ template <int MAXK, bool EW> struct Pro9 {
 // Part 1: request this thread's activations (and norm weights) — nothing waits here.  The first instructions of the kernel:
 // whatever is requested later queues behind the weight stream.  Wave-uniform branches only; a lane past the last block reads the
 // last block again (its values are replaced by zeros: the padding slots of a row's last record).
-template <int MAXK, bool EW>
-DEV void pro9_load(Pro9<MAXK, EW>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, int wv, int lane) {
+template <int MAXK, bool EW, int NW>
+DEV void pro9_load(Pro9<MAXK, EW, NW>& P, const float* __restrict__ x, const float* __restrict__ nw, int K, int pro, int wv, int lane) {
     const int nblk = K >> 8, nimg = ((nblk + 3) >> 2) << 2;
+    constexpr int RB = 4 * NW;   // blocks per round
 #pragma unroll
-    for (int rd = 0; rd < Pro9<MAXK, EW>::ROUNDS; ++rd) {
-        if (64 * rd + 4 * wv < nimg) {
-            int b = 64 * rd + 4 * wv + (lane >> 4);
+    for (int rd = 0; rd < Pro9<MAXK, EW, NW>::ROUNDS; ++rd) {
+        if (RB * rd + 4 * wv < nimg) {
+            int b = RB * rd + 4 * wv + (lane >> 4);
             b = b < nblk ? b : nblk - 1;
             const float* src = x + b * 256 + (lane & 15) * 16;
 #pragma unroll
             for (int k = 0; k < 4; ++k) P.x[rd][k] = *(const float4*)(src + 4 * k);
-            if constexpr (Pro9<MAXK, EW>::EARLY_W) {
+            if constexpr (Pro9<MAXK, EW, NW>::EARLY_W) {
                 if (pro != PRO_PLAIN) {
                     const float* wsrc = nw + b * 256 + (lane & 15) * 16;
 #pragma unroll
@@ -409,31 +416,32 @@ DEV double row16_sum(double v) { v += lane_xor1(v); v += lane_xor2(v); v += lane
 // `iscale * x + 12582912.f`, RMSNorm ggml.c:10700-10716, LayerNorm ggml.c:10605-10654 (arithmetic of generation 7's prologue; the
 // double-precision sums are order-free).  Ends with a workgroup barrier.  `emb_out` (workgroup 0 only): the
 // normalised vector as f32 — the final-norm "embeddings" output of the ABI, produced by the lm_head launch (EMB instantiation).
-template <int MAXK, bool LN, bool EMB, bool EW, bool Q6IMG>
-DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
+template <int MAXK, bool LN, bool EMB, bool EW, bool Q6IMG, int NW>
+DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
                      float eps, float* __restrict__ emb_out, int wv, int lane, bool trace, unsigned long long (&ts)[4]) {
-    constexpr int ROUNDS = Pro9<MAXK, EW>::ROUNDS;
+    constexpr int ROUNDS = Pro9<MAXK, EW, NW>::ROUNDS;
+    constexpr int RB = 4 * NW;   // blocks per round
     const int nblk = K >> 8, nimg = ((nblk + 3) >> 2) << 2;
     const int sub = lane & 15;
     const bool wave_live = 4 * wv < nimg;   // this wave owns blocks in round 0 (a wave live in round 1 is live in round 0)
     float scale = 1.0f;
     // The norm's sums: only the waves that own blocks meet (LDS arrival counter, cleared before the kernel's first barrier); a wave
     // without blocks goes straight to the final barrier — it may still be busy issuing its first weight requests.
-    const unsigned n_live = (unsigned)(nimg >> 2 < 16 ? nimg >> 2 : 16);
+    const unsigned n_live = (unsigned)(nimg >> 2 < NW ? nimg >> 2 : NW);
     const bool pow2 = (K & (K - 1)) == 0;
     const double inv_k = 1.0 / (double)K;   // exact for a power of two: tot * inv_k == tot / K bit for bit
     if (pro == PRO_RMSNORM && wave_live) {
         double s = 0.0;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (64 * rd + 4 * wv < nimg) {
+            if (RB * rd + 4 * wv < nimg) {
                 double sr = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float4 q = P.x[rd][k];
                     sr += (double)(q.x * q.x); sr += (double)(q.y * q.y); sr += (double)(q.z * q.z); sr += (double)(q.w * q.w);
                 }
-                s += (64 * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                s += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
             }
         }
         V9_STAMP(trace, ts[0]);   // the activations have arrived (their squares are summed)
@@ -452,14 +460,14 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
             double s1 = 0.0;
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd) {
-                if (64 * rd + 4 * wv < nimg) {
+                if (RB * rd + 4 * wv < nimg) {
                     double sr = 0.0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float4 q = P.x[rd][k];
                         sr += (double)q.x; sr += (double)q.y; sr += (double)q.z; sr += (double)q.w;
                     }
-                    s1 += (64 * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                    s1 += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
                 }
             }
             s1 = wave_sum_fast(s1);
@@ -472,7 +480,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
             double s2 = 0.0;
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd) {
-                if (64 * rd + 4 * wv < nimg) {
+                if (RB * rd + 4 * wv < nimg) {
                     double sr = 0.0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -480,7 +488,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
                         q.x -= mean; q.y -= mean; q.z -= mean; q.w -= mean;
                         sr += (double)(q.x * q.x); sr += (double)(q.y * q.y); sr += (double)(q.z * q.z); sr += (double)(q.w * q.w);
                     }
-                    s2 += (64 * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                    s2 += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
                 }
             }
             s2 = wave_sum_fast(s2);
@@ -495,8 +503,8 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
     }
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
-        if (64 * rd + 4 * wv < nimg) {
-            const int b = 64 * rd + 4 * wv + (lane >> 4);
+        if (RB * rd + 4 * wv < nimg) {
+            const int b = RB * rd + 4 * wv + (lane >> 4);
             const bool live = b < nblk;            // row-uniform; a dead row of a live wave writes a zero image (b < nimg) or nothing
             const int bc = live ? b : nblk - 1;
             float t[16];
@@ -505,7 +513,7 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW>& P, const float* __restrict__
                 float4 q = P.x[rd][k];
                 if (pro != PRO_PLAIN) {
                     float4 w4;
-                    if constexpr (Pro9<MAXK, EW>::EARLY_W) w4 = P.w[rd][k];
+                    if constexpr (Pro9<MAXK, EW, NW>::EARLY_W) w4 = P.w[rd][k];
                     else w4 = *(const float4*)(nw + bc * 256 + sub * 16 + k * 4);
                     q.x = (q.x * scale) * w4.x; q.y = (q.y * scale) * w4.y; q.z = (q.z * scale) * w4.z; q.w = (q.w * scale) * w4.w;
                     if constexpr (LN) {
@@ -585,7 +593,7 @@ template <bool B> struct V9Req { static constexpr bool value = B; };
 
 // All units of one wave: items first, first + stride, ... < end of the launch's concatenated unit list.
 // base / g0: first record and first item of the wave's type group.
-template <int TYPE, int MAXK, bool TWO, class Pro>
+template <int TYPE, int MAXK, bool TWO, int NS, class Pro>
 DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int g0, int first, int stride, int end, int lane, int wv,
                 Pro pro) {
     constexpr bool B32 = is_b32<TYPE>();
@@ -599,7 +607,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // ---- prefetch cursor: the step whose record is requested next (stays on the last record once everything is requested) ----
     int pf_it = first, pf_s = 0, pf_left = nu * spu;
     const uint8_t* pf_ptr = base + (size_t)((nu > 0 ? first : g0) - g0) * unit_bytes;
-    Rec9<TYPE> ring[4];
+    Rec9<TYPE> ring[NS];
     auto issue = [&](Rec9<TYPE>& slot, const Lane9& GG) __attribute__((always_inline)) {
         slot = rec9_load<TYPE>(pf_ptr, GG);   // unconditional, same instruction count every step: a conditional load in the loop makes hipcc wait vmcnt(0) per step
         if (pf_left > 1) {
@@ -637,8 +645,11 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // the lane constants are recomputed behind the prologue instead of living through it (a dozen registers the two-type
     // instantiations do not have: they spilled)
     const Lane9 G = lane9(opaque_int(lane));
+    // (deep rings, NS > 4: the host launches them only where NS divides the records of a unit — every request below and in the loop
+    // names a record that exists; a branch around a request would make hipcc wait vmcnt(0) before the first step: measured, 18 500
+    // instead of 15 000 cycles for ffn_down)
 #pragma unroll
-    for (int k = PRE; k < 4; ++k) issue(ring[k], G);
+    for (int k = PRE; k < NS; ++k) issue(ring[k], G);
     // ---- epilogue operands of lane l = (unit l >> 1, row l & 1), requested before the loop (its body must not contain a load
     //      besides the ring's); unconditional loads: operands a lane does not need are read from the activation vector ----
     const int p1 = a.njobs > 1 ? a.job[1].pair0 : 0x7fffffff, p2 = a.njobs > 2 ? a.job[2].pair0 : 0x7fffffff;
@@ -674,7 +685,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     const float2 e_cs = *(const float2*)((need_rope ? a.rope_cs : a.x) +
                                          (need_rope ? ((size_t)pos * (a.head_dim >> 1) + ((e_r % a.head_dim) >> 1)) * 2 : 0));
     // ---- consume: one flat sequence of nu * spu steps, in groups of four (the ring slots are compile-time) ----
-    const int total = nu * spu, groups = (total + 3) >> 2;
+    const int total = nu * spu, groups = (total + NS - 1) / NS;
     int s = 0, ui = 0;
     float acc = 0.0f, accm = 0.0f;
     const int* img0 = &SM.L.blk[G.c * kImg9Stride];
@@ -692,13 +703,42 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             }
         } else {
             float sv, dv, mv, pv;
-            step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
+#if defined(V9_EXP) && V9_EXP == 1   // experiment (timing only, wrong results): no block math — the record is consumed by four ALU instructions
+            if constexpr (TYPE == GT_Q4_K) {
+                sv = bits_to_f32((R.qs[0] ^ R.qs[1] ^ R.qs[2] ^ R.qs[3]) & 0x3fffffffu); dv = bits_to_f32((R.hdr[0] ^ R.hdr[1] ^ R.hdr[2] ^ R.hdr[3]) & 0x3fffffffu); mv = 0.f; pv = 0.f;
+            } else
+#endif
+#if defined(V9_EXP) && V9_EXP == 3   // experiment: the slot's next record is requested BEFORE the block math (the math runs on a copy)
             if constexpr (decltype(REQ)::value) {
+                Rec9<TYPE> cur = R;
+                issue(R, G);
+                step9<TYPE>(cur, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
+            } else
+#endif
+            step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
+#if defined(V9_EXP) && V9_EXP == 3
+            if constexpr (false) {
+#else
+            if constexpr (decltype(REQ)::value) {
+#endif
                 reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
+#if defined(V9_EXP) && V9_EXP == 2   // experiment (timing only): no re-requests — the ring's first four records are computed on again and again
+                if constexpr (TYPE != GT_Q4_K)
+#endif
                 issue(R, G);
             }
+#if defined(V9_EXP) && V9_EXP == 1
+            if constexpr (TYPE == GT_Q4_K) { acc += sv * dv; } else
+#endif
+            {
+#if defined(V9_EXP) && V9_EXP == 5   // experiment (timing only): no quad chain
+            acc = fmaf(dv, sv, acc);
+            if constexpr (mins) accm = fmaf(mv, pv, accm);
+#else
             acc = quad_chain4(acc, dv, sv);
             if constexpr (mins) accm = quad_chain4(accm, mv, pv);
+#endif
+            }
         }
         if (s + 1 < spu) { ++s; return; }
         const float t4 = acc + lane_xor16(acc);
@@ -721,9 +761,15 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // past the wave's last record (at most three, and none when a unit is a multiple of four records) reads that record again.
     // The last group requests nothing: the memory pipeline of the CU belongs to the waves that still have records to fetch.
     for (int g = 0; g + 1 < groups; ++g) {
-        step(ring[0], V9Req<true>{}); step(ring[1], V9Req<true>{}); step(ring[2], V9Req<true>{}); step(ring[3], V9Req<true>{});
+#pragma unroll
+        for (int k = 0; k < NS; ++k) step(ring[k], V9Req<true>{});
     }
-    step(ring[0], V9Req<false>{}); step(ring[1], V9Req<false>{}); step(ring[2], V9Req<false>{}); step(ring[3], V9Req<false>{});
+    {   // the last group: no requests, and no surplus steps (a branch around block math is harmless here: no load follows)
+        const int left = total - (groups - 1) * NS;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (k < left) step(ring[k], V9Req<false>{});
+    }
     if (trace) { tr[1] = t1; tr[2] = t2; tr[3] = clock64_dev(); tr[8] = ts[0]; tr[9] = ts[1]; tr[10] = ts[2]; tr[11] = ts[3]; }
     // ---- epilogue pass: lane l finishes row (l & 1) of unit l >> 1 ----
     wave_lds_sync();
@@ -758,10 +804,15 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: one group).  Dynamic LDS: sizeof(SmemV9<MAXK>).
-template <int MAXK, int TA, int TB, bool LN, bool EMB = false>
-__global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
+// NW waves per workgroup, NS ring slots per wave: (16, 4) is what the host launches.  Measured in round 4 (profiles/r04_*): NS = 6 / 8 at
+// sixteen waves spill; (8, 11 | 8 | 7) — eight waves with 256 registers and a whole unit in flight, for launches in which a wave owns
+// one unit of many records (ffn_down) — streams SLOWER (10.8 against 8.8 us per launch): a CU with eight streaming waves is served at
+// about 8.6 B/cycle whatever they have in flight, with sixteen at 10.7, with no block math at 12.
+template <int MAXK, int TA, int TB, bool LN, bool EMB = false, int NW = 16, int NS = 4>
+__global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) {
     CT_DYN_SMEM(smem_raw);
     SmemV9<MAXK>& SM = *reinterpret_cast<SmemV9<MAXK>*>(smem_raw);
+    if (a.dbg & 64) return;   // measurement only (CT_AMD_DBG=64): the launch and its boundary without the kernel's work
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     constexpr bool B32 = is_b32<TA>();
@@ -781,24 +832,26 @@ __global__ void __launch_bounds__(1024) matvec_v9_kernel(const MatvecArgs a) {
         auto pro = [&](bool, unsigned long long (&)[4]) __attribute__((always_inline)) {
             pro9b_finish<MAXK, TA == GT_Q4_0, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
         };
-        v9_run<TA, MAXK, false>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
+        static_assert(NW == 16 && NS == 4, "32-block types: the 16-wave form");
+        v9_run<TA, MAXK, false, 4>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
         if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
         return;
     } else {
-    Pro9<MAXK, TB == 0> P;
-    pro9_load<MAXK, TB == 0>(P, a.x, a.norm_w, a.K, a.pro, wv, lane);
+    Pro9<MAXK, TB == 0, NW> P;
+    pro9_load<MAXK, TB == 0, NW>(P, a.x, a.norm_w, a.K, a.pro, wv, lane);
     if (threadIdx.x == 0) SM.L.cnt = 0u;
     __syncthreads();
     const unsigned long long t0 = trace ? clock64_dev() : 0ull;
     auto pro = [&](bool trc, unsigned long long (&ts)[4]) __attribute__((always_inline)) {
-        pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane, trc, ts);
+        pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K, NW>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane, trc, ts);
     };
     if constexpr (TB != 0) {
+        static_assert(NW == 16 && NS == 4, "two-type launches: the 16-wave form");
         const int nwA = a.nwA;
-        if (wv < nwA) v9_run<TA, MAXK, true>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
-        else v9_run<TB, MAXK, true>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, pro);
+        if (wv < nwA) v9_run<TA, MAXK, true, 4>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
+        else v9_run<TB, MAXK, true, 4>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, pro);
     } else {
-        v9_run<TA, MAXK, false>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
+        v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * NW, a.n_pairs, lane, wv, pro);
     }
     if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
     }

@@ -23,11 +23,12 @@
 // of the reference touches in block slot (row, c) — so the lane that computes the integer lane sum sumi[l] also owns chain l.
 //   Q4_K record 1152 B: qs[64 lanes][16] | hdr[8 slots][16]
 //       lane dword j (0..3) = file qs bytes 32j + 4l .. +3 (low nibbles: vector 2j, high nibbles: vector 2j + 1, elements 4l .. 4l+3)
-//       hdr = f16 d | f16 dmin | W1 | W2 | W3: the sixteen 6-bit scales / mins re-encoded so that no field any lane extracts with
-//       one bit-field instruction straddles a word (the file's 12 bytes, losslessly):
-//         W1 = sc0 | sc1<<6 | sc2<<12 | sc3<<18 | sc4<<24 | (m7 & 3)<<30
-//         W2 = ((m7>>2) & 3) | sc5<<2 | sc6<<8 | sc7<<14 | m5<<20 | m6<<26
-//         W3 = ((m7>>4) & 3) | m0<<2 | m1<<8 | m2<<14 | m3<<20 | m4<<26
+//       hdr = f16 d | f16 dmin | W1 | W2 | W3: the sixteen 6-bit scales / mins re-encoded (the file's 12 bytes, losslessly).  Every lane needs
+//       all eight scales and ONE min (its own, m_l): the mins are 48 contiguous bits of the register pair W3:W2, so lane l takes
+//       `(W3:W2 >> 6l) & 63` with one 64-bit shift and no word select; scale 7 pays for the spare-bit split once for all lanes:
+//         W1 = sc0 | sc1<<6 | sc2<<12 | sc3<<18 | sc4<<24 | (sc7 & 3)<<30
+//         W2 = m0 | m1<<6 | m2<<12 | m3<<18 | m4<<24 | (m5 & 3)<<30
+//         W3 = (m5>>2) | m6<<4 | m7<<10 | sc5<<16 | sc6<<22 | (sc7>>2)<<28
 //   Q5_K record 1408 B: qs[64][16] | qh[64][4] | hdr[8][16]      lane qh word = file qh bytes 4l .. 4l+3 (bit v = vector v)
 //   Q6_K record 1680 B: ql[64][16] | qh[64][8] | sc[8][16] | d[8] f16
 //       lane ql dwords (2n, 2n+1) = file ql bytes 64n + 4l.., 64n + 32 + 4l..; qh dword n = file qh bytes 32n + 4l..;

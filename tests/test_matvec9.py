@@ -281,3 +281,4 @@ def test_file_layout_lm_head_behind_prompt_chunks(emu_lib, mirror, tmp_path, hea
     t = int(lg.argmax())
     m.eval([t])
     assert np.array_equal(m.logits.to_numpy(), o.eval([t], 13))
+

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r4i; mkdir -p $O
+for v in exp3; do
+( SITES_LIB=$PWD/ctransformers_amd/lib_$v/libctransformers.so timeout 300 python tools/gpu_sites.py $v 2>&1 | tail -1 ) >> $O/sites.txt
+done
+( timeout 300 python tools/gpu_sites.py base 2>&1 | tail -1 ) >> $O/sites.txt
+cat $O/sites.txt
