@@ -606,11 +606,23 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 activation images, kernels_pf.h
         const int Kp = (m.K + 127) & ~127;   // rows in whole groups of four blocks (zero blocks behind a row's end: kernels_pf.h)
         const int aw32 = pf_act_words_q32(Kp);
-        // 8 tokens per workgroup on the matrix-core form while their images fit the CU's LDS (K <= 16384: 144 KB); wider rows take
-        // the dot4 form with 4.  (Measured on config 3, profiles/r02_q80_chunk_sites.txt: 16 / 32 tokens per workgroup change
-        // nothing — the kernel is bound by instruction issue, not by the weight traffic — and the dot4 form at 8 tokens is 6 % slower.)
-        const int tb = (size_t)kPfTokens * aw32 * 4 <= (size_t)150 * 1024 ? kPfTokens : kPfTokens / 2;
-        const bool mfma = tb == kPfTokens;          // lane sums on v_mfma_i32_4x4x4_16b_i8 (one image per token)
+        // Tokens per workgroup of the matrix-core form: 16 where their images fit the CU's LDS (K <= 9000; gate + up keeps SiLU(gate) in LDS
+        // too), 12 at K = 11008, 8 up to K = 16384 — a CU then loads the weights once per 16 / 12 tokens instead of once per 8 (measured on
+        // config 3, profiles/r04_q80_chunk_ablations.txt: 8 -> 5 210, 16 / 12 -> 5 610, 32 on eight waves -> 5 410 prompt tok/s).  Rows whose 8
+        // images do not fit (K > 16384) take the dot4 form with 4.
+        const size_t lds_cap = (size_t)158 * 1024;
+        int ntg = 0;
+        for (int c : {4, 3, 2}) {
+            if (m.gateup && c != 4 && c != 2) continue;
+            const size_t need = (size_t)4 * c * aw32 * 4 + (m.gateup ? (size_t)16 * 8 * c * 4 * 4 : 0);
+            if (need <= lds_cap && (c == 2 || nt > 4 * (c == 3 ? 2 : c / 2))) { ntg = c; break; }   // short chunks keep more workgroups
+        }
+        if (ntg != 0) {   // experiments: CT_AMD_PFM_NTG forces a smaller group where that form exists
+            const int f = env_int("CT_AMD_PFM_NTG", ntg);
+            if (f >= 2 && f <= ntg && (f == 2 || f == 4 || (!m.gateup && f == 3))) ntg = f;
+        }
+        const int tb = ntg ? 4 * ntg : kPfTokens / 2;
+        const bool mfma = ntg != 0;                 // lane sums on v_mfma_i32_4x4x4_16b_i8 (one image per token)
         const int paired = mfma ? 0 : 1;
         if (m.K <= 12288) CT_LAUNCH((pf_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b, paired);
         else CT_LAUNCH((pf_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts_, aw32, m.norm_b, paired);
@@ -628,15 +640,20 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         const int groups = (nt + tb - 1) / tb;
         const int gx = std::max(1, std::min(chip_cus() / groups, a.m.n_pairs));
         const dim3 grid((unsigned)gx, (unsigned)groups), block(1024);
-        const size_t smem = (size_t)tb * aw32 * 4;
+        const size_t smem = (size_t)tb * aw32 * 4 + (mfma && m.gateup ? (size_t)16 * 8 * ntg * 4 * 4 : 0);
 #define PF32(TBV, GUV) do { \
             auto kfn = matvec_pf_kernel<TBV, GUV>; \
             CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); \
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
+#define PFM(GUV, NV) do { \
+            auto kfn = matvec_pfm_kernel<GUV, NV>; \
+            CT_OPTIN_ONCE(kfn, lds_cap); \
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
         if (mfma) {
-            if (m.gateup) { auto kfn = matvec_pfm_kernel<true>; CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); }
-            else { auto kfn = matvec_pfm_kernel<false>; CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); }
+            if (m.gateup) { if (ntg == 4) PFM(true, 4); else PFM(true, 2); }
+            else if (ntg == 4) PFM(false, 4); else if (ntg == 3) PFM(false, 3); else PFM(false, 2);
         } else { if (m.gateup) PF32(kPfTokens / 2, true); else PF32(kPfTokens / 2, false); }
+#undef PFM
 #undef PF32
         prof_end();
         return true;

@@ -764,7 +764,9 @@ bool Engine::alloc_state(std::string& err) {
             return false;
         pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
         if (!kq_model) {   // Q8_0 activation images of the Q8_0 / Q4_0 chunk kernel
-            if (!dev_alloc(dev_allocs_, &acts_, (size_t)kPfChunk * pf_act_words_q32((std::max(E, F) + 127) & ~127), err)) return false;
+            // + 32 images: a workgroup copies all the images of its token group (up to 32), the last group's reach past the chunk's end (their results are dropped)
+            if (!dev_alloc(dev_allocs_, &acts_, (size_t)(kPfChunk + 32) * pf_act_words_q32((std::max(E, F) + 127) & ~127), err)) return false;
+            HIP_OK(hipMemset(acts_, 0, (size_t)(kPfChunk + 32) * pf_act_words_q32((std::max(E, F) + 127) & ~127) * sizeof(int)));
         }
         if (kq_model || mixed_model) {   // 128 tokens of stage images per block and layout (kernels_pg.h PgStage)
             acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max((kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES) + 4096;

@@ -100,6 +100,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
     base.eps = hp_.rms_eps;
     base.dbg = env_int("CT_AMD_DBG", 0);
     base.dbg_sink = scores_; base.f16_tmp = f16_tmp_;
+    bool bumped = false;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
@@ -156,6 +157,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = attn_proj_; a.res2 = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD2}});
+            if (il == hp_.n_layer - 1 && !only_site_ && !prof_ && kq_can(a)) { a.bump = d_state_; bumped = true; }   // as in token_step (llama)
             apply_trace(a, "down");
             if (site_on("down")) {
                 prof_begin("down", "matvec", (double)L.w_down.bytes);
@@ -181,6 +183,6 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
             prof_end();
         }
     }
-    if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     return true;
 }

@@ -106,6 +106,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     base.eps = hp_.rms_eps;
     base.dbg = env_int("CT_AMD_DBG", 0);
     base.dbg_sink = scores_; base.f16_tmp = f16_tmp_;
+    bool bumped = false;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
@@ -164,6 +165,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             MatvecArgs a = base;
             a.K = F; a.pro = PRO_PLAIN; a.x = h_; a.out = x_; a.res = x_;
             set_jobs(a, {{&L.w_down, EPI_ADD}});
+            if (il == hp_.n_layer - 1 && !only_site_ && !prof_ && kq_can(a)) { a.bump = d_state_; bumped = true; }   // the token's last launch that does not read the cursor advances it
             apply_trace(a, "down");
             if (site_on("down")) {
                 prof_begin("down", "matvec_k12288", (double)L.w_down.bytes);
@@ -191,7 +193,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_end();
         }
     }
-    if (!only_site_) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
     if (dump_dir_) ++dump_seq_;
     return true;
 }

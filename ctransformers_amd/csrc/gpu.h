@@ -329,6 +329,23 @@ DEV uint32_t pk_mul_f16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint
 DEV uint32_t h2_from_int(int v) { const _Float16 h = (_Float16)(short)v; const f16x2 r = {h, h}; return __builtin_bit_cast(uint32_t, r); }
 #endif
 
+// ---- f32 matrix core, K = 1 (kernels_pf.h: the block-scale products of the Q8_0 / Q4_0 prompt chunks) --------------------------------
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent rank-1 updates D_b[i][m] = C + A_b[i] * B_b[m] (the lane roles of the int8 4x4x4 form:
+// lane 4b + m gives A_b[m] and B_b[m], holds D_b[i][m] in register i).  With C = 0 and operands whose product is exact in f32 (two
+// fp16 values) the result is that product, bit for bit what v_mul_f32 gives.
+#ifdef CT_EMU
+static inline f32x4 mfma_f32_4x4x1(float a, float b, f32x4 c) {
+    const int lane = (int)(threadIdx.x & 63), blk = lane >> 2;
+    for (int i = 0; i < 4; ++i) {
+        const float am = emu_shfl_any(a, 4 * blk + i);
+        c[i] = fmaf(am, b, c[i]);
+    }
+    return c;
+}
+#else
+DEV f32x4 mfma_f32_4x4x1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+#endif
+
 // ---- cross-lane moves without the LDS crossbar where the ISA allows it ----------------------------------------------
 // __shfl_xor always lowers to ds_bpermute_b32 (address VGPR + LDS pipe, ~100 cycles dependent latency).  Butterflies
 // inside a row of 16 lanes can use DPP modifiers instead: quad_perm for xor 1/2, row_half_mirror o quad_perm(3,2,1,0)

@@ -62,6 +62,8 @@ struct MatvecArgs {
     int nwA;            // generation 7, two-type launches: waves 0..nwA-1 of every workgroup walk group A, the rest group B
     const uint8_t* baseA;   // generation 7: first LAYOUT_R2C4 record of type group A / B (the group's jobs are contiguous)
     const uint8_t* baseB;
+    int* bump;          // cursor {step, pos, ..}: workgroup 0 advances it by one token at the end of the launch (the last mat-vec of a token step
+                        // that does not read it: one launch fewer per token than a separate advance_state_kernel)
     float* emb_out;     // generation 7: block 0 also stores the normalised activation vector here (final-norm output of the ABI)
     int gateup;         // 1: job[0]=gate, job[1]=up, pair t = (gate row t, up row t), epilogue SiLU(gate)*up
     int K;              // input length

@@ -33,7 +33,14 @@ struct PfArgs {
 };
 
 // ---- Q8_0 / Q4_0 weights (LAYOUT_G4, kernels_q32.h): Q8_0 activation images  q8[K/4] ([group][l][i] order) | yd[K/32] -----------
-constexpr int pf_act_words_q32(int K) { return ((K >> 2) + (K >> 5) + 3) & ~3; }   // (128 bytes of padding against same-bank images: measured, no change)
+// Words per token image, padded to 16 (mod 64): the 16 lanes one LDS cycle of a ds_read_b128 serves are four AVX lanes l x the four tokens
+// m of a token group (lane = 32 rg + 4 l + m), each reading the four words at m * act_words + 4 (8 g + l) — with images a multiple of 64
+// words apart (K = 4096: 1152) the four tokens share their banks (a 4-way conflict on every read: a third of the kernel's time,
+// profiles/r04_q80_chunk_ablations.txt); 16 (mod 64) gives the sixteen lanes sixteen different 4-bank slots.
+constexpr int pf_act_words_q32(int K) {
+    const int w = ((K >> 2) + (K >> 5) + 3) & ~3;
+    return w + ((16 - (w & 63)) & 63);
+}
 
 template <int MAXK>
 __global__ void __launch_bounds__(1024) pf_quantize_q80_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
@@ -159,32 +166,33 @@ DEV void pf_tile_q32(const uint8_t* __restrict__ tile, int ng, const int* __rest
 // the register budget — measured no faster on MI355X, the kernel is bound by instruction issue, not by re-reading the weights).
 template <int NTG> struct PfmAcc { F32x2 a[NTG][2]; };   // [token group][row pair]
 
-template <int TYPE, int NTG>
+template <int TYPE, int NTG, int PF = 3>
 DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __restrict__ lds, int act_words, int K, int nt, int lane,
                       float (&res)[NTG][4]) {
     constexpr int REC = TYPE == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
-    constexpr int PF = 3;
     const int m = lane & 3, l = (lane >> 2) & 7, rg = lane >> 5;
     const int ra = 4 * rg + m;                                           // the row this lane feeds as A
     const uint32_t qoff = TYPE == GT_Q8_0 ? (uint32_t)(ra * 8 + l) * 16u : (uint32_t)(ra * 4 + (l & 3)) * 16u;
-    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)rg * 32u;   // fp16 scales of rows 4rg..4rg+3, 8 bytes per row
+    const uint32_t doff = (TYPE == GT_Q8_0 ? 1024u : 512u) + (uint32_t)ra * 8u;   // the four fp16 block scales of row `ra` in this group
     const int sh = (TYPE == GT_Q4_0 && l >= 4) ? 4 : 0;
     const int nq = K >> 2;
     i32x4 magic;
     magic[0] = magic[1] = magic[2] = magic[3] = 0x4B400000;
+    f32x4 zero4;
+    zero4[0] = zero4[1] = zero4[2] = zero4[3] = 0.0f;
     const F32x2 unmagic = pk2(-12582912.0f, -12582912.0f);
     PfmAcc<NTG> acc;
 #pragma unroll
     for (int tg = 0; tg < NTG; ++tg) acc.a[tg][0] = acc.a[tg][1] = pk2(0.0f, 0.0f);
-    // weight dwords: a ring PF groups deep (HBM latency); the 64 scale bytes share the record's last cache line with them and are
-    // requested one group ahead
+    // weight dwords: a ring PF groups deep (HBM latency); this lane's row scales (8 bytes) share the record's last cache line with the
+    // other rows' and are requested one group ahead
     u32x4 qv[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int g = u < ng ? u : ng - 1;
         qv[u] = ld_stream16(tile + (size_t)g * REC + qoff);
     }
-    u32x4 sa_n = ld16(tile + doff), sb_n = ld16(tile + doff + 16);
+    u32x2 sc_n = ld_stream8(tile + doff);
     const int* img0 = lds + m * act_words;          // token m of group 0; group tg is 4 tg images further
     (void)nt;   // chunk tails run all eight token slots (the images behind the tail are stale, their results are never stored): no
                 // branch in the block step, the two groups' matrix instructions interleave
@@ -192,46 +200,59 @@ DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __res
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int g = g0 + u;
-            const u32x4 q = qv[u], sa = sa_n, sb = sb_n;
-            {   // the next group's scales BEFORE the ring refill: memory operations retire in order and the scales are needed one step from
-                // now — requested behind the refill, waiting for them drains the refill too (`s_waitcnt vmcnt(0)` every step).  Measured
-                // in round 3: 5 190 vs 5 109 prompt tok/s on the 7B Q8_0 model, i.e. no difference — this kernel is bound by instruction
-                // issue, not by the ring
+            const u32x4 q = qv[u];
+            const u32x2 sc = sc_n;
+            {   // the next group's scales BEFORE the ring refill (memory operations retire in order: requested behind the refill, waiting
+                // for them would drain the refill too)
+#if !(defined(PF_EXP) && PF_EXP == 2)   // experiment 2 (timing only): the ring is never refilled
                 const int g1 = (g + 1 < ng) ? g + 1 : ng - 1;
-                sa_n = ld16(tile + (size_t)g1 * REC + doff);
-                sb_n = ld16(tile + (size_t)g1 * REC + doff + 16);
+                sc_n = ld_stream8(tile + (size_t)g1 * REC + doff);
                 const int gn = (g + PF < ng) ? g + PF : ng - 1;
                 qv[u] = ld_stream16(tile + (size_t)gn * REC + qoff);
+#endif
             }
             if (g >= ng) continue;
-            // scales: sa = rows 0, 1 (two dwords = four fp16 each), sb = rows 2, 3 of this lane's row group
-            F32x2 dw01[4], dw23[4];
+            // The block-scale products fp16(x.d) * fp16(y.d) of rows 4rg .. 4rg+3 x token m come out of the f32 matrix core (K = 1: a
+            // rank-1 update with C = 0; the product of two fp16 values is exact in f32, so these ARE the reference's products): this lane
+            // gives the scale of ITS row as A and its token's y.d as B and receives the four rows' products for its token — no broadcast
+            // of y.d, four conversions per group instead of sixteen, and the packed multiplies leave the vector pipe (round 3: 10.5 vector
+            // instructions per matrix instruction, of which 6 the chain; here 5).
+            float xd[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t r0 = sa[i >> 1], r1 = sa[2 + (i >> 1)], r2 = sb[i >> 1], r3 = sb[2 + (i >> 1)];
-                const int hs = (i & 1) * 16;
-                dw01[i] = pk2(f16_bits_to_f32((uint16_t)(r0 >> hs)), f16_bits_to_f32((uint16_t)(r1 >> hs)));
-                dw23[i] = pk2(f16_bits_to_f32((uint16_t)(r2 >> hs)), f16_bits_to_f32((uint16_t)(r3 >> hs)));
-            }
+            for (int i = 0; i < 4; ++i) xd[i] = f16_bits_to_f32((uint16_t)(sc[i >> 1] >> ((i & 1) * 16)));
             int w[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 w[i] = TYPE == GT_Q8_0 ? (int)q[i] : (int)((((q[i] >> sh) & 0x0F0F0F0Fu) + 0x78787878u) ^ 0x80808080u);
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
+                // two token groups between scheduling fences: their matrix instructions interleave, and no more than two groups' operands
+                // and products are live at a time (left alone hipcc interleaves all NTG groups and spills: 67 registers at NTG = 8)
+                if (NTG > 2 && (tg & 1) == 0 && tg > 0) sched_fence();
                 const int* img = img0 + 4 * tg * act_words;
+#if defined(PF_EXP) && PF_EXP == 1   // experiment (timing only): activations from registers
+                const u32x4 y = {(uint32_t)(g + tg), (uint32_t)l, 0x01020304u, (uint32_t)m}, yd = {0x3c000000u, 0x3c000000u, 0x3c000000u, 0x3c000000u};
+                (void)img; (void)nq;
+#else
                 const u32x4 y = *(const u32x4*)(img + (g * 8 + l) * 4);
                 const u32x4 yd = *(const u32x4*)(img + nq + g * 4);
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+#if defined(PF_EXP) && PF_EXP == 3   // experiment (timing only): no matrix instructions, no chain
+                    acc.a[tg][0] = pk_add_f32(acc.a[tg][0], pk2(bits_to_f32(y[i] ^ (uint32_t)w[i]), bits_to_f32(yd[i])));
+                    (void)xd; (void)magic; (void)zero4; (void)unmagic;
+                    continue;
+#endif
                     const i32x4 d = mfma_i8_4x4x4(w[i], (int)y[i], magic);
-                    const float ys = bits_to_f32(yd[i]);
+                    const f32x4 pr = mfma_f32_4x4x1(xd[i], bits_to_f32(yd[i]), zero4);
                     const F32x2 f01 = pk_add_f32(pk2(bits_to_f32((uint32_t)d[0]), bits_to_f32((uint32_t)d[1])), unmagic);
                     const F32x2 f23 = pk_add_f32(pk2(bits_to_f32((uint32_t)d[2]), bits_to_f32((uint32_t)d[3])), unmagic);
-                    acc.a[tg][0] = pk_fma_f32(pk_mul_f32(dw01[i], pk2(ys, ys)), f01, acc.a[tg][0]);
-                    acc.a[tg][1] = pk_fma_f32(pk_mul_f32(dw23[i], pk2(ys, ys)), f23, acc.a[tg][1]);
+                    acc.a[tg][0] = pk_fma_f32(pk2(pr[0], pr[1]), f01, acc.a[tg][0]);
+                    acc.a[tg][1] = pk_fma_f32(pk2(pr[2], pr[3]), f23, acc.a[tg][1]);
                 }
             }
+            if (NTG > 2) sched_fence();
         }
     }
 #pragma unroll
@@ -252,9 +273,15 @@ DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __res
 
 // grid (x, token-groups of 8), 1024 threads: as matvec_pf_kernel, the tile product on the matrix cores.  A lane with l == 0 owns
 // rows 4rg..4rg+3 of the tile for tokens m, 4 + m, ... of the group.
-template <bool GU>
-__global__ void __launch_bounds__(1024) matvec_pfm_kernel(const PfArgs a) {
-    constexpr int TB = kPfTokens, NTG = TB / 4, NT = 1024, NW = NT / 64;
+// NTG token groups of four per workgroup: what a CU loads per pass over the weights is shared by 4 NTG tokens (the host picks 4, 3 or 2 by
+// what fits the LDS).  Where the kernel's time goes (round 4, profiles/r04_q80_chunk_ablations.txt, tools/experiments/mfma_4x4_rate.cpp):
+// a block step of a wave — two matrix instructions + the four packed chain instructions — issues in 36.6 cycles per SIMD at four waves
+// (the 4x4 matrix instructions cost 6.2 cycles each and do not hide behind the vector pipe), 806 000 steps per SIMD for a 128-token
+// chunk of the 7B = 14.7 ms of the 24 ms; the two ds_read_b128 per four steps, the s_nop behind each matrix result and the weight ring
+// are the rest.  Without the block math the chunk takes 15 ms, without weight reloads 22 ms.
+template <bool GU, int NTG, int NT = 1024>
+__global__ void __launch_bounds__(NT) matvec_pfm_kernel(const PfArgs a) {
+    constexpr int TB = 4 * NTG, NW = NT / 64;
     CT_DYN_SMEM(smem_raw);
     int* lds = reinterpret_cast<int*>(smem_raw);
     const MatvecArgs& m = a.m;
@@ -289,14 +316,29 @@ __global__ void __launch_bounds__(1024) matvec_pfm_kernel(const PfArgs a) {
         const DevMat& wj = m.job[j].w;
         const size_t rec = wj.type == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
         float res[NTG][4];
-        if (wj.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
-        else pf_tile_q32m<GT_Q4_0, NTG>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
-        float up[GU ? NTG : 1][4];
+        constexpr int PFD = (NT == 1024 && NTG >= 4 && !GU) ? 1 : ((NT == 1024 && NTG >= 4) || (GU && NTG == 2) ? 2 : 3);   // the register budget of sixteen waves
+        if (wj.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG, PFD>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
+        else pf_tile_q32m<GT_Q4_0, NTG, PFD>(wj.p[0] + (size_t)tile * ng * rec, ng, lds, a.act_words, m.K, nt, lane, res);
         if constexpr (GU) {
+            // gate + up: SiLU(gate) of the owning lanes waits in LDS while the wave walks the up tile (held in registers, the two result
+            // sets and the accumulators do not fit 128 registers beyond 8 tokens); the epilogue below then sees `res` = the up rows
+            float* mine = reinterpret_cast<float*>(lds + (size_t)TB * a.act_words) + ((size_t)wv * 8 + (size_t)(4 * rg + tm)) * (NTG * 4);
+            if (own_lane) {
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mine[tg * 4 + i] = f16_bits_to_f32(m.silu_tab[f32_to_f16_bits(res[tg][i])]);
+            }
             const DevMat& wu = m.job[1].w;
             const size_t recu = wu.type == GT_Q8_0 ? kRecQ8_0 : kRecQ4_0;
-            if (wu.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, up);
-            else pf_tile_q32m<GT_Q4_0, NTG>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, up);
+            if (wu.type == GT_Q8_0) pf_tile_q32m<GT_Q8_0, NTG, PFD>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, res);
+            else pf_tile_q32m<GT_Q4_0, NTG, PFD>(wu.p[0] + (size_t)tile * ng * recu, ng, lds, a.act_words, m.K, nt, lane, res);
+            if (own_lane) {
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[tg][i] = mine[tg * 4 + i] * res[tg][i];   // silu_table[fp16(gate)] * up
+            }
         }
         const int epi = m.job[j].epi;
 #pragma unroll
@@ -314,7 +356,7 @@ __global__ void __launch_bounds__(1024) matvec_pfm_kernel(const PfArgs a) {
                 if (row >= wj.M) continue;
                 const float v = res[tg][i];
                 if constexpr (GU) {
-                    m.out[(size_t)tok * a.ld_out + row] = f16_bits_to_f32(m.silu_tab[f32_to_f16_bits(v)]) * up[tg][i];
+                    m.out[(size_t)tok * a.ld_out + row] = v;
                 } else if (epi == EPI_ADD) {
                     m.out[(size_t)tok * a.ld_out + row] = v + m.res[(size_t)tok * a.ld_res + row];
                 } else if (epi == EPI_STORE) {

@@ -835,6 +835,7 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
         static_assert(NW == 16 && NS == 4, "32-block types: the 16-wave form");
         v9_run<TA, MAXK, false, 4>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
         if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
+        if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; }
         return;
     } else {
     Pro9<MAXK, TB == 0, NW> P;
@@ -854,5 +855,6 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
         v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * NW, a.n_pairs, lane, wv, pro);
     }
     if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
+    if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; }   // no wave of this launch reads the cursor (host: kernels.h)
     }
 }
