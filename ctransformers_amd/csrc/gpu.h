@@ -195,9 +195,48 @@ static inline u32x4 ld_stream16(const void* p) { u32x4 r; memcpy(&r, p, 16); ret
 static inline u32x4 ld16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }
 #else
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef LD_STREAM_PLAIN   // experiment: default cache policy on the weight stream
+DEV u32x4 ld_stream16(const void* p) { return *(const u32x4*)p; }
+#else
 DEV u32x4 ld_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+#endif
 DEV u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 #endif
+
+// fma8_hh / fma8_hf: acc[k] = fma(fp16 element k of a, fp16 element k of b | f[k], acc[k]) for the eight halves of a 16-byte operand, as eight
+// v_fma_mix_f32: the half operands are converted by the instruction itself (exactly, as v_cvt_f32_f16 does) and the fma rounds once — the
+// same floats as conversions followed by fmaf, in 8 instructions instead of 16 + 8 (hh) / 8 + 8 (hf).  (hipcc folds some of these itself,
+// not all: the decode attention's V*P loop ran eight conversions + four packed fmas per 32 positions.)
+#ifdef CT_EMU
+static inline void fma8_hh(float (&acc)[8], const u32x4& a, const u32x4& b) {
+    for (int k = 0; k < 4; ++k) {
+        acc[2 * k] = fmaf(_cvtsh_ss((uint16_t)(a[k] & 0xFFFFu)), _cvtsh_ss((uint16_t)(b[k] & 0xFFFFu)), acc[2 * k]);
+        acc[2 * k + 1] = fmaf(_cvtsh_ss((uint16_t)(a[k] >> 16)), _cvtsh_ss((uint16_t)(b[k] >> 16)), acc[2 * k + 1]);
+    }
+}
+static inline void fma8_hf(float (&acc)[8], const u32x4& a, const float (&f)[8]) {
+    for (int k = 0; k < 4; ++k) {
+        acc[2 * k] = fmaf(_cvtsh_ss((uint16_t)(a[k] & 0xFFFFu)), f[2 * k], acc[2 * k]);
+        acc[2 * k + 1] = fmaf(_cvtsh_ss((uint16_t)(a[k] >> 16)), f[2 * k + 1], acc[2 * k + 1]);
+    }
+}
+#else
+DEV void fma8_hh(float (&acc)[8], const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * k]) : "v"(a[k]), "v"(b[k]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * k + 1]) : "v"(a[k]), "v"(b[k]));
+    }
+}
+DEV void fma8_hf(float (&acc)[8], const u32x4& a, const float (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * k]) : "v"(a[k]), "v"(f[2 * k]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * k + 1]) : "v"(a[k]), "v"(f[2 * k + 1]));
+    }
+}
+#endif
+
 
 // ---- int8 matrix core: D[16][16] += A[16][32] * B[32][16] (v_mfma_i32_16x16x32_i8) ---------------------------------------
 // Operand layout (checked on hardware by tools/experiments/mfma_i8_layout.cpp): lane i gives A[i & 15][8q .. 8q+7] and

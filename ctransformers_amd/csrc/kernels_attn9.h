@@ -125,13 +125,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
             const int p = base + u * NQ + quad;
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float kf[8], qf[8];
-                unpack8_f16(buf[u * NC + c], kf);
-                unpack8_f16(aux[c], qf);
-#pragma unroll
-                for (int l = 0; l < 8; ++l) acc[l] = fmaf(kf[l], qf[l], acc[l]);
-            }
+            for (int c = 0; c < NC; ++c) fma8_hh(acc, buf[u * NC + c], aux[c]);   // acc[l] = fma(k[l], q[l], acc[l]): both halves converted by the fma
             if constexpr (decltype(REQ)::value) {   // the slot's K row of the NEXT pass
                 const int pn = p + NQ * PB;
                 const uint16_t* krow = kbase + (size_t)(pn < last_p ? pn : last_p) * HD;
@@ -202,8 +196,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
 #pragma unroll
         for (int u = 0; u < VB; ++u) {
             const int i = i0 + 32 * u;
-            float vf[8], pc[8];
-            unpack8_f16(buf[u], vf);
+            float pc[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) pc[l] = pn[l];
             {
@@ -211,8 +204,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
 #pragma unroll
                 for (int l = 0; l < 8; ++l) pn[l] = pr[l];
             }
-#pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pc[l], acc[l]);
+            fma8_hf(acc, buf[u], pc);   // acc[l] = fma(v[l], p[l], acc[l])
             const int in = i + 32 * VB;
             buf[u] = ld16(vrow + (in < last_c ? in : last_c) + 8 * j);
         }
@@ -221,8 +213,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     for (int u = 0; u < VB; ++u) {   // the last round requests nothing
         const int i = i0 + 32 * u;
         if (i < np) {
-            float vf[8], pc[8];
-            unpack8_f16(buf[u], vf);
+            float pc[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) pc[l] = pn[l];
             {
@@ -231,8 +222,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
 #pragma unroll
                 for (int l = 0; l < 8; ++l) pn[l] = pr[l];
             }
-#pragma unroll
-            for (int l = 0; l < 8; ++l) acc[l] = fmaf(vf[l], pc[l], acc[l]);
+            fma8_hf(acc, buf[u], pc);
         }
     }
     const float res = f16dot_reduce_exact(acc, j);
