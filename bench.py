@@ -26,7 +26,7 @@ Extra objects on the JSON line:
                 algorithmic weight bytes per launch / HIP-event time per launch, vs 8 TB/s HBM3E peak
   cpu_baseline  the REAL reference CPU build (oracle/_ref) on this box's host cores, bounded sample of the same job
   prefill       the 128-token prompt through the prompt-chunk kernels (third pass = steady state; the cold first pass beside it)
-  other_configs config 3 (always) and configs 4 / 5 (when the scratch disk has 58 GB free; CTAMD_BENCH_BIG=0 / 1 forces) as child runs: decode tok/s,
+  other_configs config 3 (always) and configs 4 / 5 (when the scratch disk has 53 GB free; CTAMD_BENCH_BIG=0 / 1 forces) as child runs: decode tok/s,
                 per-token roofline fraction, prefill
 """
 import argparse
@@ -173,7 +173,7 @@ def other_configs():
     import subprocess
     big = os.environ.get("CTAMD_BENCH_BIG")
     if big is None:   # default: on, when the scratch disk takes the 49 GB file (one big file at a time; pooled synthesis: tens of seconds each)
-        big = "1" if shutil.disk_usage(os.path.dirname(CONFIGS[5][2])).free > 58e9 else "0"
+        big = "1" if shutil.disk_usage(os.path.dirname(CONFIGS[5][2])).free > 53e9 else "0"
     todo = [(3, 240)] + ([(4, 600), (5, 900)] if big == "1" else [])
     res = []
     for cfg, limit in todo:
@@ -190,7 +190,7 @@ def other_configs():
         res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
                         prefill_tok_s=d["prefill_tok_s"], load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
                         bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
-        if cfg in (4, 5) and os.environ.get("CTAMD_BENCH_KEEP_BIG") != "1":   # 25 / 49 GB of scratch disk: not left behind
+        if (cfg in (4, 5) or big == "1") and os.environ.get("CTAMD_BENCH_KEEP_BIG") != "1":   # 7 / 25 / 49 GB of scratch disk: one file at a time, none left behind
             for f in (CONFIGS[cfg][2], CONFIGS[cfg][2] + ".stamp.json"):
                 try:
                     os.remove(f)
