@@ -18,7 +18,7 @@ from tools import gguf as G, synth  # noqa: E402
 from oracle import ref  # noqa: E402
 
 
-def model_golden(name, ftype, seed, shape="llama-tiny"):
+def model_golden(name, ftype, seed, shape="llama-tiny", quantizer=None):
     path = os.path.join(HERE, name + ".gguf")
     mt = None
     if shape.startswith("gpt2"):
@@ -36,7 +36,7 @@ def model_golden(name, ftype, seed, shape="llama-tiny"):
     elif shape.startswith("falcon"):
         hp = synth.write_falcon_gguf(path, shape, ftype, seed=seed)
     else:
-        hp = synth.write_llama_gguf(path, shape, ftype, seed=seed)
+        hp = synth.write_llama_gguf(path, shape, ftype, seed=seed, quantizer=quantizer)   # "reference": blocks from ggml_quantize_chunk itself
     cfg = dict(context_length=96, batch_size=8, threads=4, model_type=mt)
     r = ref.open_llm(path, **cfg)
     prompt = synth.prompt_tokens(11, hp["n_vocab"])
@@ -185,6 +185,10 @@ if __name__ == "__main__":
                                      ("mpt-tiny128-q40", "Q4_0", 12, "mpt-tiny128")):       # heads of 128, no clamp
         if not only or name in only:
             model_golden(name, ftype, seed, shape)
+    # the same llama-tiny Q4_K_M mix with every block out of the reference's OWN quantizer (ggml_quantize_chunk: Q6_K scales and d of
+    # either sign, make_qkx1_quants' scale searches) — what files in the field hold; tools/synth.py's numpy quantizers never emit those
+    if not only or "tiny-q4km-refq" in only:
+        model_golden("tiny-q4km-refq", "Q4_K_M", 13, "llama-tiny", quantizer="reference")
     if not only or "ops" in only:
         ops_golden()
     if not only or "falcon_ops" in only:

@@ -26,7 +26,7 @@ def chunk_tokens(m):
     return int(f(m._llm))
 
 
-@pytest.mark.parametrize("name,steps", [("tiny-q4km", 4), ("tiny-q5km", 2), ("tiny-q80", 2), ("tiny-q40", 2),
+@pytest.mark.parametrize("name,steps", [("tiny-q4km", 4), ("tiny-q4km-refq", 4), ("tiny-q5km", 2), ("tiny-q80", 2), ("tiny-q40", 2),
                                         ("falcon-tiny-q4km", 2), ("falcon-tiny7-q4km", 2), ("gpt2-tiny-q40", 2)])
 def test_logits_bit_identical_to_reference(emu_lib, name, steps):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))

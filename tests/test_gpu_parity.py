@@ -28,7 +28,7 @@ def chunk_tokens(m):
     return int(f(m._llm))
 
 
-@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q5km", "tiny-q80", "tiny-q40", "falcon-tiny-q4km", "falcon-tiny7-q4km",
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q4km-refq", "tiny-q5km", "tiny-q80", "tiny-q40", "falcon-tiny-q4km", "falcon-tiny7-q4km",
                                   "gpt2-tiny-q40"])
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_golden_logits_bit_identical(name, graph, monkeypatch):
