@@ -2,7 +2,7 @@
 (ctamd_profile_decode, include/ctransformers_amd_ext.h) folded into the `roofline` object of the bench JSON line."""
 import ctypes
 
-PMC_FILE = "r03_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
+PMC_FILE = "r04_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 MATVEC_SITES = ("qkv", "wo", "gate_up", "lm_head")  # the K=4096 instantiation of the dominant kernel
 KERNEL = "matvec_v9_kernel<16384,TA,TB,LN> at K = 4096 (QKV, Wo, gate+up, lm_head launch sites; `down` is the same kernel at K = 11008)"
@@ -57,7 +57,7 @@ def roofline(sites, traffic="pmc"):
 
     return dict(bound="hbm", kernel=KERNEL, achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                 frac=round(ach / HBM_PEAK, 4), traffic=traffic,
-                traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of the same build (tools/run_r3z.sh; x2 gfx950 correction) — a counter pass cannot share a run with the timing" % PMC_FILE if traffic else None,
+                traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of the same build (tools/measure_round.sh; x2 gfx950 correction) — a counter pass cannot share a run with the timing" % PMC_FILE if traffic else None,
                 bytes_per_launch=round(b / nl),
                 us_per_launch=round(ms * 1e3 / nl, 2),
                 timing="HIP events on the library stream around the back-to-back launches of all layers of a site" if sweep
