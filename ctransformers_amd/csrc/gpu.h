@@ -530,6 +530,7 @@ DEV int opaque_int(int v) { asm volatile("" : "+v"(v)); return v; }
 // ---- LDS arrival counters: waves of one workgroup meet without a workgroup barrier (kernels_v9.h prologue) ------------------------
 #ifdef CT_EMU
 DEV void lds_signal(unsigned* ctr, int lane, unsigned inc) {
+    emu::wave_sync();   // a wave's LDS writes (several lanes may have written) happen before its count moves: lockstep on the hardware
     if (lane == 0) *ctr += inc;
 }
 DEV void lds_wait_ge(const unsigned* ctr, unsigned target) {

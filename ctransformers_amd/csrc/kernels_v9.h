@@ -41,7 +41,7 @@
 constexpr int kImg9Stride = 144;  // dwords per block image: 64 quant words | 8 sums of 32 | y.d | 7 unused | 64 x -32 * (sum of a word's quants)
 template <int MAXK> struct Img9 {
     int blk[(MAXK / 256 + 3) * kImg9Stride];   // >= (MAXK / 512 + 1) * kImg9bStride: the 32-block image fits too
-    double red[2][16];   // per-wave partial sums (second array: LayerNorm's second moment)
+    double red[2][MAXK / 256];   // per-BLOCK partial sums of the norm (second array: LayerNorm's second moment)
     unsigned cnt;        // arrivals of the waves that own blocks: only they meet for the norm's sums
 };
 // 32-element block types (Q8_0 / Q4_0 weights x Q8_0 activations): one image per record step (16 blocks = 512 activations):
@@ -373,8 +373,10 @@ DEV void pro9b_finish(Img9<MAXK>& L, Pro9b<MAXK>& P, const float* __restrict__ n
 // ---- prologue -----------------------------------------------------------------------------------------------------------------
 // 16 lanes per 256-block (lane `sub` owns the 16 consecutive activations 16 sub .. 16 sub + 15), a wave = 4 blocks, the workgroup =
 // 64 blocks per round: K <= 16384 is ONE round.  What every workgroup of a launch recomputes is issue-bound, so it is written for
-// instruction count: the block-scalar work (amax tree, first-maximum, the two divisions) is shared by four blocks per wave, packed
-// f32 multiplies, the quant byte is the low byte of the magic-number sum (clamped as a float), sums of 16 by dot4.
+// instruction count: the block-scalar work (largest / smallest value, the two divisions) is shared by four blocks per wave, packed
+// f32 multiplies, the quant byte is the low byte of the magic-number sum (clamped as a float), sums of 16 by dot4.  Measured in
+// round 4 (profiles/r04_decode_ablations.txt): ending the prologue 400 cycles earlier moves no launch time — it runs under the
+// latency of the launch's first weight records; what it must not do is delay the REQUESTS (pro9_load, the barrier in the kernel).
 template <int MAXK, bool EW, int NW = 16> struct Pro9 {
     static constexpr int ROUNDS = MAXK / 256 / (4 * NW);   // NW waves x 4 blocks per round
     // the norm weights travel with the activations (requested later they would queue behind the weight stream: 3000 cycles) —
@@ -412,6 +414,35 @@ DEV void pro9_load(Pro9<MAXK, EW, NW>& P, const float* __restrict__ x, const flo
 
 DEV double row16_sum(double v) { v += lane_xor1(v); v += lane_xor2(v); v += lane_xor4(v); v += lane_xor8(v); return v; }
 
+// The norm's sum over the whole vector from per-lane partials `sr[rd]` of block RB * rd + 4 * wv + (lane >> 4) (zero for a block past
+// the row's end).  Every 16-lane row reduces ITS block (four DPP steps, no cross-row traffic), one lane per row parks the block's sum,
+// the waves that own blocks meet at the arrival counter, then lane `sub` of every row takes the blocks sub, sub + 16, ... and the row
+// reduces again: every lane holds the total.  (Round 3's form — a 64-lane reduce through two ds_bpermute rounds, one slot per wave,
+// a serial loop of dependent LDS reads over the live waves — took 1600 cycles from "activations arrived" to "scale known".)  The sums
+// are order-free (squares / values of floats accumulated in double stay exact), so the grouping is free.
+template <int MAXK, int NW, int ROUNDS>
+DEV double pro9_total(double* red, unsigned* cnt, unsigned target, const double (&sr)[ROUNDS], int nimg, int wv, int lane) {
+    constexpr int RB = 4 * NW;
+    const int sub = lane & 15;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        if (RB * rd + 4 * wv < nimg) {
+            const double r = row16_sum(sr[rd]);
+            if (sub == 0) red[RB * rd + 4 * wv + (lane >> 4)] = r;
+        }
+    }
+    lds_signal(cnt, lane, 1u);
+    lds_wait_ge(cnt, target);
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXK / 256 / 16; ++j) {
+        const int b = sub + 16 * j;
+        const double v = red[b < nimg ? b : 0];
+        t += b < nimg ? v : 0.0;
+    }
+    return row16_sum(t);
+}
+
 // Part 2: (RMSNorm | LayerNorm | nothing) -> Q8_K image in LDS.  Reference k_quants.c:1191-1226 with the build's fused
 // `iscale * x + 12582912.f`, RMSNorm ggml.c:10700-10716, LayerNorm ggml.c:10605-10654 (arithmetic of generation 7's prologue; the
 // double-precision sums are order-free).  Ends with a workgroup barrier.  `emb_out` (workgroup 0 only): the
@@ -431,9 +462,10 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
     const bool pow2 = (K & (K - 1)) == 0;
     const double inv_k = 1.0 / (double)K;   // exact for a power of two: tot * inv_k == tot / K bit for bit
     if (pro == PRO_RMSNORM && wave_live) {
-        double s = 0.0;
+        double sq[ROUNDS];
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
+            sq[rd] = 0.0;
             if (RB * rd + 4 * wv < nimg) {
                 double sr = 0.0;
 #pragma unroll
@@ -441,25 +473,21 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
                     const float4 q = P.x[rd][k];
                     sr += (double)(q.x * q.x); sr += (double)(q.y * q.y); sr += (double)(q.z * q.z); sr += (double)(q.w * q.w);
                 }
-                s += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                sq[rd] = (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
             }
         }
         V9_STAMP(trace, ts[0]);   // the activations have arrived (their squares are summed)
-        s = wave_sum_fast(s);
-        if (lane == 0) L.red[0][wv] = s;
-        lds_signal(&L.cnt, lane, 1u);
-        lds_wait_ge(&L.cnt, n_live);
-        double tot = 0.0;
-        for (unsigned w = 0; w < n_live; ++w) tot += L.red[0][w];
+        const double tot = pro9_total<MAXK, NW, ROUNDS>(L.red[0], &L.cnt, n_live, sq, nimg, wv, lane);
         const float mean = (float)(pow2 ? tot * inv_k : tot / (double)K);
         scale = 1.0f / sqrtf(mean + eps);
         V9_STAMP(trace, ts[1]);   // the norm's scale is known
     }
     if constexpr (LN) {
         if (pro == PRO_LAYERNORM && wave_live) {
-            double s1 = 0.0;
+            double m1[ROUNDS];
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd) {
+                m1[rd] = 0.0;
                 if (RB * rd + 4 * wv < nimg) {
                     double sr = 0.0;
 #pragma unroll
@@ -467,19 +495,15 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
                         const float4 q = P.x[rd][k];
                         sr += (double)q.x; sr += (double)q.y; sr += (double)q.z; sr += (double)q.w;
                     }
-                    s1 += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                    m1[rd] = (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
                 }
             }
-            s1 = wave_sum_fast(s1);
-            if (lane == 0) L.red[0][wv] = s1;
-            lds_signal(&L.cnt, lane, 1u);
-            lds_wait_ge(&L.cnt, n_live);
-            double tot = 0.0;
-            for (unsigned w = 0; w < n_live; ++w) tot += L.red[0][w];
+            const double tot = pro9_total<MAXK, NW, ROUNDS>(L.red[0], &L.cnt, n_live, m1, nimg, wv, lane);
             const float mean = (float)(pow2 ? tot * inv_k : tot / (double)K);
-            double s2 = 0.0;
+            double m2[ROUNDS];
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd) {
+                m2[rd] = 0.0;
                 if (RB * rd + 4 * wv < nimg) {
                     double sr = 0.0;
 #pragma unroll
@@ -488,15 +512,10 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
                         q.x -= mean; q.y -= mean; q.z -= mean; q.w -= mean;
                         sr += (double)(q.x * q.x); sr += (double)(q.y * q.y); sr += (double)(q.z * q.z); sr += (double)(q.w * q.w);
                     }
-                    s2 += (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
+                    m2[rd] = (RB * rd + 4 * wv + (lane >> 4) < nblk) ? sr : 0.0;
                 }
             }
-            s2 = wave_sum_fast(s2);
-            if (lane == 0) L.red[1][wv] = s2;
-            lds_signal(&L.cnt, lane, 1u);
-            lds_wait_ge(&L.cnt, 2u * n_live);
-            double tot2 = 0.0;
-            for (unsigned w = 0; w < n_live; ++w) tot2 += L.red[1][w];
+            const double tot2 = pro9_total<MAXK, NW, ROUNDS>(L.red[1], &L.cnt, 2u * n_live, m2, nimg, wv, lane);
             const float variance = (float)(pow2 ? tot2 * inv_k : tot2 / (double)K);
             scale = 1.0f / sqrtf(variance + eps);
         }
@@ -528,27 +547,37 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
                 }
                 t[4 * k] = live ? q.x : 0.0f; t[4 * k + 1] = live ? q.y : 0.0f; t[4 * k + 2] = live ? q.z : 0.0f; t[4 * k + 3] = live ? q.w : 0.0f;
             }
-            float am = fabsf(t[0]);
+            // amax and the element that attains it first (k_quants.c:1198-1204: `if (ax > amax) { amax = ax; max = x[j]; }` — the FIRST
+            // element of largest magnitude keeps its sign).  Largest and smallest SIGNED value of the block instead of the largest
+            // magnitude + a search for its first position: amax = max(hi, -lo), and unless hi == -lo (both +amax and -amax occur: then the
+            // order decides, the wave takes the search below — in practice never) the sign follows from which of the two it is.
+            float hi = fmaxf(fmaxf(t[0], t[1]), t[2]), lo = fminf(fminf(t[0], t[1]), t[2]);
 #pragma unroll
-            for (int e = 1; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+            for (int e = 3; e < 15; e += 2) { hi = fmaxf(fmaxf(hi, t[e]), t[e + 1]); lo = fminf(fminf(lo, t[e]), t[e + 1]); }
+            hi = fmaxf(hi, t[15]); lo = fminf(lo, t[15]);
 #ifdef V9_PROTRACE
-            if (trace && rd == 0 && pro == PRO_PLAIN) { reg_fence(am, t[0], t[1], t[2]); ts[0] = clock64_dev(); }   // the activations have arrived
+            if (trace && rd == 0 && pro == PRO_PLAIN) { reg_fence(hi, t[0], t[1], t[2]); ts[0] = clock64_dev(); }   // the activations have arrived
 #endif
-            float amax = am;
-            amax = fmaxf(amax, lane_xor1(amax));
-            amax = fmaxf(amax, lane_xor2(amax));
-            amax = fmaxf(amax, lane_xor4(amax));
-            amax = fmaxf(amax, lane_xor8(amax));
-            // the first element (lowest index) attaining amax keeps its sign: first lane of the row with a hit, first hit in it
-            const unsigned long long hit = __ballot(am == amax);
-            const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
-            const int first = __ffsll((unsigned long long)row_bits) - 1;
-            float mine = 0.0f;
+            hi = fmaxf(hi, lane_xor1(hi)); lo = fminf(lo, lane_xor1(lo));
+            hi = fmaxf(hi, lane_xor2(hi)); lo = fminf(lo, lane_xor2(lo));
+            hi = fmaxf(hi, lane_xor4(hi)); lo = fminf(lo, lane_xor4(lo));
+            hi = fmaxf(hi, lane_xor8(hi)); lo = fminf(lo, lane_xor8(lo));
+            const float amax = fmaxf(hi, -lo);
+            float maxv = hi == amax ? hi : lo;
+            if (__ballot(hi == -lo && amax != 0.0f) != 0ull) {   // a block holds +amax and -amax: the first of them, by position
+                float am = fabsf(t[0]);
 #pragma unroll
-            for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
-            uint32_t mb = sub == first ? f32_to_bits(mine) : 0u;
-            mb |= lane_xor1(mb); mb |= lane_xor2(mb); mb |= lane_xor4(mb); mb |= lane_xor8(mb);
-            const float maxv = bits_to_f32(mb);
+                for (int e = 1; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+                const unsigned long long hit = __ballot(am == amax);
+                const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
+                const int first = __ffsll((unsigned long long)row_bits) - 1;
+                float mine = 0.0f;
+#pragma unroll
+                for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
+                uint32_t mb = sub == first ? f32_to_bits(mine) : 0u;
+                mb |= lane_xor1(mb); mb |= lane_xor2(mb); mb |= lane_xor4(mb); mb |= lane_xor8(mb);
+                maxv = bits_to_f32(mb);
+            }
             const bool nz = amax != 0.0f;
             const float iscale = nz ? -128.f / maxv : 0.0f;
             const float d = nz ? 1.0f / iscale : 0.0f;

@@ -109,6 +109,28 @@ def test_fuzz_blocks_cover_the_field_ranges():
     assert (synth.fuzz_blocks(4096, G.Q8_0, 0.05, rng)[:, 2:].view(np.int8) == -128).any()
 
 
+def _write_tie_model(p, shape, seed):
+    """Activation blocks in which +amax AND -amax occur: the Q8_K quantizer keeps the sign of the FIRST element of largest magnitude
+    (k_quants.c:1198-1204), so the order inside a block decides `iscale`.  Embedding rows of {+-1, +-0.5, +-0.25} in F32 behind norm
+    gains of exactly 1: every 256-block of layer 0's normalised input holds both signs of its maximum, the first one at random."""
+    hp0 = dict(synth.LLAMA_SHAPES[shape])
+    rng = np.random.default_rng(seed)
+    E, V = hp0["n_embd"], hp0["n_vocab"]
+    emb = rng.choice(np.array([1.0, -1.0, 0.5, -0.5, 0.25, -0.25], dtype=np.float32), size=(V, E))
+    emb[:, 0::256] = np.where(rng.random((V, (E + 255) // 256)) < 0.5, 1.0, -1.0)   # the block's first element already is +-amax ...
+    emb[:, 7::256] = -emb[:, 0::256]                                               # ... and its negative follows
+    ones = np.ones(E, dtype=np.float32)
+    return synth.write_llama_gguf(p, shape, "Q4_K_M", seed=seed, type_overrides={"token_embd.weight": G.F32},
+                                  tensor_data={"token_embd.weight": emb, "blk.0.attn_norm.weight": ones, "blk.0.ffn_norm.weight": ones})
+
+
+@pytest.mark.parametrize("shape", ["llama-tiny", "llama-small"])
+def test_emulator_build_first_of_two_opposite_maxima(ref, emu_lib, tmp_path, monkeypatch, shape):
+    p = str(tmp_path / "m.gguf")
+    hp = _write_tie_model(p, shape, seed=3)
+    _compare(ref, emu_lib, p, hp, n_prompt=13, n_decode=3, threads=2, monkeypatch=monkeypatch)
+
+
 # ---- GPU: the HIP library at the real widths ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,ftype,quantizer,n_prompt,n_decode", [
@@ -136,4 +158,13 @@ def test_hip_build_on_reference_quantized_and_arbitrary_blocks(ref, tmp_path, mo
         sc, d = _q6k_signs(p)
         assert sc > 0.9 and 0.2 < d < 0.8, (sc, d)
     _compare(ref, None, p, hp, n_prompt, n_decode, threads=16, monkeypatch=monkeypatch)
+    os.remove(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["llama-7b-2l", "llama-70b-2l"])
+def test_hip_build_first_of_two_opposite_maxima(ref, tmp_path, monkeypatch, shape):
+    p = str(tmp_path / "m.gguf")
+    hp = _write_tie_model(p, shape, seed=5)
+    _compare(ref, None, p, hp, 20, 8, threads=16, monkeypatch=monkeypatch)
     os.remove(p)

@@ -462,8 +462,9 @@ def make_spm_vocab(n_vocab=512):
 
 
 def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_train=4096, pooled=None,
-                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None, type_overrides=None, quantizer=None):
+                     rope_freq_base=None, rms_eps=1e-5, overrides=None, vocab=None, type_overrides=None, quantizer=None, tensor_data=None):
     """Write a synthetic llama-architecture GGUF v2 file.  Returns the hparams dict.
+    tensor_data: {tensor name: float32 array} — these tensors hold the given values (quantized to the tensor's type) instead of random ones.
     type_overrides: {tensor name or dotted name suffix: ggml type} applied on top of the ftype's mix (e.g. {"attn_v.weight": G.Q8_0};
     "output.weight" names the head only, not blk.N.attn_output.weight).  quantizer: see `quantize`."""
     hp = dict(LLAMA_SHAPES[shape]) if isinstance(shape, str) else dict(shape)
@@ -504,12 +505,22 @@ def write_llama_gguf(path, shape="llama-2-7b", ftype="Q4_K_M", seed=1234, n_ctx_
     w.add_u32("tokenizer.ggml.eos_token_id", 2)
     w.add_u32("tokenizer.ggml.unknown_token_id", 0)
 
+    given = tensor_data or {}
+
     def mat(name, rows, K, sigma):
         t = types[name]
-        w.add_tensor(name, (K, rows), t, lambda: src.matrix(rows, K, t, sigma))
+        if name in given:
+            x = np.ascontiguousarray(given[name], dtype=np.float32).reshape(rows, K)
+            w.add_tensor(name, (K, rows), t, lambda: quantize(x, t, quantizer).reshape(-1))
+        else:
+            w.add_tensor(name, (K, rows), t, lambda: src.matrix(rows, K, t, sigma))
 
     def vec(name, n):
-        w.add_tensor(name, (n,), G.F32, lambda: src.norm(n).view(np.uint8))
+        if name in given:
+            v = np.ascontiguousarray(given[name], dtype=np.float32).reshape(n)
+            w.add_tensor(name, (n,), G.F32, lambda: v.view(np.uint8))
+        else:
+            w.add_tensor(name, (n,), G.F32, lambda: src.norm(n).view(np.uint8))
 
     s_e = 1.0 / np.sqrt(n_embd)
     s_f = 1.0 / np.sqrt(n_ff)
