@@ -738,7 +738,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             } else
 #endif
 #if defined(V9_EXP) && V9_EXP == 3   // experiment: the slot's next record is requested BEFORE the block math (the math runs on a copy)
-            if constexpr (decltype(REQ)::value) {
+            if constexpr (decltype(REQ)::value && TYPE == GT_Q4_K && !TWO) {   // (the other instantiations spill with the copy)
                 Rec9<TYPE> cur = R;
                 issue(R, G);
                 step9<TYPE>(cur, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
@@ -746,7 +746,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 #endif
             step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
 #if defined(V9_EXP) && V9_EXP == 3
-            if constexpr (false) {
+            if constexpr (decltype(REQ)::value && !(TYPE == GT_Q4_K && !TWO)) {
 #else
             if constexpr (decltype(REQ)::value) {
 #endif
