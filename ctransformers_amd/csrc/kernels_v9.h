@@ -5,7 +5,7 @@
 // hand the chain operands to the lanes that replay the reference's f32 chain, and a prologue that 4 of 16 waves computed for all
 // 256 workgroups (profiles/r02_v7_*: 133 VALU instructions per 1152-byte record, a third of every launch spent before the first
 // block math).  Generation 9 keeps the work decomposition — a wave owns a PAIR OF ROWS from its first byte to its epilogue, a step
-// is one record of 2 rows x 4 consecutive K-blocks, a 4-deep register ring of records per wave — and changes what a lane does:
+// is one record of 2 rows x 4 consecutive K-blocks, a register ring of three or four records per wave (matvec_v9_kernel) — and changes what a lane does:
 //   * layout LAYOUT_L9 (quant.h): lane (row, l, c) = 32 * row + 4 * l + c of a step holds, in ONE 16-byte load, the four dwords
 //     that AVX lane l of the reference touches in block 4 * s + c of its row (all eight 32-element vectors, four elements each).
 //     It computes the block's complete integer lane sum sumi[l] locally — 8 x dot4 against the Q8_K image, 8 scale multiplies —
@@ -655,7 +655,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 #ifndef V9_PRE
 #define V9_PRE ((TYPE == GT_Q6_K || B32) ? 2 : 3)   // measured on the 7B: 1 -> 687, 2 -> 715, 3 -> 737, 4 -> 730 tok/s
 #endif
-    constexpr int PRE = V9_PRE;
+    constexpr int PRE = (V9_PRE) < NS ? (V9_PRE) : NS;
     if (nu == 0) {   // its own copy of the prologue: the path with requests below stays free of conditional loads
         unsigned long long ts0[4];
         pro(false, ts0);
@@ -833,7 +833,8 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 }
 
 // TA / TB: weight types of the two job groups (TB == 0: one group).  Dynamic LDS: sizeof(SmemV9<MAXK>).
-// NW waves per workgroup, NS ring slots per wave: (16, 4) is what the host launches.  Measured in round 4 (profiles/r04_*): NS = 6 / 8 at
+// NW waves per workgroup, NS ring slots per wave: the host launches (16, 3) for single-type K-quant launches and (16, 4) otherwise
+// (engine.cc:launch_matvec_kq has the measurement).  Measured in round 4 (profiles/r04_*): NS = 6 / 8 at
 // sixteen waves spill; (8, 11 | 8 | 7) — eight waves with 256 registers and a whole unit in flight, for launches in which a wave owns
 // one unit of many records (ffn_down) — streams SLOWER (10.8 against 8.8 us per launch): a CU with eight streaming waves is served at
 // about 8.6 B/cycle whatever they have in flight, with sixteen at 10.7, with no block math at 12.
@@ -876,10 +877,10 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
         pro9_finish<MAXK, LN, EMB, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K, NW>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out, wv, lane, trc, ts);
     };
     if constexpr (TB != 0) {
-        static_assert(NW == 16 && NS == 4, "two-type launches: the 16-wave form");
+        static_assert(NW == 16, "two-type launches: the 16-wave form");
         const int nwA = a.nwA;
-        if (wv < nwA) v9_run<TA, MAXK, true, 4>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
-        else v9_run<TB, MAXK, true, 4>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, pro);
+        if (wv < nwA) v9_run<TA, MAXK, true, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
+        else v9_run<TB, MAXK, true, NS>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, pro);
     } else {
         v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * NW, a.n_pairs, lane, wv, pro);
     }
