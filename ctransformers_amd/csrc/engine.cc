@@ -181,7 +181,8 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         if (tb != 0 && a.K > 16384) { err = "mixed-type launch with K > 16384"; return false; }
         // Ring slots per wave (records in flight): THREE for the single-type K-quant launches, four for the two-type (QKV) launch and the
         // 32-block types.  Measured late in round 4 (profiles/r04_decode_ablations.txt, alternating on one box, three boxes): 2 -> 736,
-        // 3 -> 746-750, 4 -> 740-744 tok/s, 5 (125 registers, no spills) -> 728-734; the two-type launch with three: 742-745 against 747-750.
+        // 3 -> 746-750, 4 -> 740-744 tok/s, 5 (125 registers, no spills) -> 728-734; the two-type launch with three: 742-745 against 747-750;
+        // Q8_0 (config 3) with three: 535 against 539.
         // More requests in flight per wave lengthen a launch on this memory system; gate+up gains most (11.9 -> 11.2 us).
 #ifndef V9_NS_K
 #define V9_NS_K 3
@@ -189,8 +190,11 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
 #ifndef V9_NS_K2
 #define V9_NS_K2 4
 #endif
+#ifndef V9_NS_B
+#define V9_NS_B 4
+#endif
 #define V9L(MK, TAV, TBV, LNV, EMBV) do { \
-        auto kfn = matvec_v9_kernel<MK, TAV, TBV, LNV, EMBV, 16, ((TAV == GT_Q4_K || TAV == GT_Q5_K || TAV == GT_Q6_K) ? (TBV == 0 ? V9_NS_K : V9_NS_K2) : 4)>; \
+        auto kfn = matvec_v9_kernel<MK, TAV, TBV, LNV, EMBV, 16, ((TAV == GT_Q4_K || TAV == GT_Q5_K || TAV == GT_Q6_K) ? (TBV == 0 ? V9_NS_K : V9_NS_K2) : V9_NS_B)>; \
         constexpr size_t smem = sizeof(SmemV9<MK>); \
         CT_OPTIN_ONCE(kfn, smem); \
         CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)

@@ -862,8 +862,8 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
         auto pro = [&](bool, unsigned long long (&)[4]) __attribute__((always_inline)) {
             pro9b_finish<MAXK, TA == GT_Q4_0, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
         };
-        static_assert(NW == 16 && NS == 4, "32-block types: the 16-wave form");
-        v9_run<TA, MAXK, false, 4>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
+        static_assert(NW == 16, "32-block types: the 16-wave form");
+        v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
         if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
         if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; }
         return;
