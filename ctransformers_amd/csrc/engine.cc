@@ -534,13 +534,15 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     for (int j = 0; j < m.njobs; ++j) (m.job[j].w.type == GT_Q6_K ? has6 : has45) = true;
     uint8_t* img45 = has45 ? acts_h_ : nullptr;
     uint8_t* img6 = has6 ? acts_h_ + acts_h_half_ : nullptr;
-    const dim3 qg((unsigned)nt), qb(1024);
+    static const int pgq_remap = env_int("CT_AMD_PGQ_REMAP", 1);
+    const int qn = pgq_remap ? nt : -1;
+    const dim3 qg((unsigned)(pgq_remap ? 8 * ((nt + 7) / 8) : nt)), qb(1024);
     if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
-        if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b);
-        else CT_LAUNCH((pg_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b);
-    } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
-    else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
-    else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr);
+        if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b, qn);
+        else CT_LAUNCH((pg_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b, qn);
+    } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
+    else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
+    else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
     constexpr int NW = kPgWaves;
     for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
         PgArgs a;

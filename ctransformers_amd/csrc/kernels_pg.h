@@ -59,9 +59,18 @@ struct PgArgs {
 template <int MAXK, bool LN>
 __global__ void __launch_bounds__(1024) pg_quantize_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
                                                            int pro, float eps, uint8_t* __restrict__ img45, uint8_t* __restrict__ img6,
-                                                           int tg, const float* __restrict__ nb_) {
+                                                           int tg, const float* __restrict__ nb_, int n_tok) {
     __shared__ ActLdsX<MAXK> L;
-    const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
+    // Workgroup -> token: the eight tokens whose 16-byte pieces fill one 128-byte line of a stage image go to workgroups on ONE XCD
+    // (linear ids equal mod 8 when the chunk has 16 lines of tokens), so that its L2 writes the line back whole instead of eight
+    // XCDs writing 16 bytes each.  grid = 8 * ceil(n_tok / 8); n_tok < 0: the identity (A/B switch CT_AMD_PGQ_REMAP=0).
+    int t = (int)blockIdx.x;
+    if (n_tok >= 0) {
+        const int G = (int)gridDim.x >> 3;
+        t = (t % G) * 8 + t / G;
+        if (t >= n_tok) return;
+    }
+    const int tid = (int)threadIdx.x;
     if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);
     else prologue_q8k_exact16<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
     const int nb = K >> 8, g = t / tg, tt = t - g * tg;
