@@ -562,7 +562,7 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
     // (wave-uniform branches), not run it predicated off — the prologue is VALU-issue bound (about 250 wave
     // instructions), and for K = 4096 only 4 of the 16 waves (one per SIMD) are live.
     const bool wave_live = uniform_int(wv * 4) < nblk;
-    float4 v[ROUNDS][4];
+    float4 v[ROUNDS][4], nwv[ROUNDS][4];   // the norm weights travel with the activations: requested behind the sums they cost a second memory latency
     double s = 0.0;
     if (wave_live) {
 #pragma unroll
@@ -570,8 +570,13 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
             const int b = grp + rd * NG;
             if (b < nblk) {
 #pragma unroll
+                for (int k = 0; k < 4; ++k) v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
+                if (pro == PRO_RMSNORM) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nwv[rd][k] = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[rd][k] = *(const float4*)(x + b * 256 + sub * 16 + k * 4);
                     if (pro == PRO_RMSNORM) {
                         s += (double)(v[rd][k].x * v[rd][k].x);
                         s += (double)(v[rd][k].y * v[rd][k].y);
@@ -592,8 +597,11 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
         }
         __syncthreads();
         if (wave_live) {
-            double tot = 0.0;
-            for (int w = 0; w < NW; ++w) tot += L.red[w];
+            // sixteen per-wave partials: lane `sub` of every 16-lane row takes one, the row reduces (a serial loop of dependent LDS reads
+            // cost a microsecond here); the sum is order-free
+            static_assert(NW == 16, "one partial per lane of a 16-lane row");
+            double tot = L.red[sub];
+            tot += lane_xor1(tot); tot += lane_xor2(tot); tot += lane_xor4(tot); tot += lane_xor8(tot);
             const float mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + eps);
         }
@@ -608,7 +616,7 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
             for (int k = 0; k < 4; ++k) {
                 float4 q = live ? v[rd][k] : float4{0.f, 0.f, 0.f, 0.f};
                 if (live && pro == PRO_RMSNORM) {
-                    const float4 w4 = *(const float4*)(nw + b * 256 + sub * 16 + k * 4);
+                    const float4 w4 = nwv[rd][k];
                     q.x = (q.x * scale) * w4.x;
                     q.y = (q.y * scale) * w4.y;
                     q.z = (q.z * scale) * w4.z;
@@ -616,34 +624,43 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
                 }
                 t[4 * k] = q.x; t[4 * k + 1] = q.y; t[4 * k + 2] = q.z; t[4 * k + 3] = q.w;
             }
-            float am = 0.0f;
+            // largest / smallest signed value instead of a search for the first element of largest magnitude; the search only where a block
+            // holds +amax and -amax (kernels_v9.h:pro9_finish has the argument)
+            float hi = fmaxf(fmaxf(t[0], t[1]), t[2]), lo = fminf(fminf(t[0], t[1]), t[2]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
-            float amax = am;
-            amax = fmaxf(amax, lane_xor1(amax));
-            amax = fmaxf(amax, lane_xor2(amax));
-            amax = fmaxf(amax, lane_xor4(amax));
-            amax = fmaxf(amax, lane_xor8(amax));
-            // first element (lowest index) attaining amax keeps its sign
-            const unsigned long long hit = __ballot(am == amax);
-            const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
-            const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
-            float mine = 0.0f;
+            for (int e = 3; e < 15; e += 2) { hi = fmaxf(fmaxf(hi, t[e]), t[e + 1]); lo = fminf(fminf(lo, t[e]), t[e + 1]); }
+            hi = fmaxf(hi, t[15]); lo = fminf(lo, t[15]);
+            hi = fmaxf(hi, lane_xor1(hi)); lo = fminf(lo, lane_xor1(lo));
+            hi = fmaxf(hi, lane_xor2(hi)); lo = fminf(lo, lane_xor2(lo));
+            hi = fmaxf(hi, lane_xor4(hi)); lo = fminf(lo, lane_xor4(lo));
+            hi = fmaxf(hi, lane_xor8(hi)); lo = fminf(lo, lane_xor8(lo));
+            const float amax = fmaxf(hi, -lo);
+            float maxv = hi == amax ? hi : lo;
+            if (__ballot(hi == -lo && amax != 0.0f) != 0ull) {   // the first element (lowest index) attaining amax keeps its sign
+                float am = 0.0f;
 #pragma unroll
-            for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
-            const float maxv = __shfl(mine, first);
-            int packed[4] = {0, 0, 0, 0}, s16 = 0;
-            float d = 0.0f;
-            if (amax != 0.0f) {
-                const float iscale = -128.f / maxv;
+                for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(t[e]));
+                const unsigned long long hit = __ballot(am == amax);
+                const unsigned row_bits = (unsigned)((hit >> (lane & 48)) & 0xFFFFu);
+                const int first = (lane & 48) + (__ffsll((unsigned long long)row_bits) - 1);
+                float mine = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int q = ((int)f32_to_bits(fmaf(iscale, t[e], 12582912.f)) & 0x007fffff) - 0x00400000;
-                    q = q > 127 ? 127 : q;
-                    packed[e >> 2] |= (q & 0xff) << (8 * (e & 3));
-                    s16 += q;
-                }
-                d = 1.0f / iscale;
+                for (int e = 15; e >= 0; --e) mine = (fabsf(t[e]) == amax) ? t[e] : mine;
+                maxv = __shfl(mine, first);
+            }
+            // nearest_int(iscale * x) = bits(fma(iscale, x, 1.5 * 2^23)) - bits(1.5 * 2^23): the sum stays in the binade of ulp 1, so the quant is
+            // its low byte and MIN(127, .) is a float minimum against 1.5 * 2^23 + 127 (the decode prologue's form)
+            const bool nz = amax != 0.0f;
+            const float iscale = nz ? -128.f / maxv : 0.0f;
+            const float d = nz ? 1.0f / iscale : 0.0f;
+            int packed[4], s16 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t by[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) by[e] = f32_to_bits(fminf(fmaf(iscale, t[4 * k + e], 12582912.f), 12583039.f));
+                packed[k] = (int)pack_low_bytes(by[0], by[1], by[2], by[3]);
+                s16 = sdot4(packed[k], 0x01010101, s16);
             }
             const int s32 = s16 + lane_xor1(s16);
             if (live) {
