@@ -519,17 +519,24 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
 // One mat-vec site of a prompt chunk on the f16 matrix cores (kernels_pg.h): stage images of the nt activation rows in the
 // layout(s) the site's weight types read, then one launch per weight type over the LAYOUT_R2C4 records of the decode path.
 bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err) {
-    // Tokens per workgroup: 32 amortise the weight unpack over two matrix products — unless the site then has fewer workgroups than
-    // the chip has CUs (Wo, ffn_down of a 7B: 32 x 4): 16-token groups double the workgroups and every CU gets one.
-    int tg = nt > 16 ? 32 : 16;
-    if (tg == 32) {
-        int items = 0;
-        for (int j = 0; j < m.njobs; ++j) items += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;
-        if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus() * (8 / kPgWaves)) tg = 16;
+    // Tokens per workgroup: 32 amortise the weight unpack over two matrix products — unless the launch then has fewer workgroups than
+    // the chip has CUs (Wo, ffn_down of a 7B: 32 x 4; the Q6_K attn_v beside Q4_K q / k): 16-token groups double the workgroups and every
+    // CU gets one.  The two image layouts (Q4_K / Q5_K launches, Q6_K launch) choose separately: their launches are separate.
+    auto tg_of = [&](bool q6) {
+        int tg = nt > 16 ? 32 : 16;
+        if (tg == 32) {
+            int items = 0;
+            for (int j = 0; j < m.njobs; ++j)
+                if ((m.job[j].w.type == GT_Q6_K) == q6) items += m.gateup ? (m.job[j].w.M + 7) / 8 : (m.job[j].w.M + 15) / 16;
+            if (((items + kPgWaves - 1) / kPgWaves) * ((nt + 31) / 32) < chip_cus() * (8 / kPgWaves)) tg = 16;
+        }
+        if (pg_force_tg_ == 16 || pg_force_tg_ == 32) tg = pg_force_tg_;
+        return tg;
+    };
+    const int tg45 = tg_of(false), tg6 = tg_of(true), nb = m.K / 256;
+    if ((size_t)((nt + tg45 - 1) / tg45) * nb * pg_stage_bytes(tg45) > acts_h_half_ || (size_t)((nt + tg6 - 1) / tg6) * nb * pg_stage_bytes(tg6) > acts_h_half_) {
+        err = "stage images exceed their buffer"; return false;
     }
-    if (pg_force_tg_ == 16 || pg_force_tg_ == 32) tg = pg_force_tg_;
-    const int groups = (nt + tg - 1) / tg, nb = m.K / 256;
-    if ((size_t)groups * nb * pg_stage_bytes(tg) > acts_h_half_) { err = "stage images exceed their buffer"; return false; }
     bool has45 = false, has6 = false;
     for (int j = 0; j < m.njobs; ++j) (m.job[j].w.type == GT_Q6_K ? has6 : has45) = true;
     uint8_t* img45 = has45 ? acts_h_ : nullptr;
@@ -538,16 +545,17 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     const int qn = pgq_remap ? nt : -1;
     const dim3 qg((unsigned)(pgq_remap ? 8 * ((nt + 7) / 8) : nt)), qb(1024);
     if (m.pro == PRO_LAYERNORM) {   // falcon: n_embd-long inputs only
-        if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b, qn);
-        else CT_LAUNCH((pg_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, m.norm_b, qn);
-    } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
-    else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
-    else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg, (const float*)nullptr, qn);
+        if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg45, tg6, m.norm_b, qn);
+        else CT_LAUNCH((pg_quantize_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg45, tg6, m.norm_b, qn);
+    } else if (m.K <= 4096) CT_LAUNCH((pg_quantize_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg45, tg6, (const float*)nullptr, qn);
+    else if (m.K <= 12288) CT_LAUNCH((pg_quantize_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg45, tg6, (const float*)nullptr, qn);
+    else CT_LAUNCH((pg_quantize_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, img45, img6, tg45, tg6, (const float*)nullptr, qn);
     constexpr int NW = kPgWaves;
     for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K}) {
         PgArgs a;
         a.m = m;
         a.acts = ty == GT_Q6_K ? img6 : img45;
+        const int tg = ty == GT_Q6_K ? tg6 : tg45, groups = (nt + tg - 1) / tg;
         a.n_tok = nt; a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
         int nj = 0, item0 = 0;
         for (int j = 0; j < m.njobs; ++j) {

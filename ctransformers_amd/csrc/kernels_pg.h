@@ -59,11 +59,12 @@ struct PgArgs {
 template <int MAXK, bool LN>
 __global__ void __launch_bounds__(1024) pg_quantize_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, int K,
                                                            int pro, float eps, uint8_t* __restrict__ img45, uint8_t* __restrict__ img6,
-                                                           int tg, const float* __restrict__ nb_, int n_tok) {
+                                                           int tg45, int tg6, const float* __restrict__ nb_, int n_tok) {
     __shared__ ActLdsX<MAXK> L;
     // Workgroup -> token: the eight tokens whose 16-byte pieces fill one 128-byte line of a stage image go to workgroups on ONE XCD
     // (linear ids equal mod 8 when the chunk has 16 lines of tokens), so that its L2 writes the line back whole instead of eight
     // XCDs writing 16 bytes each.  grid = 8 * ceil(n_tok / 8); n_tok < 0: the identity (A/B switch CT_AMD_PGQ_REMAP=0).
+    // tg45 / tg6: tokens per group of the two image layouts (the launches of the two weight-type families choose their own: engine.cc).
     int t = (int)blockIdx.x;
     if (n_tok >= 0) {
         const int G = (int)gridDim.x >> 3;
@@ -73,15 +74,17 @@ __global__ void __launch_bounds__(1024) pg_quantize_kernel(const float* __restri
     const int tid = (int)threadIdx.x;
     if constexpr (LN) prologue_q8k_exact16_ln<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps, nb_);
     else prologue_q8k_exact16<1024, MAXK>(L, x + (size_t)t * ldx, nw, K, pro, eps);
-    const int nb = K >> 8, g = t / tg, tt = t - g * tg;
-    const int sums = 512 * tg, sum_stride = 8 * tg + ((8 * tg) % 256 == 128 ? 0 : 128), yd_off = sums + 4 * sum_stride;
-    const size_t sbytes = (size_t)pg_stage_bytes(tg);
-    for (int i = tid; i < nb * 32; i += 1024) {
-        const int b = i >> 5, l = (i >> 2) & 7, p = i & 3;
+    const int nb = K >> 8;
 #pragma unroll
-        for (int lay = 0; lay < 2; ++lay) {
-            uint8_t* img = lay ? img6 : img45;
-            if (!img) continue;
+    for (int lay = 0; lay < 2; ++lay) {
+        uint8_t* img = lay ? img6 : img45;
+        if (!img) continue;
+        const int tg = lay ? tg6 : tg45;
+        const int g = t / tg, tt = t - g * tg;
+        const int sums = 512 * tg, sum_stride = 8 * tg + ((8 * tg) % 256 == 128 ? 0 : 128), yd_off = sums + 4 * sum_stride;
+        const size_t sbytes = (size_t)pg_stage_bytes(tg);
+        for (int i = tid; i < nb * 32; i += 1024) {
+            const int b = i >> 5, l = (i >> 2) & 7, p = i & 3;
             const int va = lay ? 4 * (p >> 1) + (p & 1) : 2 * p, vb = lay ? va + 2 : va + 1;
             const uint32_t wa = (uint32_t)L.q8[b * 64 + va * 8 + l], wb = (uint32_t)L.q8[b * 64 + vb * 8 + l];
             uint32_t o[4];
@@ -96,19 +99,16 @@ __global__ void __launch_bounds__(1024) pg_quantize_kernel(const float* __restri
             uint32_t* dst = (uint32_t*)(img + ((size_t)g * nb + b) * sbytes + (size_t)((l * 4 + p) * tg + tt) * 16);
             dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
         }
-    }
-    for (int i = tid; i < nb * 4; i += 1024) {
-        const int b = i >> 2, kg = i & 3;
-        if (img45) {
-            const uint32_t s0 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg]), s1 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 1]);
-            const uint32_t s2 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 2]), s3 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 3]);
-            uint32_t* dst = (uint32_t*)(img45 + ((size_t)g * nb + b) * sbytes + sums + kg * sum_stride + tt * 8);
-            dst[0] = s0 | (s1 << 16); dst[1] = s2 | (s3 << 16);
+        if (!lay) {   // the sums of 16 feed the min term: Q4_K / Q5_K images only
+            for (int i = tid; i < nb * 4; i += 1024) {
+                const int b = i >> 2, kg = i & 3;
+                const uint32_t s0 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg]), s1 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 1]);
+                const uint32_t s2 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 2]), s3 = f32_to_f16_bits((float)L.bsums[b * 16 + 4 * kg + 3]);
+                uint32_t* dst = (uint32_t*)(img + ((size_t)g * nb + b) * sbytes + sums + kg * sum_stride + tt * 8);
+                dst[0] = s0 | (s1 << 16); dst[1] = s2 | (s3 << 16);
+            }
         }
-    }
-    for (int b = tid; b < nb; b += 1024) {
-        if (img45) *(float*)(img45 + ((size_t)g * nb + b) * sbytes + yd_off + tt * 4) = L.yd[b];
-        if (img6) *(float*)(img6 + ((size_t)g * nb + b) * sbytes + yd_off + tt * 4) = L.yd[b];
+        for (int b = tid; b < nb; b += 1024) *(float*)(img + ((size_t)g * nb + b) * sbytes + yd_off + tt * 4) = L.yd[b];
     }
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# chunk quantize kernel: + the norm sum from 16 per-wave partials by one LDS read per lane and a row reduce (new) / round-3 prologue (old)
+# token-group size chosen per weight-type launch (the Q6_K attn_v launch beside Q4_K q / k takes 16-token groups: 256 workgroups instead of 128) (new) / per site (old)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r4R; mkdir -p $O
 M=/tmp/ctamd_llama2_7b_q4km_r2.gguf
@@ -9,7 +9,7 @@ for v in new old new old; do
 done
 cd /tmp
 CT_AMD_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o pf -- python $GRAFT_REPO_ROOT/tools/decode_loop.py --model $M --prompt 128 --decode 2 > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
-grep "pg_quantize" $(find $GRAFT_REPO_ROOT/$O/prof -name "*kernel_stats.csv" | head -1) | cut -c1-200 >> $GRAFT_REPO_ROOT/$O/kstats.txt
+grep "matmul_pg\|pg_quantize" $(find $GRAFT_REPO_ROOT/$O/prof -name "*kernel_stats.csv" | head -1) | cut -c1-200 >> $GRAFT_REPO_ROOT/$O/kstats.txt
 cd $GRAFT_REPO_ROOT; rm -rf $O/prof
 ( timeout 1500 python -m pytest tests/test_weight_population.py tests/test_gpu_parity.py -m gpu -x -q -k "not big_config and not eight_stages" 2>&1 | tail -3 ) > $O/pytest.txt
 cat $O/prefill.txt $O/kstats.txt $O/pytest.txt
