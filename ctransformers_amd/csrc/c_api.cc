@@ -146,7 +146,11 @@ int ctransformers_llm_sample(ctransformers_llm* llm, const int* last_tokens, int
     // logits whatever top_p / temperature / seed are (llama.cc:53-84: one candidate is left, llama_sample_token draws index 0): taken on
     // the GPU — unless the caller has fetched, and possibly edited, the logits since the eval (then the host chain below runs on them)
     int greedy = 0;
-    if (top_k <= 1 && (repetition_penalty == 1.0f || n_last <= 0) && llm->tail().greedy_token(greedy)) return greedy;
+    if (top_k <= 1 && (repetition_penalty == 1.0f || n_last <= 0) && llm->tail().greedy_token(greedy)) {
+        llm->tail().note_sample(true);   // a greedy chain: the engine may queue the next token step before it is asked for (engine.h)
+        return greedy;
+    }
+    llm->tail().note_sample(false);
     if (llm->engine().vocab().type == ctamd::VOCAB_GPT)
         return ctamd::sample_token_gpt(llm->tail().logits(), llm->engine().hparams().n_vocab, last_tokens, n_last, top_k, top_p,
                                        temperature, repetition_penalty, seed);
@@ -216,6 +220,7 @@ int ctamd_n_layer(ctransformers_llm* llm) { return llm->engine().hparams().n_lay
 int ctamd_n_embd(ctransformers_llm* llm) { return llm->engine().hparams().n_embd; }
 long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine().chunk_tokens(); }
 long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
+long long ctamd_qa_launches(ctransformers_llm* llm) { return llm->engine().qa_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {
@@ -230,6 +235,17 @@ double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals)
     return llm->pipe.issue_us(stage);
 }
 
+double ctamd_decode_burst(ctransformers_llm* llm, int n) {
+    std::string err;
+    double us = 0.0;
+    if (llm->pipe.n_stages() != 1 || !llm->engine().decode_burst(n, &us, err)) { fprintf(stderr, "ctransformers_amd: burst failed: %s\n", err.c_str()); return -1.0; }
+    return us;
+}
+long long ctamd_spec_hits(ctransformers_llm* llm, long long* launched) {
+    if (launched) *launched = llm->engine().spec_launched();
+    return llm->engine().spec_hits();
+}
+int ctamd_read_stamps(ctransformers_llm* llm, unsigned long long* out, int max) { return llm->engine().read_stamps(out, max); }
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine().weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
     std::string err;

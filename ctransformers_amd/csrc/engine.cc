@@ -14,6 +14,7 @@
 #include "gguf_reader.h"
 #include "kernels_v9.h"
 #include "kernels_attn9.h"
+#include "kernels_qa9.h"
 #include "kernels_q32.h"
 #include "kernels_pf.h"
 #include "kernels_pg.h"
@@ -47,11 +48,21 @@ void Engine::free_all() {
     h_logits_ = h_emb_ = nullptr;
     h_scalars_ = nullptr;
 #ifndef CT_EMU
+    if (stream_) (void)hipStreamSynchronize(stream_);   // a speculative continuation step may still be running
+    spec_inflight_ = false;
     if (graph_step_) (void)hipGraphExecDestroy(graph_step_);
     if (graph_step_head_) (void)hipGraphExecDestroy(graph_step_head_);
     graph_step_ = graph_step_head_ = nullptr;
-    for (auto& kv : chunk_graphs_) (void)hipGraphExecDestroy(kv.second);
+    for (int b = 0; b < 2; ++b) {
+        if (graph_cont_[b]) (void)hipGraphExecDestroy(graph_cont_[b]);
+        if (ev_step_[b]) (void)hipEventDestroy(ev_step_[b]);
+        graph_cont_[b] = nullptr;
+        ev_step_[b] = nullptr;
+    }
+    for (auto& kv : chunk_graphs_) (void)hipGraphExecDestroy(kv.second.exec);
     chunk_graphs_.clear();
+    for (hipGraphExec_t g : retired_graphs_) (void)hipGraphExecDestroy(g);
+    retired_graphs_.clear();
 #endif
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
@@ -115,13 +126,14 @@ static bool kq_can(const MatvecArgs& a) {
     return true;
 }
 
+static thread_local int g_last_kq_grid = 0;   // workgroups of the issuing thread's last generation-9 launch (Engine::launch_pick: key slots of the head launch)
 static long long g_kq_launches = 0;   // test hook (ctamd_kq_launches): K-quant decode mat-vec launches (kernels_v9.h) of this process
 long long kq_launches() { return g_kq_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
 long long pg_launches() { return g_pg_launches; }
 
-static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
-    ++g_kq_launches;
+// unit bookkeeping of a generation-9 launch: the jobs' units concatenated (type group A first), the groups' arenas, the wave split
+static bool kq_prepare(MatvecArgs& a, int& tb_out, std::string& err) {
     for (int j = 0; j < a.njobs; ++j) {
         if (!a.job[j].w.r9) { err = "mat-vec: K-quant matrix without a LAYOUT_L9 arena"; return false; }
     }
@@ -159,6 +171,15 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bytes_b / (bytes_a + bytes_b))));
         a.nwA = 16 - nwb;
     }
+    tb_out = tb;
+    return true;
+}
+
+static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
+    ++g_kq_launches;
+    int tb = 0;
+    if (!kq_prepare(a, tb, err)) return false;
+    const int ta = a.job[0].w.type, na = a.n_groupA;
     const bool ln = a.pro == PRO_LAYERNORM;
     if (ln && tb != 0) { err = "LayerNorm prologue with a mixed-type launch"; return false; }
     // one workgroup per CU; more only where a wave would otherwise own more than kV9MaxUnits units (its results wait in LDS
@@ -169,13 +190,12 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         if (a.nwA > 0) gx = std::max(gx, (na + a.nwA * kV9MaxUnits - 1) / (a.nwA * kV9MaxUnits));
         if (nb_units > 0) gx = std::max(gx, (nb_units + nwb * kV9MaxUnits - 1) / (nwb * kV9MaxUnits));
     }
-    // Launches in which a wave would own at most one unit of MANY records (ffn_down of every llama: 2048 row pairs of eleven records on
-    // 4096 waves; the 70B's: 28 records) take the 8-wave form with a 12-slot ring: the whole unit (or three times the records) in
-    // flight per wave instead of four steps per memory latency (kernels_v9.h:matvec_v9_kernel).
     // (Measured and NOT taken, round 4: an 8-wave workgroup with a ring of 11 / 8 / 7 slots for launches in which a wave owns one unit of many
     // records — ffn_down, 2048 row pairs of eleven records — so that the whole unit is in flight: 10.8 us against 8.8 us per launch.  A CU
     // with eight streaming waves is served at about 8.6 B/cycle whatever their requests in flight, with sixteen at 10.7: DESIGN.md 5.)
     const dim3 grid((unsigned)gx), block(1024);
+    g_last_kq_grid = gx;
+    if (a.pick_ws && gx > 2048) { err = "head launch with more than 2048 workgroups"; return false; }
     {
         if (a.emb_out && (tb != 0 || a.K > 16384)) { err = "emb_out on a mixed-type or wide launch"; return false; }
         if (tb != 0 && a.K > 16384) { err = "mixed-type launch with K > 16384"; return false; }
@@ -184,20 +204,11 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         // 3 -> 746-750, 4 -> 740-744 tok/s, 5 (125 registers, no spills) -> 728-734; the two-type launch with three: 742-745 against 747-750;
         // Q8_0 (config 3) with three: 535 against 539.
         // More requests in flight per wave lengthen a launch on this memory system; gate+up gains most (11.9 -> 11.2 us).
-#ifndef V9_NS_K
-#define V9_NS_K 3
-#endif
-#ifndef V9_NS_K2
-#define V9_NS_K2 4
-#endif
-#ifndef V9_NS_B
-#define V9_NS_B 4
-#endif
 #define V9L(MK, TAV, TBV, LNV, EMBV) do { \
         auto kfn = matvec_v9_kernel<MK, TAV, TBV, LNV, EMBV, 16, ((TAV == GT_Q4_K || TAV == GT_Q5_K || TAV == GT_Q6_K) ? (TBV == 0 ? V9_NS_K : V9_NS_K2) : V9_NS_B)>; \
         constexpr size_t smem = sizeof(SmemV9<MK>); \
         CT_OPTIN_ONCE(kfn, smem); \
-        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a); } while (0)
+        CT_LAUNCH_DYN(kfn, grid, block, smem, s, a.x, a.norm_w, a.K, a.pro, a); } while (0)
 #define V9T(MK, TAV) do { \
         if (a.emb_out) { if (ln) V9L(16384, TAV, 0, true, true); else V9L(16384, TAV, 0, false, true); } \
         else if (ln) V9L(MK, TAV, 0, true, false); \
@@ -369,10 +380,112 @@ bool Engine::run_matvec(MatvecArgs& a, std::string& err) {
     return launch_matvec(a, stream_, err);
 }
 
+// The head launch of the generation-9 mat-vec picks the greedy token itself and, where the token step advanced the cursor in its last
+// ffn_down launch (`cont`), prepares the next step of a greedy chain (kernels_v9.h:v9_pick_store + kernels.h:pick_cont_kernel).  Legacy graphs sample on the host
+// (models/llm.h), file-layout heads (F16, Q4_1, ...) keep the argmax launch.
+bool Engine::head_folds() const {
+    return fold_on_ && l1_ == hp_.n_layer && !hp_.legacy() && output_.r9 && (is_kquant(output_.type) || is_block32(output_.type)) && hp_.n_embd <= 16384;
+}
+void Engine::set_head_fold(MatvecArgs& a, bool cont) {
+    head_cont_ = false;
+    if (!head_folds() || !a.emb_out) return;
+    a.pick_ws = pick_ws_;
+    head_cont_ = cont && l0_ == 0 && tok_embd_.raw && fold_on_ == 1 && ggml_row_bytes(tok_embd_.type, hp_.n_embd) <= (size_t)64 * 1024;
+}
+// behind a folding head launch: the pick's second half (+ the continuation of a greedy chain where the head said so)
+void Engine::launch_pick() {
+    if (!head_folds()) return;
+    const bool c = head_cont_;
+    const size_t rb = c ? (size_t)ggml_row_bytes(tok_embd_.type, hp_.n_embd) + 16 : 16;
+    CT_OPTIN_ONCE(pick_cont_kernel, (size_t)80 * 1024);
+    CT_LAUNCH_DYN(pick_cont_kernel, dim3(1), dim3(1024), rb, stream_, (const unsigned long long*)pick_ws_, 16 * g_last_kq_grid, d_argmax_, pick_host_, c ? d_state_ : (int*)nullptr,
+              c ? x_ : (float*)nullptr, (const uint8_t*)tok_embd_.raw, tok_embd_.type, hp_.n_embd);
+}
+
 // One fused attention launch for the current token over this layer's fp16 KV cache (kernels_exact.h).
-void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
-    const int hd = hp_.head_dim();
+// The fused QKV + attention launch of a token step (kernels_qa9.h) takes a layer whose q / k / v matrices can share ONE generation-9
+// launch (K-quants in one arena run: q and k of one type — Q4_K or Q5_K —, v the same or Q6_K), heads of 64 or 128, the ring form of
+// contexts up to 1024, and a device on which the attention grid (n_head x channel groups <= CUs, one 1024-thread workgroup per CU) is
+// resident as a whole: the workgroups of a KV head wait for each other's rows (kernels_qa9.h: co-residency).
+bool Engine::qa_can(const Layer& L) const {
+    if (!fuse_qa_ || hp_.falcon() || hp_.legacy() || !xq_) return false;
+    const int hd = hp_.head_dim(), E = hp_.n_embd;
+    if (!(hd == 128 || hd == 64) || E > 16384 || n_ctx_ > 1024 || hp_.n_head % hp_.n_head_kv) return false;
+    const DevMat *q = &L.wq, *k = &L.wk, *v = &L.wv;
+    if (!q->r9 || !k->r9 || !v->r9 || q->type != k->type || !(q->type == GT_Q4_K || q->type == GT_Q5_K)) return false;
+    if (!(v->type == q->type || v->type == GT_Q6_K)) return false;
+    if (k->r9 != q->r9 + (size_t)((q->M + 1) / 2) * l9_spu(q->type, E) * l9_record_bytes(q->type)) return false;
+    if (v->type == q->type && v->r9 != k->r9 + (size_t)((k->M + 1) / 2) * l9_spu(k->type, E) * l9_record_bytes(k->type)) return false;
+    int ng = hd / 16;
+    while (ng > hd / 64 && hp_.n_head * ng > chip_cus()) ng >>= 1;
+    const int pvw = hd / ng / 16;
+    if (hp_.n_head * ng > chip_cus() || !(pvw == 1 || (pvw == 2 && hd == 128))) return false;
+    // at most two units per wave (kernels_qa9.h:QaItems): the group's (rep + 2) * hd / 2 units over its rep * ng workgroups of sixteen waves —
+    // with a second weight type for v, the waves are split by bytes and either part may be as small as one wave per workgroup
+    const int rep = hp_.n_head / hp_.n_head_kv, NG = rep * ng;
+    if ((rep & (rep - 1)) || (ng & (ng - 1))) return false;   // the workgroup map is shifts and masks
+    if (v->type == q->type) { if ((rep + 2) * (hd / 2) > 2 * 16 * NG) return false; }
+    else {   // kq_prepare's split of the sixteen waves by bytes
+        const double ba = (double)((q->M + 1) / 2 + (k->M + 1) / 2) * l9_record_bytes(q->type), bb = (double)((v->M + 1) / 2) * l9_record_bytes(v->type);
+        const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bb / (ba + bb))));
+        if ((rep + 1) * (hd / 2) > 2 * (16 - nwb) * NG || hd / 2 > 2 * nwb * NG) return false;
+    }
+    return true;
+}
+
+bool Engine::launch_qkv_attn(MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, std::string& err) {
+    int tb = 0;
+    if (!kq_prepare(a, tb, err)) return false;
+    const int hd = hp_.head_dim(), ta = a.job[0].w.type;
+    {
+        int ng0 = hd / 16;
+        while (ng0 > hd / 64 && hp_.n_head * ng0 > chip_cus()) ng0 >>= 1;
+        const int rep = hp_.n_head / hp_.n_head_kv, NG = rep * ng0;
+        const bool ok = tb == 0 ? (rep + 2) * (hd / 2) <= 2 * 16 * NG : ((rep + 1) * (hd / 2) <= 2 * a.nwA * NG && hd / 2 <= 2 * (16 - a.nwA) * NG);
+        if (!ok) { err = "fused QKV + attention launch: more than two units per wave"; return false; }
+    }
     AttnArgsX ax = AttnArgsX();
+    fill_attn_args(ax, kc, vc, 0);
+    int ng = hd / 16;
+    while (ng > hd / 64 && hp_.n_head * ng > chip_cus()) ng >>= 1;
+    const int pvw = hd / ng / 16;
+    QaArgs qa;
+    qa.xq = xq_; qa.epoch = (const unsigned*)(d_state_ + 4 + n_ctx_); qa.err = qa_err_; qa.layer = il & 255; qa.ng = ng; qa.phase = 0;
+    qa.ng_sh = 0; while ((1 << qa.ng_sh) < ng) ++qa.ng_sh;
+    qa.rep_sh = 0; while ((1 << qa.rep_sh) < hp_.n_head / hp_.n_head_kv) ++qa.rep_sh;
+    qa.out = ax.out; qa.exp_tab = ax.exp_tab; qa.trace = ax.trace; qa.kq_scale = ax.kq_scale; qa.n_head = ax.n_head; qa.n_head_kv = ax.n_head_kv;
+    static const int exp_phase1 = env_int("CT_AMD_QA_PHASE1", 0);   // experiment: the fused launch's mat-vec phase only, the attention as its own launch
+    if (exp_phase1) qa.phase = 1;
+    const size_t al = 15;
+    const size_t smem = ((sizeof(SmemV9<16384>) + al) & ~al) + ((sizeof(QaSmem) + al) & ~al) + (size_t)((n_ctx_ + 63) & ~63) * 4;
+    const dim3 grid((unsigned)(hp_.n_head * ng)), block(1024);
+    ++g_kq_launches;
+    ++qa_launches_;
+#ifdef CT_EMU
+#define QAL(TAV, TBV, HDV, NWVV) do { \
+        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2)>; \
+        qa.phase = 1; CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); \
+        qa.phase = 2; CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); } while (0)
+#else
+#define QAL(TAV, TBV, HDV, NWVV) do { \
+        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2)>; \
+        CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); \
+        CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); } while (0)
+#endif
+#define QAT(TAV, TBV) do { \
+        if (hd == 64) QAL(TAV, TBV, 64, 15); \
+        else if (pvw == 1) QAL(TAV, TBV, 128, 15); \
+        else QAL(TAV, TBV, 128, 14); } while (0)
+    if (ta == GT_Q4_K) { if (tb) QAT(GT_Q4_K, GT_Q6_K); else QAT(GT_Q4_K, 0); }
+    else { if (tb) QAT(GT_Q5_K, GT_Q6_K); else QAT(GT_Q5_K, 0); }
+#undef QAT
+#undef QAL
+    if (exp_phase1) launch_attention(kc, vc);
+    return true;
+}
+
+void Engine::fill_attn_args(AttnArgsX& ax, uint16_t* kc, uint16_t* vc, int nt) {
+    const int hd = hp_.head_dim();
     ax.q_f16 = nt ? q_f16_b_ : q_f16_; ax.kcache = kc; ax.vcache = vc; ax.out = nt ? attn_out_b_ : attn_out_; ax.pos = d_state_ + 1;
     ax.q_stride = hp_.n_embd; ax.out_stride = hp_.n_embd;
     ax.exp_tab = exp_tab_; ax.n_total = d_state_ + 2; ax.n_head = hp_.n_head; ax.n_head_kv = hp_.n_head_kv; ax.head_dim = hd;
@@ -383,7 +496,13 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     ax.kq_scale = hp_.legacy() ? (float)(1.0 / sqrt((double)((float)hp_.n_embd / (float)hp_.n_head)))
                                : 1.0f / sqrtf((float)hp_.n_embd / (float)hp_.n_head);
     ax.alibi = alibi_;
-    if (trace_site_ && !strcmp(trace_site_, "attn")) ax.trace = trace_buf_;
+    if (trace_site_ && (!strcmp(trace_site_, "attn") || !strcmp(trace_site_, "qa"))) ax.trace = trace_buf_;
+}
+
+void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
+    const int hd = hp_.head_dim();
+    AttnArgsX ax = AttnArgsX();
+    fill_attn_args(ax, kc, vc, nt);
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
     const size_t smem = (size_t)((n_ctx_ + 63) & ~63) * 4;   // the probability row
 #define ATTN(NTV, HDV, ALLV, GRID) do { \
@@ -642,7 +761,8 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             if (need <= lds_cap && (c == 2 || nt > 4 * (c == 3 ? 2 : c / 2))) { ntg = c; break; }   // short chunks keep more workgroups
         }
         if (ntg != 0) {   // experiments: CT_AMD_PFM_NTG forces a smaller group where that form exists
-            const int f = env_int("CT_AMD_PFM_NTG", ntg);
+            static const int forced = env_int("CT_AMD_PFM_NTG", 0);
+            const int f = forced ? forced : ntg;
             if (f >= 2 && f <= ntg && (f == 2 || f == 4 || (!m.gateup && f == 3))) ntg = f;
         }
         const int tb = ntg ? 4 * ntg : kPfTokens / 2;
@@ -720,17 +840,22 @@ bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
             (void)hipGraphDestroy(g);
             if (ei != hipSuccess) { err = std::string("hipGraphInstantiate (chunk) failed: ") + hipGetErrorString(ei); return false; }
             // a pipeline stage keys its graphs by micro-batch offset too (n_ctx / micro-batch offsets x shapes): bound what stays
-            // instantiated — past the cap the oldest-keyed graph goes (a later use of its shape captures again)
+            // instantiated — past the cap the LEAST RECENTLY USED graph goes (a long prompt walks its offsets in ascending order pass after
+            // pass: evicting the lowest key would destroy and recapture the same graphs on alternating passes).  Launches of the evicted
+            // graph may still be in flight on stream_: it is only retired here and destroyed behind the next stream sync (req_wait).
             if (chunk_graphs_.size() >= kMaxChunkGraphs) {
                 auto old = chunk_graphs_.begin();
-                (void)hipGraphExecDestroy(old->second);
+                for (auto jt = chunk_graphs_.begin(); jt != chunk_graphs_.end(); ++jt)
+                    if (jt->second.last_use < old->second.last_use) old = jt;
+                retired_graphs_.push_back(old->second.exec);
                 chunk_seen_.erase(old->first);
                 chunk_graphs_.erase(old);
             }
-            it = chunk_graphs_.emplace(key, ex).first;
+            it = chunk_graphs_.emplace(key, ChunkGraph{ex, 0ull}).first;
         }
         if (it != chunk_graphs_.end()) {
-            HIP_OK(hipGraphLaunch(it->second, stream_));
+            it->second.last_use = ++chunk_use_clock_;
+            HIP_OK(hipGraphLaunch(it->second.exec, stream_));
             return true;
         }
     }
@@ -755,13 +880,87 @@ bool Engine::ensure_graphs(std::string& err) {
         HIP_OK(hipGraphDestroy(g));
         (head ? graph_step_head_ : graph_step_) = ex;
     }
+    // continuation steps of a greedy chain: no embedding launch (the previous head launch left the row, the token id and the cursor),
+    // outputs into pair member b
+    if (spec_possible()) {
+        for (int b = 0; b < 2; ++b) {
+            hipGraph_t g = nullptr;
+            select_out(b);
+            cont_mode_ = true;
+            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+            const bool ok = token_step(true, err);
+            hipError_t e = hipStreamEndCapture(stream_, &g);
+            cont_mode_ = false;
+            select_out(0);
+            if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
+            if (e != hipSuccess) { err = std::string("hipStreamEndCapture (continuation) failed: ") + hipGetErrorString(e); return false; }
+            if (!head_cont_) {   // this graph's head does not prepare the next step (the cursor was not advanced before it): no chains
+                (void)hipGraphDestroy(g);
+                if (graph_cont_[0]) { (void)hipGraphExecDestroy(graph_cont_[0]); graph_cont_[0] = nullptr; }
+                break;
+            }
+            HIP_OK(hipGraphInstantiate(&graph_cont_[b], g, nullptr, nullptr, 0));
+            HIP_OK(hipGraphDestroy(g));
+            HIP_OK(hipEventCreateWithFlags(&ev_step_[b], hipEventDisableTiming));
+        }
+    }
 #endif
     (void)err;
     return true;
 }
 
+#ifndef CT_EMU
+// A whole-model llama / falcon handle whose head launch folds the pick and whose token step advances the cursor before the head.
+bool Engine::spec_possible() const {
+    return spec_on_ && use_graph_ && l0_ == 0 && head_folds() && fold_on_ == 1 && !dump_dir_ && !hp_.legacy() && tok_embd_.raw;
+}
+
+bool Engine::launch_spec(int buf, int pos, std::string& err) {
+    HIP_OK(hipGraphLaunch(graph_cont_[buf], stream_));
+    HIP_OK(hipEventRecord(ev_step_[buf], stream_));
+    spec_inflight_ = true;
+    spec_buf_ = buf;
+    spec_pos_ = pos;
+    ++spec_launched_;
+    return true;
+}
+
+bool Engine::drain_spec(std::string& err) {
+    if (spec_inflight_ || ev_pending_) HIP_OK(hipStreamSynchronize(stream_));
+    spec_inflight_ = false;
+    ev_pending_ = false;
+    return true;
+}
+#endif
+
 bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
     if (l0_ != 0 || l1_ != hp_.n_layer) { err = "this handle is a pipeline stage: use eval_stage"; return false; }
+#ifndef CT_EMU
+    const bool armed = greedy_armed_;
+    greedy_armed_ = false;   // one eval per sample(): a second eval without a pick in between is not a greedy chain
+    if (spec_inflight_) {
+        spec_inflight_ = false;
+        if (n == 1 && tokens && tokens[0] == last_pick_ && n_past == spec_pos_ && armed) {
+            // the queued continuation step IS this eval: its outputs become the committed ones; the next one goes behind it
+            HIP_OK(hipSetDevice(device_));
+            const int b = spec_buf_;
+            ++spec_hits_;
+            if (n_past + 1 < n_ctx_ && !launch_spec(b ^ 1, n_past + 1, err)) return false;   // the guess after this one, before waiting
+            HIP_OK(hipEventSynchronize(ev_step_[b]));
+            HIP_OK(hipGetLastError());
+            cur_buf_ = b;
+            have_logits_ = true;
+            outputs_on_host_ = false;
+            last_token_ = tokens[0];
+            last_pos_ = n_past;
+            last_pick_ = h_scalars_[n_ctx_ + 12 + b];
+            return true;
+        }
+        // not what was guessed: the queued step finishes first (stream order); what it wrote is a KV position nobody has evaluated
+        // and the other output buffer
+    }
+    spec_want_ = armed && n == 1 && n_past + 1 < n_ctx_ && spec_possible();
+#endif
     return eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch);
 }
 
@@ -816,26 +1015,53 @@ bool Engine::req_range(int c0, int nt, bool last_of_request, std::string& err) {
 bool Engine::req_logits(std::string& err) {
     if (l1_ != hp_.n_layer) { err = "logits live on the last stage"; return false; }
     HIP_OK(hipSetDevice(device_));
-    CT_LAUNCH(argmax_first_kernel, dim3(1), dim3(1024), stream_, (const float*)d_logits_, hp_.n_vocab, d_argmax_);
-    HIP_OK(hipMemcpyAsync(&h_scalars_[n_ctx_ + 12], d_argmax_, 4, hipMemcpyDeviceToHost, stream_));
+    if (!head_folds()) {   // (a folding head launch wrote the pick into the pinned word itself)
+        CT_LAUNCH(argmax_first_kernel, dim3(1), dim3(1024), stream_, (const float*)d_logits_, hp_.n_vocab, d_argmax_);
+        HIP_OK(hipMemcpyAsync(&h_scalars_[n_ctx_ + 12], d_argmax_, 4, hipMemcpyDeviceToHost, stream_));
+    }
     outputs_on_host_ = false;
+    cur_buf_ = 0;
+#ifndef CT_EMU
+    if (spec_want_) {   // a greedy chain: wait for THIS step's event, the guessed next step runs behind it
+        spec_want_ = false;
+        if (!ensure_graphs(err)) return false;
+        if (graph_cont_[1]) {
+            HIP_OK(hipEventRecord(ev_step_[0], stream_));
+            ev_pending_ = true;
+            if (!launch_spec(1, req_past_ + req_n_, err)) return false;
+        }
+    }
+#endif
     return true;
 }
 
 void Engine::fetch_outputs() {
     if (outputs_on_host_ || !have_logits_) return;
     (void)hipSetDevice(device_);
-    (void)hipMemcpy(h_logits_, d_logits_, ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h_logits_, d_logits2_[cur_buf_], ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost);
     outputs_on_host_ = true;
 }
 
 bool Engine::req_wait(int n, int n_past, std::string& err) {
     HIP_OK(hipSetDevice(device_));
+#ifndef CT_EMU
+    if (ev_pending_) {   // a speculative step is queued behind this eval: wait for the eval, not for the stream
+        ev_pending_ = false;
+        HIP_OK(hipEventSynchronize(ev_step_[0]));
+        HIP_OK(hipGetLastError());
+    } else {
+        HIP_OK(hipStreamSynchronize(stream_));
+        HIP_OK(hipGetLastError());
+        for (hipGraphExec_t g : retired_graphs_) (void)hipGraphExecDestroy(g);   // evicted chunk graphs: nothing of them is in flight now
+        retired_graphs_.clear();
+    }
+#else
     HIP_OK(hipStreamSynchronize(stream_));
-    HIP_OK(hipGetLastError());
+#endif
     have_logits_ = l1_ == hp_.n_layer;
     last_token_ = h_scalars_[4 + n - 1];
     last_pos_ = n_past + n - 1;
+    last_pick_ = h_scalars_[n_ctx_ + 12];
     return true;
 }
 
@@ -877,6 +1103,7 @@ void Engine::prof_end() {
 bool Engine::trace_site(const char* site, unsigned long long* out, int n, std::string& err) {
 #ifndef CT_EMU
     HIP_OK(hipSetDevice(device_));
+    if (!drain_spec(err)) return false;
     if (last_pos_ < 0) { err = "nothing evaluated yet"; return false; }
     h_scalars_[0] = 0; h_scalars_[1] = last_pos_; h_scalars_[2] = last_pos_ + 1; h_scalars_[4] = last_token_;
     HIP_OK(hipMemcpyAsync(d_tokens_, &h_scalars_[4], 4, hipMemcpyHostToDevice, stream_));
@@ -886,10 +1113,52 @@ bool Engine::trace_site(const char* site, unsigned long long* out, int n, std::s
     trace_site_ = nullptr;
     if (!ok) return false;
     HIP_OK(hipStreamSynchronize(stream_));
-    HIP_OK(hipMemcpy(out, trace_buf_, (size_t)std::min(n, 256) * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out, trace_buf_, (size_t)std::min(n, 512) * 8, hipMemcpyDeviceToHost));
     return true;
 #else
     (void)site; (void)out; (void)n; err = "needs the HIP build"; return false;
+#endif
+}
+
+int Engine::read_stamps(unsigned long long* out, int max) {
+    if (!stamps_) return 0;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    unsigned long long n = 0;
+    (void)hipMemcpy(&n, stamps_, 8, hipMemcpyDeviceToHost);
+    const int k = (int)std::min<unsigned long long>(n, (unsigned long long)max);
+    (void)hipMemcpy(out, stamps_ + 1, (size_t)k * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(stamps_, 0, 8);
+    return k;
+}
+
+bool Engine::decode_burst(int n, double* us_per_token, std::string& err) {
+#ifndef CT_EMU
+    HIP_OK(hipSetDevice(device_));
+    if (last_pos_ < 0 || !use_graph_) { err = "decode_burst: nothing evaluated yet, or graphs are off"; return false; }
+    if (last_pos_ + 1 + n >= n_ctx_ || n < 1 || n > 100) { err = "decode_burst: would run past the context"; return false; }
+    if (!drain_spec(err)) return false;
+    if (!ensure_graphs(err)) return false;
+    // the cursor as the next eval would set it; the token ids are whatever the last request left in d_tokens_ (timing only) — with
+    // continuation graphs the burst IS the greedy chain (each head launch hands the next step its token)
+    h_scalars_[0] = 0; h_scalars_[1] = last_pos_ + 1; h_scalars_[2] = last_pos_ + 1 + (graph_cont_[0] ? 1 : n); h_scalars_[3] = 0;
+    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], 16, hipMemcpyHostToDevice, stream_));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipGraphLaunch(graph_step_head_, stream_));   // one untimed step: the burst starts with the GPU busy
+    HIP_OK(hipEventRecord(e0, stream_));
+    for (int i = 1; i < n; ++i) HIP_OK(hipGraphLaunch(graph_cont_[0] ? graph_cont_[i & 1] : graph_step_head_, stream_));
+    HIP_OK(hipEventRecord(e1, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    float ms = 0.0f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *us_per_token = (double)ms * 1e3 / (double)(n - 1);
+    return true;
+#else
+    (void)n; (void)us_per_token; err = "needs the HIP build"; return false;
 #endif
 }
 
@@ -897,6 +1166,7 @@ bool Engine::profile_decode(int iters, std::vector<LaunchStat>& out, std::string
     out.clear();
 #ifndef CT_EMU
     HIP_OK(hipSetDevice(device_));
+    if (!drain_spec(err)) return false;
     if (last_pos_ < 0) { err = "profile_decode: nothing evaluated yet"; return false; }
     std::vector<ProfRec> recs;
     for (int it = 0; it < iters; ++it) {

@@ -13,6 +13,7 @@
 #include "quant.h"
 
 struct MatvecArgs;
+struct AttnArgsX;
 
 namespace ctamd {
 
@@ -96,10 +97,20 @@ class Engine {
     float* logits() { fetch_outputs(); return h_logits_; }
     int logits_size() const { return have_logits_ ? hp_.n_vocab : 0; }
     const float* embeddings() { fetch_outputs(); return h_emb_; }
-    bool greedy_token(int& token) const { if (!have_logits_ || outputs_on_host_ || hp_.legacy()) return false; token = h_scalars_[n_ctx_ + 12]; return true; }
+    bool greedy_token(int& token) const { if (!have_logits_ || outputs_on_host_ || hp_.legacy()) return false; token = h_scalars_[n_ctx_ + 12 + cur_buf_]; return true; }
     void fetch_outputs();
+    // Greedy chains.  ctransformers_llm_sample tells the engine whether the caller's last pick was the device-side
+    // first maximum: after such a pick the next eval is, in every generate() loop, that token at the next position — the engine then
+    // queues that token step BEHIND the one it is waiting for (token id, cursor and embedding row are already on the device: the head
+    // launch prepared them), and an eval that asks for exactly it only waits for its event.  Anything else the caller does is served
+    // as before (the speculative step wrote a KV position nobody has evaluated yet and a logits buffer nobody reads).
+    void note_sample(bool device_greedy) { greedy_armed_ = device_greedy; }
     int embeddings_size() const { return have_logits_ && !hp_.legacy() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
+    int read_stamps(unsigned long long* out, int max);   // measurement only: copies and clears the stamps
+    long long qa_launches() const { return qa_launches_; }   // fused QKV + attention launches issued (eager launches and graph captures)
+    long long spec_hits() const { return spec_hits_; }           // evals served by a speculative continuation step
+    long long spec_launched() const { return spec_launched_; }   // continuation steps queued
     long long chunk_tokens() const { return chunk_tokens_; }
 
     // Measurement hook (exported as ctamd_profile_decode): replays the LAST evaluated token `iters` times with eager
@@ -108,6 +119,9 @@ class Engine {
     bool profile_decode(int iters, std::vector<LaunchStat>& out, std::string& err);
     // measurement only: run ONE launch site of the last token with in-kernel timestamps (CT_AMD_DBG=32) and copy them out
     bool trace_site(const char* site, unsigned long long* out, int n, std::string& err);
+    // measurement only (ctamd_decode_burst): n token steps with the head, queued back to back on the stream with no host round trip
+    // between them (HIP events around the burst) -> device microseconds per token step.  The cursor continues from the last eval.
+    bool decode_burst(int n, double* us_per_token, std::string& err);
     const char* trace_site_ = nullptr;
     unsigned long long* trace_buf_ = nullptr;
     void apply_trace(::MatvecArgs& a, const char* site);
@@ -135,6 +149,9 @@ class Engine {
     bool pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err);
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
+    void fill_attn_args(::AttnArgsX& ax, uint16_t* kc, uint16_t* vc, int nt);
+    bool qa_can(const Layer& L) const;   // this layer's token step takes the fused QKV + attention launch (kernels_qa9.h)
+    bool launch_qkv_attn(::MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, std::string& err);
     bool token_step_falcon(bool want_logits, std::string& err);
     bool token_step_gpt2(bool want_logits, std::string& err);
     bool token_step_mpt(bool want_logits, std::string& err);
@@ -204,12 +221,52 @@ class Engine {
 #ifndef CT_EMU
     hipGraphExec_t graph_step_ = nullptr, graph_step_head_ = nullptr;
     static constexpr size_t kMaxChunkGraphs = 64;
-    std::map<long long, hipGraphExec_t> chunk_graphs_;   // prompt chunks, keyed by (stage: row offset + 1) << 24 | 4 * n_tokens + 2 * below-128 + want_logits; captured on second use
+    struct ChunkGraph { hipGraphExec_t exec; unsigned long long last_use; };
+    std::map<long long, ChunkGraph> chunk_graphs_;   // prompt chunks, keyed by (stage: row offset + 1) << 24 | 4 * n_tokens + 2 * below-128 + want_logits; captured on second use
     std::map<long long, int> chunk_seen_;
+    unsigned long long chunk_use_clock_ = 0;         // least-recently-used eviction past kMaxChunkGraphs
+    std::vector<hipGraphExec_t> retired_graphs_;     // evicted while launches of them may still be in flight: destroyed behind the next stream sync (req_wait)
 #endif
     bool have_logits_ = false;
     bool outputs_on_host_ = true;   // false after an eval until logits() / embeddings() fetched them
     int* d_argmax_ = nullptr;
+    // Output buffers come in pairs: [0] is written by every eval the caller asked for, a speculative continuation step writes the one
+    // the last committed eval did NOT write.  d_logits_ / d_emb_ / d_argmax_ / pick_host_ name the pair member the launches being
+    // issued (or captured) write; cur_buf_ the one holding the last committed eval's outputs.
+    float* d_logits2_[2] = {nullptr, nullptr};
+    int* d_argmax2_[2] = {nullptr, nullptr};
+    int* pick_host_ = nullptr;        // device view of h_scalars_[n_ctx_ + 12 + buffer]
+    int* pick_host2_[2] = {nullptr, nullptr};
+    uint32_t* xq_ = nullptr;          // fused QKV + attention launch: the KV-head groups' exchange records (kernels_qa9.h)
+    int* qa_err_ = nullptr;           // device view of the pinned word h_scalars_[n_ctx_ + 14] a timed-out sweep raises
+    bool fuse_qa_ = true;             // CT_AMD_FUSE_QA (read at load)
+    long long qa_launches_ = 0;
+    unsigned* pick_ws_ = nullptr;     // head launch: one 64-bit key per wave, [workgroup][16] (kernels_v9.h:v9_pick_store)
+    int cur_buf_ = 0;
+    void select_out(int buf) { d_logits_ = d_logits2_[buf]; d_emb_ = d_logits_ + hp_.n_vocab; d_argmax_ = d_argmax2_[buf]; pick_host_ = pick_host2_[buf]; }
+    bool head_folds() const;          // the head launch picks the greedy token itself (no argmax launch, no 4-byte copy)
+    void set_head_fold(::MatvecArgs& a, bool cont);
+    void launch_pick();
+    int stamps_level_ = 0;
+    unsigned long long* stamps_ = nullptr;   // measurement only (CT_AMD_STAMPS=1): wall-clock stamps at the start and end of every token step
+    bool head_cont_ = false;          // the head launch being issued belongs to a token step that advanced the cursor before it
+    int fold_on_ = 1;       // CT_AMD_HEAD_FOLD (read at load: A/B and tests): 0 argmax over the logits, 1 per-workgroup keys from the head launch + pick_cont_kernel with the continuation, 2 without the continuation
+    bool spec_on_ = true;   // CT_AMD_SPEC
+    bool cont_mode_ = false;          // token_step is being captured as a continuation step: no embedding launch (the row is there)
+    bool greedy_armed_ = false;       // the caller's last sample() was the device-side greedy pick
+    bool spec_want_ = false;          // the eval being issued is a step of a greedy chain: queue the guessed next step behind it
+    bool spec_inflight_ = false;      // a continuation step for position spec_pos_ is queued (outputs: buffer spec_buf_)
+    int spec_buf_ = 0, spec_pos_ = -1;
+    int last_pick_ = -1;              // greedy pick of the last committed eval
+    long long spec_hits_ = 0, spec_launched_ = 0;
+#ifndef CT_EMU
+    hipGraphExec_t graph_cont_[2] = {nullptr, nullptr};
+    hipEvent_t ev_step_[2] = {nullptr, nullptr};
+    bool ev_pending_ = false;         // req_wait waits for ev_step_[0] instead of draining the stream (a speculative step is queued behind)
+    bool spec_possible() const;
+    bool launch_spec(int buf, int pos, std::string& err);
+    bool drain_spec(std::string& err);
+#endif
     int last_token_ = -1, last_pos_ = -1;
     int req_n_ = 0;           // tokens of the request in flight (req_begin)
     struct ProfRec { const char* site; const char* kernel; double bytes; void* e0; void* e1; };

@@ -728,11 +728,21 @@ bool Engine::alloc_state(std::string& err) {
     if (!dev_alloc(dev_allocs_, &x_, (size_t)E, err) || !dev_alloc(dev_allocs_, &attn_out_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &h_, (size_t)F, err) || !dev_alloc(dev_allocs_, &q_f16_, (size_t)E, err) ||
         !dev_alloc(dev_allocs_, &scores_, (size_t)hp_.n_head * n_ctx_, err) ||
-        !dev_alloc(dev_allocs_, &d_logits_, (size_t)V + E, err) ||   // [logits | final-norm embedding]: one D2H copy per eval
-        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_argmax_, 4, err) || !dev_alloc(dev_allocs_, &d_state_, (size_t)n_ctx_ + 4, err))   // [cursor(4) | tokens]: one H2D copy
+        !dev_alloc(dev_allocs_, &d_logits2_[0], (size_t)V + E, err) ||   // [logits | final-norm embedding]: one D2H copy per eval
+        !dev_alloc(dev_allocs_, &d_logits2_[1], (size_t)V + E, err) ||   // the pair member a speculative continuation step writes (engine.h)
+        !dev_alloc(dev_allocs_, &pick_ws_, 2 * 16 * 2048, err) ||
+        !dev_alloc(dev_allocs_, &trace_buf_, 512, err) || !dev_alloc(dev_allocs_, &d_argmax2_[0], 8, err) || !dev_alloc(dev_allocs_, &d_state_, (size_t)n_ctx_ + 8, err))   // [cursor(4) | tokens]: one H2D copy
         return false;
-    d_emb_ = d_logits_ + V;
+    d_argmax2_[1] = d_argmax2_[0] + 1;
+    HIP_OK(hipMemset(pick_ws_, 0, (size_t)2 * 16 * 2048 * 4));
     d_tokens_ = d_state_ + 4;
+    HIP_OK(hipMemset(d_state_, 0, ((size_t)n_ctx_ + 8) * 4));   // [4 + n_ctx]: the token epoch (kernels_qa9.h)
+    fuse_qa_ = env_int("CT_AMD_FUSE_QA", 1) != 0 && !hp_.falcon() && !hp_.legacy();
+    if (fuse_qa_) {
+        const size_t words = (size_t)(hp_.n_head + 2 * hp_.n_head_kv) * (hp_.head_dim() / 2) * 2;
+        if (!dev_alloc(dev_allocs_, &xq_, words + 16, err)) return false;
+        HIP_OK(hipMemset(xq_, 0, (words + 16) * 4));
+    }
     if (has_raw_ && !dev_alloc(dev_allocs_, &f16_tmp_, (size_t)std::max(std::max(V, 2 * F), E + 2 * G) + 64, err)) return false;
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
     pf_ok_ = E <= 12288 && F <= 32768 && n_ctx_ <= kMaxCtxFused && env_int("CT_AMD_PF", 1) != 0;
@@ -781,7 +791,33 @@ bool Engine::alloc_state(std::string& err) {
     HIP_OK(hipHostMalloc(&h_logits_, ((size_t)V + E) * 4));
     h_emb_ = h_logits_ + V;
     HIP_OK(hipHostMalloc(&h_scalars_, ((size_t)n_ctx_ + 16) * 4));
+    memset(h_scalars_, 0, ((size_t)n_ctx_ + 16) * 4);
+    for (int b = 0; b < 2; ++b) {   // the head launch writes the greedy pick straight into this pinned word
+#ifdef CT_EMU
+        pick_host2_[b] = &h_scalars_[n_ctx_ + 12 + b];
+#else
+        void* dp = nullptr;
+        HIP_OK(hipHostGetDevicePointer(&dp, &h_scalars_[n_ctx_ + 12 + b], 0));
+        pick_host2_[b] = (int*)dp;
+#endif
+    }
+    select_out(0);
+#ifdef CT_EMU
+    qa_err_ = &h_scalars_[n_ctx_ + 14];
+#else
+    {
+        void* dp = nullptr;
+        HIP_OK(hipHostGetDevicePointer(&dp, &h_scalars_[n_ctx_ + 14], 0));
+        qa_err_ = (int*)dp;
+    }
+#endif
     use_graph_ = env_int("CT_AMD_GRAPH", 1) != 0;
+    fold_on_ = env_int("CT_AMD_HEAD_FOLD", 1);
+    spec_on_ = env_int("CT_AMD_SPEC", 1) != 0;
+    if ((stamps_level_ = env_int("CT_AMD_STAMPS", 0)) != 0) {
+        if (!dev_alloc(dev_allocs_, &stamps_, 40008, err)) return false;
+        HIP_OK(hipMemset(stamps_, 0, 40008 * 8));
+    }
     dump_dir_ = getenv("CT_AMD_DUMP");
     if (dump_dir_ && !*dump_dir_) dump_dir_ = nullptr;
     if (dump_dir_) use_graph_ = false;

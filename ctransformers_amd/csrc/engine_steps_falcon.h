@@ -62,12 +62,14 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
         HIP_OK(hipMemcpyAsync(xio_ + (size_t)c0 * E, xb_, (size_t)nt * E * 4, hipMemcpyDeviceToDevice, stream_));
     } else if (want_logits) {
         const float* xl = xb_ + (size_t)(nt - 1) * E;
-        CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, (const float*)output_norm_b_,
-                  d_emb_, E, hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_LAYERNORM; a.x = xl; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        if (kq_can(a) && E <= 16384) { a.emb_out = d_emb_; set_head_fold(a, false); }   // as the llama head: final-norm output from the prologue, greedy pick in the epilogue
+        else CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, (const float*)output_norm_b_,
+                       d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
+        if (a.pick_ws) launch_pick();
     }
     CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
     return true;
@@ -79,7 +81,9 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
 bool Engine::token_step_falcon(bool want_logits, std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
-    if (l0_ == 0) {
+    if (l0_ == 0 && cont_mode_) {
+        // continuation step of a greedy chain (token_step, llama): the embedding row is in x_
+    } else if (l0_ == 0) {
         if (site_on("embed")) {
             CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
                       (const int*)d_tokens_, (const int*)d_state_, x_);
@@ -170,19 +174,22 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
         CT_LAUNCH(stage_row_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), stream_, (const float*)x_, xio_, E,
                   (const int*)d_state_, 1);
     } else if (want_logits) {
-        if (!only_site_)
-            CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_,
-                      (const float*)output_norm_b_, d_emb_, E, hp_.rms_eps);
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_LAYERNORM; a.x = x_; a.norm_w = output_norm_; a.norm_b = output_norm_b_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
+        if (bumped) a.pos = nullptr;   // as in token_step (llama): the cursor was advanced already
+        if (kq_can(a) && E <= 16384) { a.emb_out = d_emb_; set_head_fold(a, bumped); }   // as the llama head
+        else if (!only_site_)
+            CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_,
+                      (const float*)output_norm_b_, d_emb_, E, hp_.rms_eps);
         apply_trace(a, "lm_head");
         if (site_on("lm_head")) {
             prof_begin("lm_head", "matvec", (double)output_.bytes);
             if (!run_matvec(a, err)) return false;
             prof_end();
         }
+        if (a.pick_ws && !only_site_) launch_pick();
     }
-    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
     return true;
 }

@@ -175,7 +175,7 @@ bool Engine::token_step_gpt2(bool want_logits, std::string& err) {
         set_jobs(a, {{&output_, EPI_STORE}});
         if (!run_matvec(a, err)) return false;
     }
-    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
     return true;
 }
 
@@ -236,6 +236,6 @@ bool Engine::token_step_mpt(bool want_logits, std::string& err) {
         set_jobs(a, {{&output_, EPI_STORE}});
         if (!run_matvec(a, err)) return false;
     }
-    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
     return true;
 }

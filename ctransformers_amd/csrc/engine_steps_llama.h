@@ -69,9 +69,10 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = xl; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (kq_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (kq_can(a)) { a.emb_out = d_emb_; set_head_fold(a, false); }   // the head launch stores the final-norm output from its prologue and picks the greedy token
         else CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
+        if (a.pick_ws) launch_pick();
     }
     CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
     return true;
@@ -84,7 +85,10 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     if (hp_.mpt()) return token_step_mpt(want_logits, err);
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, hd = hp_.head_dim();
     const int* d_pos = d_state_ + 1;
-    if (l0_ == 0) {
+    if (stamps_) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 1ull);
+    if (l0_ == 0 && cont_mode_) {
+        // continuation step of a greedy chain: the previous head launch left the embedding row of its pick in x_
+    } else if (l0_ == 0) {
         if (site_on("embed")) {
         prof_begin("embed", "embed_row_kernel", (double)ggml_row_bytes(tok_embd_.type, E));
         CT_LAUNCH(embed_row_kernel, dim3((unsigned)std::max(1, E / 256)), dim3(256), stream_, tok_embd_.raw, tok_embd_.type, E,
@@ -111,25 +115,35 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         const Layer& L = layers_[il];
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
-        {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append
+        {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append [-> attention, where the fused launch applies]
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = L.attn_norm;
             a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
             set_jobs(a, {{&L.wq, EPI_ROPE_Q}, {&L.wk, EPI_ROPE_K}, {&L.wv, EPI_V}});  // types may differ per matrix
             apply_trace(a, "qkv");
-            if (site_on("qkv")) {
-                prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
-                if (!run_matvec(a, err)) return false;
-                prof_end();
+            const bool fused = qa_can(L) && !only_site_ && !prof_ && (!trace_site_ || !strcmp(trace_site_, "qa"));
+            if (fused) {
+                if (trace_site_) { a.dbg |= 32; a.dbg_sink = (float*)(trace_buf_ + 256); }   // (ctamd_trace_site("qa"): the mat-vec phase's stamps behind the attention phase's)
+                if (!launch_qkv_attn(a, kc, vc, il, err)) return false;
+                debug_dump("2attn", il);
+                if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 4ull);
+            } else {
+                if (site_on("qkv")) {
+                    prof_begin("qkv", "matvec", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes));
+                    if (!run_matvec(a, err)) return false;
+                    prof_end();
+                }
+                debug_dump("1qkv", il);
+                if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 3ull);
+                if (site_on("attn_fused")) {
+                    prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
+                    launch_attention(kc, vc);
+                    prof_end();
+                }
+                debug_dump("2attn", il);
+                if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 4ull);
             }
-            debug_dump("1qkv", il);
         }
-        if (site_on("attn_fused")) {
-            prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
-            launch_attention(kc, vc);
-            prof_end();
-        }
-        debug_dump("2attn", il);
         {   // Q8_K(attn) -> Wo -> + residual
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_PLAIN; a.x = attn_out_; a.out = x_; a.res = x_;
@@ -141,6 +155,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
                 prof_end();
             }
             debug_dump("3wo", il);
+            if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 5ull);
         }
         {   // RMSNorm -> Q8_K -> {W_gate, W_up} -> SiLU(gate)*up
             MatvecArgs a = base;
@@ -160,6 +175,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
                 prof_end();
             }
             debug_dump("4gateup", il);
+            if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 6ull);
         }
         {   // Q8_K(h) -> W_down -> + residual
             MatvecArgs a = base;
@@ -173,6 +189,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
                 prof_end();
             }
             debug_dump("5down", il);
+            if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 7ull);
         }
     }
     if (l1_ < hp_.n_layer) {  // hand this token's residual-stream row to the next stage
@@ -182,7 +199,8 @@ bool Engine::token_step(bool want_logits, std::string& err) {
         MatvecArgs a = base;
         a.K = E; a.pro = PRO_RMSNORM; a.x = x_; a.norm_w = output_norm_; a.out = d_logits_;
         set_jobs(a, {{&output_, EPI_STORE}});
-        if (kq_can(a)) a.emb_out = d_emb_;   // generation 7 stores the final-norm output from its prologue
+        if (bumped) a.pos = nullptr;   // the cursor was advanced by the last layer's ffn_down launch: nothing of the head launch may read it
+        if (kq_can(a)) { a.emb_out = d_emb_; set_head_fold(a, bumped); }   // the head launch stores the final-norm output from its prologue, picks the greedy token and prepares the next step
         else if (!only_site_)
             CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, (const float*)x_, (const float*)output_norm_, d_emb_, E,
                       hp_.rms_eps);
@@ -192,8 +210,11 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             if (!run_matvec(a, err)) return false;
             prof_end();
         }
+        if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 8ull);
+        if (a.pick_ws && !only_site_) launch_pick();
     }
-    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_);
+    if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
+    if (stamps_) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 2ull);
     if (dump_dir_) ++dump_seq_;
     return true;
 }

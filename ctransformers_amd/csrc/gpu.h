@@ -645,3 +645,22 @@ static inline unsigned long long clock64_dev() { return 0; }
 #else
 DEV unsigned long long clock64_dev() { return __builtin_amdgcn_s_memtime(); }
 #endif
+
+// ---- device-scope ("agent": all XCDs of the chip) words that workgroups of one launch hand to each other ------------------------------
+// The L2 of an XCD is not coherent with the other seven: a plain store stays in the writer's L2 until the kernel ends.  These are
+// RELAXED device-scope atomics (performed at the memory side, no cache maintenance): an acquire / release fence at this scope is a
+// write-back + invalidate of the XCD's whole L2 — measured in round 5 at ~13 us when the 256 workgroups of a head launch each issued one
+// (profiles/r05_head_fold.txt).  Ordering comes from the RETURN VALUES instead: an atomic whose result has arrived has been performed.
+#ifdef CT_EMU
+static inline unsigned agent_add_u32(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }   // workgroups run one after the other
+static inline unsigned long long agent_max_u64(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
+static inline unsigned agent_ld_u32(const unsigned* p) { return *p; }
+static inline void agent_st_u32(unsigned* p, unsigned v) { *p = v; }
+static inline void agent_st_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+#else
+DEV unsigned agent_add_u32(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV unsigned long long agent_max_u64(unsigned long long* p, unsigned long long v) { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV unsigned agent_ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void agent_st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void agent_st_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif

@@ -86,6 +86,9 @@ struct MatvecArgs {
     int n_ctx, head_dim, n_embd_gqa, v_stride;
     const uint16_t* silu_tab;  // 65536-entry fp16->fp16 table (reference ggml.c:4328-4332)
     float* f16_tmp;            // F16 weight matrices (kernels_f16.h): raw results of the launch's rows, between the dot kernel and the epilogue kernel
+    // Greedy pick, first half (kernels_v9.h:v9_pick_store; the EMB instantiations): every wave of the head launch leaves the first maximum
+    // of ITS logits rows as a 64-bit key in pick_ws[workgroup][wave]; pick_cont_kernel finishes.  Null: no pick.
+    unsigned* pick_ws;
     float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
     int dbg;                   // measurement only (CT_AMD_DBG / ctamd_trace_site): bit 32 = write in-kernel s_memtime stamps to dbg_sink
 };
@@ -93,6 +96,70 @@ struct MatvecArgs {
 // ------------------------------------------------------------------------------------------------------------------
 // Token embedding: dequantize one row of token_embd (file layout) -> f32   (reference ggml.c:11615-11642 get_rows_q)
 // ------------------------------------------------------------------------------------------------------------------
+// element e of a token_embd row in file layout (every weight type the loaders accept for the table)
+DEV float embed_value(const uint8_t* __restrict__ row, int type, int e) {
+    float y;
+    if (type == GT_F32) {
+        y = ((const float*)row)[e];
+    } else if (type == GT_F16) {
+        y = f16_bits_to_f32(((const uint16_t*)row)[e]);
+    } else if (type == GT_Q8_0) {
+        const uint8_t* b = row + (size_t)(e >> 5) * 34;
+        const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
+        y = (float)(int8_t)b[2 + (e & 31)] * d;
+    } else if (type == GT_Q4_0) {
+        const uint8_t* b = row + (size_t)(e >> 5) * 18;
+        const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
+        const int j = e & 31;
+        const int q = (j < 16) ? (b[2 + j] & 0xF) : (b[2 + j - 16] >> 4);
+        y = (float)(q - 8) * d;
+    } else if (type == GT_Q4_1 || type == GT_Q5_0 || type == GT_Q5_1) {   // ggml.c:1538-1610; q * d is exact (5 x 11 bits): x0*d + m rounds once, fused or not
+        const int bbk = type == GT_Q4_1 ? 20 : (type == GT_Q5_0 ? 22 : 24), hdr = type == GT_Q5_0 ? 2 : 4;
+        const uint8_t* b = row + (size_t)(e >> 5) * bbk;
+        const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
+        const float m = type == GT_Q5_0 ? 0.0f : f16_bits_to_f32((uint16_t)(b[2] | (b[3] << 8)));
+        const int j = e & 31;
+        const uint8_t* qs = b + hdr + (type == GT_Q4_1 ? 0 : 4);
+        int q = (j < 16) ? (qs[j] & 0xF) : (qs[j - 16] >> 4);
+        if (type != GT_Q4_1) q |= ((b[hdr + (j >> 3)] >> (j & 7)) & 1) << 4;
+        y = type == GT_Q5_0 ? (float)(q - 16) * d : fmaf((float)q, d, m);
+    } else if (type == GT_Q4_K || type == GT_Q5_K) {
+        const int bb = (type == GT_Q4_K) ? 144 : 176;
+        const uint8_t* b = row + (size_t)(e >> 8) * bb;
+        const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
+        const float dmin = f16_bits_to_f32((uint16_t)(b[2] | (b[3] << 8)));
+        const int el = e & 255, j = el >> 5, l = el & 31, c = j >> 1;
+        const uint8_t* s = b + 4;
+        int sc, m;
+        if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
+        else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
+        int q;
+        if (type == GT_Q4_K) {
+            const uint8_t v = b[16 + 32 * c + l];
+            q = (j & 1) ? (v >> 4) : (v & 0xF);
+        } else {
+            const uint8_t v = b[48 + 32 * c + l];
+            const uint8_t hb = b[16 + l];
+            q = ((j & 1) ? (v >> 4) : (v & 0xF)) + (((hb >> j) & 1) ? 16 : 0);
+        }
+        const float d1 = d * (float)sc, m1 = dmin * (float)m;
+        y = d1 * (float)q - m1;
+    } else {  // GT_Q6_K
+        const uint8_t* b = row + (size_t)(e >> 8) * 210;
+        const int el = e & 255, n = el >> 7, r = el & 127, grp = r >> 5, l = r & 31;
+        const uint8_t* ql = b + 64 * n;
+        const uint8_t* qh = b + 128 + 32 * n;
+        const int8_t* sc = (const int8_t*)(b + 192 + 8 * n);
+        const float d = f16_bits_to_f32((uint16_t)(b[208] | (b[209] << 8)));
+        const uint8_t lo = (grp & 1) ? ql[l + 32] : ql[l];
+        const int nib = (grp & 2) ? (lo >> 4) : (lo & 0xF);
+        const int q = (int)(int8_t)(nib | (((qh[l] >> (2 * grp)) & 3) << 4)) - 32;
+        const int is = l >> 4;
+        y = d * (float)sc[is + 2 * grp] * (float)q;
+    }
+    return y;
+}
+
 __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restrict__ raw, int type, int K,
                                                         const int* __restrict__ tokens, const int* __restrict__ state,
                                                         float* __restrict__ out, const float* __restrict__ wpe = nullptr) {
@@ -100,65 +167,7 @@ __global__ void __launch_bounds__(256) embed_row_kernel(const uint8_t* __restric
     const uint8_t* row = raw + (size_t)token * ggml_row_bytes(type, K);
     out += (size_t)blockIdx.y * K;
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < K; e += (int)(gridDim.x * blockDim.x)) {
-        float y;
-        if (type == GT_F32) {
-            y = ((const float*)row)[e];
-        } else if (type == GT_F16) {
-            y = f16_bits_to_f32(((const uint16_t*)row)[e]);
-        } else if (type == GT_Q8_0) {
-            const uint8_t* b = row + (size_t)(e >> 5) * 34;
-            const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
-            y = (float)(int8_t)b[2 + (e & 31)] * d;
-        } else if (type == GT_Q4_0) {
-            const uint8_t* b = row + (size_t)(e >> 5) * 18;
-            const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
-            const int j = e & 31;
-            const int q = (j < 16) ? (b[2 + j] & 0xF) : (b[2 + j - 16] >> 4);
-            y = (float)(q - 8) * d;
-        } else if (type == GT_Q4_1 || type == GT_Q5_0 || type == GT_Q5_1) {   // ggml.c:1538-1610; q * d is exact (5 x 11 bits): x0*d + m rounds once, fused or not
-            const int bbk = type == GT_Q4_1 ? 20 : (type == GT_Q5_0 ? 22 : 24), hdr = type == GT_Q5_0 ? 2 : 4;
-            const uint8_t* b = row + (size_t)(e >> 5) * bbk;
-            const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
-            const float m = type == GT_Q5_0 ? 0.0f : f16_bits_to_f32((uint16_t)(b[2] | (b[3] << 8)));
-            const int j = e & 31;
-            const uint8_t* qs = b + hdr + (type == GT_Q4_1 ? 0 : 4);
-            int q = (j < 16) ? (qs[j] & 0xF) : (qs[j - 16] >> 4);
-            if (type != GT_Q4_1) q |= ((b[hdr + (j >> 3)] >> (j & 7)) & 1) << 4;
-            y = type == GT_Q5_0 ? (float)(q - 16) * d : fmaf((float)q, d, m);
-        } else if (type == GT_Q4_K || type == GT_Q5_K) {
-            const int bb = (type == GT_Q4_K) ? 144 : 176;
-            const uint8_t* b = row + (size_t)(e >> 8) * bb;
-            const float d = f16_bits_to_f32((uint16_t)(b[0] | (b[1] << 8)));
-            const float dmin = f16_bits_to_f32((uint16_t)(b[2] | (b[3] << 8)));
-            const int el = e & 255, j = el >> 5, l = el & 31, c = j >> 1;
-            const uint8_t* s = b + 4;
-            int sc, m;
-            if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
-            else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
-            int q;
-            if (type == GT_Q4_K) {
-                const uint8_t v = b[16 + 32 * c + l];
-                q = (j & 1) ? (v >> 4) : (v & 0xF);
-            } else {
-                const uint8_t v = b[48 + 32 * c + l];
-                const uint8_t hb = b[16 + l];
-                q = ((j & 1) ? (v >> 4) : (v & 0xF)) + (((hb >> j) & 1) ? 16 : 0);
-            }
-            const float d1 = d * (float)sc, m1 = dmin * (float)m;
-            y = d1 * (float)q - m1;
-        } else {  // GT_Q6_K
-            const uint8_t* b = row + (size_t)(e >> 8) * 210;
-            const int el = e & 255, n = el >> 7, r = el & 127, grp = r >> 5, l = r & 31;
-            const uint8_t* ql = b + 64 * n;
-            const uint8_t* qh = b + 128 + 32 * n;
-            const int8_t* sc = (const int8_t*)(b + 192 + 8 * n);
-            const float d = f16_bits_to_f32((uint16_t)(b[208] | (b[209] << 8)));
-            const uint8_t lo = (grp & 1) ? ql[l + 32] : ql[l];
-            const int nib = (grp & 2) ? (lo >> 4) : (lo & 0xF);
-            const int q = (int)(int8_t)(nib | (((qh[l] >> (2 * grp)) & 3) << 4)) - 32;
-            const int is = l >> 4;
-            y = d * (float)sc[is + 2 * grp] * (float)q;
-        }
+        float y = embed_value(row, type, e);
         if (wpe) y = y + wpe[(size_t)(state[1] + (int)blockIdx.y) * K + e];   // gpt2: wte[token] + wpe[pos] (gpt2.cc:441-444)
         out[e] = y;
     }
@@ -437,9 +446,100 @@ __global__ void __launch_bounds__(1024) argmax_first_kernel(const float* __restr
     }
 }
 
-__global__ void advance_state_kernel(int* state) {
+// first maximum: the larger value, on equal values the lower row (argmax_first_kernel's rule; NaN and -inf never win)
+DEV void pick_merge(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+DEV void pick_wave_reduce(float& bv, int& bi) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(bv, m);
+        const int oi = __shfl_xor(bi, m);
+        pick_merge(bv, bi, ov, oi);
+    }
+}
+// order-preserving 64-bit key of (value, row): a larger key = a larger value, or the same value in a lower row
+DEV unsigned long long pick_key(float v, int row) {
+    if (!(v > -INFINITY)) return 0ull;                       // -inf / NaN never win (argmax_first_kernel: `x > best` from -inf)
+    uint32_t b = v == 0.0f ? 0u : f32_to_bits(v);            // +0 and -0 compare equal: one key
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+}
+
+// The greedy pick, second half, and the continuation of a greedy chain: ONE workgroup behind the head launch.  Reads the n keys the head
+// launch's waves left (v9_pick_store: 16 per workgroup) — 32 KB instead of the n_vocab logits argmax_first_kernel walks, and every load
+// of a thread in flight at once — and writes the token to
+// device memory AND straight into the pinned host word the caller's sample() reads (no copy node); then, where the token step advanced
+// the cursor in its last ffn_down launch (cont_state != null), prepares the NEXT token step of a greedy chain on the device: token id,
+// cursor {0, pos + 1, pos + 2, 0}, and the residual-stream row = the picked token's embedding row (embed_row_kernel's arithmetic) — so
+// that step needs no host copy and no embedding launch (engine.h: continuation graphs).
+__global__ void __launch_bounds__(1024) pick_cont_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ out, int* __restrict__ host,
+                                                         int* __restrict__ cont_state, float* __restrict__ cont_x,
+                                                         const uint8_t* __restrict__ embd, int type, int K) {
+    __shared__ unsigned long long part[16];
+    __shared__ int s_tok;
+    CT_DYN_SMEM(smem_raw);   // the picked token's embedding row in file layout (<= 4 K bytes)
+    const int tid = (int)threadIdx.x;
+    unsigned long long best = 0ull;
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+        unsigned long long k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 1024 * u; k[u] = keys[i < n ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) best = k[u] > best ? k[u] : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
+    if ((tid & 63) == 0) part[tid >> 6] = best;
+    __syncthreads();
+    if (tid < 64) {   // the sixteen per-wave maxima: one more reduce inside wave 0
+        best = part[tid & 15];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
+        if (tid == 0) {
+            const int tok = best ? (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull)) : 0;   // all -inf / NaN: the reference's heap keeps element 0
+            s_tok = tok;
+            *out = tok;
+            if (host) *host = tok;
+            if (cont_state) {
+                cont_state[0] = 0;
+                cont_state[2] = cont_state[1] + 1;
+                cont_state[3] = 0;
+                cont_state[4] = tok;
+            }
+        }
+    }
+    if (!cont_x) return;   // (kernel argument: uniform)
+    __syncthreads();
+    // The row travels to LDS in 4-byte pieces, all in flight at once (2.3 KB for a Q4_K row of 4096: dequantizing straight from global
+    // memory is some sixty byte-wide loads per thread through ONE CU's memory pipe: 5 us, measured), then embed_row_kernel's arithmetic
+    // reads the LDS copy.
+    const size_t rb = ggml_row_bytes(type, K);
+    const uint8_t* __restrict__ row = embd + (size_t)s_tok * rb;
+    uint8_t* lrow = smem_raw;
+    const int words = (int)(rb >> 2);
+    if ((((uintptr_t)row) & 3u) == 0) {
+        for (int w = tid; w < words; w += 1024) ((uint32_t*)lrow)[w] = ((const uint32_t*)row)[w];
+        for (int b = 4 * words + tid; b < (int)rb; b += 1024) lrow[b] = row[b];
+    } else {
+        for (int b = tid; b < (int)rb; b += 1024) lrow[b] = row[b];
+    }
+    __syncthreads();
+    for (int e = tid; e < K; e += 1024) cont_x[e] = embed_value(lrow, type, e);
+}
+
+// measurement only (CT_AMD_STAMPS=1): the 100 MHz wall clock at this point of the stream, appended to buf[1 + buf[0]++]
+__global__ void stamp_kernel(unsigned long long* buf, unsigned long long tag) {
+#ifndef CT_EMU
+    const unsigned long long i = buf[0];
+    if (i < 40000) { buf[1 + i] = (wall_clock64() << 4) | tag; buf[0] = i + 1; }
+#endif
+}
+
+__global__ void advance_state_kernel(int* state, int n_ctx) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         state[0] += 1;
         state[1] += 1;
+        state[4 + n_ctx] += 1;   // the token epoch behind the token ids (kernels_qa9.h: tags of the in-launch exchange)
     }
 }

@@ -598,7 +598,7 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
         __syncthreads();
         if (wave_live) {
             // sixteen per-wave partials: lane `sub` of every 16-lane row takes one, the row reduces (a serial loop of dependent LDS reads
-            // cost a microsecond here); the sum is order-free
+            // cost a microsecond here); the sum is regrouped (exact, hence order-free, within the dynamic range kernels_v9.h:pro9_total states)
             static_assert(NW == 16, "one partial per lane of a 16-lane row");
             double tot = L.red[sub];
             tot += lane_xor1(tot); tot += lane_xor2(tot); tot += lane_xor4(tot); tot += lane_xor8(tot);

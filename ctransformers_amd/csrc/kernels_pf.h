@@ -204,12 +204,10 @@ DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __res
             const u32x2 sc = sc_n;
             {   // the next group's scales BEFORE the ring refill (memory operations retire in order: requested behind the refill, waiting
                 // for them would drain the refill too)
-#if !(defined(PF_EXP) && PF_EXP == 2)   // experiment 2 (timing only): the ring is never refilled
                 const int g1 = (g + 1 < ng) ? g + 1 : ng - 1;
                 sc_n = ld_stream8(tile + (size_t)g1 * REC + doff);
                 const int gn = (g + PF < ng) ? g + PF : ng - 1;
                 qv[u] = ld_stream16(tile + (size_t)gn * REC + qoff);
-#endif
             }
             if (g >= ng) continue;
             // The block-scale products fp16(x.d) * fp16(y.d) of rows 4rg .. 4rg+3 x token m come out of the f32 matrix core (K = 1: a
@@ -230,20 +228,10 @@ DEV void pf_tile_q32m(const uint8_t* __restrict__ tile, int ng, const int* __res
                 // and products are live at a time (left alone hipcc interleaves all NTG groups and spills: 67 registers at NTG = 8)
                 if (NTG > 2 && (tg & 1) == 0 && tg > 0) sched_fence();
                 const int* img = img0 + 4 * tg * act_words;
-#if defined(PF_EXP) && PF_EXP == 1   // experiment (timing only): activations from registers
-                const u32x4 y = {(uint32_t)(g + tg), (uint32_t)l, 0x01020304u, (uint32_t)m}, yd = {0x3c000000u, 0x3c000000u, 0x3c000000u, 0x3c000000u};
-                (void)img; (void)nq;
-#else
                 const u32x4 y = *(const u32x4*)(img + (g * 8 + l) * 4);
                 const u32x4 yd = *(const u32x4*)(img + nq + g * 4);
-#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-#if defined(PF_EXP) && PF_EXP == 3   // experiment (timing only): no matrix instructions, no chain
-                    acc.a[tg][0] = pk_add_f32(acc.a[tg][0], pk2(bits_to_f32(y[i] ^ (uint32_t)w[i]), bits_to_f32(yd[i])));
-                    (void)xd; (void)magic; (void)zero4; (void)unmagic;
-                    continue;
-#endif
                     const i32x4 d = mfma_i8_4x4x4(w[i], (int)y[i], magic);
                     const f32x4 pr = mfma_f32_4x4x1(xd[i], bits_to_f32(yd[i]), zero4);
                     const F32x2 f01 = pk_add_f32(pk2(bits_to_f32((uint32_t)d[0]), bits_to_f32((uint32_t)d[1])), unmagic);
@@ -484,3 +472,4 @@ __global__ void advance_state_n_kernel(int* state, int n) {
         state[1] += n;
     }
 }
+

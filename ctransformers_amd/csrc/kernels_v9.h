@@ -53,6 +53,18 @@ template <int MAXK> struct SmemV9 {
     float RES[16][2 * kV9MaxUnits];   // [wave][2 * unit + row]
 };
 
+// The greedy pick, first half, at the end of the head launch (MatvecArgs::pick_ws; reference semantics: llama_sample_top_k with k = 1
+// keeps the first maximum, models/llms/llama.cc:53-84).  Every WAVE leaves the first maximum of ITS logits rows as one 64-bit key (kernels.h:
+// pick_key) in its own slot [workgroup][wave], with a plain store: no atomics, no barrier, nobody waits for anybody.  pick_cont_kernel
+// (kernels.h) reads the 16 x grid slots instead of the n_vocab logits.  (Round 5 measured the one-launch forms first — every workgroup
+// merging into one word with device-scope atomics, the last arriver finishing the job: + 6.8 us on the head launch for the atomics of 256
+// workgroups on one address, + 7 us for the embedding row behind them; and a workgroup-level key behind a barrier: + 2.2 us.
+// profiles/r05_head_fold.txt.)
+DEV void v9_pick_store(const MatvecArgs& a, int wv, int lane, float bv, int bi) {
+    pick_wave_reduce(bv, bi);
+    if (lane == 0) ((unsigned long long*)a.pick_ws)[(int)blockIdx.x * 16 + wv] = pick_key(bv, bi);
+}
+
 struct Lane9 {
     int c, l, row, slot;
     uint32_t o16, o8, o4, o_hdr, o_hdr5, o_sc6, o_d6;   // byte offsets inside a record
@@ -162,14 +174,9 @@ DEV int scaled_sum6(uint32_t lo, uint32_t hi, const int (&d)[8]) {
 // mv = -y.d * fp16(dmin).  `img`: the block's image in LDS (Img9).
 template <int TYPE>
 DEV void step9(const Rec9<TYPE>& R, const int* img, const Lane9& G, float& sv, float& dv, float& mv, float& pv) {
-#if defined(V9_EXP) && V9_EXP == 4   // experiment (timing only): the activation words come from registers, not from LDS
-    const u32x4 a_lo = {(uint32_t)G.a_w, (uint32_t)G.c, (uint32_t)G.l, 0x01020304u}, a_hi = {(uint32_t)G.row, 0x7f7f7f7fu, (uint32_t)G.o16, 0x11111111u};
-    const float yd = 0.001f;
-#else
     const u32x4 a_lo = *(const u32x4*)(img + G.a_w);        // vectors 0..3, elements 4l .. 4l+3
     const u32x4 a_hi = *(const u32x4*)(img + 32 + G.a_w);   // vectors 4..7
     const float yd = bits_to_f32((uint32_t)img[72]);
-#endif
     int a8[8], w8[8], d8[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a8[k] = (int)a_lo[k]; a8[4 + k] = (int)a_hi[k]; }
@@ -188,11 +195,7 @@ DEV void step9(const Rec9<TYPE>& R, const int* img, const Lane9& G, float& sv, f
         dot4x8(d8, w8, a8);
         const uint32_t W1 = R.hdr[1], W2 = R.hdr[2], W3 = R.hdr[3];
         sv = (float)scaled_sum45(W1, W3, d8);
-#if defined(V9_EXP) && V9_EXP == 4
-        int p = mul24(min45(W2, W3, G), G.a_w + 77);
-#else
         int p = mul24(min45(W2, W3, G), img[64 + G.l]);
-#endif
         // prod[t] = m[2t] * q8s[2t] + m[2t+1] * q8s[2t+1] in the lanes of EVEN l (one DPP add from lane + 4: l + 1); the odd-l lanes keep a
         // value nobody reads — their copy of chain t never reaches the row result (the end-of-unit sums below read even l only)
         p = lane_up4_add(p);
@@ -418,8 +421,11 @@ DEV double row16_sum(double v) { v += lane_xor1(v); v += lane_xor2(v); v += lane
 // the row's end).  Every 16-lane row reduces ITS block (four DPP steps, no cross-row traffic), one lane per row parks the block's sum,
 // the waves that own blocks meet at the arrival counter, then lane `sub` of every row takes the blocks sub, sub + 16, ... and the row
 // reduces again: every lane holds the total.  (Round 3's form — a 64-lane reduce through two ds_bpermute rounds, one slot per wave,
-// a serial loop of dependent LDS reads over the live waves — took 1600 cycles from "activations arrived" to "scale known".)  The sums
-// are order-free (squares / values of floats accumulated in double stay exact), so the grouping is free.
+// a serial loop of dependent LDS reads over the live waves — took 1600 cycles from "activations arrived" to "scale known".)  The
+// grouping differs from the reference's sequential ggml_float sum: the double sum of float squares / values is exact — hence
+// order-free — only while the addends of a row span less than ~2^26 in magnitude (53-bit significand against 48-bit squares of 4096+
+// addends); beyond that a regrouping can change the last bit of the double, which survives the rounding to float with probability
+// ~1e-9 per op (the one place where the reference's order is not reproduced).
 template <int MAXK, int NW, int ROUNDS>
 DEV double pro9_total(double* red, unsigned* cnt, unsigned target, const double (&sr)[ROUNDS], int nimg, int wv, int lane) {
     constexpr int RB = 4 * NW;
@@ -445,7 +451,7 @@ DEV double pro9_total(double* red, unsigned* cnt, unsigned target, const double 
 
 // Part 2: (RMSNorm | LayerNorm | nothing) -> Q8_K image in LDS.  Reference k_quants.c:1191-1226 with the build's fused
 // `iscale * x + 12582912.f`, RMSNorm ggml.c:10700-10716, LayerNorm ggml.c:10605-10654 (arithmetic of generation 7's prologue; the
-// double-precision sums are order-free).  Ends with a workgroup barrier.  `emb_out` (workgroup 0 only): the
+// double-precision sums are regrouped: see pro9_total).  Ends with a workgroup barrier.  `emb_out` (workgroup 0 only): the
 // normalised vector as f32 — the final-norm "embeddings" output of the ABI, produced by the lm_head launch (EMB instantiation).
 template <int MAXK, bool LN, bool EMB, bool EW, bool Q6IMG, int NW>
 DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restrict__ nw, const float* __restrict__ nbias, int K, int pro,
@@ -620,10 +626,29 @@ DEV void pro9_finish(Img9<MAXK>& L, Pro9<MAXK, EW, NW>& P, const float* __restri
 
 template <bool B> struct V9Req { static constexpr bool value = B; };
 
-// All units of one wave: items first, first + stride, ... < end of the launch's concatenated unit list.
-// base / g0: first record and first item of the wave's type group.
-template <int TYPE, int MAXK, bool TWO, int NS, class Pro>
-DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int g0, int first, int stride, int end, int lane, int wv,
+// Ring slots per wave (records in flight) of the three launch families (engine.cc:launch_matvec_kq has the measurements): single-type
+// K-quant launches, the two-type (QKV) launch, the 32-block types.
+#ifndef V9_NS_K
+#define V9_NS_K 3
+#endif
+#ifndef V9_NS_K2
+#define V9_NS_K2 4
+#endif
+#ifndef V9_NS_B
+#define V9_NS_B 4
+#endif
+
+// The units of one wave, as a list of items of the launch's concatenated unit list.
+// Items9: first, first + stride, ... < end — the plain launch form (a workgroup's waves interleave with every other workgroup's).
+struct Items9 {
+    int first, stride, end;
+    DEV int count() const { return first < end ? (end - first + stride - 1) / stride : 0; }
+    DEV int at(int k) const { return first + k * stride; }
+};
+// All units of one wave (`items`).  base / g0: first record and first item of the wave's type group.
+// XQ (fused QKV + attention launch): the RoPE / V epilogues also publish their fp16 results as tagged granules (a.xq: kernels_qa9.h).
+template <int TYPE, int MAXK, bool TWO, int NS, bool PICK, bool XQ = false, class Items, class Pro>
+DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int g0, Items& items, int lane, int wv,
                 Pro pro) {
     constexpr bool B32 = is_b32<TYPE>();
     constexpr bool mins = TYPE == GT_Q4_K || TYPE == GT_Q5_K;
@@ -632,10 +657,10 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     const size_t unit_bytes = (size_t)spu * REC;
     const bool trace = (a.dbg & 32) && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = (unsigned long long*)a.dbg_sink + 16 * wv;
-    const int nu = first < end ? (end - first + stride - 1) / stride : 0;   // units of this wave (host: <= kV9MaxUnits)
+    const int nu = items.count();   // units of this wave (host: <= kV9MaxUnits)
     // ---- prefetch cursor: the step whose record is requested next (stays on the last record once everything is requested) ----
-    int pf_it = first, pf_s = 0, pf_left = nu * spu;
-    const uint8_t* pf_ptr = base + (size_t)((nu > 0 ? first : g0) - g0) * unit_bytes;
+    int pf_k = 0, pf_s = 0, pf_left = nu * spu;
+    const uint8_t* pf_ptr = base + (size_t)((nu > 0 ? items.at(0) : g0) - g0) * unit_bytes;
     Rec9<TYPE> ring[NS];
     auto issue = [&](Rec9<TYPE>& slot, const Lane9& GG) __attribute__((always_inline)) {
         slot = rec9_load<TYPE>(pf_ptr, GG);   // unconditional, same instruction count every step: a conditional load in the loop makes hipcc wait vmcnt(0) per step
@@ -644,8 +669,8 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             pf_ptr += REC;
             if (++pf_s == spu) {
                 pf_s = 0;
-                pf_it += stride;
-                pf_ptr = base + (size_t)(pf_it - g0) * unit_bytes;
+                ++pf_k;
+                pf_ptr = base + (size_t)(items.at(pf_k) - g0) * unit_bytes;
             }
         }
     };
@@ -659,6 +684,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     if (nu == 0) {   // its own copy of the prologue: the path with requests below stays free of conditional loads
         unsigned long long ts0[4];
         pro(false, ts0);
+        if constexpr (PICK) { if (a.pick_ws && lane == 0) ((unsigned long long*)a.pick_ws)[(int)blockIdx.x * 16 + wv] = 0ull; }   // no rows: no candidate
         return;
     }
     {
@@ -682,7 +708,7 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     // ---- epilogue operands of lane l = (unit l >> 1, row l & 1), requested before the loop (its body must not contain a load
     //      besides the ring's); unconditional loads: operands a lane does not need are read from the activation vector ----
     const int p1 = a.njobs > 1 ? a.job[1].pair0 : 0x7fffffff, p2 = a.njobs > 2 ? a.job[2].pair0 : 0x7fffffff;
-    const int e_it = first + (lane >> 1) * stride;
+    const int e_it = items.at(lane >> 1);
     const bool e_valid = (lane >> 1) < nu;
     const int e_j = e_it >= p2 ? 2 : (e_it >= p1 ? 1 : 0);
     const int e_p0 = e_j == 2 ? p2 : (e_j == 1 ? p1 : 0);
@@ -705,7 +731,8 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     bool need_pos = false;
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) need_pos = need_pos || (jj < a.njobs && (a.job[jj].epi == EPI_ROPE_Q || a.job[jj].epi == EPI_ROPE_K || a.job[jj].epi == EPI_V));
-    const int pos = (need_pos && a.pos) ? sload_i32(a.pos) : 0;
+    int pos = (need_pos && a.pos && !XQ) ? sload_i32(a.pos) : 0;
+    if constexpr (XQ) { items.load_scalars(a); pos = items.cursor_pos(); }   // the position and the token epoch, one scalar-cache round trip (kernels_qa9.h)
     const bool want_res = need_res || (B32 && need_res_b);
     const float e_res = (want_res ? a.res : a.x)[want_res ? e_r : 0];
     float e_bias = 0.0f;   // the bias epilogues exist for the legacy (gpt2 / starcoder / mpt) graphs only: 32-block weight types
@@ -732,41 +759,14 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
             }
         } else {
             float sv, dv, mv, pv;
-#if defined(V9_EXP) && V9_EXP == 1   // experiment (timing only, wrong results): no block math — the record is consumed by four ALU instructions
-            if constexpr (TYPE == GT_Q4_K) {
-                sv = bits_to_f32((R.qs[0] ^ R.qs[1] ^ R.qs[2] ^ R.qs[3]) & 0x3fffffffu); dv = bits_to_f32((R.hdr[0] ^ R.hdr[1] ^ R.hdr[2] ^ R.hdr[3]) & 0x3fffffffu); mv = 0.f; pv = 0.f;
-            } else
-#endif
-#if defined(V9_EXP) && V9_EXP == 3   // experiment: the slot's next record is requested BEFORE the block math (the math runs on a copy)
-            if constexpr (decltype(REQ)::value && TYPE == GT_Q4_K && !TWO) {   // (the other instantiations spill with the copy)
-                Rec9<TYPE> cur = R;
-                issue(R, G);
-                step9<TYPE>(cur, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
-            } else
-#endif
             step9<TYPE>(R, img0 + s * (4 * kImg9Stride), G, sv, dv, mv, pv);
-#if defined(V9_EXP) && V9_EXP == 3
-            if constexpr (decltype(REQ)::value && !(TYPE == GT_Q4_K && !TWO)) {
-#else
             if constexpr (decltype(REQ)::value) {
-#endif
                 reg_fence(sv, dv, mv, pv);   // every use of the record is over before its registers are given to the next load
-#if defined(V9_EXP) && V9_EXP == 2   // experiment (timing only): no re-requests — the ring's first four records are computed on again and again
-                if constexpr (TYPE != GT_Q4_K)
-#endif
                 issue(R, G);
             }
-#if defined(V9_EXP) && V9_EXP == 1
-            if constexpr (TYPE == GT_Q4_K) { acc += sv * dv; } else
-#endif
             {
-#if defined(V9_EXP) && V9_EXP == 5   // experiment (timing only): no quad chain
-            acc = fmaf(dv, sv, acc);
-            if constexpr (mins) accm = fmaf(mv, pv, accm);
-#else
             acc = quad_chain4(acc, dv, sv);
             if constexpr (mins) accm = quad_chain4(accm, mv, pv);
-#endif
             }
         }
         if (s + 1 < spu) { ++s; return; }
@@ -804,11 +804,24 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     wave_lds_sync();
     const float res = SM.RES[wv][lane];
     const float other = lane_xor1(res);   // the unit's other row (RoPE partner / up projection)
+    if constexpr (PICK) {   // head launch: this wave's first maximum of the logits it is about to store (v9_pick_store)
+        if (a.pick_ws) {
+            const float bv = (e_own && e_epi == EPI_STORE && res > -INFINITY) ? res : -INFINITY;
+            v9_pick_store(a, wv, lane, bv, bv > -INFINITY ? e_r : 0x7fffffff);
+        }
+    }
     if (a.gateup) {   // fused matrix: row 0 of the pair = gate row u, row 1 = up row u
         if (e_own && (lane & 1) == 0) a.out[e_r] = f16_bits_to_f32(a.silu_tab[f32_to_f16_bits(res)]) * other;
         return;
     }
     if (!e_own) return;
+    if constexpr (XQ) {   // fused QKV + attention launch: the pair's two fp16 results as one tagged granule (kernels_qa9.h); a QKV unit is a whole
+                          // row pair, so both lanes of a pair are here
+        float val = res;
+        if (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K) val = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
+        const uint32_t hb = f32_to_f16_bits(val), ho = lane_xor1(hb);
+        if ((lane & 1) == 0) items.publish(lane >> 1, hb | (ho << 16));
+    }
     if (e_epi == EPI_ADD) {
         a.out[e_r] = res + e_res;
     } else if (e_epi == EPI_STORE) {
@@ -838,11 +851,19 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
 // sixteen waves spill; (8, 11 | 8 | 7) — eight waves with 256 registers and a whole unit in flight, for launches in which a wave owns
 // one unit of many records (ffn_down) — streams SLOWER (10.8 against 8.8 us per launch): a CU with eight streaming waves is served at
 // about 8.6 B/cycle whatever they have in flight, with sixteen at 10.7, with no block math at 12.
+// x0 / nw0 / K0 / pro0 repeat a.x, a.norm_w, a.K, a.pro as LEADING scalar arguments: the build preloads a kernel's first argument dwords
+// into scalar registers at wave launch (-mllvm -amdgpu-kernarg-preload-count, Makefile), so the activation requests — the first thing every
+// wave does — wait for no kernel-argument fetch (a by-value struct is not preloaded: its fields arrive by scalar loads, one or two cache-miss
+// round trips after wave start).
 template <int MAXK, int TA, int TB, bool LN, bool EMB = false, int NW = 16, int NS = 4>
-__global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) {
+__global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const float* x0, const float* nw0, int K0, int pro0, const MatvecArgs a) {
+    // (preloading the arenas and unit counts too — what the first weight requests need, 13 dwords — measured 0.3 % slower than these 6)
     CT_DYN_SMEM(smem_raw);
     SmemV9<MAXK>& SM = *reinterpret_cast<SmemV9<MAXK>*>(smem_raw);
-    if (a.dbg & 64) return;   // measurement only (CT_AMD_DBG=64): the launch and its boundary without the kernel's work
+    if (a.dbg & 64) {   // measurement only (CT_AMD_DBG=64): the launch and its boundary without the kernel's work (the cursor still advances)
+        if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }
+        return;
+    }
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     constexpr bool B32 = is_b32<TA>();
@@ -856,20 +877,20 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
     const int grid = (int)gridDim.x, bx = (int)blockIdx.x;
     if constexpr (B32) {
         Pro9b<MAXK> P;
-        pro9b_load<MAXK>(P, a.x, a.norm_w, a.K, a.pro);
+        pro9b_load<MAXK>(P, x0, nw0, K0, pro0);
         __syncthreads();
         const unsigned long long t0 = trace ? clock64_dev() : 0ull;
         auto pro = [&](bool, unsigned long long (&)[4]) __attribute__((always_inline)) {
             pro9b_finish<MAXK, TA == GT_Q4_0, EMB>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, a.emb_out);
         };
         static_assert(NW == 16, "32-block types: the 16-wave form");
-        v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * 16, a.n_pairs, lane, wv, pro);
+        { Items9 it{bx + grid * wv, grid * 16, a.n_pairs}; v9_run<TA, MAXK, false, NS, EMB>(a, SM, a.baseA, 0, it, lane, wv, pro); }
         if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
-        if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; }
+        if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }
         return;
     } else {
     Pro9<MAXK, TB == 0, NW> P;
-    pro9_load<MAXK, TB == 0, NW>(P, a.x, a.norm_w, a.K, a.pro, wv, lane);
+    pro9_load<MAXK, TB == 0, NW>(P, x0, nw0, K0, pro0, wv, lane);
     if (threadIdx.x == 0) SM.L.cnt = 0u;
     __syncthreads();
     const unsigned long long t0 = trace ? clock64_dev() : 0ull;
@@ -879,12 +900,13 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const MatvecArgs a) 
     if constexpr (TB != 0) {
         static_assert(NW == 16, "two-type launches: the 16-wave form");
         const int nwA = a.nwA;
-        if (wv < nwA) v9_run<TA, MAXK, true, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * nwA, a.n_groupA, lane, wv, pro);
-        else v9_run<TB, MAXK, true, NS>(a, SM, a.baseB, a.n_groupA, a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs, lane, wv, pro);
+        if (wv < nwA) { Items9 it{bx + grid * wv, grid * nwA, a.n_groupA}; v9_run<TA, MAXK, true, NS, false>(a, SM, a.baseA, 0, it, lane, wv, pro); }
+        else { Items9 it{a.n_groupA + bx + grid * (wv - nwA), grid * (16 - nwA), a.n_pairs}; v9_run<TB, MAXK, true, NS, false>(a, SM, a.baseB, a.n_groupA, it, lane, wv, pro); }
     } else {
-        v9_run<TA, MAXK, false, NS>(a, SM, a.baseA, 0, bx + grid * wv, grid * NW, a.n_pairs, lane, wv, pro);
+        { Items9 it{bx + grid * wv, grid * NW, a.n_pairs}; v9_run<TA, MAXK, false, NS, EMB>(a, SM, a.baseA, 0, it, lane, wv, pro); }
     }
     if (trace) { tr[0] = t0; tr[6] = clock64_dev(); }
-    if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; }   // no wave of this launch reads the cursor (host: kernels.h)
+    if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }   // no wave of this launch reads the cursor (host: kernels.h); [4 + n_ctx]: the token epoch (kernels_qa9.h)
     }
 }
+

@@ -17,6 +17,16 @@ typedef struct {
  * sites written to `out`, or -1. */
 int ctamd_profile_decode(ctransformers_llm* llm, int iters, ctamd_launch_stat* out, int max_out);
 double ctamd_weight_bytes(ctransformers_llm* llm);
+/* Device microseconds per decode step when `n` steps (2..100) are queued back to back with no host round trip between them (HIP events
+ * around the burst; continues at the position behind the last eval, token ids arbitrary): the gap to a measured eval + sample loop is
+ * what the host adds per token.  -1.0 on failure. */
+double ctamd_decode_burst(ctransformers_llm* llm, int n);
+/* Greedy chains: evals that were served by a token step the engine had queued ahead (the caller fed back the device-side greedy pick
+ * at the next position); *launched = steps queued ahead so far (launched - hits = guesses nobody asked for). */
+long long ctamd_spec_hits(ctransformers_llm* llm, long long* launched);
+/* measurement only (CT_AMD_STAMPS=1 at load): the (100 MHz wall clock << 4 | tag) stamps taken at the start (tag 1) and end (tag 2) of every
+ * token step since the last call; returns how many were copied. */
+int ctamd_read_stamps(ctransformers_llm* llm, unsigned long long* out, int max);
 /* In-kernel s_memtime stamps of workgroup 0 of the last launch of `site` (16 waves x 16 slots of uint64; slots: 0 entry,
  * 1 first loads issued, 2 prologue done, 3 round-0 block math done, 4 barrier passed, 5 chain+epilogue done, 6 exit). */
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n);
@@ -44,6 +54,8 @@ int ctamd_n_embd(ctransformers_llm* llm);
 long long ctamd_chunk_tokens(ctransformers_llm* llm);
 /* K-quant decode mat-vec launches (kernels_v9.h) issued by this process so far (eager launches and graph captures). */
 long long ctamd_kq_launches(void);
+/* fused QKV + attention launches (kernels_qa9.h) this handle has issued (eager launches and graph captures) */
+long long ctamd_qa_launches(ctransformers_llm* llm);
 /* prompt-chunk launches on the f16 matrix cores (kernels_pg.h) issued by this process so far */
 long long ctamd_pg_launches(void);
 /* In-process pipeline (CT_AMD_DEVICES, csrc/pipeline.h): number of stages of this handle (1 = single GPU) and the layer range of a
