@@ -190,6 +190,7 @@ DEV float mix_mulneg_f16hi(uint32_t h, float f) {
 struct u32x4 {
     uint32_t v[4];
     uint32_t operator[](int i) const { return v[i]; }
+    uint32_t& operator[](int i) { return v[i]; }
 };
 static inline u32x4 ld_stream16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }
 static inline u32x4 ld16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }

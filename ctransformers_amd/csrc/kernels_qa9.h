@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
             if (i >= need) gi[t] = -1;
         }
         const unsigned long long t0 = wall_ticks();
+        (void)t0;
         for (;;) {
             uint32_t dat[3], tg[3];
             bool ok = true;

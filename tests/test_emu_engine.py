@@ -48,6 +48,40 @@ def test_logits_bit_identical_to_reference(emu_lib, name, steps):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
 
 
+def qa_launches(m):
+    """Fused QKV + attention launches this handle has issued (kernels_qa9.h)."""
+    import ctypes
+    f = m._lib.ctamd_qa_launches
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
+@pytest.mark.parametrize("name", ["tiny-q4km", "tiny-q4km-refq", "tiny-q5km"])
+def test_fused_qkv_attention_launch(emu_lib, name, monkeypatch):
+    """Token steps of the llama graph with K-quant q / k / v take the fused QKV + attention launch (the test build runs its two phases as
+    two passes); with CT_AMD_FUSE_QA=0 the two launches of round 4.  Both: the golden logits, bit for bit, beyond the first 32-step of the
+    V*P dot (positions 11 .. 40: the new position in the leftover part and, at 32, as the last element of a 32-step)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CT_AMD_FUSE_QA", fuse)
+        m = open_emu(emu_lib, name)
+        m.eval(list(g["prompt"]))
+        seq = []
+        for i in range(30):
+            t = m.sample(top_k=1, repetition_penalty=1.0)
+            if i < len(g["greedy"]):
+                assert t == int(g["greedy"][i])
+            m.eval([t])
+            if i + 1 < len(g["logits"]):
+                assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
+            seq.append(t)
+        n = qa_launches(m)
+        assert (n > 0) == (fuse == "1"), n
+        outs.append((seq, m.logits.to_numpy().copy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_batch_structure(emu_lib):
     """One 45-token batch: bit-identical to the reference's one-batch result (the chunks-of-8 form of the same prompt is
     covered through the pipeline in tests/test_pipeline.py::test_gloo_pipeline_world2)."""

@@ -52,6 +52,9 @@ def test_greedy_chain_is_the_reference(ref, tmp_path, shape, ftype, n_prompt, n_
     hits, launched = spec_counts(m)
     assert hits >= min(n_decode, ctx - n_prompt) - 2, (hits, launched)   # every step but the first was served by a queued step
     assert launched - hits <= 1
+    f = m._lib.ctamd_qa_launches
+    f.restype, f.argtypes = ctypes.c_longlong, [ctypes.c_void_p]
+    assert (int(f(m._llm)) > 0) == (not shape.startswith("falcon") and ftype != "Q8_0")   # llama graph, K-quants: the fused QKV + attention launch
 
 
 def test_wrong_guesses_and_rollbacks(ref, tmp_path):

@@ -1,10 +1,9 @@
 B="timeout 600 python bench.py --no-cpu-baseline --no-other-configs"
-NP=$PWD/ctransformers_amd/lib_nopre/libctransformers.so
-P8=$PWD/ctransformers_amd/lib_pre8/libctransformers.so
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden" 2>&1 | tail -2
+BF=$PWD/ctransformers_amd/lib_barrier_first/libctransformers.so
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or bit_identical_to_reference_build" 2>&1 | tail -2
 for i in 1 2 3; do
-$B 2>/dev/null | head -c 120 | cut -c40-120; echo " fused, preload 13 dwords"
-CT_AMD_FUSE_QA=0 $B 2>/dev/null | head -c 120 | cut -c40-120; echo " plain, preload 13 dwords"
-CTRANSFORMERS_AMD_LIB=$P8 $B 2>/dev/null | head -c 120 | cut -c40-120; echo " fused, preload 6 dwords"
-CTRANSFORMERS_AMD_LIB=$NP $B 2>/dev/null | head -c 120 | cut -c40-120; echo " fused, no preload"
+$B 2>/dev/null | head -c 120 | cut -c40-120; echo " fused, barrier behind the first requests"
+CTRANSFORMERS_AMD_LIB=$BF $B 2>/dev/null | head -c 120 | cut -c40-120; echo " fused, barrier first"
+CT_AMD_FUSE_QA=0 $B 2>/dev/null | head -c 120 | cut -c40-120; echo " plain, barrier behind the first requests"
+CTRANSFORMERS_AMD_LIB=$BF CT_AMD_FUSE_QA=0 $B 2>/dev/null | head -c 120 | cut -c40-120; echo " plain, barrier first"
 done
