@@ -11,7 +11,7 @@ all layers on the GPU(s), 128-token prefill + 256-token decode, context 512.
 
 N > 1 (north_star: whole layers spread over the GPUs of the node, activations handed from GPU to GPU): the product path is the
 in-process pipeline of the library (ctransformers_amd/csrc/pipeline.cc, CT_AMD_DEVICES): ONE process drives a stage per GPU,
-hand-off by hipMemcpyPeerAsync over xGMI.  `python bench.py --gpus N` therefore brings the N stages up itself.  When the
+hand-off in-stream over xGMI (a kernel stores the rows into the next stage's peer-mapped buffer, the next stage's stream waits on a sequence word).  `python bench.py --gpus N` therefore brings the N stages up itself.  When the
 driver launches N ranks with torch.distributed.run, rank 0 drives the N stages and the other ranks take part in the barriers
 and the MAX reduction only (backend gloo: they own no GPU work); where a rank cannot see N devices the one-process-per-GPU
 RCCL pipeline of tools/rccl_pipeline.py runs instead.  Decode of one sequence is serial over the stages (strong
@@ -247,13 +247,29 @@ def main():
     n_gpus = max(1, a.gpus)
     devices = os.environ.get("CTAMD_BENCH_DEVICES", str(n_gpus) if n_gpus > 1 else "")   # e.g. "0,0": two stages on one GPU (1-GPU box)
     group = None
+    rccl_ranks = None
     if world > 1:
         if os.environ.get("CTAMD_FORCE_RCCL_PIPELINE") == "1" or (n_gpus > 1 and not os.environ.get("CTAMD_BENCH_DEVICES") and visible_gpus() < n_gpus):
             from tools import rccl_pipeline as pipeline   # one process per GPU, RCCL point-to-point hand-off
             return pipeline.bench_main(a, MODEL, SHAPE, FTYPE)
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # every rank joins ONE RCCL all-reduce on its own GPU (how many ranks RCCL saw is reported as config.rccl_ranks); the data path of
+        # the in-process pipeline itself needs no collective: rank 0 drives every stage, the hand-off is in-stream (csrc/pipeline.cc)
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if torch.cuda.is_available() and torch.cuda.device_count() > local:
+            try:
+                torch.cuda.set_device(local)
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+                one = torch.ones(1, device="cuda:%d" % local)
+                dist.all_reduce(one)
+                torch.cuda.synchronize()
+                rccl_ranks = int(one.item())
+                dist.destroy_process_group()
+            except Exception as e:   # noqa: BLE001 — reported, never fatal: the bench itself runs without RCCL
+                rccl_ranks = "failed: %s" % str(e)[:120]
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         group = dist
 
@@ -321,7 +337,14 @@ def main():
     wbytes = synth.weight_bytes_per_token(MODEL)
     hd = shape_dims()   # K + V rows of every layer, fp16, at the average position of the timed steps
     kv_avg = 2 * hd["n_layer"] * (N_PROMPT + a.warmup + steps / 2.0) * (hd["n_embd"] // hd["n_head"] * hd["n_head_kv"]) * 2
-    par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hipMemcpyPeerAsync hand-off)" % n_stages
+    import ctypes as _ct
+    llm._lib.ctamd_handoff.restype, llm._lib.ctamd_handoff.argtypes = _ct.c_char_p, [_ct.c_void_p]
+    handoff_mode = llm._lib.ctamd_handoff(llm._llm).decode()
+    HANDOFF = {"none": "none (one stage)",
+               "flag": "in-stream: a kernel on the producer's stream stores the [tokens][n_embd] f32 rows into the next stage's peer-mapped buffer (xGMI) and publishes a "
+                       "sequence number; the next stage's stream waits on it with hipStreamWaitValue32 (csrc/pipeline.cc) — no event, no SDMA copy, no RCCL call on this path",
+               "event": "hipMemcpyPeerAsync of the [tokens][n_embd] f32 rows + event record / stream wait (CT_AMD_HANDOFF=event: the round-4 form)"}[handoff_mode]
+    par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hand-off: %s)" % (n_stages, handoff_mode)
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,
                ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
                dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)",
@@ -332,8 +355,7 @@ def main():
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, a.warmup, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
                            devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached,
-                           handoff="none (one stage)" if n_stages == 1 else "hipMemcpyPeerAsync of the [tokens][n_embd] f32 rows, stage to stage "
-                                   "(in-process pipeline: ranks other than 0 only join the barriers — no RCCL traffic on this path)"),
+                           handoff=HANDOFF, rccl_ranks=rccl_ranks),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
                token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4),
                                    note="one sequence: the stages of a pipeline are serial, the denominator is ONE GPU's HBM"),

@@ -223,6 +223,7 @@ long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
 long long ctamd_qa_launches(ctransformers_llm* llm) { return llm->engine().qa_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
+const char* ctamd_handoff(ctransformers_llm* llm) { return llm->pipe.handoff(); }
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {
     if (stage < 0 || stage >= llm->pipe.n_stages() || llm->pipe.ranges().empty()) return -1;
     *layer_begin = llm->pipe.ranges()[stage].first;
@@ -246,6 +247,7 @@ long long ctamd_spec_hits(ctransformers_llm* llm, long long* launched) {
     return llm->engine().spec_hits();
 }
 int ctamd_read_stamps(ctransformers_llm* llm, unsigned long long* out, int max) { return llm->engine().read_stamps(out, max); }
+int ctamd_read_stamps_stage(ctransformers_llm* llm, int stage, unsigned long long* out, int max) { return llm->pipe.stage(stage).read_stamps(out, max); }
 double ctamd_weight_bytes(ctransformers_llm* llm) { return (double)llm->engine().weight_bytes(); }
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n) {
     std::string err;

@@ -1068,6 +1068,22 @@ bool Engine::req_wait(int n, int n_past, std::string& err) {
 #else
     HIP_OK(hipStreamSynchronize(stream_));
 #endif
+    if (h_scalars_[n_ctx_ + 14] != 0) {   // a sweep of the fused QKV + attention launch gave up (kernels_qa9.h): its workgroups were not all resident
+        h_scalars_[n_ctx_ + 14] = 0;
+        fuse_qa_ = false;                 // the handle goes on with the two-launch form (the graphs are captured again)
+#ifndef CT_EMU
+        if (graph_step_) { (void)hipGraphExecDestroy(graph_step_); graph_step_ = nullptr; }
+        if (graph_step_head_) { (void)hipGraphExecDestroy(graph_step_head_); graph_step_head_ = nullptr; }
+        for (int b = 0; b < 2; ++b) {
+            if (graph_cont_[b]) { (void)hipGraphExecDestroy(graph_cont_[b]); graph_cont_[b] = nullptr; }
+            if (ev_step_[b]) { (void)hipEventDestroy(ev_step_[b]); ev_step_[b] = nullptr; }
+        }
+        spec_inflight_ = false;
+#endif
+        err = "the fused QKV + attention launch timed out waiting for workgroups of its own grid (is the device shared?): this eval's results are "
+              "invalid; the handle continues with separate launches";
+        return false;
+    }
     have_logits_ = l1_ == hp_.n_layer;
     last_token_ = h_scalars_[4 + n - 1];
     last_pos_ = n_past + n - 1;

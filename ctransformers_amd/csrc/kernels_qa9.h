@@ -24,8 +24,10 @@
 //     double-precision leftovers) with 15 - (pv waves - 1) score waves instead of seven.
 // Co-residency: the sweep waits for granules other workgroups of the group produce, so all of a group's workgroups must be resident.  The
 // host launches this kernel only with grid <= CUs of the device at one 1024-thread workgroup per CU (engine.cc:qa_can), and the sweep gives
-// up after 20 ms (a device shared with another process): it raises MatvecArgs-independent QaArgs::err, the host reports the eval as
-// failed and stops using the fused form.
+// up after 20 ms: it raises QaArgs::err, the host reports the eval as failed and the handle goes on with the two-launch form.  Seen on
+// MI355X: ANY other resident wave breaks residency for the 127-register instantiations (four of their waves fill a SIMD's register
+// file) — e.g. the polling shader the runtime parks on the device for a hipStreamWaitValue32 of another stream (pipeline.cc: why stages
+// that share a device hand over by events).
 // Test builds (CT_EMU) run workgroups one after the other: the host launches phase 1 and phase 2 as two passes (QaArgs::phase).
 #pragma once
 #include "kernels_v9.h"
@@ -67,6 +69,8 @@ DEV void st_granule(uint32_t* p, uint32_t data, uint32_t tag) {
     const unsigned long long v = ((unsigned long long)tag << 32) | data;
     __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
 }
+// (Polling with a memory-side atomic instead — fetch_or with 0 — was measured: no different in outcome, and the fused launch lost its
+// whole gain over two launches: 734 against 732 tok/s.)
 DEV void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) {
     const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     data = (uint32_t)v;

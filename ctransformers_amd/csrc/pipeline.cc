@@ -6,10 +6,32 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <thread>
+#include <string.h>
 
 #include "gguf_reader.h"
 
 namespace ctamd {
+
+#ifndef CT_EMU
+// The hand-off of rows [row0, row0 + n / E) from a stage to its successor: `src` is the producer's own stage buffer, `dst` the consumer's
+// (peer-mapped: the stores travel over xGMI).  Every thread fences its stores at system scope; the last workgroup to arrive advances the
+// boundary's sequence number and publishes it in the consumer's signal word, which the consumer's stream is waiting on.
+__global__ void __launch_bounds__(256) handoff_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4, unsigned* flag, unsigned* prod) {
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n4; i += (int)(gridDim.x * blockDim.x)) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!flag) return;   // (hand-off form "event": the copy only; an event behind this kernel orders the next stage)
+        const unsigned old = __hip_atomic_fetch_add(prod, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(prod, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seq = prod[1] + 1u;   // (only ever touched here, one launch at a time: the stream serialises them)
+            prod[1] = seq;
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
 
 std::vector<std::pair<int, int>> partition_layers(const std::vector<double>& layer_bytes, double head_bytes, int n_stages) {
     const int L = (int)layer_bytes.size();
@@ -83,6 +105,16 @@ Pipeline::~Pipeline() {
         if (s < dev_.size()) (void)hipSetDevice(dev_[s]);
         for (hipEvent_t e : ev_[s]) (void)hipEventDestroy(e);
     }
+#ifndef CT_EMU
+    for (size_t s = 0; s < st_.size(); ++s) {   // the stages' streams may still reference the words: drain first
+        (void)hipSetDevice(dev_[s]);
+        (void)hipStreamSynchronize(st_[s]->stream());
+    }
+    for (size_t s = 0; s < flag_.size(); ++s) {
+        if (flag_[s]) { (void)hipSetDevice(dev_[s + 1]); (void)hipFree(flag_[s]); }
+        if (prod_[s]) { (void)hipSetDevice(dev_[s]); (void)hipFree(prod_[s]); }
+    }
+#endif
 }
 
 bool Pipeline::load_gpt2(const std::string& path, std::string& err, bool starcoder) {
@@ -190,6 +222,44 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
         }
     }
     ev_.assign(dev_.size(), {});
+#ifndef CT_EMU
+    // hand-off words of the in-stream form (pipeline.h): signal memory for the consumer's stream wait, on the consumer's device; the
+    // producer needs the direct peer mapping (a stage pair without it keeps the copy + event form, and so does CT_AMD_HANDOFF=event)
+    {
+        // Default: "flag" where every stage has its own device; stages that SHARE a device (the 1-GPU test form "0,0") hand over by events: the
+        // runtime serves a pending hipStreamWaitValue32 with a polling wave on that device, which takes a CU away from the producer stage's
+        // one-workgroup-per-CU kernels (+1.2 us per launch, measured) and breaks the residency of its fused QKV + attention launch.
+        // CT_AMD_HANDOFF=flag / event forces either.
+        const char* hm = getenv("CT_AMD_HANDOFF");
+        bool distinct = true;
+        for (size_t s = 0; s < dev_.size(); ++s)
+            for (size_t t = s + 1; t < dev_.size(); ++t) distinct = distinct && dev_[s] != dev_[t];
+        flag_mode_ = hm && *hm ? !strcmp(hm, "flag") : distinct;
+        for (size_t s = 0; flag_mode_ && s + 1 < dev_.size(); ++s) {
+            if (dev_[s] == dev_[s + 1]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) != hipSuccess || !can) flag_mode_ = false;
+        }
+        direct_.assign(dev_.size() - 1, 0);
+        for (size_t s = 0; s + 1 < dev_.size(); ++s) {
+            int can = dev_[s] == dev_[s + 1] ? 1 : 0;
+            if (!can && hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) != hipSuccess) can = 0;
+            direct_[s] = can && (st_[0]->hparams().n_embd % 4 == 0) ? 1 : 0;
+        }
+        flag_.assign(dev_.size() - 1, nullptr);
+        prod_.assign(dev_.size() - 1, nullptr);
+        issued_.assign(dev_.size() - 1, 0u);
+        for (size_t s = 0; flag_mode_ && s + 1 < dev_.size(); ++s) {
+            (void)hipSetDevice(dev_[s + 1]);
+            if (hipExtMallocWithFlags((void**)&flag_[s], 8, hipMallocSignalMemory) != hipSuccess) { flag_[s] = nullptr; flag_mode_ = false; (void)hipGetLastError(); break; }
+            (void)hipMemset(flag_[s], 0, 8);
+            (void)hipSetDevice(dev_[s]);
+            if (hipMalloc((void**)&prod_[s], 256) != hipSuccess) { prod_[s] = nullptr; flag_mode_ = false; (void)hipGetLastError(); break; }
+            (void)hipMemset(prod_[s], 0, 256);
+        }
+        for (size_t s = 0; s < dev_.size(); ++s) { (void)hipSetDevice(dev_[s]); (void)hipDeviceSynchronize(); }
+    }
+#endif
     // Tokens per micro-batch of a prompt.  A (stage, micro-batch) unit of a 7B costs 1.96 / 2.6 / 4.0 ms x 2 / stages at 32 / 64 / 128
     // tokens (bench.py --gpus 2 on one GPU, `tok_s_by_micro_batch`: fewer passes over the weights with larger ones), a 128-token
     // prompt takes (micro-batches + stages - 1) units: 64 tokens win up to four stages, 32 beyond.  CT_AMD_PP_MB overrides.
@@ -214,6 +284,18 @@ bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int 
     if (eval_stages(tokens, n, n_past, err, batch)) return true;
     // a host-side failure in the middle of a request: the stages already fed keep running and writing into the next stage's hand-off
     // buffer and KV cache — drain every stream before the caller sees the error, so that a retry does not overlap stale work
+#ifndef CT_EMU
+    if (flag_mode_) {   // a stage may be waiting for a hand-off that was never queued: release it (the request is lost anyway), keep the sequence in step
+        for (size_t s = 0; s + 1 < st_.size(); ++s) {
+            (void)hipSetDevice(dev_[s]);
+            (void)hipStreamSynchronize(st_[s]->stream());
+            const unsigned v[2] = {0u, issued_[s]};
+            (void)hipMemcpy(prod_[s], v, 8, hipMemcpyHostToDevice);
+            (void)hipSetDevice(dev_[s + 1]);
+            (void)hipMemcpy(flag_[s], &issued_[s], 4, hipMemcpyHostToDevice);
+        }
+    }
+#endif
     for (size_t s = 0; s < st_.size(); ++s) {
         (void)hipSetDevice(dev_[s]);
         (void)hipStreamSynchronize(st_[s]->stream());
@@ -223,12 +305,11 @@ bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int 
 
 bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& err, int batch) {
     const int S = (int)st_.size(), E = st_[0]->hparams().n_embd;
-    for (int s = 0; s < S; ++s)
-        if (!st_[s]->req_begin(tokens, n, n_past, batch, err)) return false;
+    // (each stage's cursor + token ids go out right before its first range: stage 0 starts on the GPU while the host is still queueing the others)
     // micro-batches: every stage gets its ranges in order; stage s + 1's stream waits for the event behind stage s's copy
     const int mb = n == 1 ? 1 : std::max(2, micro_batch_);
     const int n_mb = (n + mb - 1) / mb;
-    for (int s = 0; s + 1 < S; ++s) {
+    for (int s = 0; s + 1 < S && !flag_mode_; ++s) {
         PIPE_OK(hipSetDevice(dev_[s]));
         while ((int)ev_[s].size() < n_mb) {
             hipEvent_t e;
@@ -246,10 +327,34 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
             const auto t_issue = std::chrono::steady_clock::now();
             struct Acc { double& d; std::chrono::steady_clock::time_point t0; ~Acc() { d += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } acc{issue_us_[s], t_issue};
             PIPE_OK(hipSetDevice(dev_[s]));
+            if (k == 0 && !st.req_begin(tokens, n, n_past, batch, err)) return false;
+#ifndef CT_EMU
+            if (flag_mode_) {
+                // stage s's stream waits (its command processor polls) for the sequence number the (k + 1)-th ... hand-off of boundary s - 1 publishes
+                if (s > 0) PIPE_OK(hipStreamWaitValue32(st.stream(), flag_[s - 1], issued_[s - 1], hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if (!st.req_range(c0, nt, last_mb, err)) return false;
+                if (s + 1 < S) {
+                    const size_t off = (size_t)c0 * E;
+                    const int n4 = nt * E / 4;
+                    const int gx = std::max(1, std::min(256, (n4 + 255) / 256));
+                    ++issued_[s];
+                    hipLaunchKernelGGL(handoff_rows_kernel, dim3((unsigned)gx), dim3(256), 0, st.stream(), (const float4*)(st.xio() + off),
+                                       (float4*)(st_[s + 1]->xio() + off), n4, flag_[s], prod_[s]);
+                }
+                continue;
+            }
+#endif
             if (s > 0) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));
             if (!st.req_range(c0, nt, last_mb, err)) return false;
             if (s + 1 < S) {
                 const size_t off = (size_t)c0 * E;
+#ifndef CT_EMU
+                if (direct_[s]) {   // the rows go straight into the next stage's buffer from a kernel (no copy engine: ~3 us less per hop)
+                    const int n4 = nt * E / 4;
+                    hipLaunchKernelGGL(handoff_rows_kernel, dim3((unsigned)std::max(1, std::min(256, (n4 + 255) / 256))), dim3(256), 0, st.stream(),
+                                       (const float4*)(st.xio() + off), (float4*)(st_[s + 1]->xio() + off), n4, (unsigned*)nullptr, (unsigned*)nullptr);
+                } else
+#endif
                 PIPE_OK(hipMemcpyPeerAsync(st_[s + 1]->xio() + off, dev_[s + 1], st.xio() + off, dev_[s], (size_t)nt * E * sizeof(float), st.stream()));
                 PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
             }

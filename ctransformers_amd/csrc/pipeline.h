@@ -1,13 +1,17 @@
 // In-process layer pipeline over the GPUs of one node: what `ctransformers_llm_create` builds when
 // CT_AMD_DEVICES names more than one device.  One Engine stage per device, each owning a contiguous block of layers (weights +
 // that block's KV cache resident on its GPU; token embedding on stage 0, final norm + lm_head on the last stage).  The only
-// exchange is the [n_tokens][n_embd] f32 residual stream from stage s to stage s + 1: a peer copy over the direct xGMI link
-// (hipMemcpyPeerAsync) on the producer's stream, ordered for the consumer by an event — no host round trip, no collective, no
-// torch.  A prompt is cut into micro-batches so that stage s works on micro-batch c while stage s - 1 already works on c + 1;
+// exchange is the [n_tokens][n_embd] f32 residual stream from stage s to stage s + 1, IN-STREAM (round 5): a kernel on the producer's
+// stream stores the rows straight into the consumer's peer-mapped hand-off buffer over the direct xGMI link and publishes a sequence
+// number behind them (system-scope release); the consumer's STREAM waits for that number with hipStreamWaitValue32 — its command
+// processor polls a word in its own HBM, no CU is occupied, no event, no SDMA copy (5 us per hop against 17 for the peer copy + event
+// pair of round 4: tools/experiments/handoff_probe.cpp, profiles/r05_handoff_probe.txt; CT_AMD_HANDOFF=event keeps the old form for
+// A/B).  No host round trip, no collective, no torch.  A prompt is cut into micro-batches so that stage s works on micro-batch c while stage s - 1 already works on c + 1;
 // results do not depend on the cut (the cursor carries the reference's batch structure, c_api.cc).
 // What the reference does instead: `gpu_layers` / `tensor_split` split tensors inside one process with peer copies per mat-mul
 // (reference models/ggml/llama.cpp:1913-1919, :1938-2070; ggml-cuda.cu:5798-6119).
 #pragma once
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -38,6 +42,7 @@ class Pipeline {
     bool coalesces_batches() const { return st_.front()->coalesces_batches() || st_.size() > 1; }
     Engine& first() { return *st_.front(); }
     Engine& last() { return *st_.back(); }
+    Engine& stage(int s) { return *st_[(size_t)std::max(0, std::min(s, (int)st_.size() - 1))]; }
     int n_stages() const { return (int)st_.size(); }
     const std::vector<std::pair<int, int>>& ranges() const { return ranges_; }
     // host time (us) the ONE issuing thread has spent queueing stage s's launches, waits and copies so far, and the evals counted
@@ -51,7 +56,17 @@ class Pipeline {
     std::vector<std::unique_ptr<Engine>> st_;
     std::vector<int> dev_;
     std::vector<std::pair<int, int>> ranges_;
-    std::vector<std::vector<hipEvent_t>> ev_;   // ev_[s][k]: micro-batch k's rows have left stage s
+    std::vector<std::vector<hipEvent_t>> ev_;   // ev_[s][k]: micro-batch k's rows have left stage s (hand-off form "event")
+    // hand-off form "flag": per boundary s -> s + 1 a sequence word in signal memory on the CONSUMER's device, the producer's arrival counter
+    // + running sequence number on the producer's device, and the number of hand-offs issued so far (what the consumer's stream waits for)
+    std::vector<unsigned*> flag_;
+    std::vector<unsigned*> prod_;
+    std::vector<unsigned> issued_;
+    std::vector<char> direct_;   // boundary s -> s + 1: the producer can store into the consumer's buffer (same device or peer access)
+    bool flag_mode_ = false;
+   public:
+    const char* handoff() const { return st_.size() < 2 ? "none" : (flag_mode_ ? "flag" : "event"); }
+   private:
     int micro_batch_ = 32;
     std::vector<double> issue_us_;
     long long issue_evals_ = 0;

@@ -27,6 +27,7 @@ long long ctamd_spec_hits(ctransformers_llm* llm, long long* launched);
 /* measurement only (CT_AMD_STAMPS=1 at load): the (100 MHz wall clock << 4 | tag) stamps taken at the start (tag 1) and end (tag 2) of every
  * token step since the last call; returns how many were copied. */
 int ctamd_read_stamps(ctransformers_llm* llm, unsigned long long* out, int max);
+int ctamd_read_stamps_stage(ctransformers_llm* llm, int stage, unsigned long long* out, int max);   /* the same for one stage of a pipeline */
 /* In-kernel s_memtime stamps of workgroup 0 of the last launch of `site` (16 waves x 16 slots of uint64; slots: 0 entry,
  * 1 first loads issued, 2 prologue done, 3 round-0 block math done, 4 barrier passed, 5 chain+epilogue done, 6 exit). */
 int ctamd_trace_site(ctransformers_llm* llm, const char* site, unsigned long long* out, int n);
@@ -62,6 +63,9 @@ long long ctamd_pg_launches(void);
    stage (returns -1 for a single-stage handle). */
 int ctamd_n_stages(ctransformers_llm* llm);
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end);
+/* the hand-off between the stages of this handle: "none" (one stage), "flag" (rows stored into the peer-mapped buffer by a kernel, the next
+   stage's stream waits on a sequence word: csrc/pipeline.h) or "event" (hipMemcpyPeerAsync + event, CT_AMD_HANDOFF=event) */
+const char* ctamd_handoff(ctransformers_llm* llm);
 /* Host microseconds the one issuing thread of the in-process pipeline has spent queueing stage `stage`'s launches, event waits and peer
    copies since the handle was created; *evals = the multi-stage evals counted (0.0 for a single-stage handle). */
 double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals);

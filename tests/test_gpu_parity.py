@@ -589,17 +589,35 @@ def _stage_count(m):
     return int(f(m._llm))
 
 
+def _handoff(m):
+    import ctypes
+    m._lib.ctamd_handoff.restype, m._lib.ctamd_handoff.argtypes = ctypes.c_char_p, [ctypes.c_void_p]
+    return m._lib.ctamd_handoff(m._llm).decode()
+
+
+def _force_handoff(monkeypatch, form):
+    """Stages that share a device hand over by events (the default there); "flag" — the form stages on distinct devices take: rows stored
+    into the next stage's buffer by a kernel, the next stage's stream waiting on a sequence word — is forced for the test, with the
+    two-launch decode form (the runtime serves the stream wait with a polling wave on the device, which the fused launch's residency
+    does not survive: csrc/pipeline.cc)."""
+    monkeypatch.setenv("CT_AMD_HANDOFF", form)
+    if form == "flag":
+        monkeypatch.setenv("CT_AMD_FUSE_QA", "0")
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["event", "flag"])
 @pytest.mark.parametrize("name", ["tiny-q4km", "falcon-tiny-q4km"])
-def test_inprocess_pipeline_on_gpu(name, monkeypatch):
+def test_inprocess_pipeline_on_gpu(name, form, monkeypatch):
     """The in-process pipeline of the library (csrc/pipeline.cc) on hardware: CT_AMD_DEVICES=0,0 puts two stages on the one GPU of
-    the test box — their own streams, the peer-copy hand-off and the event ordering are the N-GPU code path.  Goldens of the
+    the test box — their own streams and both hand-off forms are the N-GPU code path.  Goldens of the
     reference build: prompt (reference batches 8 + 3, micro-batches of 4), greedy steps."""
     monkeypatch.setenv("CT_AMD_DEVICES", "0,0")
     monkeypatch.setenv("CT_AMD_PP_MB", "4")
+    _force_handoff(monkeypatch, form)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_hip(os.path.join(GOLDEN, name + ".gguf"))
-    assert _stage_count(m) == 2
+    assert _stage_count(m) == 2 and _handoff(m) == form
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
     assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
@@ -610,11 +628,13 @@ def test_inprocess_pipeline_on_gpu(name, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_inprocess_pipeline_7b_widths_vs_reference(ref, tmp_path, monkeypatch):
+@pytest.mark.parametrize("form", ["event", "flag"])
+def test_inprocess_pipeline_7b_widths_vs_reference(ref, tmp_path, monkeypatch, form):
     """Two real-width 7B layers, one per stage: 40-token prompt in reference batches of 8 (micro-batches of 16) + greedy steps against
-    the reference build on the same file."""
+    the reference build on the same file, with either hand-off form."""
     monkeypatch.setenv("CT_AMD_DEVICES", "0,0")
     monkeypatch.setenv("CT_AMD_PP_MB", "16")
+    _force_handoff(monkeypatch, form)
     p = str(tmp_path / "m.gguf")
     hp = synth.write_llama_gguf(p, "llama-7b-2l", "Q4_K_M", seed=5)
     cfg = dict(context_length=128, batch_size=8, threads=8)

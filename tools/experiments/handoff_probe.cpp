@@ -40,6 +40,24 @@ __global__ void produce(const float* __restrict__ src, float* __restrict__ dst, 
         }
     }
 }
+// form C: the flag word and the arrival counter live in different allocations
+__global__ void produce2(const float* __restrict__ src, float* __restrict__ dst, int n, unsigned* flag, unsigned* cnt, unsigned seq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)g_spin_ticks) {}
+    }
+    if (i < n) __builtin_nontemporal_store(src[i] + 1.0f, dst + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 __global__ void consume(const float* __restrict__ src, float* __restrict__ dst, int n, const unsigned* flag, unsigned seq) {
     if (flag) {
         if (threadIdx.x == 0) {
@@ -66,9 +84,17 @@ int main(int argc, char** argv) {
     CK(hipSetDevice(dB)); CK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
     CK(hipMalloc(&xb, n * 4)); CK(hipMalloc(&xb2, n * 4));
     // the flag lives on the consumer's device, in signal memory (what hipStreamWaitValue32 requires)
-    hipError_t ef = hipExtMallocWithFlags((void**)&flag, 256, hipMallocSignalMemory);
-    if (ef != hipSuccess) { printf("hipMallocSignalMemory: %s -> plain hipMalloc\n", hipGetErrorString(ef)); CK(hipMalloc((void**)&flag, 256)); }
-    CK(hipMemset(flag, 0, 256));
+    // hipStreamWaitValue32 wants signal memory: 8 bytes per allocation.  Two flags (one per direction) + the arrival counters of form C
+    // in ordinary memory behind them.
+    unsigned* sig[2] = {nullptr, nullptr};
+    hipError_t ef = hipSuccess;
+    for (int d = 0; d < 2; ++d) {
+        hipError_t e = hipExtMallocWithFlags((void**)&sig[d], 8, hipMallocSignalMemory);
+        if (e != hipSuccess) { ef = e; printf("hipMallocSignalMemory(8): %s\n", hipGetErrorString(e)); }
+    }
+    CK(hipMalloc((void**)&flag, 512));
+    CK(hipMemset(flag, 0, 512));
+    if (ef == hipSuccess) { CK(hipMemset(sig[0], 0, 8)); CK(hipMemset(sig[1], 0, 8)); }
     if (dA != dB) {
         int can = 0;
         CK(hipDeviceCanAccessPeer(&can, dA, dB));
@@ -111,15 +137,15 @@ int main(int argc, char** argv) {
                         CK(hipStreamWaitEvent(sc, e, 0));
                         consume<<<g, b, 0, sc>>>(dst, cdst, n, nullptr, 0);
                     } else if (form == 'C') {
-                        produce<<<g, b, 0, sp>>>(src, dst, n, flag + 32 * dir, seq);
+                        produce2<<<g, b, 0, sp>>>(src, dst, n, sig[dir], flag + 32 * dir, seq);
                         CK(hipSetDevice(dc));
-                        CK(hipStreamWaitValue32(sc, flag + 32 * dir, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                        CK(hipStreamWaitValue32(sc, sig[dir], seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                         consume<<<g, b, 0, sc>>>(dst, cdst, n, nullptr, 0);
                     } else if (form == 'D') {
                         produce<<<g, b, 0, sp>>>(src, dst, n, nullptr, 0);
-                        CK(hipStreamWriteValue32(sp, flag + 32 * dir, seq, 0));
+                        CK(hipStreamWriteValue32(sp, sig[dir], seq, 0));
                         CK(hipSetDevice(dc));
-                        CK(hipStreamWaitValue32(sc, flag + 32 * dir, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                        CK(hipStreamWaitValue32(sc, sig[dir], seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                         consume<<<g, b, 0, sc>>>(dst, cdst, n, nullptr, 0);
                     } else {
                         produce<<<g, b, 0, sp>>>(src, dst, n, flag + 32 * dir, seq);
