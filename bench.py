@@ -46,12 +46,25 @@ from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
 N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
-MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
+def _ref_quantizer():
+    """BASELINE.md 3 quantizes with ggml_quantize_chunk: where the reference build travelled with the snapshot (oracle/_ref exports it) the
+    block pools of the synthetic files come from it; else from this repo's numpy quantizers (tools/synth.py)."""
+    try:
+        from oracle import ref
+        return "reference" if ref.available() else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+QUANTIZER = _ref_quantizer()
+_QTAG = "refq" if QUANTIZER else "r2"
+MODEL = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_%s.gguf" % _QTAG)
 SHAPE, FTYPE = os.environ.get("CTAMD_BENCH_SHAPE", "llama-2-7b"), os.environ.get("CTAMD_BENCH_FTYPE", "Q4_K_M")
-GEN_VERSION = "synth-r2:%s:%s:seed1234" % (SHAPE, FTYPE)
+GEN_VERSION = "synth-%s:%s:%s:seed1234" % (_QTAG, SHAPE, FTYPE)
 CONFIG = 2
-CONFIGS = {2: ("llama-2-7b", "Q4_K_M", "/tmp/ctamd_llama2_7b_q4km_r2.gguf"), 3: ("llama-2-7b", "Q8_0", "/tmp/ctamd_llama2_7b_q80_r2.gguf"),
-           4: ("falcon-40b", "Q4_K_M", "/tmp/ctamd_falcon_40b_q4km_r2.gguf"), 5: ("llama-2-70b", "Q5_K_M", "/tmp/ctamd_llama2_70b_q5km_r2.gguf")}
+CONFIGS = {2: ("llama-2-7b", "Q4_K_M", "/tmp/ctamd_llama2_7b_q4km_%s.gguf" % _QTAG), 3: ("llama-2-7b", "Q8_0", "/tmp/ctamd_llama2_7b_q80_%s.gguf" % _QTAG),
+           4: ("falcon-40b", "Q4_K_M", "/tmp/ctamd_falcon_40b_q4km_%s.gguf" % _QTAG), 5: ("llama-2-70b", "Q5_K_M", "/tmp/ctamd_llama2_70b_q5km_%s.gguf" % _QTAG)}
+N_PROMPT_2K, N_CTX_2K, N_DECODE_2K = 2048, 2304, 32
 
 
 def shape_dims():
@@ -84,9 +97,9 @@ def ensure_model():
             pass
     tmp = MODEL + ".tmp%d" % os.getpid()
     if SHAPE.startswith("falcon"):
-        synth.write_falcon_gguf(tmp, SHAPE, FTYPE, seed=1234)
+        synth.write_falcon_gguf(tmp, SHAPE, FTYPE, seed=1234, quantizer=QUANTIZER)
     else:
-        synth.write_llama_gguf(tmp, SHAPE, FTYPE, seed=1234)
+        synth.write_llama_gguf(tmp, SHAPE, FTYPE, seed=1234, quantizer=QUANTIZER)
     os.replace(tmp, MODEL)
     json.dump(_fingerprint(MODEL), open(stamp, "w"))
     return False
@@ -188,7 +201,8 @@ def other_configs():
             res.append(dict(config=cfg, note="did not finish within %d s" % limit))
             continue
         res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
-                        prefill_tok_s=d["prefill_tok_s"], load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
+                        prefill_tok_s=d["prefill_tok_s"], prefill_2k_tok_s=d.get("prefill_2k_tok_s"), decode_tok_s_at_2k=d.get("decode_tok_s_at_2k"),
+                        load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
                         bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
         if (cfg in (4, 5) or big == "1") and os.environ.get("CTAMD_BENCH_KEEP_BIG") != "1":   # 7 / 25 / 49 GB of scratch disk: one file at a time, none left behind
             for f in (CONFIGS[cfg][2], CONFIGS[cfg][2] + ".stamp.json"):
@@ -230,6 +244,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 3, 4 and 5")
+    ap.add_argument("--no-long-context", action="store_true", help="skip the 2048-token prompt / decode-at-2k measurement")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2: the headline)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
@@ -238,7 +253,7 @@ def main():
     CONFIG = a.config
     if a.config != 2:
         SHAPE, FTYPE, MODEL = CONFIGS[a.config]
-        GEN_VERSION = "synth-r2:%s:%s:seed1234" % (SHAPE, FTYPE)
+        GEN_VERSION = "synth-%s:%s:%s:seed1234" % (_QTAG, SHAPE, FTYPE)
     if a.cpu_worker is not None:
         _cpu_worker(a.cpu_worker, a.cpu_vocab)
         return 0
@@ -348,8 +363,10 @@ def main():
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,
                ms_per_step=round(dt / steps * 1e3, 4), higher_is_better=True, scaling="weak" if n_gpus == 1 else "strong", vs_baseline=None,
                dtype="int8 dot products, f32 accumulation chain (bit-identical to the reference CPU build)",
-               data="synthetic (random-init weights at the real shapes and tensor-type mix; quantized blocks drawn from a pool of 8192 per type "
-                    "produced by this repo's numpy quantizer, tools/synth.py — not ggml_quantize_chunk; synthetic prompt tokens)",
+               data=("synthetic (random-init weights at the real shapes and tensor-type mix; quantized blocks drawn from a pool of 8192 per type "
+                     + ("produced by the reference's own ggml_quantize_chunk (oracle/_ref, BASELINE.md 3)" if QUANTIZER else
+                        "produced by this repo's numpy quantizer, tools/synth.py — oracle/_ref did not travel, so not ggml_quantize_chunk")
+                     + "; synthetic prompt tokens)"),
                config=dict(workload=("Llama-2-7B GGUF Q4_K_M, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps (positions %d..%d; BASELINE "
                                      "configs[1] decodes 256: --steps 256 --warmup 0), ctx 512" % (n_gpus, a.warmup, steps, N_PROMPT + a.warmup, N_PROMPT + a.warmup + steps - 1))
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, a.warmup, steps),
@@ -369,6 +386,36 @@ def main():
                                   else "matvec_pfm_kernel<GU> (lane sums on v_mfma_i32_4x4x4_16b_i8 with the 1.5*2^23 addend, packed f32 chain, Q8_0 activation images)") + ", one hipGraph per chunk shape",
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
+    out["prefill"]["frac"] = round(out["prefill"]["tops"] / 2500.0, 4) if out["prefill"]["tops"] else None
+    out["prefill"]["frac_note"] = "tops / dense f16 MFMA peak; MFMA-busy counters of the chunk kernels: profiles/r05_prefill_mfma_pmc.txt"
+    if n_gpus == 1 and not a.no_long_context:
+        # BASELINE configs[4] says "2k-ctx prefill": a 2048-token prompt at context 2304 (batch_size 128, as the 128-token prompt), then 32
+        # greedy steps at positions 2048.. — for every config, on a fresh handle (the context length is fixed at load)
+        del llm
+        llm = None
+        h = LLM(MODEL, config=Config(context_length=N_CTX_2K, batch_size=N_PROMPT, gpu_layers=1000))
+        p2k = synth.prompt_tokens(N_PROMPT_2K, n_vocab)
+        h.eval(p2k)                 # cold + graph capture of the chunk shapes beyond position 128
+        h._context = []
+        h.eval(p2k)
+        h._context = []
+        t0 = time.perf_counter()
+        h.eval(p2k)
+        t2k = time.perf_counter() - t0
+        tk = h.sample(top_k=1, repetition_penalty=1.0)
+        for _ in range(4):
+            h.eval([tk])
+            tk = h.sample(top_k=1, repetition_penalty=1.0)
+        t0 = time.perf_counter()
+        for _ in range(N_DECODE_2K):
+            h.eval([tk])
+            tk = h.sample(top_k=1, repetition_penalty=1.0)
+        td = time.perf_counter() - t0
+        out["prefill_2k_tok_s"] = round(N_PROMPT_2K / t2k, 1)
+        out["decode_tok_s_at_2k"] = round(N_DECODE_2K / td, 2)
+        out["long_context"] = dict(n_prompt=N_PROMPT_2K, context_length=N_CTX_2K, batch_size=N_PROMPT, decode_steps=N_DECODE_2K,
+                                   decode_positions="%d..%d" % (N_PROMPT_2K + 4, N_PROMPT_2K + 4 + N_DECODE_2K - 1))
+        del h
     if issue is not None:
         out["config"]["host_issue"] = issue
     if n_stages > 1:
