@@ -626,11 +626,19 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
             // 16.2 against 16.7 us (7B) and 16.4 against 17.4 us (70B widths), profiles/r03_attn9_ring_fix.txt.  At contexts <= 1024
             // the forms measure the same per token (717-727 tok/s); the shallow one stays there.
             const dim3 b9d((unsigned)(64 * (4 + pv_waves)));
-#define ATTN9D(HDV) do { \
-            auto kfn = attn_decode9_kernel<HDV, 4, 16, 4, 512>; \
+#define ATTN9D(HDV, SHV) do { \
+            auto kfn = attn_decode9_kernel<HDV, 4, 16, 4, 512, SHV>; \
             CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
             CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax, ng); } while (0)
-            if (hd == 128) ATTN9D(128); else ATTN9D(64);
+            // one score row per head, shared by its channel groups (kernels_attn9.h: SHARE) where the whole grid is resident at once
+            bool share = attn_share_ && xs_ && ng >= 2 && hp_.n_head * ng <= chip_cus();
+#ifdef CT_EMU
+            share = false;   // (the test build runs workgroups one after the other: a gather would wait for ever)
+#endif
+            if (share) {
+                ax.xs = xs_; ax.epoch = (const unsigned*)(d_state_ + 4 + n_ctx_); ax.err = qa_err_; ax.layer = cur_layer_ & 255;
+                if (hd == 128) ATTN9D(128, true); else ATTN9D(64, true);
+            } else if (hd == 128) ATTN9D(128, false); else ATTN9D(64, false);
 #undef ATTN9D
             return;
         }
@@ -703,14 +711,14 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 #define PG(TYV, TGV, GUV) do { \
             auto kfn = matmul_pg_kernel<TYV, TGV, NW, GUV>; \
             CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<TGV>::BYTES); ++g_pg_launches; \
-            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a); } while (0)
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.acts, a.m.K, a.n_items, a); } while (0)
 #define PG_T(TYV) do { if (tg == 16) { if (m.gateup) PG(TYV, 16, true); else PG(TYV, 16, false); } \
                        else { if (m.gateup) PG(TYV, 32, true); else PG(TYV, 32, false); } } while (0)
         static const char* pg_trace = getenv("CT_AMD_PG_TRACE");   // measurement only: "gate_up" / "qkv" / "wo" / "down": in-kernel stamps of that site
         if (pg_trace && ty == GT_Q4_K && tg == 32 && pg_trace_site_ && !strcmp(pg_trace, pg_trace_site_) && nt > 32) {
             a.m.dbg |= 32; a.m.dbg_sink = (float*)trace_buf_;
-            if (m.gateup) { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, true, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a); }
-            else { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, false, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a); }
+            if (m.gateup) { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, true, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a.acts, a.m.K, a.n_items, a); }
+            else { auto kfn = matmul_pg_kernel<GT_Q4_K, 32, NW, false, true>; CT_OPTIN_ONCE(kfn, 3 * (size_t)PgStage<32>::BYTES + 1024); CT_LAUNCH_DYN(kfn, grid, block, smem + 1024, stream_, a.acts, a.m.K, a.n_items, a); }
             HIP_OK(hipStreamSynchronize(stream_));
             unsigned long long h[120];
             HIP_OK(hipMemcpy(h, trace_buf_, sizeof h, hipMemcpyDeviceToHost));
@@ -1070,7 +1078,8 @@ bool Engine::req_wait(int n, int n_past, std::string& err) {
 #endif
     if (h_scalars_[n_ctx_ + 14] != 0) {   // a sweep of the fused QKV + attention launch gave up (kernels_qa9.h): its workgroups were not all resident
         h_scalars_[n_ctx_ + 14] = 0;
-        fuse_qa_ = false;                 // the handle goes on with the two-launch form (the graphs are captured again)
+        fuse_qa_ = false;                 // the handle goes on with the two-launch form and the recomputed score rows (the graphs are captured again)
+        attn_share_ = false;
 #ifndef CT_EMU
         if (graph_step_) { (void)hipGraphExecDestroy(graph_step_); graph_step_ = nullptr; }
         if (graph_step_head_) { (void)hipGraphExecDestroy(graph_step_head_); graph_step_head_ = nullptr; }
@@ -1080,8 +1089,8 @@ bool Engine::req_wait(int n, int n_past, std::string& err) {
         }
         spec_inflight_ = false;
 #endif
-        err = "the fused QKV + attention launch timed out waiting for workgroups of its own grid (is the device shared?): this eval's results are "
-              "invalid; the handle continues with separate launches";
+        err = "a decode launch whose workgroups hand data to each other (fused QKV + attention, shared score rows) timed out waiting for workgroups of "
+              "its own grid (is the device shared?): this eval's results are invalid; the handle continues with the forms that need no residency";
         return false;
     }
     have_logits_ = l1_ == hp_.n_layer;

@@ -240,6 +240,9 @@ class Engine {
     uint32_t* xq_ = nullptr;          // fused QKV + attention launch: the KV-head groups' exchange records (kernels_qa9.h)
     int* qa_err_ = nullptr;           // device view of the pinned word h_scalars_[n_ctx_ + 14] a timed-out sweep raises
     bool fuse_qa_ = true;             // CT_AMD_FUSE_QA (read at load)
+    bool attn_share_ = true;          // CT_AMD_ATTN_SHARE: long-context decode attention shares one score row per head (kernels_attn9.h)
+    uint32_t* xs_ = nullptr;          // the shared score rows: [n_head][n_ctx] granules
+    int cur_layer_ = 0;               // layer whose launches are being issued (tags of the in-launch exchanges)
     long long qa_launches_ = 0;
     unsigned* pick_ws_ = nullptr;     // head launch: one 64-bit key per wave, [workgroup][16] (kernels_v9.h:v9_pick_store)
     int cur_buf_ = 0;

@@ -743,6 +743,12 @@ bool Engine::alloc_state(std::string& err) {
         if (!dev_alloc(dev_allocs_, &xq_, words + 16, err)) return false;
         HIP_OK(hipMemset(xq_, 0, (words + 16) * 4));
     }
+    attn_share_ = env_int("CT_AMD_ATTN_SHARE", 1) != 0 && !hp_.legacy();
+    if (attn_share_ && n_ctx_ > 1024 && n_ctx_ <= kMaxCtxFused) {   // (the deep form of the decode attention: contexts above 1024)
+        const size_t words = (size_t)hp_.n_head * n_ctx_ * 2;
+        if (!dev_alloc(dev_allocs_, &xs_, words + 16, err)) return false;
+        HIP_OK(hipMemset(xs_, 0, (words + 16) * 4));
+    }
     if (has_raw_ && !dev_alloc(dev_allocs_, &f16_tmp_, (size_t)std::max(std::max(V, 2 * F), E + 2 * G) + 64, err)) return false;
     // prompt chunks (kernels_pg.h: K-quants; kernels_pf.h: Q8_0 / Q4_0): n_embd <= 12288, n_ff <= 32768
     pf_ok_ = E <= 12288 && F <= 32768 && n_ctx_ <= kMaxCtxFused && env_int("CT_AMD_PF", 1) != 0;

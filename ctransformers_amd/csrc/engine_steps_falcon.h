@@ -23,6 +23,7 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
     base.eps = hp_.rms_eps;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
+        cur_layer_ = il;
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated), one row of E + 2G per token
@@ -107,6 +108,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
     bool bumped = false;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
+        cur_layer_ = il;
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated)

@@ -26,6 +26,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
     base.eps = hp_.rms_eps;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
+        cur_layer_ = il;
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {
@@ -113,6 +114,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
     bool bumped = false;
     for (int il = l0_; il < l1_; ++il) {
         const Layer& L = layers_[il];
+        cur_layer_ = il;
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
         {   // RMSNorm -> Q8_K -> {Wq,Wk,Wv} -> RoPE -> fp16 Q / KV-cache append [-> attention, where the fused launch applies]

@@ -21,6 +21,28 @@
 #pragma once
 #include "kernels_exact.h"
 
+// ---- tagged granules: the in-launch hand-off between workgroups (MI355X_MICROARCH.md "handoff-1to1" / "allgather"; used by the shared score
+// row below and by the fused QKV + attention launch, kernels_qa9.h) ----
+// one granule: {payload, tag} in one 8-byte device-scope store / load
+#ifdef CT_EMU
+static inline void st_granule(uint32_t* p, uint32_t data, uint32_t tag) { p[0] = data; p[1] = tag; }
+static inline void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) { data = p[0]; tag = p[1]; }
+static inline unsigned long long wall_ticks() { return 0ull; }
+#else
+DEV void st_granule(uint32_t* p, uint32_t data, uint32_t tag) {
+    const unsigned long long v = ((unsigned long long)tag << 32) | data;
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
+}
+// (Polling with a memory-side atomic instead — fetch_or with 0 — was measured: no different in outcome, and the fused launch lost its
+// whole gain over two launches: 734 against 732 tok/s.)
+DEV void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    data = (uint32_t)v;
+    tag = (uint32_t)(v >> 32);
+}
+DEV unsigned long long wall_ticks() { return wall_clock64(); }   // 100 MHz
+#endif
+
 // PB / VB: K-row slots per quad / V chunk slots per V*P lane — the depth of the request rings.  The host picks (2, 4) for contexts up
 // to 1024 (the requests of a deeper ring only delay the short chain) and (4, 16) above.
 template <bool B> struct A9Req { static constexpr bool value = B; };
@@ -28,7 +50,15 @@ template <bool B> struct A9Req { static constexpr bool value = B; };
 // NWV score waves.  Short contexts: seven, beside up to four V*P waves (<= 768 threads, three waves on a SIMD: 170 registers).  The deep
 // rings of the long-context form need more registers than that: it runs four score waves (one per SIMD) beside the V*P waves, at most
 // 512 threads, two waves per SIMD.
-template <int HD, int PB, int VB, int NWV = 7, int MAXT = 768>
+// SHARE (long contexts): the ng channel-group workgroups of a head share ONE score row instead of each recomputing it (at 2001 positions the
+// score phase was 14 600 of 33 000 cycles, ng = 4 .. 8 times over): workgroup `grp` computes the scores of positions [grp * per, (grp + 1) * per),
+// per = ceil(n_kv / ng), and publishes them as tagged granules {score bits, tag} in a.xs[head][position] (one 8-byte device-scope store each);
+// then every workgroup gathers the head's whole row into LDS, polling until every tag is this launch's (tag = (token epoch, layer): a
+// granule of an earlier token step never matches).  The scores are per position and unchanged, so the row — and everything after it —
+// is bit for bit the recomputed one.  The workgroups of a head wait for each other: the grid (about one workgroup per CU, at most 512
+// threads) must be resident as a whole; a gather that sees nothing new for 20 ms raises a.err (the host reports the eval as failed and
+// goes back to the recomputing form).
+template <int HD, int PB, int VB, int NWV = 7, int MAXT = 768, bool SHARE = false>
 __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, int ng) {
     constexpr int NT = 64 * NWV, NQ = NT / 4;   // score threads; NQ quads: positions per pass and slot
     constexpr int NC = HD / 32;                     // 16-byte chunks of a K row per quad lane
@@ -36,7 +66,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     CT_DYN_SMEM(smem_raw);   // the score / probability row of this token: n_ctx floats
     float* prob = reinterpret_cast<float*>(smem_raw);
     __shared__ double red[NWV];
-    __shared__ float redf[NWV];
+    __shared__ float redf[SHARE ? 16 : NWV];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = tid & 3, quad = tid >> 2;
     // workgroup -> (head, channel group): the workgroups that read the same K / V rows (the query heads of one KV head, all their
     // channel groups) take consecutive positions on ONE XCD (blockIdx % 8) where the head counts allow it — for speed only
@@ -75,7 +105,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
 #pragma unroll
         for (int c = 0; c < NC; ++c) aux[c] = ld16(qrow + 32 * c + 8 * j);
 #pragma unroll
-        for (int u = 0; u < PSPEC; ++u) {
+        for (int u = 0; u < (SHARE ? 0 : PSPEC); ++u) {   // (SHARE: the workgroup's slice of the row starts where the cursor says)
             int p = u * NQ + quad;
             p = p < a.n_ctx ? p : a.n_ctx - 1;
             const uint16_t* krow = kbase + (size_t)p * HD;
@@ -103,6 +133,11 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     // every slot, the last requests nothing (kernels_v9.h has the same rule for the weight ring).
     const int last_c = np >= 32 ? np - 32 : 0;   // first position of the last 32-position V chunk of the fma part
     const int last_p = n_kv - 1;
+    // SHARE: this workgroup's slice [p0, p1) of the score row
+    const int per = SHARE ? (n_kv + ng - 1) / ng : n_kv;
+    const int p0 = SHARE ? grp * per : 0, p1 = SHARE ? (p0 + per < n_kv ? p0 + per : n_kv) : n_kv;
+    uint32_t tag = 0u;
+    if constexpr (SHARE) tag = (((uint32_t)sload_i32((const int*)a.epoch) + 1u) << 8) | (uint32_t)a.layer;
     if (pv_wave) {   // the rest of the first V chunks, the leftover positions' values (the row is padded: np + 31 stays inside the cache)
 #pragma unroll
         for (int u = VSPEC; u < VB; ++u) buf[u] = ld16(vrow + (32 * u < last_c ? 32 * u : last_c) + 8 * j);
@@ -110,8 +145,8 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
         for (int c = 0; c < 4; ++c) aux[c] = ld16(vrow + np + 8 * c);
     } else {         // the K rows of the first pass beyond the speculative slots
 #pragma unroll
-        for (int u = PSPEC; u < PB; ++u) {
-            const int p = u * NQ + quad;
+        for (int u = (SHARE ? 0 : PSPEC); u < PB; ++u) {
+            const int p = p0 + u * NQ + quad;
             const uint16_t* krow = kbase + (size_t)(p < last_p ? p : last_p) * HD;
 #pragma unroll
             for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
@@ -133,13 +168,15 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
                 for (int c = 0; c < NC; ++c) buf[u * NC + c] = ld16(krow + 32 * c);
             }
             const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
-            if (p < n_kv) {
+            if constexpr (SHARE) {
+                if (p < p1 && j == 0) st_granule(a.xs + ((size_t)h * a.n_ctx + p) * 2, f32_to_bits(sc), tag);
+            } else if (p < n_kv) {
                 mx = fmaxf(mx, sc);
                 if (j == 0) prob[p] = sc;
             }
         };
-        int base = 0;
-        for (; base + NQ * PB < n_kv; base += NQ * PB) {
+        int base = p0;
+        for (; base + NQ * PB < p1; base += NQ * PB) {
 #pragma unroll
             for (int u = 0; u < PB; ++u) slot(u, base, A9Req<true>{});
         }
@@ -147,12 +184,57 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
         for (int u = 0; u < PB; ++u) slot(u, base, A9Req<false>{});
     }
     if (trace) tr[2] = clock64_dev();
+    if constexpr (SHARE) {
+        // gather the head's row: every thread of the workgroup (score and V*P waves alike) takes positions tid, tid + T, ..; eight granules in
+        // flight per thread and round, a round repeats until the wave has seen this launch's tag on all of its granules.  (Gathering by the
+        // V*P waves alone, from the start of the launch, so that the row is in LDS when the last slice lands, measured WORSE: one wave needs
+        // four dependent rounds of device-scope loads — 24 000 cycles at 2001 positions against 6 800 for this form.)
+        const int T = (int)blockDim.x;
+        const uint32_t* row = a.xs + (size_t)h * a.n_ctx * 2;
+        const unsigned long long t0 = wall_ticks();
+        (void)t0;
+        bool gave_up = false;
+        for (int i0 = 0; i0 < n_kv && !gave_up; i0 += 8 * T) {
+            for (;;) {
+                uint32_t dat[8], tg[8];
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * T + tid;
+                    dat[u] = 0u; tg[u] = tag;
+                    if (i < n_kv) ld_granule(row + 2 * i, dat[u], tg[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ok = ok && tg[u] == tag;
+                if (__ballot(!ok) == 0ull) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * T + tid;
+                        if (i < n_kv) { const float sc = bits_to_f32(dat[u]); prob[i] = sc; mx = fmaxf(mx, sc); }
+                    }
+                    break;
+                }
+#ifdef CT_EMU
+                emu::spin_yield();
+#else
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_ticks() - t0 > 2000000ull) { if (lane == 0) *a.err = 1; gave_up = true; break; }   // 20 ms: a workgroup of the head is not running
+#endif
+            }
+        }
+        mx = fmaxf(mx, lane_xor1(mx)); mx = fmaxf(mx, lane_xor2(mx));
+    }
     mx = fmaxf(mx, lane_xor4(mx)); mx = fmaxf(mx, lane_xor8(mx)); mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
-    if (lane == 0 && !pv_wave) redf[wv] = mx;
+    if (lane == 0 && (SHARE || !pv_wave)) redf[wv] = mx;
     __syncthreads();
     mx = redf[0];
+    if constexpr (SHARE) {
+        const int nwaves = (int)(blockDim.x >> 6);
+        for (int w = 1; w < nwaves; ++w) mx = fmaxf(mx, redf[w]);
+    } else {
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+        for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+    }
     if (trace) tr[3] = clock64_dev();
     // ---- softmax: fp16 exp table, order-free double sum (the addends are multiples of 2^-24 in (0, 1]) ----
     double sum = 0.0;

@@ -82,6 +82,10 @@ struct AttnArgsX {
     unsigned long long* trace;   // measurement only: s_memtime stamps of workgroup (0,0)
     int q_stride, out_stride;    // prompt chunks (kernels_pf.h): token blockIdx.z has position *pos + z, query row z, output row z
     const float* alibi;          // MPT: per-head slope m_k; the scaled score of key position i becomes fma(m_k, i, score) (ggml.c:12193-12254)
+    uint32_t* xs;                // attn_decode9_kernel<.., SHARE>: the heads' shared score rows as tagged granules [n_head][n_ctx] x {score, tag}
+    const unsigned* epoch;       // token epoch behind the cursor's token ids (kernels.h:advance_state_kernel); with `layer` the granules' tag
+    int* err;                    // pinned host word a timed-out gather raises
+    int layer;
     int vt_off, vt_row;          // attn_decode9_kernel<.., VLDS>: byte offset of the V tile in dynamic LDS, halves per channel row of it
 };
 
@@ -599,8 +603,8 @@ DEV void prologue_q8k_exact16(ActLdsX<MAXK>& L, const float* __restrict__ x, con
         if (wave_live) {
             // sixteen per-wave partials: lane `sub` of every 16-lane row takes one, the row reduces (a serial loop of dependent LDS reads
             // cost a microsecond here); the sum is regrouped (exact, hence order-free, within the dynamic range kernels_v9.h:pro9_total states)
-            static_assert(NW == 16, "one partial per lane of a 16-lane row");
-            double tot = L.red[sub];
+            static_assert(NW <= 16, "one partial per lane of a 16-lane row");
+            double tot = sub < NW ? L.red[sub] : 0.0;
             tot += lane_xor1(tot); tot += lane_xor2(tot); tot += lane_xor4(tot); tot += lane_xor8(tot);
             const float mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + eps);

@@ -59,26 +59,6 @@ struct QaSmem {
     float redf[16];
 };
 
-// one granule: {payload, tag} in one 8-byte device-scope store / load
-#ifdef CT_EMU
-static inline void st_granule(uint32_t* p, uint32_t data, uint32_t tag) { p[0] = data; p[1] = tag; }
-static inline void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) { data = p[0]; tag = p[1]; }
-static inline unsigned long long wall_ticks() { return 0ull; }
-#else
-DEV void st_granule(uint32_t* p, uint32_t data, uint32_t tag) {
-    const unsigned long long v = ((unsigned long long)tag << 32) | data;
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
-}
-// (Polling with a memory-side atomic instead — fetch_or with 0 — was measured: no different in outcome, and the fused launch lost its
-// whole gain over two launches: 734 against 732 tok/s.)
-DEV void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) {
-    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    data = (uint32_t)v;
-    tag = (uint32_t)(v >> 32);
-}
-DEV unsigned long long wall_ticks() { return wall_clock64(); }   // 100 MHz
-#endif
-
 // The units of one wave of the fused launch: at most two (host: engine.cc:qa_can) — local units wl and wl + gw of the group's list, as
 // items of the launch's unit list; their granules.  Few scalars on purpose (see QaArgs).
 struct QaItems {
