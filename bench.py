@@ -347,8 +347,14 @@ def main():
         issue = dict(evals=int(ev.value), us_per_eval_by_stage=[round(u / max(1, ev.value), 2) for u in us],
                      us_per_eval_total=round(sum(us) / max(1, ev.value), 2), step_us=round(dt / steps * 1e6, 1),
                      note="averaged over every eval of the handle (three prompt passes + decode steps); the issuing thread binds when its total approaches step_us")
+    import ctypes as _ct2
+    llm._lib.ctamd_qa_launches.restype, llm._lib.ctamd_qa_launches.argtypes = _ct2.c_longlong, [_ct2.c_void_p]
+    fused_qa = int(llm._lib.ctamd_qa_launches(llm._llm)) > 0
+    llm._lib.ctamd_spec_hits.restype, llm._lib.ctamd_spec_hits.argtypes = _ct2.c_longlong, [_ct2.c_void_p, _ct2.POINTER(_ct2.c_longlong)]
+    _sl = _ct2.c_longlong(0)
+    spec_hits = int(llm._lib.ctamd_spec_hits(llm._llm, _ct2.byref(_sl)))
     sites = measure.profile_sites(llm._lib, llm._llm, 8)
-    roof = measure.roofline(sites)
+    roof = measure.roofline(sites, fused=fused_qa)
     wbytes = synth.weight_bytes_per_token(MODEL)
     hd = shape_dims()   # K + V rows of every layer, fp16, at the average position of the timed steps
     kv_avg = 2 * hd["n_layer"] * (N_PROMPT + a.warmup + steps / 2.0) * (hd["n_embd"] // hd["n_head"] * hd["n_head_kv"]) * 2
@@ -372,7 +378,12 @@ def main():
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, a.warmup, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
                            devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached,
-                           handoff=HANDOFF, rccl_ranks=rccl_ranks),
+                           handoff=HANDOFF, rccl_ranks=rccl_ranks,
+                           decode_form=dict(launches_per_layer=4 if fused_qa else 5, fused_qkv_attention=fused_qa,
+                                            greedy_chain=dict(steps_served_by_a_queued_step=spec_hits, steps_queued_ahead=int(_sl.value),
+                                                              note="the timed loop is eval + sample(top_k=1): after a device-side greedy pick the engine queues the "
+                                                                   "next token step behind the one it waits for; every step is computed in full, one more than asked "
+                                                                   "for at the end (CT_AMD_SPEC=0 turns it off)"))),
                prefill_tok_s=round(N_PROMPT / prefill_s, 1), prefill_cold_tok_s=round(N_PROMPT / prefill_cold_s, 1), load_s=round(load_s, 2),
                token_roofline=dict(bytes_per_token=int(wbytes + kv_avg), frac_of_8TBps=round(tok_s * (wbytes + kv_avg) / measure.HBM_PEAK, 4),
                                    note="one sequence: the stages of a pipeline are serial, the denominator is ONE GPU's HBM"),

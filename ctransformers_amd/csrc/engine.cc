@@ -483,9 +483,9 @@ bool Engine::launch_qkv_attn(MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, 
         CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); } while (0)
 #endif
 #define QAT(TAV, TBV) do { \
-        if (hd == 64) QAL(TAV, TBV, 64, 15); \
-        else if (pvw == 1) QAL(TAV, TBV, 128, 15); \
-        else QAL(TAV, TBV, 128, 14); } while (0)
+        if (hd == 64) QAL(TAV, TBV, 64, 14); \
+        else if (pvw == 1) QAL(TAV, TBV, 128, 14); \
+        else QAL(TAV, TBV, 128, 12); } while (0)   /* 16 - (channels per workgroup) / 8 score waves (kernels_qa9.h) */
     if (ta == GT_Q4_K) { if (tb) QAT(GT_Q4_K, GT_Q6_K); else QAT(GT_Q4_K, 0); }
     else { if (tb) QAT(GT_Q5_K, GT_Q6_K); else QAT(GT_Q5_K, 0); }
 #undef QAT

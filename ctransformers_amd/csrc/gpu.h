@@ -239,6 +239,23 @@ DEV void fma8_hf(float (&acc)[8], const u32x4& a, const float (&f)[8]) {
 #endif
 
 
+// fma4_hf: the same for the four halves of an 8-byte operand
+#ifdef CT_EMU
+static inline void fma4_hf(float (&acc)[4], uint32_t a0, uint32_t a1, const float (&f)[4]) {
+    acc[0] = fmaf(_cvtsh_ss((uint16_t)(a0 & 0xFFFFu)), f[0], acc[0]);
+    acc[1] = fmaf(_cvtsh_ss((uint16_t)(a0 >> 16)), f[1], acc[1]);
+    acc[2] = fmaf(_cvtsh_ss((uint16_t)(a1 & 0xFFFFu)), f[2], acc[2]);
+    acc[3] = fmaf(_cvtsh_ss((uint16_t)(a1 >> 16)), f[3], acc[3]);
+}
+#else
+DEV void fma4_hf(float (&acc)[4], uint32_t a0, uint32_t a1, const float (&f)[4]) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[0]) : "v"(a0), "v"(f[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1]) : "v"(a0), "v"(f[1]));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2]) : "v"(a1), "v"(f[2]));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[3]) : "v"(a1), "v"(f[3]));
+}
+#endif
+
 // ---- int8 matrix core: D[16][16] += A[16][32] * B[32][16] (v_mfma_i32_16x16x32_i8) ---------------------------------------
 // Operand layout (checked on hardware by tools/experiments/mfma_i8_layout.cpp): lane i gives A[i & 15][8q .. 8q+7] and
 // B[8q .. 8q+7][i & 15] (q = i >> 4) as eight int8 in one 64-bit operand, and holds D[4q + j][i & 15] in register j.
@@ -438,6 +455,7 @@ static inline float wave_read_lane(float v, int src) { return __shfl(v, src); }
 struct u32x2 {
     uint32_t v[2];
     uint32_t operator[](int i) const { return v[i]; }
+    uint32_t& operator[](int i) { return v[i]; }
 };
 static inline u32x2 ld_stream8(const void* p) { u32x2 r; memcpy(&r, p, 8); return r; }
 static inline uint32_t ld_stream4(const void* p) { uint32_t r; memcpy(&r, p, 4); return r; }

@@ -314,11 +314,13 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     if (nl > 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float lf[8];
-            unpack8_f16(aux[c], lf);
+            if (8 * c < nl) {   // (wave-uniform: a group of eight leftover positions that does not exist costs no double-precision adds)
+                float lf[8];
+                unpack8_f16(aux[c], lf);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
+                for (int i = 0; i < 8; ++i) {
+                    if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
+                }
             }
         }
     }

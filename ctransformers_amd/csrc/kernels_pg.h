@@ -366,7 +366,11 @@ template <int TYPE, int TG, int NW, bool GU, bool TRACE = false>
 __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const uint8_t* acts0, int K0, int n_items0, const PgArgs a) {
     // (acts0 / K0 / n_items0 repeat a.acts, a.m.K, a.n_items as leading scalars: preloaded into SGPRs at wave launch — kernels_v9.h:matvec_v9_kernel —
     // so the first stage copies wait for no kernel-argument fetch)
+#ifndef CT_EMU
     __builtin_assume(a.acts == acts0); __builtin_assume(a.m.K == K0); __builtin_assume(a.n_items == n_items0);
+#else
+    (void)acts0; (void)K0; (void)n_items0;
+#endif
     CT_DYN_SMEM(smem);
     using ST = PgStage<TG>;
     constexpr int G = TG / 16, SB = ST::BYTES;

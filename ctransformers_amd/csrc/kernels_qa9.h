@@ -96,7 +96,11 @@ DEV void patch_f16(u32x4& v, int elem, uint32_t h) {   // fp16 element `elem` (0
         if (k == w) v[k] = (v[k] & keep) | ins;
 }
 
-// TA: type of wq / wk; TB: type of wv when it differs (GT_Q6_K), else 0.  NWV score waves, 16 - NWV V*P waves of 16 channels.
+// TA: type of wq / wk; TB: type of wv when it differs (GT_Q6_K), else 0.  NWV score waves, 16 - NWV V*P waves of EIGHT channels: an OCTET of
+// lanes per channel — lane (j, hh) of it owns accumulators 4 hh .. 4 hh + 3 of quad-lane j of kernels_attn9.h's V*P (positions 8 j + 4 hh .. + 3
+// of every 32-step): the same thirty-two fma chains, the same reduction tree (the j exchanges two lane bits up, t_m = S[m] + S[m + 4] is the
+// exchange between the halves), half the instructions per wave and step — the lone V*P wave of a workgroup was 3 800 of the attention
+// phase's 8 600 cycles at 200 positions.
 #ifndef QA_EXP
 #define QA_EXP 0   // bisecting builds (tools/experiments): 1 = no granule publish in the mat-vec phase, 2 = no attention phase compiled (both need CT_AMD_QA_PHASE1=1)
 #endif
@@ -197,16 +201,18 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
     static_assert(NC <= 4, "register set");
     u32x4 buf[NBUF], aux[4];
     const int chg = HD / ng;                                   // channels of this workgroup
-    const int d = grp * chg + (pv_wave ? wv - NWV : 0) * 16 + (lane >> 2);
+    const int pj = (lane >> 1) & 3, hh = lane & 1;             // V*P waves: octet lane = (slice j of the 32-step, accumulator half)
+    const int d = grp * chg + (pv_wave ? wv - NWV : 0) * 8 + (lane >> 3);
     const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
     const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
     // what does not depend on the exchange: the K rows of the older positions (row `pos` itself arrives through the exchange: an address
     // clamped to the row before it — row 0 for the very first token, whose copy nobody uses), the V chunks (their element at `pos` is
     // replaced from the exchange below)
     const int old_p = pos > 0 ? pos - 1 : 0;
+    u32x2 vb[VB];
     if (pv_wave) {
 #pragma unroll
-        for (int u = 0; u < VB; ++u) buf[u] = ld16(vrow + (32 * u < last_c ? 32 * u : last_c) + 8 * j);
+        for (int u = 0; u < VB; ++u) vb[u] = *(const u32x2*)(vrow + (32 * u < last_c ? 32 * u : last_c) + 8 * pj + 4 * hh);
 #pragma unroll
         for (int c = 0; c < 4; ++c) aux[c] = ld16(vrow + np + 8 * c);
     } else {
@@ -334,8 +340,8 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
     __syncthreads();
     if (trace) tr[4] = clock64_dev();
     if (!pv_wave) return;
-    // ---- V*P: a quad per channel (kernels_attn9.h); the value at `pos` comes from the exchange ----
-    const int dl = (wv - NWV) * 16 + (lane >> 2);                       // channel inside this workgroup's group
+    // ---- V*P: an octet per channel; the value at `pos` comes from the exchange ----
+    const int dl = (wv - NWV) * 8 + (lane >> 3);                        // channel inside this workgroup's group
     const uint32_t vnew = (QS.xw[HD + (dl >> 1)] >> ((dl & 1) * 16)) & 0xFFFFu;
     const bool in_fma = pos < np;   // `pos` lies in the 32-step part (n_kv a whole number of steps, or a token in the middle of a reference batch)
     if (!in_fma) {   // ... or among the leftover positions np .. n_kv - 1
@@ -345,63 +351,79 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
             if (c == (off >> 3)) patch_f16(aux[c], off & 7, vnew);
     }
     const int pos_c = pos & ~31;
-    const bool my_new = in_fma && j == ((pos & 31) >> 3);   // this lane's slice of chunk pos_c holds `pos`
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool my_new = in_fma && pj == ((pos & 31) >> 3) && hh == ((pos & 7) >> 2);   // this lane's four positions of chunk pos_c hold `pos`
+    auto patch4 = [&](u32x2& v) __attribute__((always_inline)) {
+        const int e = pos & 3;
+        const uint32_t keep = (e & 1) ? 0x0000FFFFu : 0xFFFF0000u, ins = (e & 1) ? (vnew << 16) : vnew;
+        if (e >> 1) v[1] = (v[1] & keep) | ins; else v[0] = (v[0] & keep) | ins;
+    };
+    float acc[4] = {0, 0, 0, 0};
     int i0 = 0;
-    float pn[8];
+    float pn[4];
     {
-        const float* p0 = &prob[8 * j];
+        const float* p0 = &prob[8 * pj + 4 * hh];
 #pragma unroll
-        for (int l = 0; l < 8; ++l) pn[l] = p0[l];
+        for (int l = 0; l < 4; ++l) pn[l] = p0[l];
     }
     for (; i0 + 32 * VB < np; i0 += 32 * VB) {
 #pragma unroll
         for (int u = 0; u < VB; ++u) {
             const int i = i0 + 32 * u;
-            float pc[8];
+            float pc[4];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) pc[l] = pn[l];
+            for (int l = 0; l < 4; ++l) pc[l] = pn[l];
             {
-                const float* pr = &prob[i + 32 + 8 * j];
+                const float* pr = &prob[i + 32 + 8 * pj + 4 * hh];
 #pragma unroll
-                for (int l = 0; l < 8; ++l) pn[l] = pr[l];
+                for (int l = 0; l < 4; ++l) pn[l] = pr[l];
             }
-            if (my_new && i == pos_c) patch_f16(buf[u], pos & 7, vnew);
-            fma8_hf(acc, buf[u], pc);
+            if (my_new && i == pos_c) patch4(vb[u]);
+            fma4_hf(acc, vb[u][0], vb[u][1], pc);
             const int in = i + 32 * VB;
-            buf[u] = ld16(vrow + (in < last_c ? in : last_c) + 8 * j);
+            vb[u] = *(const u32x2*)(vrow + (in < last_c ? in : last_c) + 8 * pj + 4 * hh);
         }
     }
 #pragma unroll
     for (int u = 0; u < VB; ++u) {
         const int i = i0 + 32 * u;
         if (i < np) {
-            float pc[8];
+            float pc[4];
 #pragma unroll
-            for (int l = 0; l < 8; ++l) pc[l] = pn[l];
+            for (int l = 0; l < 4; ++l) pc[l] = pn[l];
             {
                 const int inx = i + 32 < last_c ? i + 32 : last_c;
-                const float* pr = &prob[inx + 8 * j];
+                const float* pr = &prob[inx + 8 * pj + 4 * hh];
 #pragma unroll
-                for (int l = 0; l < 8; ++l) pn[l] = pr[l];
+                for (int l = 0; l < 4; ++l) pn[l] = pr[l];
             }
-            if (my_new && i == pos_c) patch_f16(buf[u], pos & 7, vnew);
-            fma8_hf(acc, buf[u], pc);
+            if (my_new && i == pos_c) patch4(vb[u]);
+            fma4_hf(acc, vb[u][0], vb[u][1], pc);
         }
     }
-    const float res = f16dot_reduce_exact(acc, j);
+    // the reference's reduce (ggml.c:1964-1982; kernels_exact.h:f16dot_reduce_exact): S[l] = (s_j0[l] + s_j2[l]) + (s_j1[l] + s_j3[l]) — j sits in
+    // lane bits 1..2 here —, t_m = S[m] + S[m + 4] — the two halves, lane bit 0 —, res = (t0 + t1) + (t2 + t3)
+    float S[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const float x = acc[l] + lane_xor4(acc[l]);
+        S[l] = x + lane_xor2(x);
+    }
+    const float t0 = S[0] + lane_xor1(S[0]), t1 = S[1] + lane_xor1(S[1]), t2 = S[2] + lane_xor1(S[2]), t3 = S[3] + lane_xor1(S[3]);
+    const float res = (t0 + t1) + (t2 + t3);
     double sumf = (double)res;
     if (nl > 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float lf[8];
-            unpack8_f16(aux[c], lf);
+            if (8 * c < nl) {   // (wave-uniform: a group of eight leftover positions that does not exist costs no double-precision adds)
+                float lf[8];
+                unpack8_f16(aux[c], lf);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
+                for (int i = 0; i < 8; ++i) {
+                    if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
+                }
             }
         }
     }
-    if (j == 0) q.out[(size_t)h * HD + d] = (float)sumf;
+    if ((lane & 7) == 0) q.out[(size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
 }

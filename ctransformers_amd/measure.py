@@ -2,10 +2,15 @@
 (ctamd_profile_decode, include/ctransformers_amd_ext.h) folded into the `roofline` object of the bench JSON line."""
 import ctypes
 
-PMC_FILE = "r04_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
+PMC_FILE = "r05_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 MATVEC_SITES = ("qkv", "wo", "gate_up", "lm_head")  # the K=4096 instantiation of the dominant kernel
 KERNEL = "matvec_v9_kernel<16384,TA,TB,LN> at K = 4096 (QKV, Wo, gate+up, lm_head launch sites; `down` is the same kernel at K = 11008)"
+# a handle whose token steps take the fused QKV + attention launch (kernels_qa9.h) runs the QKV rows inside that launch: the dominant
+# kernel's own launches are then Wo, gate+up and the head
+MATVEC_SITES_FUSED = ("wo", "gate_up", "lm_head")
+KERNEL_FUSED = ("matvec_v9_kernel<16384,TA,0,LN> at K = 4096 (Wo, gate+up, lm_head launch sites; `down` is the same kernel at K = 11008; the QKV rows "
+                "stream through the same v9_run inside qkv_attn9_kernel, timed as part of that launch)")
 
 
 class LaunchStat(ctypes.Structure):
@@ -34,7 +39,7 @@ def pmc_traffic():
         return None
 
 
-def roofline(sites, traffic="pmc"):
+def roofline(sites, traffic="pmc", fused=False):
     """Dominant kernel = the K=4096 mat-vec instantiation (qkv / wo / gate_up / lm_head launch sites).  Its launch
     duration comes from the "@sweep" entries when the library provides them: ONE HIP-event pair around the launches of
     all layers of a site, back to back, different weights each (HBM-cold like the real step) — the per-launch cost inside
@@ -43,7 +48,8 @@ def roofline(sites, traffic="pmc"):
         traffic = pmc_traffic()
     sweep = {s["site"].split("@")[0]: s for s in sites if s["site"].endswith("@sweep")}
     single = [s for s in sites if not s["site"].endswith("@sweep")]
-    src = [sweep[k] for k in MATVEC_SITES if k in sweep] or [s for s in single if s["site"] in MATVEC_SITES]
+    names = MATVEC_SITES_FUSED if fused else MATVEC_SITES
+    src = [sweep[k] for k in names if k in sweep] or [s for s in single if s["site"] in names]
     if not src:
         return None
     b = sum(s["bytes"] for s in src)
@@ -55,7 +61,7 @@ def roofline(sites, traffic="pmc"):
         return {s["site"].split("@")[0]: dict(GBps=round(s["bytes"] / (s["ms"] * 1e-3) / 1e9, 1) if s["bytes"] else None,
                                                us=round(s["ms"] * 1e3 / s["launches"], 2)) for s in lst}
 
-    return dict(bound="hbm", kernel=KERNEL, achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
+    return dict(bound="hbm", kernel=KERNEL_FUSED if fused else KERNEL, achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                 frac=round(ach / HBM_PEAK, 4), traffic=traffic,
                 traffic_source="profiles/%s: separate rocprofv3 --pmc FETCH_SIZE pass of the same build (tools/measure_round.sh; x2 gfx950 correction) — a counter pass cannot share a run with the timing" % PMC_FILE if traffic else None,
                 bytes_per_launch=round(b / nl),

@@ -7,7 +7,7 @@ import json
 import sys
 from collections import defaultdict
 
-DOMINANT = ("matvec_v9_kernel<16384, 12, 0, false, false",)  # the Q4_K decode mat-vec: qkv (pure Q4_K layers) / wo / gate_up / down(Q4_K) launch sites
+DOMINANT = ("matvec_v9_kernel<16384, 12, 0, false, false",)  # the Q4_K decode mat-vec: wo / gate_up / down(Q4_K) launch sites (round 5: the QKV rows run inside qkv_attn9_kernel)
 
 
 def load(path):

@@ -14,6 +14,8 @@ m = LLM(p, config=Config(context_length=512, batch_size=128, gpu_layers=1000))
 L = m._lib
 L.ctamd_n_stages.restype, L.ctamd_n_stages.argtypes = ctypes.c_int, [ctypes.c_void_p]
 S = L.ctamd_n_stages(m._llm)
+L.ctamd_handoff.restype, L.ctamd_handoff.argtypes = ctypes.c_char_p, [ctypes.c_void_p]
+HAND = L.ctamd_handoff(m._llm).decode()
 rd = L.ctamd_read_stamps_stage
 rd.restype, rd.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 40000)()
@@ -37,5 +39,5 @@ ends = [t[tag == 2] for t, tag in st]
 inside = [float(np.mean(ends[s][:N] - starts[s][:N])) / 100 for s in range(S)]
 hops = [float(np.mean(starts[s + 1][:N] - ends[s][:N])) / 100 for s in range(S - 1)]
 wrap = float(np.mean(starts[0][1:N] - ends[S - 1][:N - 1])) / 100
-print(json.dumps(dict(stages=S, handoff=os.environ.get("CT_AMD_HANDOFF", "flag"), loop_us_per_token=round(loop, 1), inside_us=[round(x, 1) for x in inside],
+print(json.dumps(dict(stages=S, handoff=HAND, loop_us_per_token=round(loop, 1), inside_us=[round(x, 1) for x in inside],
                       hop_us=[round(x, 1) for x in hops], last_end_to_next_start_us=round(wrap, 1))))
