@@ -22,8 +22,8 @@ struct ctransformers_config {
                            with several visible MI355X the value sets the pipeline STAGE COUNT: 0 < gpu_layers < n_layer spreads the
                            layers over ceil(n_layer / gpu_layers) GPUs (at most the visible ones; stages balanced by weight bytes),
                            <= 0 or >= n_layer keeps the model on one GPU.  CT_AMD_DEVICES overrides (csrc/pipeline.cc:plan_devices). */
-    bool mmap;
-    bool mlock;
+    bool mmap;          /* accepted and ignored: the file goes to the GPU once through pinned staging, nothing of it stays mapped */
+    bool mlock;         /* accepted and ignored */
 };
 
 typedef struct ctransformers_llm ctransformers_llm; /* opaque handle (reference: class LLM, models/llm.h:13) */
