@@ -616,7 +616,7 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
 #define ATTN9(HDV, PBV, VBV) do { \
         auto kfn = attn_decode9_kernel<HDV, PBV, VBV>; \
         CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
-        CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax, ng); } while (0)
+        CT_LAUNCH_DYN(kfn, g9, b9, smem, stream_, ax.pos - 1, ng, ax.n_head, ax.n_head_kv, ax); } while (0)
         // ring depth of the K / V requests; seven score waves with two K-row slots each measured best at contexts <= 1024 (3 / 4 / 5 score
         // waves, four slots: 0-4 % slower per token on the 7B, profiles/r03_attn9_score_waves_ab.txt)
         const bool deep = n_ctx_ > 1024;
@@ -629,7 +629,7 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
 #define ATTN9D(HDV, SHV) do { \
             auto kfn = attn_decode9_kernel<HDV, 4, 16, 4, 512, SHV>; \
             CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
-            CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax, ng); } while (0)
+            CT_LAUNCH_DYN(kfn, g9, b9d, smem, stream_, ax.pos - 1, ng, ax.n_head, ax.n_head_kv, ax); } while (0)
             // one score row per head, shared by its channel groups (kernels_attn9.h: SHARE) where the whole grid is resident at once
             bool share = attn_share_ && xs_ && ng >= 2 && hp_.n_head * ng <= chip_cus();
 #ifdef CT_EMU

@@ -539,6 +539,26 @@ DEV int sload_i32(const int* p) {
 }
 #endif
 
+// kernarg_touch<BYTES>: one batch of scalar loads, a dword of every 64-byte line of the kernel-argument segment, at the top of a kernel.  hipcc fetches
+// the fields of a by-value argument struct where they are first used, and each cold line is a round trip to L2: the fused QKV + attention launch read its
+// 620 bytes in seven places one after the other and reached its first weight request 2 200 cycles after the plain mat-vec launch did.  After the touch
+// every later read hits the scalar cache.
+#ifdef CT_EMU
+template <int BYTES> static inline void kernarg_touch() {}
+#else
+template <int BYTES> DEV void kernarg_touch() {
+    typedef __attribute__((address_space(4))) const uint32_t* kptr;
+    kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int N = (BYTES + 63) / 64;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = kp[16 * i];
+    t[N] = kp[(BYTES - 4) / 4];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) asm volatile("" ::"s"(t[i]));
+}
+#endif
+
 // opaque_int: the value, but the compiler cannot see where it came from — what is derived from it is recomputed, not kept in registers.
 #ifdef CT_EMU
 static inline int opaque_int(int v) { return v; }

@@ -59,7 +59,10 @@ template <bool B> struct A9Req { static constexpr bool value = B; };
 // threads) must be resident as a whole; a gather that sees nothing new for 20 ms raises a.err (the host reports the eval as failed and
 // goes back to the recomputing form).
 template <int HD, int PB, int VB, int NWV = 7, int MAXT = 768, bool SHARE = false>
-__global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, int ng) {
+// The four leading arguments repeat what the first dependent requests need (the cursor's address, the workgroup map's inputs): the build preloads
+// them into scalar registers (Makefile: PRELOAD), so the cursor load leaves at wave start instead of behind the kernel-argument fetch.
+__global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int ng, int n_head, int n_head_kv, const AttnArgsX a) {
+    kernarg_touch<24 + sizeof(AttnArgsX)>();
     constexpr int NT = 64 * NWV, NQ = NT / 4;   // score threads; NQ quads: positions per pass and slot
     constexpr int NC = HD / 32;                     // 16-byte chunks of a K row per quad lane
     constexpr int PSPEC = 2, VSPEC = 4;             // slots requested before the cursor is known (a slot is re-requested for the next pass right after its use)
@@ -72,8 +75,8 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     // channel groups) take consecutive positions on ONE XCD (blockIdx % 8) where the head counts allow it — for speed only
     int h, grp;
     {
-        const int b = (int)blockIdx.x, rep = a.n_head / a.n_head_kv;
-        if ((a.n_head_kv & 7) == 0) {
+        const int b = (int)blockIdx.x, rep = n_head / n_head_kv;
+        if ((n_head_kv & 7) == 0) {
             const int i = b >> 3, per = rep * ng;
             const int hkv = (b & 7) + 8 * (i / per), r = (i / ng) % rep;
             h = hkv * rep + r; grp = i % ng;
@@ -82,7 +85,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     const bool trace = a.trace && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = a.trace + 16 * (wv < 16 ? wv : 15);
     if (trace) tr[0] = clock64_dev();
-    const int hk = h / (a.n_head / a.n_head_kv);
+    const int hk = h / (n_head / n_head_kv);
     const bool pv_wave = wv >= NWV;                 // V*P: 16 channels x 4 lanes per wave, HD / ng / 16 such waves
     // ---- requests that do not depend on the cursor ----
     const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     }
     // ---- the cursor: {step, pos, n_past + n, batch} (kernels.h), one scalar load ----
     int cur[4];
-    sload_i32x4(a.pos - 1, cur);
+    sload_i32x4(cur0, cur);
     const int n_kv = cur[1] + 1;
     // The length of the value dot product is that of the reference batch this token belongs to (attn_fused_exact_kernel).
     int n_tot = cur[2];
@@ -311,19 +314,7 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const AttnArgsX a, i
     double sumf = (double)res;
     if (trace) tr[5] = clock64_dev();
     // leftover positions np .. n_kv - 1: ggml_vec_dot_f16's scalar tail, sumf += (double)(x[i] * y[i]) in order
-    if (nl > 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (8 * c < nl) {   // (wave-uniform: a group of eight leftover positions that does not exist costs no double-precision adds)
-                float lf[8];
-                unpack8_f16(aux[c], lf);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
-                }
-            }
-        }
-    }
+    if (nl > 0) sumf = f16_tail32(sumf, aux, prob + np, nl);
     if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
 }

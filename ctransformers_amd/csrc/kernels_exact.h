@@ -67,6 +67,30 @@ DEV float f16dot_reduce_exact(const float* acc, int j) {
     return (t0 + t1) + (t2 + t3);
 }
 
+// ggml_vec_dot_f16's scalar tail (ggml.c:2420-2423) over nl (1..31) leftover positions of a V*P dot: sumf += (double)(v[i] * p[i]) in order.
+// `p` = the 32 probabilities behind the fma part (16-byte aligned; all 32 lie inside the LDS row, which is rounded up to 64 positions).  They are read
+// UNCONDITIONALLY — eight 16-byte LDS reads, one wait; with the read inside `if (i < nl)` every leftover position cost an LDS round trip behind a branch,
+// ~100 cycles each and ~1 500 cycles of an average decode attention launch — and so are the products; only the adds are conditional (adding +0.0 could
+// turn a -0.0 sum into +0.0).  nl is wave-uniform.
+DEV double f16_tail32(double sumf, const u32x4* v, const float* p, int nl) {
+    u32x4 pb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pb[c] = *(const u32x4*)(p + 4 * c);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (8 * c < nl) {   // (a group of eight leftover positions that does not exist costs no double-precision adds)
+            float lf[8], pr[8];
+            unpack8_f16(v[c], lf);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pr[i] = lf[i] * bits_to_f32(pb[2 * c + (i >> 2)][i & 3]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * c + i < nl) sumf += (double)pr[i];
+        }
+    }
+    return sumf;
+}
+
 struct AttnArgsX {
     const uint16_t* q_f16;
     const uint16_t* kcache;  // layer base [n_head_kv][n_ctx][head_dim] (kcache_off)

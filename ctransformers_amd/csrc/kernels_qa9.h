@@ -134,10 +134,16 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
     };
 
     // ---------------------------------------------------------------- phase 1: the group's q / k / v rows (kernels_v9.h)
-    if (!(q.phase & 2)) {
+#ifdef CT_EMU
+    const bool run1 = !(q.phase & 2);
+#else
+    constexpr bool run1 = true;   // (phase 2 alone is the CPU emulation's second pass: the product reads no argument in front of the activation requests)
+#endif
+    if (run1) {
         const int lane = lane_id(), wv = uniform_int(wave_id());
         Pro9<MAXK, TB == 0, 16> P;
         pro9_load<MAXK, TB == 0, 16>(P, x0, nw0, K0, pro0, wv, lane);   // the activation requests FIRST: nothing in front of them
+        kernarg_touch<24 + sizeof(MatvecArgs) + sizeof(QaArgs)>();   // (gpu.h) behind them: one round trip for every argument line
         if (q.trace && blockIdx.x == 0 && lane == 0) q.trace[16 * wv] = clock64_dev();
         if (threadIdx.x == 0) SM.L.cnt = 0u;
         __syncthreads();
@@ -411,19 +417,7 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
     const float t0 = S[0] + lane_xor1(S[0]), t1 = S[1] + lane_xor1(S[1]), t2 = S[2] + lane_xor1(S[2]), t3 = S[3] + lane_xor1(S[3]);
     const float res = (t0 + t1) + (t2 + t3);
     double sumf = (double)res;
-    if (nl > 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (8 * c < nl) {   // (wave-uniform: a group of eight leftover positions that does not exist costs no double-precision adds)
-                float lf[8];
-                unpack8_f16(aux[c], lf);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (8 * c + i < nl) sumf += (double)(lf[i] * prob[np + 8 * c + i]);
-                }
-            }
-        }
-    }
+    if (nl > 0) sumf = f16_tail32(sumf, aux, prob + np, nl);
     if ((lane & 7) == 0) q.out[(size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
 }

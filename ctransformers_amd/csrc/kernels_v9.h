@@ -860,10 +860,6 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const float* x0, con
     // (preloading the arenas and unit counts too — what the first weight requests need, 13 dwords — measured 0.3 % slower than these 6)
     CT_DYN_SMEM(smem_raw);
     SmemV9<MAXK>& SM = *reinterpret_cast<SmemV9<MAXK>*>(smem_raw);
-    if (a.dbg & 64) {   // measurement only (CT_AMD_DBG=64): the launch and its boundary without the kernel's work (the cursor still advances)
-        if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }
-        return;
-    }
     const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     constexpr bool B32 = is_b32<TA>();
@@ -878,6 +874,11 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const float* x0, con
     if constexpr (B32) {
         Pro9b<MAXK> P;
         pro9b_load<MAXK>(P, x0, nw0, K0, pro0);
+        kernarg_touch<24 + sizeof(MatvecArgs)>();
+        if (a.dbg & 64) {   // measurement only (CT_AMD_DBG=64), as below
+            if (a.bump && bx == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }
+            return;
+        }
         __syncthreads();
         const unsigned long long t0 = trace ? clock64_dev() : 0ull;
         auto pro = [&](bool, unsigned long long (&)[4]) __attribute__((always_inline)) {
@@ -891,6 +892,11 @@ __global__ void __launch_bounds__(64 * NW) matvec_v9_kernel(const float* x0, con
     } else {
     Pro9<MAXK, TB == 0, NW> P;
     pro9_load<MAXK, TB == 0, NW>(P, x0, nw0, K0, pro0, wv, lane);
+    kernarg_touch<24 + sizeof(MatvecArgs)>();   // (gpu.h) behind the activation requests: one round trip for every argument line
+    if (a.dbg & 64) {   // measurement only (CT_AMD_DBG=64): the launch and its boundary without the kernel's work (the cursor still advances)
+        if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) { a.bump[0] += 1; a.bump[1] += 1; a.bump[4 + a.n_ctx] += 1; }
+        return;
+    }
     if (threadIdx.x == 0) SM.L.cnt = 0u;
     __syncthreads();   // (round 5: moved behind the waves' first weight requests — so that the first waves do not wait for the last wave's launch, ~2000
                        // cycles — the token rate DROPPED 3.4 %: 712 against 737 tok/s, alternating on one box.  The order this barrier enforces is worth more.)
