@@ -132,8 +132,25 @@ long long kq_launches() { return g_kq_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
 long long pg_launches() { return g_pg_launches; }
 
+// Two-type launch: how many of a workgroup's sixteen waves walk type group B.  A launch ends with its slowest wave, and a wave's time goes with the
+// bytes of its units: the split with the smallest LARGEST per-wave byte count, ties to the split nearest the groups' byte shares.  (Round 5: the split
+// by byte shares alone gave the 7B's QKV launch 9 + 7 waves — one V wave per workgroup with two Q6_K units, 13.4 KB against 9.2 KB for every other
+// wave, and that wave ended the mat-vec phase of the fused launch 2 500 cycles after the rest; 8 + 8 leaves no wave above 9.2 KB.)
+static int kq_split_waves(int units_a, double unit_bytes_a, int units_b, double unit_bytes_b, int slots) {
+    const double share = 16.0 * units_b * unit_bytes_b / (units_a * unit_bytes_a + units_b * unit_bytes_b);
+    int best = 1;
+    double best_cost = 0.0;
+    for (int nwb = 1; nwb <= 15; ++nwb) {
+        const int nwa = 16 - nwb;
+        const double ca = (double)((units_a + slots * nwa - 1) / (slots * nwa)) * unit_bytes_a, cb = (double)((units_b + slots * nwb - 1) / (slots * nwb)) * unit_bytes_b;
+        const double cost = std::max(ca, cb);
+        if (nwb == 1 || cost < best_cost || (cost == best_cost && fabs(nwb - share) < fabs(best - share))) { best = nwb; best_cost = cost; }
+    }
+    return best;
+}
+
 // unit bookkeeping of a generation-9 launch: the jobs' units concatenated (type group A first), the groups' arenas, the wave split
-static bool kq_prepare(MatvecArgs& a, int& tb_out, std::string& err) {
+static bool kq_prepare(MatvecArgs& a, int& tb_out, std::string& err, int slots = 0) {   // slots: workgroups of the launch (0: the plain launch's grid)
     for (int j = 0; j < a.njobs; ++j) {
         if (!a.job[j].w.r9) { err = "mat-vec: K-quant matrix without a LAYOUT_L9 arena"; return false; }
     }
@@ -167,10 +184,7 @@ static bool kq_prepare(MatvecArgs& a, int& tb_out, std::string& err) {
         }
     }
     a.nwA = 16;
-    if (tb != 0) {
-        const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bytes_b / (bytes_a + bytes_b))));
-        a.nwA = 16 - nwb;
-    }
+    if (tb != 0) a.nwA = 16 - kq_split_waves(na, (double)spu * l9_record_bytes(ta), item0 - na, (double)spu * l9_record_bytes(tb), slots > 0 ? slots : std::max(1, std::min(chip_cus(), item0)));
     tb_out = tb;
     return true;
 }
@@ -209,6 +223,8 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
         constexpr size_t smem = sizeof(SmemV9<MK>); \
         CT_OPTIN_ONCE(kfn, smem); \
         CT_LAUNCH_DYN(kfn, grid, block, smem, s, a.x, a.norm_w, a.K, a.pro, a); } while (0)
+        // (Round 5, measured and NOT taken: eight-wave workgroups for a launch whose units reach only waves 0..7 — the 7B's attention output projection —
+        // 786.7 against 793.0 tok/s, alternating on one box: the idle waves' share of the prologue is worth more than their launch costs.)
 #define V9T(MK, TAV) do { \
         if (a.emb_out) { if (ln) V9L(16384, TAV, 0, true, true); else V9L(16384, TAV, 0, false, true); } \
         else if (ln) V9L(MK, TAV, 0, true, false); \
@@ -431,29 +447,30 @@ bool Engine::qa_can(const Layer& L) const {
     if ((rep & (rep - 1)) || (ng & (ng - 1))) return false;   // the workgroup map is shifts and masks
     if (v->type == q->type) { if ((rep + 2) * (hd / 2) > 2 * 16 * NG) return false; }
     else {   // kq_prepare's split of the sixteen waves by bytes
-        const double ba = (double)((q->M + 1) / 2 + (k->M + 1) / 2) * l9_record_bytes(q->type), bb = (double)((v->M + 1) / 2) * l9_record_bytes(v->type);
-        const int nwb = std::max(1, std::min(15, (int)lround(16.0 * bb / (ba + bb))));
+        const int ua = (q->M + 1) / 2 + (k->M + 1) / 2, ub = (v->M + 1) / 2, spu = l9_spu(q->type, E);
+        const int nwb = kq_split_waves(ua, (double)spu * l9_record_bytes(q->type), ub, (double)spu * l9_record_bytes(v->type), hp_.n_head * ng);
         if ((rep + 1) * (hd / 2) > 2 * (16 - nwb) * NG || hd / 2 > 2 * nwb * NG) return false;
     }
     return true;
 }
 
 bool Engine::launch_qkv_attn(MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, std::string& err) {
-    int tb = 0;
-    if (!kq_prepare(a, tb, err)) return false;
-    const int hd = hp_.head_dim(), ta = a.job[0].w.type;
+    const int hd = hp_.head_dim();
 #ifdef CT_EMU
     const int cus = 256;
 #else
     const int cus = chip_cus();
 #endif
+    int tb = 0;
     {
         int ng0 = hd / 16;
         while (ng0 > hd / 64 && hp_.n_head * ng0 > cus) ng0 >>= 1;
+        if (!kq_prepare(a, tb, err, hp_.n_head * ng0)) return false;
         const int rep = hp_.n_head / hp_.n_head_kv, NG = rep * ng0;
         const bool ok = tb == 0 ? (rep + 2) * (hd / 2) <= 2 * 16 * NG : ((rep + 1) * (hd / 2) <= 2 * a.nwA * NG && hd / 2 <= 2 * (16 - a.nwA) * NG);
         if (!ok) { err = "fused QKV + attention launch: more than two units per wave"; return false; }
     }
+    const int ta = a.job[0].w.type;
     AttnArgsX ax = AttnArgsX();
     fill_attn_args(ax, kc, vc, 0);
     int ng = hd / 16;

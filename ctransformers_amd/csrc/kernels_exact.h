@@ -129,6 +129,7 @@ struct AttnArgsX {
 // context length (llama.cc:90-92); this form is the slow path that keeps such handles loadable.
 template <int NT, int HD, bool ALLCH = false, bool ALIBI = false, bool GPROB = false>
 __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a) {
+    kernarg_touch<sizeof(AttnArgsX)>();   // (gpu.h)
     static_assert(!GPROB || ALLCH, "the global probability row has one writer: all channels of a head in one workgroup");
     constexpr int NWV = NT / 64, NQ = NT / 4;   // NQ quads: positions per pass
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
@@ -324,6 +325,7 @@ __global__ void __launch_bounds__(NT) attn_fused_exact_kernel(const AttnArgsX a)
 // Dynamic LDS: WPB probability rows of row_floats each (engine.cc picks WPB so that they fit).
 template <int HD, int WPB>
 __global__ void __launch_bounds__(WPB * 64) attn_chunk_wave_kernel(const AttnArgsX a, int n_tok, int row_floats) {
+    kernarg_touch<sizeof(AttnArgsX)>();   // (gpu.h)
     constexpr int NC = HD / 32;                 // 16-byte chunks of a K row per quad lane
     constexpr int PB = 4;                       // positions per quad whose K rows are in flight together
     constexpr int VB = 4;                       // V chunks (32 positions each) in flight together
@@ -453,6 +455,7 @@ __global__ void __launch_bounds__(WPB * 64) attn_chunk_wave_kernel(const AttnArg
 // The 64-byte pads put the four quads of a ds_read_b128 phase on different banks (row strides 320 / 192 bytes: 16 (p mod 4) + 4 j).
 template <int HD>
 __global__ void __launch_bounds__(1024) attn_chunk_tile_kernel(const AttnArgsX a, int n_tok) {
+    kernarg_touch<sizeof(AttnArgsX)>();   // (gpu.h)
     constexpr int NC = HD / 32, PB = 4, VB = 4;
     constexpr int KS = HD * 2 + 64, VS = 256 + 64, ROW = 160, NCH = HD / 8;   // bytes, bytes, floats, 16-byte chunks per K row
     CT_DYN_SMEM(smem_raw);
@@ -915,6 +918,7 @@ DEV LaneGeom lane_geom(int lane) {
 // token, or past its own last position — walks all tiles of the workgroup.
 template <int HD, int NTOK>
 __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnArgsX a, int n_tok, int row_floats) {
+    kernarg_touch<sizeof(AttnArgsX)>();   // (gpu.h)
     constexpr int NC = HD / 32, PB = 4, TP = 64, NT = NTOK * 64;
     constexpr int KS = HD * 2 + 64, VS = TP * 2 + 64, NCH = HD / 8, NPASS = HD / 16;   // bytes per staged K row / V row
     constexpr int TILE_BYTES = TP * KS > HD * VS ? TP * KS : HD * VS;

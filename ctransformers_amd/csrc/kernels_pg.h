@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const uint8_t* ac
 #else
     (void)acts0; (void)K0; (void)n_items0;
 #endif
+    kernarg_touch<16 + sizeof(PgArgs)>();   // (gpu.h) one round trip for every argument line
     CT_DYN_SMEM(smem);
     using ST = PgStage<TG>;
     constexpr int G = TG / 16, SB = ST::BYTES;
