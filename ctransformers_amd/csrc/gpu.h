@@ -524,6 +524,7 @@ template <class T> DEV T wave_sum_fast(T v) {
 #ifdef CT_EMU
 static inline int sload_i32(const int* p) { return *p; }
 static inline void sload_i32x4(const int* p, int (&v)[4]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+static inline int sload_i32x4_and(const int* p, int (&v)[4], const int* q) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; return *q; }
 #else
 // four consecutive dwords, one scalar load
 DEV void sload_i32x4(const int* p, int (&v)[4]) {
@@ -531,6 +532,15 @@ DEV void sload_i32x4(const int* p, int (&v)[4]) {
     i32x4s r;
     asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
     v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+}
+// four consecutive dwords and one more from another line: both loads in flight together, one wait
+DEV int sload_i32x4_and(const int* p, int (&v)[4], const int* q) {
+    typedef int i32x4s __attribute__((ext_vector_type(4)));
+    i32x4s r;
+    int w;
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r), "=&s"(w) : "s"(p), "s"(q) : "memory");
+    v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+    return w;
 }
 DEV int sload_i32(const int* p) {
     int v;

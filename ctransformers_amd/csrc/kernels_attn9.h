@@ -33,6 +33,9 @@ DEV void st_granule(uint32_t* p, uint32_t data, uint32_t tag) {
     const unsigned long long v = ((unsigned long long)tag << 32) | data;
     __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
 }
+// (A plain store instead — the line then stays in the writer's XCD L2, where the other workgroups of a KV head sit when the head counts allow it —
+// measured +0.2 % decode, +0.6 % at 2k positions, and is not safe: a reader on another XCD never sees the line; it timed out in
+// tests/test_gpu_parity.py::test_context_above_8192.  Same-XCD placement stays a speed bonus, never something correctness rests on.)
 // (Polling with a memory-side atomic instead — fetch_or with 0 — was measured: no different in outcome, and the fused launch lost its
 // whole gain over two launches: 734 against 732 tok/s.)
 DEV void ld_granule(const uint32_t* p, uint32_t& data, uint32_t& tag) {
@@ -118,7 +121,9 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int
     }
     // ---- the cursor: {step, pos, n_past + n, batch} (kernels.h), one scalar load ----
     int cur[4];
-    sload_i32x4(cur0, cur);
+    uint32_t tag = 0u;
+    if constexpr (SHARE) tag = (((uint32_t)sload_i32x4_and(cur0, cur, (const int*)a.epoch) + 1u) << 8) | (uint32_t)a.layer;   // (one scalar round trip for both)
+    else sload_i32x4(cur0, cur);
     const int n_kv = cur[1] + 1;
     // The length of the value dot product is that of the reference batch this token belongs to (attn_fused_exact_kernel).
     int n_tot = cur[2];
@@ -139,8 +144,6 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int
     // SHARE: this workgroup's slice [p0, p1) of the score row
     const int per = SHARE ? (n_kv + ng - 1) / ng : n_kv;
     const int p0 = SHARE ? grp * per : 0, p1 = SHARE ? (p0 + per < n_kv ? p0 + per : n_kv) : n_kv;
-    uint32_t tag = 0u;
-    if constexpr (SHARE) tag = (((uint32_t)sload_i32((const int*)a.epoch) + 1u) << 8) | (uint32_t)a.layer;
     if (pv_wave) {   // the rest of the first V chunks, the leftover positions' values (the row is padded: np + 31 stays inside the cache)
 #pragma unroll
         for (int u = VSPEC; u < VB; ++u) buf[u] = ld16(vrow + (32 * u < last_c ? 32 * u : last_c) + 8 * j);

@@ -186,9 +186,8 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
     const uint32_t* rec = q.xq + (size_t)hk * lu_all * 2;
     const bool trace = q.trace && blockIdx.x == 0 && lane == 0;
     unsigned long long* tr = q.trace + 16 * wv;
-    const uint32_t tag = (((uint32_t)sload_i32((const int*)q.epoch) + 1u) << 8) | (uint32_t)q.layer;
     int cur[4];
-    sload_i32x4(a.pos - 1, cur);
+    const uint32_t tag = (((uint32_t)sload_i32x4_and(a.pos - 1, cur, (const int*)q.epoch) + 1u) << 8) | (uint32_t)q.layer;   // one scalar round trip for both
     if (trace) tr[1] = clock64_dev();   // this wave's rows are done
 
     // ---------------------------------------------------------------- phase 2: attention of (head h, channel group grp)

@@ -1,0 +1,9 @@
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/g41; mkdir -p $O
+CTRANSFORMERS_AMD_LIB=$PWD/ctransformers_amd/lib_plain/libctransformers.so timeout 900 python -m pytest tests -m gpu -q -x -k "chain or smoke or context" > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+for i in 1 2 3; do
+for L in lib lib_plain; do
+  CTRANSFORMERS_AMD_LIB=$PWD/ctransformers_amd/$L/libctransformers.so timeout 600 python bench.py --no-cpu-baseline --no-other-configs --steps 64 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$L', d['value'], d['prefill_tok_s'], d.get('prefill_2k_tok_s'), d.get('decode_tok_s_at_2k'))"
+done; done 2>&1 | tee $O/bench_ab.txt
+CTRANSFORMERS_AMD_LIB=$PWD/ctransformers_amd/lib_plain/libctransformers.so python tools/qa_trace.py 2>&1 | grep -v amdgpu | cut -c1-150 | sed -n 1,3p
