@@ -364,6 +364,8 @@ def main():
     HANDOFF = {"none": "none (one stage)",
                "flag": "in-stream: a kernel on the producer's stream stores the [tokens][n_embd] f32 rows into the next stage's peer-mapped buffer (xGMI) and publishes a "
                        "sequence number; the next stage's stream waits on it with hipStreamWaitValue32 (csrc/pipeline.cc) — no event, no SDMA copy, no RCCL call on this path",
+               "stream": "the stages share ONE device and ONE stream: a kernel stores the [tokens][n_embd] f32 rows into the next stage's buffer, stream order is the "
+                         "hand-off (no event, no wait; stages on distinct devices take the flag form)",
                "event": "hipMemcpyPeerAsync of the [tokens][n_embd] f32 rows + event record / stream wait (CT_AMD_HANDOFF=event: the round-4 form)"}[handoff_mode]
     par = "1 GPU" if n_stages == 1 else "pp%d in-process (one stage per device, hand-off: %s)" % (n_stages, handoff_mode)
     out = dict(metric="decode_tokens_per_s", value=round(tok_s, 2), unit="tokens/s", n_gpus=n_gpus, steps=steps, warmup=a.warmup,

@@ -38,6 +38,17 @@ static int env_int(const char* name, int dflt) {
 
 Engine::~Engine() { free_all(); }
 
+bool Engine::adopt_stream(hipStream_t s) {
+    if (!s || s == stream_) return true;
+    if (stream_) {
+        if (hipStreamSynchronize(stream_) != hipSuccess) return false;
+        if (stream_owned_) (void)hipStreamDestroy(stream_);
+    }
+    stream_ = s;
+    stream_owned_ = false;
+    return true;
+}
+
 void Engine::free_all() {
     release_staged();
     if (stream_ || !dev_allocs_.empty()) (void)hipSetDevice(device_);
@@ -64,7 +75,7 @@ void Engine::free_all() {
     for (hipGraphExec_t g : retired_graphs_) (void)hipGraphExecDestroy(g);
     retired_graphs_.clear();
 #endif
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_ && stream_owned_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
 }
 
@@ -999,7 +1010,7 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int ba
     return eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch);
 }
 
-bool Engine::req_begin(const int* tokens, int n, int n_past, int batch, std::string& err) {
+bool Engine::req_begin(const int* tokens, int n, int n_past, int batch, std::string& err, bool upload) {
     if (n <= 0) { err = "empty request"; return false; }
     if (n_past < 0 || n_past + n > n_ctx_) { err = "eval past the context window"; return false; }
     if (l0_ == 0 && !tokens) { err = "first stage needs token ids"; return false; }
@@ -1014,7 +1025,7 @@ bool Engine::req_begin(const int* tokens, int n, int n_past, int batch, std::str
     h_scalars_[2] = n_past + n;  // end of the eval; with [3] the attention kernels derive the reference batch each token belongs to
     h_scalars_[3] = batch > 0 && batch < n ? batch : 0;   // 0: the reference runs these n tokens as ONE batch
     if (env_int("CT_AMD_DBG_ONE_BATCH", 0)) h_scalars_[3] = 0;   // tests of the tests: ignore the batch structure on purpose
-    HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
+    if (upload) HIP_OK(hipMemcpyAsync(d_state_, &h_scalars_[0], (size_t)(4 + n) * 4, hipMemcpyHostToDevice, stream_));   // cursor + token ids
     req_n_ = n;
     req_past_ = n_past;
     return true;

@@ -76,12 +76,21 @@ class Engine {
     //               [c0, c0 + nt) (ranges must be submitted in order: the device cursor advances with them)
     //   req_logits  (last stage) logits + final-norm embedding of the request's last token -> pinned host buffers
     //   req_wait    drain the stream; marks the logits valid
-    bool req_begin(const int* tokens, int n, int n_past, int batch, std::string& err);
+    bool req_begin(const int* tokens, int n, int n_past, int batch, std::string& err, bool upload = true);   // upload = false: the cursor reaches the device
+                                                                                                              // with the previous stage's hand-off kernel (pipeline.cc)
+    // One token step's launches on this stage's stream (the pipeline captures the steps of stages that share a stream into ONE graph: pipeline.cc)
+    bool capture_step(bool want_logits, std::string& err) { return token_step(want_logits, err); }
+    bool uses_graphs() const { return use_graph_ && !dump_dir_; }
+    const int* req_cursor() const { return h_scalars_; }   // {step, pos, n_past + n, batch} of the request in flight
+    int* state_dev() { return d_state_; }
     bool req_range(int c0, int nt, bool last_of_request, std::string& err);
     bool req_logits(std::string& err);
     bool req_wait(int n, int n_past, std::string& err);
     float* xio() { return xio_; }
     hipStream_t stream() { return stream_; }
+    // Pipeline stages that share a device run on ONE stream (pipeline.cc): the stage gives up its own (idle) stream and queues behind the stage before it —
+    // no event, no cross-stream wait between them.  Called once, right after load.
+    bool adopt_stream(hipStream_t s);
     int device() const { return device_; }
     int layer_begin() const { return l0_; }
     int layer_end() const { return l1_; }
@@ -182,6 +191,7 @@ class Engine {
     size_t weight_bytes_ = 0;
 
     hipStream_t stream_ = nullptr;
+    bool stream_owned_ = true;
     uint16_t* kcache_ = nullptr;
     uint16_t* vcache_ = nullptr;
     float *x_ = nullptr, *attn_out_ = nullptr, *h_ = nullptr, *scores_ = nullptr, *d_logits_ = nullptr, *d_emb_ = nullptr;

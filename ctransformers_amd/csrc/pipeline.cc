@@ -16,8 +16,16 @@ namespace ctamd {
 // The hand-off of rows [row0, row0 + n / E) from a stage to its successor: `src` is the producer's own stage buffer, `dst` the consumer's
 // (peer-mapped: the stores travel over xGMI).  Every thread fences its stores at system scope; the last workgroup to arrive advances the
 // boundary's sequence number and publishes it in the consumer's signal word, which the consumer's stream is waiting on.
-__global__ void __launch_bounds__(256) handoff_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4, unsigned* flag, unsigned* prod) {
+// cur_dst (first micro-batch of a request; else null): the consumer's cursor {step, pos, n_past + n, batch} goes with the rows — one host-to-device copy
+// per stage and request less in the consumer's stream (~5 us each: 35 us of an eight-stage token step).
+__global__ void __launch_bounds__(256) handoff_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4, unsigned* flag, unsigned* prod,
+                                                           int* cur_dst, int c0, int c1, int c2, int c3, const int* cur_src) {
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n4; i += (int)(gridDim.x * blockDim.x)) dst[i] = src[i];
+    if (cur_dst && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (cur_src) {   // (inside the one-graph token step: the producer's cursor on its device, one token step further than the consumer's)
+            cur_dst[0] = cur_src[0] - 1; cur_dst[1] = cur_src[1] - 1; cur_dst[2] = cur_src[2]; cur_dst[3] = cur_src[3];
+        } else { cur_dst[0] = c0; cur_dst[1] = c1; cur_dst[2] = c2; cur_dst[3] = c3; }
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -115,6 +123,10 @@ Pipeline::~Pipeline() {
         if (prod_[s]) { (void)hipSetDevice(dev_[s]); (void)hipFree(prod_[s]); }
     }
 #endif
+#ifndef CT_EMU
+    if (step_graph_) (void)hipGraphExecDestroy(step_graph_);
+#endif
+    while (!st_.empty()) st_.pop_back();   // last stage first: a stage that shares the stream of the one before it goes before the stream's owner
 }
 
 bool Pipeline::load_gpt2(const std::string& path, std::string& err, bool starcoder) {
@@ -222,6 +234,17 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
         }
     }
     ev_.assign(dev_.size(), {});
+    // Consecutive stages on ONE device (the 1-GPU test form "0,0", or more stages than GPUs) share a stream: the hand-off between them is stream order —
+    // no event record + cross-stream wait (~22 us per hop on a shared device, profiles/r05_pipeline_handoff.txt).  CT_AMD_PP_SHARED_STREAM=0: one stream per stage.
+    {
+        const char* sh = getenv("CT_AMD_PP_SHARED_STREAM");
+        const bool share = !(sh && *sh == '0');
+        for (size_t s = 1; share && s < dev_.size(); ++s) {
+            if (dev_[s] != dev_[s - 1]) continue;
+            (void)hipSetDevice(dev_[s]);
+            if (!st_[s]->adopt_stream(st_[s - 1]->stream())) { err = "pipeline: sharing the stream of stage " + std::to_string(s - 1) + " failed"; return false; }
+        }
+    }
 #ifndef CT_EMU
     // hand-off words of the in-stream form (pipeline.h): signal memory for the consumer's stream wait, on the consumer's device; the
     // producer needs the direct peer mapping (a stage pair without it keeps the copy + event form, and so does CT_AMD_HANDOFF=event)
@@ -303,11 +326,78 @@ bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int 
     return false;
 }
 
+// A decode step of stages that share one stream: see step_graph_ (pipeline.h).  taken = false: the caller goes the per-stage way.
+bool Pipeline::eval_one_graph(const int* tokens, int n_past, std::string& err, int batch, bool& taken) {
+    taken = false;
+#ifndef CT_EMU
+    const int S = (int)st_.size(), E = st_[0]->hparams().n_embd;
+    if (step_graph_off_ || flag_mode_) return true;
+    for (int s = 0; s < S; ++s) {
+        if (!st_[s]->uses_graphs()) return true;
+        if (s + 1 < S && (st_[s]->stream() != st_[s + 1]->stream() || !direct_[s])) return true;
+    }
+    {   // CT_AMD_PP_ONE_GRAPH=0: one graph per stage (the A/B partner); read per call so that a test can switch it between handles
+        const char* og = getenv("CT_AMD_PP_ONE_GRAPH");
+        if (og && *og == '0') return true;
+    }
+    taken = true;
+    hipStream_t stream = st_[0]->stream();
+    PIPE_OK(hipSetDevice(dev_[0]));
+    if ((int)issue_us_.size() != S) issue_us_.assign(S, 0.0);
+    ++issue_evals_;
+    const auto t_issue = std::chrono::steady_clock::now();
+    for (int s = 0; s < S; ++s)
+        if (!st_[s]->req_begin(tokens, 1, n_past, batch, err, s == 0)) return false;
+    if (!step_graph_) {
+        hipGraph_t g = nullptr;
+        PIPE_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+        bool ok = true;
+        for (int s = 0; s < S && ok; ++s) {
+            ok = st_[s]->capture_step(s == S - 1, err);
+            if (ok && s + 1 < S)
+                hipLaunchKernelGGL(handoff_rows_kernel, dim3((unsigned)std::max(1, std::min(256, (E / 4 + 255) / 256))), dim3(256), 0, stream, (const float4*)st_[s]->xio(),
+                                   (float4*)st_[s + 1]->xio(), E / 4, (unsigned*)nullptr, (unsigned*)nullptr, st_[s + 1]->state_dev(), 0, 0, 0, 0, (const int*)st_[s]->state_dev());
+        }
+        hipError_t e = hipStreamEndCapture(stream, &g);
+        if (!ok || e != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            if (ok) err = std::string("hipStreamEndCapture (pipeline step) failed: ") + hipGetErrorString(e);
+            step_graph_off_ = true;   // the per-stage way from now on
+            return false;
+        }
+        hipError_t ei = hipGraphInstantiate(&step_graph_, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { step_graph_ = nullptr; step_graph_off_ = true; err = std::string("hipGraphInstantiate (pipeline step) failed: ") + hipGetErrorString(ei); return false; }
+    }
+    PIPE_OK(hipGraphLaunch(step_graph_, stream));
+    issue_us_[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_issue).count();
+    if (!st_[S - 1]->req_logits(err)) return false;
+    for (int s = S - 1; s >= 0; --s) {
+        if (!st_[s]->req_wait(1, n_past, err)) {   // (a stage changed its launch forms: the step is captured again)
+            (void)hipGraphExecDestroy(step_graph_);
+            step_graph_ = nullptr;
+            return false;
+        }
+    }
+#else
+    (void)tokens; (void)n_past; (void)err; (void)batch;
+#endif
+    return true;
+}
+
 bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& err, int batch) {
     const int S = (int)st_.size(), E = st_[0]->hparams().n_embd;
+    if (n == 1) {
+        bool taken = false;
+        const bool ok = eval_one_graph(tokens, n_past, err, batch, taken);
+        if (taken || !ok) return ok;
+    }
     // (each stage's cursor + token ids go out right before its first range: stage 0 starts on the GPU while the host is still queueing the others)
     // micro-batches: every stage gets its ranges in order; stage s + 1's stream waits for the event behind stage s's copy
-    const int mb = n == 1 ? 1 : std::max(2, micro_batch_);
+    // (stages that all share one stream cannot overlap: micro-batches would only add passes over the weights)
+    bool one_stream = true;
+    for (int s = 0; s + 1 < S; ++s) one_stream = one_stream && st_[s]->stream() == st_[s + 1]->stream();
+    const int mb = n == 1 ? 1 : (one_stream && !getenv("CT_AMD_PP_MB") ? n : std::max(2, micro_batch_));
     const int n_mb = (n + mb - 1) / mb;
     for (int s = 0; s + 1 < S && !flag_mode_; ++s) {
         PIPE_OK(hipSetDevice(dev_[s]));
@@ -327,11 +417,22 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
             const auto t_issue = std::chrono::steady_clock::now();
             struct Acc { double& d; std::chrono::steady_clock::time_point t0; ~Acc() { d += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } acc{issue_us_[s], t_issue};
             PIPE_OK(hipSetDevice(dev_[s]));
-            if (k == 0 && !st.req_begin(tokens, n, n_past, batch, err)) return false;
+            // (a stage behind a direct boundary gets its cursor from the hand-off kernel of the stage before it; stages > 0 use no token ids)
+            bool cur_by_kernel = false;
+#ifndef CT_EMU
+            cur_by_kernel = s > 0 && (flag_mode_ || direct_[s - 1]);
+#endif
+            if (k == 0 && !st.req_begin(tokens, n, n_past, batch, err, !cur_by_kernel)) return false;
+            int* cur_next = nullptr;
+            const int* cq = st.req_cursor();
+#ifndef CT_EMU
+            if (k == 0 && s + 1 < S && (flag_mode_ || direct_[s])) cur_next = st_[s + 1]->state_dev();
+#endif
+            (void)cur_next; (void)cq;
 #ifndef CT_EMU
             if (flag_mode_) {
                 // stage s's stream waits (its command processor polls) for the sequence number the (k + 1)-th ... hand-off of boundary s - 1 publishes
-                if (s > 0) PIPE_OK(hipStreamWaitValue32(st.stream(), flag_[s - 1], issued_[s - 1], hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if (s > 0 && st.stream() != st_[s - 1]->stream()) PIPE_OK(hipStreamWaitValue32(st.stream(), flag_[s - 1], issued_[s - 1], hipStreamWaitValueGte, 0xFFFFFFFFu));
                 if (!st.req_range(c0, nt, last_mb, err)) return false;
                 if (s + 1 < S) {
                     const size_t off = (size_t)c0 * E;
@@ -339,12 +440,12 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
                     const int gx = std::max(1, std::min(256, (n4 + 255) / 256));
                     ++issued_[s];
                     hipLaunchKernelGGL(handoff_rows_kernel, dim3((unsigned)gx), dim3(256), 0, st.stream(), (const float4*)(st.xio() + off),
-                                       (float4*)(st_[s + 1]->xio() + off), n4, flag_[s], prod_[s]);
+                                       (float4*)(st_[s + 1]->xio() + off), n4, flag_[s], prod_[s], cur_next, cq[0], cq[1], cq[2], cq[3], (const int*)nullptr);
                 }
                 continue;
             }
 #endif
-            if (s > 0) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));
+            if (s > 0 && st.stream() != st_[s - 1]->stream()) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));   // (a shared stream orders the stages by itself)
             if (!st.req_range(c0, nt, last_mb, err)) return false;
             if (s + 1 < S) {
                 const size_t off = (size_t)c0 * E;
@@ -352,11 +453,11 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
                 if (direct_[s]) {   // the rows go straight into the next stage's buffer from a kernel (no copy engine: ~3 us less per hop)
                     const int n4 = nt * E / 4;
                     hipLaunchKernelGGL(handoff_rows_kernel, dim3((unsigned)std::max(1, std::min(256, (n4 + 255) / 256))), dim3(256), 0, st.stream(),
-                                       (const float4*)(st.xio() + off), (float4*)(st_[s + 1]->xio() + off), n4, (unsigned*)nullptr, (unsigned*)nullptr);
+                                       (const float4*)(st.xio() + off), (float4*)(st_[s + 1]->xio() + off), n4, (unsigned*)nullptr, (unsigned*)nullptr, cur_next, cq[0], cq[1], cq[2], cq[3], (const int*)nullptr);
                 } else
 #endif
                 PIPE_OK(hipMemcpyPeerAsync(st_[s + 1]->xio() + off, dev_[s + 1], st.xio() + off, dev_[s], (size_t)nt * E * sizeof(float), st.stream()));
-                PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
+                if (st.stream() != st_[s + 1]->stream()) PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
             }
         }
     }

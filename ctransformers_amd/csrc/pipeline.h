@@ -6,7 +6,8 @@
 // number behind them (system-scope release); the consumer's STREAM waits for that number with hipStreamWaitValue32 — its command
 // processor polls a word in its own HBM, no CU is occupied, no event, no SDMA copy (5 us per hop against 17 for the peer copy + event
 // pair of round 4: tools/experiments/handoff_probe.cpp, profiles/r05_handoff_probe.txt; CT_AMD_HANDOFF=event keeps the old form for
-// A/B).  No host round trip, no collective, no torch.  A prompt is cut into micro-batches so that stage s works on micro-batch c while stage s - 1 already works on c + 1;
+// A/B).  Consecutive stages on ONE device (more stages than GPUs; the 1-GPU test form) share ONE stream: stream order is their hand-off, and a decode step of a
+// pipeline whose stages all share a stream is ONE graph (eval_one_graph).  No host round trip, no collective, no torch.  A prompt is cut into micro-batches so that stage s works on micro-batch c while stage s - 1 already works on c + 1;
 // results do not depend on the cut (the cursor carries the reference's batch structure, c_api.cc).
 // What the reference does instead: `gpu_layers` / `tensor_split` split tensors inside one process with peer copies per mat-mul
 // (reference models/ggml/llama.cpp:1913-1919, :1938-2070; ggml-cuda.cu:5798-6119).
@@ -64,8 +65,21 @@ class Pipeline {
     std::vector<unsigned> issued_;
     std::vector<char> direct_;   // boundary s -> s + 1: the producer can store into the consumer's buffer (same device or peer access)
     bool flag_mode_ = false;
+    // Stages that all share one device and one stream: the token steps of all stages and the hand-offs between them as ONE graph — a decode step is one
+    // host-to-device copy (stage 0's cursor + token id) and one graph launch, whatever the stage count (graph launches follow each other ~11 us apart).
+#ifndef CT_EMU
+    hipGraphExec_t step_graph_ = nullptr;
+#endif
+    bool step_graph_off_ = false;
+    bool eval_one_graph(const int* tokens, int n_past, std::string& err, int batch, bool& taken);
    public:
-    const char* handoff() const { return st_.size() < 2 ? "none" : (flag_mode_ ? "flag" : "event"); }
+    // "stream": every boundary lies between stages that share one device and one stream (nothing to wait for); else the form of the cross-stream boundaries
+    const char* handoff() const {
+        if (st_.size() < 2) return "none";
+        bool all_shared = true;
+        for (size_t s = 0; s + 1 < st_.size(); ++s) all_shared = all_shared && st_[s]->stream() == st_[s + 1]->stream();
+        return all_shared ? "stream" : (flag_mode_ ? "flag" : "event");
+    }
    private:
     int micro_batch_ = 32;
     std::vector<double> issue_us_;

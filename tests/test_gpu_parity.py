@@ -596,17 +596,23 @@ def _handoff(m):
 
 
 def _force_handoff(monkeypatch, form):
-    """Stages that share a device hand over by events (the default there); "flag" — the form stages on distinct devices take: rows stored
+    """Stages that share a device share ONE stream ("stream", the default there); with one stream per stage they hand over by events; "flag" — the form stages on distinct devices take: rows stored
     into the next stage's buffer by a kernel, the next stage's stream waiting on a sequence word — is forced for the test, with the
     two-launch decode form (the runtime serves the stream wait with a polling wave on the device, which the fused launch's residency
     does not survive: csrc/pipeline.cc)."""
+    if form in ("stream", "stream-stage-graphs"):   # the default of stages that share a device (round 5): ONE stream, the hand-off is stream order,
+        monkeypatch.delenv("CT_AMD_HANDOFF", raising=False)   # a decode step of all stages ONE graph ("stream-stage-graphs": a graph per stage)
+        monkeypatch.delenv("CT_AMD_PP_SHARED_STREAM", raising=False)
+        monkeypatch.setenv("CT_AMD_PP_ONE_GRAPH", "0" if form == "stream-stage-graphs" else "1")
+        return
+    monkeypatch.setenv("CT_AMD_PP_SHARED_STREAM", "0")   # one stream per stage: the cross-stream forms
     monkeypatch.setenv("CT_AMD_HANDOFF", form)
     if form == "flag":
         monkeypatch.setenv("CT_AMD_FUSE_QA", "0")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["event", "flag"])
+@pytest.mark.parametrize("form", ["stream", "stream-stage-graphs", "event", "flag"])
 @pytest.mark.parametrize("name", ["tiny-q4km", "falcon-tiny-q4km"])
 def test_inprocess_pipeline_on_gpu(name, form, monkeypatch):
     """The in-process pipeline of the library (csrc/pipeline.cc) on hardware: CT_AMD_DEVICES=0,0 puts two stages on the one GPU of
@@ -617,7 +623,7 @@ def test_inprocess_pipeline_on_gpu(name, form, monkeypatch):
     _force_handoff(monkeypatch, form)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     m = open_hip(os.path.join(GOLDEN, name + ".gguf"))
-    assert _stage_count(m) == 2 and _handoff(m) == form
+    assert _stage_count(m) == 2 and _handoff(m) == form.split("-")[0]
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
     assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
@@ -628,7 +634,7 @@ def test_inprocess_pipeline_on_gpu(name, form, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["event", "flag"])
+@pytest.mark.parametrize("form", ["stream", "stream-stage-graphs", "event", "flag"])
 def test_inprocess_pipeline_7b_widths_vs_reference(ref, tmp_path, monkeypatch, form):
     """Two real-width 7B layers, one per stage: 40-token prompt in reference batches of 8 (micro-batches of 16) + greedy steps against
     the reference build on the same file, with either hand-off form."""
