@@ -16,8 +16,11 @@ for S in 2 4 8; do
   D=$(python -c "print(','.join(['0'] * $S))")
   CTAMD_BENCH_DEVICES=$D timeout 600 python bench.py --gpus $S --steps 64 --no-cpu-baseline --no-other-configs > $O/bench_gpus${S}_inprocess_one_gpu.json 2> $O/bench_$S.err
 done
+# the cross-stream forms on the one device (one stream per stage): events, and the flag form stages on distinct devices take (two-launch decode form)
+CT_AMD_PP_SHARED_STREAM=0 CTAMD_BENCH_DEVICES=0,0,0,0,0,0,0,0 timeout 600 python bench.py --gpus 8 --steps 64 --no-cpu-baseline --no-other-configs --no-long-context > $O/bench_gpus8_events_one_gpu.json 2> $O/bench_8e.err
+CT_AMD_PP_SHARED_STREAM=0 CT_AMD_HANDOFF=flag CT_AMD_FUSE_QA=0 CTAMD_BENCH_DEVICES=0,0,0,0 timeout 600 python bench.py --gpus 4 --steps 64 --no-cpu-baseline --no-other-configs --no-long-context > $O/bench_gpus4_flag_one_gpu.json 2> $O/bench_4f.err
 ( cd tools/experiments && hipcc -O2 --offload-arch=gfx950 -o handoff_probe handoff_probe.cpp 2>/dev/null; timeout 120 ./handoff_probe 8 ) > $O/handoff_probe.txt 2>&1
-( python tools/pp_stamps.py; CT_AMD_DEVICES=0,0 python tools/pp_stamps.py; CT_AMD_DEVICES=0,0,0,0 python tools/pp_stamps.py; CT_AMD_HANDOFF=flag CT_AMD_FUSE_QA=0 CT_AMD_DEVICES=0,0,0,0 python tools/pp_stamps.py ) 2>&1 | grep -v amdgpu.ids > $O/pipeline_stamps.txt
+( python tools/pp_stamps.py; CT_AMD_DEVICES=0,0 python tools/pp_stamps.py; CT_AMD_DEVICES=0,0,0,0 python tools/pp_stamps.py; CT_AMD_PP_SHARED_STREAM=0 CT_AMD_DEVICES=0,0,0,0 python tools/pp_stamps.py; CT_AMD_PP_SHARED_STREAM=0 CT_AMD_HANDOFF=flag CT_AMD_FUSE_QA=0 CT_AMD_DEVICES=0,0,0,0 python tools/pp_stamps.py ) 2>&1 | grep -v amdgpu.ids > $O/pipeline_stamps.txt
 ( python tools/stamps.py; CT_AMD_SPEC=0 python tools/stamps.py; CT_AMD_SPEC=0 CT_AMD_HEAD_FOLD=0 python tools/stamps.py ) 2>&1 | grep -v amdgpu.ids > $O/token_step_stamps.txt
 cd /tmp
 CT_AMD_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o v9 -- python $R/bench.py --no-cpu-baseline --no-other-configs --no-long-context --steps 64 > $R/$O/prof.log 2>&1
@@ -40,7 +43,7 @@ timeout 300 python tools/prefill_sweep.py $M 8 16 32 64 128 > $O/prefill_sweep_7
 timeout 600 python tools/legacy_speed.py > $O/legacy_arch_speed.txt 2>&1
 python - <<PY
 import json
-for n in ("bench_default", "bench_gpus2_inprocess_one_gpu", "bench_gpus4_inprocess_one_gpu", "bench_gpus8_inprocess_one_gpu"):
+for n in ("bench_default", "bench_gpus2_inprocess_one_gpu", "bench_gpus4_inprocess_one_gpu", "bench_gpus8_inprocess_one_gpu", "bench_gpus8_events_one_gpu", "bench_gpus4_flag_one_gpu"):
     try:
         d = json.loads([l for l in open("$O/%s.json" % n) if l.startswith("{")][-1])
         print(n, d["value"], "tok/s prefill", d["prefill_tok_s"], "2k", d.get("prefill_2k_tok_s"), d.get("decode_tok_s_at_2k"), d["config"]["parallelism"], "load", d["load_s"],
