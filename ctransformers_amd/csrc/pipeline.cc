@@ -249,7 +249,8 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
     // hand-off words of the in-stream form (pipeline.h): signal memory for the consumer's stream wait, on the consumer's device; the
     // producer needs the direct peer mapping (a stage pair without it keeps the copy + event form, and so does CT_AMD_HANDOFF=event)
     {
-        // Default: "flag" where every stage has its own device; stages that SHARE a device (the 1-GPU test form "0,0") hand over by events: the
+        // Default: "flag" where every stage has its own device; stages that SHARE a device share a stream (above) — given a stream each
+        // (CT_AMD_PP_SHARED_STREAM=0) they hand over by events: the
         // runtime serves a pending hipStreamWaitValue32 with a polling wave on that device, which takes a CU away from the producer stage's
         // one-workgroup-per-CU kernels (+1.2 us per launch, measured) and breaks the residency of its fused QKV + attention launch.
         // CT_AMD_HANDOFF=flag / event forces either.
