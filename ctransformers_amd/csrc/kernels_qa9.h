@@ -104,10 +104,13 @@ DEV void patch_f16(u32x4& v, int elem, uint32_t h) {   // fp16 element `elem` (0
 #ifndef QA_EXP
 #define QA_EXP 0   // bisecting builds (tools/experiments): 1 = no granule publish in the mat-vec phase, 2 = no attention phase compiled (both need CT_AMD_QA_PHASE1=1)
 #endif
+#ifndef QA_VB
+#define QA_VB 6   // V chunk slots per V*P lane: 4 -> 773.3, 6 -> 776.1, 8 (six registers spilled) -> 765.8 tok/s over 256 steps (positions 144..400), alternating on one box
+#endif
 template <int TA, int TB, int HD, int NWV, int NS>
 __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const float* nw0, int K0, int pro0, const MatvecArgs a, const QaArgs q) {   // (leading scalars: kernels_v9.h:matvec_v9_kernel)
     constexpr int MAXK = 16384;
-    constexpr int PB = 2, VB = 4;
+    constexpr int PB = 2, VB = QA_VB;
     constexpr int NT = 64 * NWV, NQ = NT / 4, NC = HD / 32;
     CT_DYN_SMEM(smem_raw);
     SmemV9<MAXK>& SM = *reinterpret_cast<SmemV9<MAXK>*>(smem_raw);
