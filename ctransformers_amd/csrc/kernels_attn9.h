@@ -48,6 +48,7 @@ DEV unsigned long long wall_ticks() { return wall_clock64(); }   // 100 MHz
 
 // PB / VB: K-row slots per quad / V chunk slots per V*P lane — the depth of the request rings.  The host picks (2, 4) for contexts up
 // to 1024 (the requests of a deeper ring only delay the short chain) and (4, 16) above.
+template <bool B> struct A9Req { static constexpr bool value = B; };
 
 // NWV score waves.  Short contexts: seven, beside up to four V*P waves (<= 768 threads, three waves on a SIMD: 170 registers).  The deep
 // rings of the long-context form need more registers than that: it runs four score waves (one per SIMD) beside the V*P waves, at most

@@ -22,9 +22,6 @@
 #pragma once
 #include "kernels.h"
 
-// compile-time switch of a ring step: "request the slot's next use" or not (the peeled last round of a request ring requests nothing)
-template <bool B> struct A9Req { static constexpr bool value = B; };
-
 template <int MAXK> struct ActLdsX {
     int q8[MAXK / 4];        // int8 quants, 4 per word
     float yd[MAXK / 256];    // Q8_K block scale d
@@ -962,39 +959,37 @@ __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnAr
             for (int l = 0; l < 4; ++l) qf[c][l] = pk2(q8[2 * l], q8[2 * l + 1]);
         }
         const uint16_t* kb = a.kcache + (size_t)hk * a.n_ctx * HD;
-        // The next THREE tiles' 16-byte pieces travel in registers while the current tile is used: a tile load is a ~1.5 us round trip to L2, a tile's
-        // dot products ~0.6 us, and the one workgroup a CU holds (the probability rows fill its LDS) has nothing else to hide it behind — with one tile
-        // ahead (rounds 3-5) the kernel ran at the fetch latency: 234 us for the last chunk of a 2048-token prompt against ~80 us of VALU work.
-        // Every request is unconditional (rows past the workgroup's last position re-read that row): hipcc counts the ring with vmcnt(N).
+        // the next tile's 16-byte pieces travel in registers while the current tile is used (a tile load is a ~1.5 us round trip to
+        // L2 that nothing else hides: one workgroup per CU)
         constexpr int KPT = (TP * NCH + NT - 1) / NT;   // pieces per thread
-        constexpr int RD = NTOK >= 16 ? 1 : 3;          // tiles in flight (sixteen waves: 128 registers each — three tiles spill)
-        u32x4 nx[RD][KPT];
-        const int last_row = n_kv_wg - 1;
-        auto k_fetch = [&](u32x4 (&dst)[KPT], int t0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < KPT; ++q) {
-                int i = tid + q * NT;
-                i = i < TP * NCH ? i : TP * NCH - 1;
-                const int p = i / NCH, c = i - p * NCH;
-                const int pp = t0 + p < last_row ? t0 + p : last_row;
-                dst[q] = ld16(kb + (size_t)pp * HD + 8 * c);
-            }
-        };
-        auto k_tile = [&](u32x4 (&src)[KPT], int t0, auto REQ) __attribute__((always_inline)) {
-            __syncthreads();                        // the previous tile has been read by every wave
+        u32x4 nx[KPT];
+        auto k_fetch = [&](int t0) {
+            const int rows = n_kv_wg - t0 < TP ? n_kv_wg - t0 : TP;
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const int i = tid + q * NT, p = i / NCH, c = i - p * NCH;
-                if (i < TP * NCH) *(u32x4*)(T + p * KS + c * 16) = src[q];
+                if (i < rows * NCH) nx[q] = ld16(kb + (size_t)(t0 + p) * HD + 8 * c);
+            }
+        };
+        k_fetch(0);
+        for (int t0 = 0; t0 < n_kv_wg; t0 += TP) {
+            __syncthreads();                        // the previous tile has been read by every wave
+            {
+                const int rows = n_kv_wg - t0 < TP ? n_kv_wg - t0 : TP;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    const int i = tid + q * NT, p = i / NCH, c = i - p * NCH;
+                    if (i < rows * NCH) *(u32x4*)(T + p * KS + c * 16) = nx[q];
+                }
             }
             __syncthreads();
-            if constexpr (decltype(REQ)::value) k_fetch(src, t0 + RD * TP);
+            if (t0 + TP < n_kv_wg) k_fetch(t0 + TP);
             if (t0 < n_kv) {
                 u32x4 kv[PB][NC];
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) kv[u][c] = *(const u32x4*)(T + (u * 16 + quad) * KS + (32 * c + 8 * j) * 2);   // rows past the last position: copies of it, unused
+                    for (int c = 0; c < NC; ++c) kv[u][c] = *(const u32x4*)(T + (u * 16 + quad) * KS + (32 * c + 8 * j) * 2);   // rows past `rows`: stale, unused
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
                     const int p = t0 + u * 16 + quad;
@@ -1016,17 +1011,7 @@ __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnAr
                     }
                 }
             }
-        };
-#pragma unroll
-        for (int d = 0; d < RD; ++d) k_fetch(nx[d], d * TP);
-        int t0 = 0;
-        for (; t0 + RD * TP <= n_kv_wg; t0 += RD * TP) {   // whole rounds: no condition around a tile or a request
-#pragma unroll
-            for (int d = 0; d < RD; ++d) k_tile(nx[d], t0 + d * TP, A9Req<true>{});
         }
-#pragma unroll
-        for (int d = 0; d < RD; ++d)                        // the last, partial round requests nothing (workgroup-uniform conditions: the barriers stay whole)
-            if (t0 + d * TP < n_kv_wg) k_tile(nx[d], t0 + d * TP, A9Req<false>{});
     }
     // ---- softmax over the wave's own row -----------------------------------------------------------------------------------
     mx = wave_max(mx);
@@ -1054,31 +1039,24 @@ __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnAr
     // leftovers: np >= n_kv >= 1) the one that holds its last full step
     const int t_left = (nl > 0 ? np : np - 1) & ~(TP - 1);
     constexpr int VPT = (HD * (TP / 8) + NT - 1) / NT;
-    constexpr int RDV = NTOK >= 16 ? 1 : 3;             // tiles in flight, as for the K rows
-    u32x4 nv[RDV][VPT];
-    const int last_tile = n_tot_wg > 0 ? (n_tot_wg - 1) & ~(TP - 1) : 0;   // requests past it re-read it
-    auto v_fetch = [&](u32x4 (&dst)[VPT], int t0) __attribute__((always_inline)) {   // 64 positions of every channel (past the row's end: slack bytes, never used)
-        const int tt = t0 < last_tile ? t0 : last_tile;
+    u32x4 nv[VPT];
+    auto v_fetch = [&](int t0) {                        // 64 positions of every channel (past the row's end: slack bytes, never used)
 #pragma unroll
         for (int q = 0; q < VPT; ++q) {
-            int i = tid + q * NT;
-            i = i < HD * (TP / 8) ? i : HD * (TP / 8) - 1;
-            const int ch = i / (TP / 8), c = i - ch * (TP / 8);
-            dst[q] = ld16(vb + (size_t)ch * a.v_stride + tt + 8 * c);
+            const int i = tid + q * NT, ch = i / (TP / 8), c = i - ch * (TP / 8);
+            if (i < HD * (TP / 8)) nv[q] = ld16(vb + (size_t)ch * a.v_stride + t0 + 8 * c);
         }
     };
-#pragma unroll
-    for (int d = 0; d < RDV; ++d) v_fetch(nv[d], d * TP);
-    // one tile: stage, request the tile three further on (REQ), the full 32-steps of this wave in it, and — in the wave's last tile — reduce, leftovers, store
-    auto v_tile = [&](u32x4 (&src)[VPT], int t0, auto REQ) __attribute__((always_inline)) {
+    v_fetch(0);
+    for (int t0 = 0; t0 < n_tot_wg; t0 += TP) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < VPT; ++q) {
             const int i = tid + q * NT, ch = i / (TP / 8), c = i - ch * (TP / 8);
-            if (i < HD * (TP / 8)) *(u32x4*)(T + ch * VS + c * 16) = src[q];
+            if (i < HD * (TP / 8)) *(u32x4*)(T + ch * VS + c * 16) = nv[q];
         }
         __syncthreads();
-        if constexpr (decltype(REQ)::value) v_fetch(src, t0 + RDV * TP);
+        if (t0 + TP < n_tot_wg) v_fetch(t0 + TP);
         if (t0 < np) {
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
@@ -1116,13 +1094,5 @@ __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnAr
                 if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
             }
         }
-    };
-    int t0 = 0;
-    for (; t0 + RDV * TP <= n_tot_wg; t0 += RDV * TP) {
-#pragma unroll
-        for (int d = 0; d < RDV; ++d) v_tile(nv[d], t0 + d * TP, A9Req<true>{});
     }
-#pragma unroll
-    for (int d = 0; d < RDV; ++d)
-        if (t0 + d * TP < n_tot_wg) v_tile(nv[d], t0 + d * TP, A9Req<false>{});
 }
