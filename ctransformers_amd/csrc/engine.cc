@@ -600,12 +600,13 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
         if (ntok) {
             const dim3 gl((unsigned)hp_.n_head, (unsigned)((nt + ntok - 1) / ntok));
             const size_t sm = tile_bytes + (size_t)ntok * row * 4;
-#define ATTNL(HDV, NTV) do { \
-                auto kfn = attn_chunk_long_kernel<HDV, NTV>; \
+#define ATTNL(KERN, HDV, NTV) do { \
+                auto kfn = KERN<HDV, NTV>; \
                 CT_OPTIN_ONCE(kfn, cap); \
                 CT_LAUNCH_DYN(kfn, gl, dim3(NTV * 64), sm, stream_, ax, nt, row); } while (0)
-            if (hd == 128) { if (ntok == 16) ATTNL(128, 16); else ATTNL(128, 8); }
-            else { if (ntok == 16) ATTNL(64, 16); else ATTNL(64, 8); }
+            // (eight rows: the form with three tiles in flight, kernels_exact.h:attn_chunk_long8_kernel)
+            if (hd == 128) { if (ntok == 16) ATTNL(attn_chunk_long_kernel, 128, 16); else ATTNL(attn_chunk_long8_kernel, 128, 8); }
+            else { if (ntok == 16) ATTNL(attn_chunk_long_kernel, 64, 16); else ATTNL(attn_chunk_long8_kernel, 64, 8); }
 #undef ATTNL
             return;
         }

@@ -1096,3 +1096,216 @@ __global__ void __launch_bounds__(NTOK * 64) attn_chunk_long_kernel(const AttnAr
         }
     }
 }
+
+// The EIGHT-token form of attn_chunk_long_kernel (contexts above 2048: eight probability rows fill the LDS, one workgroup of eight waves per CU) with THREE
+// K / V tiles in flight in registers instead of one, every request unconditional and the loops peeled so that hipcc counts the ring (vmcnt(N)): a tile load
+// is a ~1.5 us round trip that two waves per SIMD do not cover.  2048-token prompt (7B, ctx 2304): 12 713 against 12 379 tok/s.  A kernel of its own because
+// the same source as a sixteen-token instantiation (128 registers) spills (profiles/r05_decode_ab.txt section 6); arithmetic and order are attn_chunk_long_kernel's.
+template <bool B> struct A9ReqX { static constexpr bool value = B; };
+template <int HD, int NTOK>
+__global__ void __launch_bounds__(NTOK * 64) attn_chunk_long8_kernel(const AttnArgsX a, int n_tok, int row_floats) {
+    kernarg_touch<sizeof(AttnArgsX)>();   // (gpu.h)
+    constexpr int NC = HD / 32, PB = 4, TP = 64, NT = NTOK * 64;
+    constexpr int KS = HD * 2 + 64, VS = TP * 2 + 64, NCH = HD / 8, NPASS = HD / 16;   // bytes per staged K row / V row
+    constexpr int TILE_BYTES = TP * KS > HD * VS ? TP * KS : HD * VS;
+    CT_DYN_SMEM(smem_raw);
+    unsigned char* T = smem_raw;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = lane & 3, quad = lane >> 2;
+    const int h = (int)blockIdx.x, tok0 = (int)blockIdx.y * NTOK, tok = tok0 + wv;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const bool live = tok < n_tok;
+    const int pos0 = *a.pos;
+    float* prob = reinterpret_cast<float*>(smem_raw + TILE_BYTES) + wv * row_floats;
+    // end of the reference batch a token belongs to (see attn_fused_exact_kernel); monotone in the token index
+    auto batch_end = [&](int t) {
+        int nt_ = *a.n_total;
+        const int bs = a.n_total[1];
+        if (bs > 0) {
+            const int idx = a.pos[-1] + t, base = pos0 - a.pos[-1];
+            const int end = (idx / bs + 1) * bs, n_eval = nt_ - base;
+            nt_ = base + (end < n_eval ? end : n_eval);
+        }
+        return nt_;
+    };
+    const int t_last = (tok0 + NTOK < n_tok ? tok0 + NTOK : n_tok) - 1;   // last token of this workgroup
+    const int n_kv_wg = pos0 + t_last + 1, n_tot_wg = batch_end(t_last);
+    const int n_kv = live ? pos0 + tok + 1 : 0;
+    const int n_tot = live ? batch_end(tok) : 0;
+    const int np = n_tot & ~31, nl = n_kv - np;         // full 32-steps; leftover positions (< 32 when > 0), wave-uniform
+    // ---- scores ------------------------------------------------------------------------------------------------------------
+    float mx = -INFINITY;
+    {
+        F32x2 qf[NC][4];   // the fma chains of the eight AVX lanes run two lanes per instruction (v_pk_fma_f32: each half is the IEEE fma)
+        const uint16_t* qrow = a.q_f16 + (size_t)(live ? tok : 0) * a.q_stride + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float q8[8];
+            unpack8_f16(ld16(qrow + 32 * c + 8 * j), q8);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) qf[c][l] = pk2(q8[2 * l], q8[2 * l + 1]);
+        }
+        const uint16_t* kb = a.kcache + (size_t)hk * a.n_ctx * HD;
+        // The next THREE tiles' 16-byte pieces travel in registers while the current tile is used: a tile load is a ~1.5 us round trip to L2, a tile's
+        // dot products ~0.6 us, and the one workgroup a CU holds (the probability rows fill its LDS) has nothing else to hide it behind — with one tile
+        // ahead (rounds 3-5) the kernel ran at the fetch latency: 234 us for the last chunk of a 2048-token prompt against ~80 us of VALU work.
+        // Every request is unconditional (rows past the workgroup's last position re-read that row): hipcc counts the ring with vmcnt(N).
+        constexpr int KPT = (TP * NCH + NT - 1) / NT;   // pieces per thread
+        constexpr int RD = 3;                           // tiles in flight
+        u32x4 nx[RD][KPT];
+        const int last_row = n_kv_wg - 1;
+        auto k_fetch = [&](u32x4 (&dst)[KPT], int t0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                int i = tid + q * NT;
+                i = i < TP * NCH ? i : TP * NCH - 1;
+                const int p = i / NCH, c = i - p * NCH;
+                const int pp = t0 + p < last_row ? t0 + p : last_row;
+                dst[q] = ld16(kb + (size_t)pp * HD + 8 * c);
+            }
+        };
+        auto k_tile = [&](u32x4 (&src)[KPT], int t0, auto REQ) __attribute__((always_inline)) {
+            __syncthreads();                        // the previous tile has been read by every wave
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const int i = tid + q * NT, p = i / NCH, c = i - p * NCH;
+                if (i < TP * NCH) *(u32x4*)(T + p * KS + c * 16) = src[q];
+            }
+            __syncthreads();
+            if constexpr (decltype(REQ)::value) k_fetch(src, t0 + RD * TP);
+            if (t0 < n_kv) {
+                u32x4 kv[PB][NC];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) kv[u][c] = *(const u32x4*)(T + (u * 16 + quad) * KS + (32 * c + 8 * j) * 2);   // rows past the last position: copies of it, unused
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const int p = t0 + u * 16 + quad;
+                    F32x2 ac[4] = {pk2(0.0f, 0.0f), pk2(0.0f, 0.0f), pk2(0.0f, 0.0f), pk2(0.0f, 0.0f)};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        float kf[8];
+                        unpack8_f16(kv[u][c], kf);
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) ac[l] = pk_fma_f32(pk2(kf[2 * l], kf[2 * l + 1]), qf[c][l], ac[l]);
+                    }
+                    float acc[8];
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { acc[2 * l] = pk_lo(ac[l]); acc[2 * l + 1] = pk_hi(ac[l]); }
+                    const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+                    if (p < n_kv) {
+                        mx = fmaxf(mx, sc);
+                        if (j == 0) prob[p] = sc;
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < RD; ++d) k_fetch(nx[d], d * TP);
+        int t0 = 0;
+        for (; t0 + RD * TP <= n_kv_wg; t0 += RD * TP) {   // whole rounds: no condition around a tile or a request
+#pragma unroll
+            for (int d = 0; d < RD; ++d) k_tile(nx[d], t0 + d * TP, A9ReqX<true>{});
+        }
+#pragma unroll
+        for (int d = 0; d < RD; ++d)                        // the last, partial round requests nothing (workgroup-uniform conditions: the barriers stay whole)
+            if (t0 + d * TP < n_kv_wg) k_tile(nx[d], t0 + d * TP, A9ReqX<false>{});
+    }
+    // ---- softmax over the wave's own row -----------------------------------------------------------------------------------
+    mx = wave_max(mx);
+    wave_lds_sync();
+    {
+        double sum = 0.0;
+        for (int i0 = 0; i0 < n_kv; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < n_kv) { const float e = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(prob[i] - mx)]); prob[i] = e; sum += (double)e; }
+        }
+        sum = wave_sum(sum);
+        const float inv = (float)(1.0 / sum);
+        for (int i = lane; i < n_kv; i += 64) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+        for (int i = n_kv + lane; i < np; i += 64) prob[i] = 0.0f;   // masked columns of this batch
+    }
+    wave_lds_sync();
+    // ---- V * P: 16 channels per pass (a quad each), the accumulators of all passes carried through the position tiles ----------
+    F32x2 acc[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[ps][l] = pk2(0.0f, 0.0f);
+    const uint16_t* vb = a.vcache + (size_t)hk * HD * a.v_stride;
+    // the tile after whose full steps this wave is finished: the one that holds the leftover positions np .. n_kv - 1, or (no
+    // leftovers: np >= n_kv >= 1) the one that holds its last full step
+    const int t_left = (nl > 0 ? np : np - 1) & ~(TP - 1);
+    constexpr int VPT = (HD * (TP / 8) + NT - 1) / NT;
+    constexpr int RDV = 3;                              // tiles in flight, as for the K rows
+    u32x4 nv[RDV][VPT];
+    const int last_tile = n_tot_wg > 0 ? (n_tot_wg - 1) & ~(TP - 1) : 0;   // requests past it re-read it
+    auto v_fetch = [&](u32x4 (&dst)[VPT], int t0) __attribute__((always_inline)) {   // 64 positions of every channel (past the row's end: slack bytes, never used)
+        const int tt = t0 < last_tile ? t0 : last_tile;
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            int i = tid + q * NT;
+            i = i < HD * (TP / 8) ? i : HD * (TP / 8) - 1;
+            const int ch = i / (TP / 8), c = i - ch * (TP / 8);
+            dst[q] = ld16(vb + (size_t)ch * a.v_stride + tt + 8 * c);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < RDV; ++d) v_fetch(nv[d], d * TP);
+    // one tile: stage, request the tile three further on (REQ), the full 32-steps of this wave in it, and — in the wave's last tile — reduce, leftovers, store
+    auto v_tile = [&](u32x4 (&src)[VPT], int t0, auto REQ) __attribute__((always_inline)) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int i = tid + q * NT, ch = i / (TP / 8), c = i - ch * (TP / 8);
+            if (i < HD * (TP / 8)) *(u32x4*)(T + ch * VS + c * 16) = src[q];
+        }
+        __syncthreads();
+        if constexpr (decltype(REQ)::value) v_fetch(src, t0 + RDV * TP);
+        if (t0 < np) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned char* vrow = T + (ps * 16 + quad) * VS;
+#pragma unroll
+                for (int u = 0; u < TP / 32; ++u) {
+                    if (t0 + 32 * u < np) {
+                        float vf[8];
+                        unpack8_f16(*(const u32x4*)(vrow + (32 * u + 8 * j) * 2), vf);
+                        const float* pr = &prob[t0 + 32 * u + 8 * j];
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) acc[ps][l] = pk_fma_f32(pk2(vf[2 * l], vf[2 * l + 1]), pk2(pr[2 * l], pr[2 * l + 1]), acc[ps][l]);
+                    }
+                }
+            }
+        }
+        if (live && t0 == t_left) {                     // every full step of this wave is done: reduce, leftovers, store
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int d = ps * 16 + quad;
+                float a8[8];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) { a8[2 * l] = pk_lo(acc[ps][l]); a8[2 * l + 1] = pk_hi(acc[ps][l]); }
+                double sumf = (double)f16dot_reduce_exact(a8, j);
+                if (nl > 0) {
+                    const unsigned char* vrow = T + d * VS + (np - t0) * 2;
+                    float lf[32];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) unpack8_f16(*(const u32x4*)(vrow + c * 16), lf + 8 * c);
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        if (i < nl) sumf += (double)(lf[i] * prob[np + i]);
+                    }
+                }
+                if (j == 0) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + d] = (float)sumf;
+            }
+        }
+    };
+    int t0 = 0;
+    for (; t0 + RDV * TP <= n_tot_wg; t0 += RDV * TP) {
+#pragma unroll
+        for (int d = 0; d < RDV; ++d) v_tile(nv[d], t0 + d * TP, A9ReqX<true>{});
+    }
+#pragma unroll
+    for (int d = 0; d < RDV; ++d)
+        if (t0 + d * TP < n_tot_wg) v_tile(nv[d], t0 + d * TP, A9ReqX<false>{});
+}
