@@ -335,7 +335,7 @@ bool Pipeline::eval_one_graph(const int* tokens, int n_past, std::string& err, i
     if (step_graph_off_ || flag_mode_) return true;
     for (int s = 0; s < S; ++s) {
         if (!st_[s]->uses_graphs()) return true;
-        if (s + 1 < S && (st_[s]->stream() != st_[s + 1]->stream() || !direct_[s])) return true;
+        if (s + 1 < S && (!shares_stream(s) || !direct_[s])) return true;
     }
     {   // CT_AMD_PP_ONE_GRAPH=0: one graph per stage (the A/B partner); read per call so that a test can switch it between handles
         const char* og = getenv("CT_AMD_PP_ONE_GRAPH");
@@ -397,7 +397,7 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
     // micro-batches: every stage gets its ranges in order; stage s + 1's stream waits for the event behind stage s's copy
     // (stages that all share one stream cannot overlap: micro-batches would only add passes over the weights)
     bool one_stream = true;
-    for (int s = 0; s + 1 < S; ++s) one_stream = one_stream && st_[s]->stream() == st_[s + 1]->stream();
+    for (int s = 0; s + 1 < S; ++s) one_stream = one_stream && shares_stream(s);
     const int mb = n == 1 ? 1 : (one_stream && !getenv("CT_AMD_PP_MB") ? n : std::max(2, micro_batch_));
     const int n_mb = (n + mb - 1) / mb;
     for (int s = 0; s + 1 < S && !flag_mode_; ++s) {
@@ -433,7 +433,7 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
 #ifndef CT_EMU
             if (flag_mode_) {
                 // stage s's stream waits (its command processor polls) for the sequence number the (k + 1)-th ... hand-off of boundary s - 1 publishes
-                if (s > 0 && st.stream() != st_[s - 1]->stream()) PIPE_OK(hipStreamWaitValue32(st.stream(), flag_[s - 1], issued_[s - 1], hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if (s > 0 && !shares_stream(s - 1)) PIPE_OK(hipStreamWaitValue32(st.stream(), flag_[s - 1], issued_[s - 1], hipStreamWaitValueGte, 0xFFFFFFFFu));
                 if (!st.req_range(c0, nt, last_mb, err)) return false;
                 if (s + 1 < S) {
                     const size_t off = (size_t)c0 * E;
@@ -446,7 +446,7 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
                 continue;
             }
 #endif
-            if (s > 0 && st.stream() != st_[s - 1]->stream()) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));   // (a shared stream orders the stages by itself)
+            if (s > 0 && !shares_stream(s - 1)) PIPE_OK(hipStreamWaitEvent(st.stream(), ev_[s - 1][k], 0));   // (a shared stream orders the stages by itself)
             if (!st.req_range(c0, nt, last_mb, err)) return false;
             if (s + 1 < S) {
                 const size_t off = (size_t)c0 * E;
@@ -458,7 +458,7 @@ bool Pipeline::eval_stages(const int* tokens, int n, int n_past, std::string& er
                 } else
 #endif
                 PIPE_OK(hipMemcpyPeerAsync(st_[s + 1]->xio() + off, dev_[s + 1], st.xio() + off, dev_[s], (size_t)nt * E * sizeof(float), st.stream()));
-                if (st.stream() != st_[s + 1]->stream()) PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
+                if (!shares_stream(s)) PIPE_OK(hipEventRecord(ev_[s][k], st.stream()));
             }
         }
     }

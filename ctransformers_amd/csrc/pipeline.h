@@ -74,10 +74,12 @@ class Pipeline {
     bool eval_one_graph(const int* tokens, int n_past, std::string& err, int batch, bool& taken);
    public:
     // "stream": every boundary lies between stages that share one device and one stream (nothing to wait for); else the form of the cross-stream boundaries
+    // boundary s -> s + 1 lies inside one stream (the two stages sit on one device and queue on the same stream: load())
+    bool shares_stream(int s) const { return dev_[(size_t)s] == dev_[(size_t)s + 1] && st_[(size_t)s]->stream() == st_[(size_t)s + 1]->stream(); }
     const char* handoff() const {
         if (st_.size() < 2) return "none";
         bool all_shared = true;
-        for (size_t s = 0; s + 1 < st_.size(); ++s) all_shared = all_shared && st_[s]->stream() == st_[s + 1]->stream();
+        for (size_t s = 0; s + 1 < st_.size(); ++s) all_shared = all_shared && shares_stream((int)s);
         return all_shared ? "stream" : (flag_mode_ ? "flag" : "event");
     }
    private:

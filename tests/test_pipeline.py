@@ -186,7 +186,8 @@ def _stages(m):
     return n, out
 
 
-@pytest.mark.parametrize("name,devices", [("tiny-q4km", "2"), ("falcon-tiny-q4km", "0,1"), ("tiny-q5km", "2")])
+@pytest.mark.parametrize("name,devices", [("tiny-q4km", "2"), ("falcon-tiny-q4km", "0,1"), ("tiny-q5km", "2"),
+                                          ("tiny-q4km", "0,0")])   # two stages on ONE device: they share a stream (round 5), the hand-off is stream order
 def test_inprocess_pipeline_equals_reference(emu_lib, monkeypatch, name, devices):
     """`AutoModelForCausalLM`-style use, nothing but the C ABI: the handle spans two (emulated) devices, one stage each; logits,
     embeddings and greedy tokens equal the reference build's goldens — prompt in reference batches of 8 (micro-batched through the
@@ -200,6 +201,9 @@ def test_inprocess_pipeline_equals_reference(emu_lib, monkeypatch, name, devices
     m = LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(context_length=96, batch_size=8, threads=1), lib=emu_lib)
     n, ranges = _stages(m)
     assert n == 2 and ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 2
+    import ctypes
+    m._lib.ctamd_handoff.restype, m._lib.ctamd_handoff.argtypes = ctypes.c_char_p, [ctypes.c_void_p]
+    assert m._lib.ctamd_handoff(m._llm).decode() == ("stream" if devices == "0,0" else "event")
     m.eval(list(g["prompt"]))
     assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
     assert np.array_equal(m.embeddings.to_numpy(), g["embeddings"][0])
