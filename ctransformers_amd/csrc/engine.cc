@@ -167,16 +167,14 @@ static bool kq_prepare(MatvecArgs& a, int& tb_out, std::string& err, int slots =
     }
     const int ta = a.job[0].w.type;
     int tb = 0, item0 = 0, na = 0;
-    double bytes_a = 0.0, bytes_b = 0.0;
     const int spu = l9_spu(ta, a.K);
     for (int j = 0; j < a.njobs; ++j) {
         const int tj = a.job[j].w.type;
         const int units = a.gateup ? a.job[j].w.M : (a.job[j].w.M + 1) / 2;
         a.job[j].pair0 = item0;
         item0 += units;
-        const double bytes = (double)units * spu * l9_record_bytes(tj);
-        if (tj == ta && tb == 0) { na += units; bytes_a += bytes; }
-        else if ((tb == 0 && tj == GT_Q6_K) || tj == tb) { tb = tj; bytes_b += bytes; }
+        if (tj == ta && tb == 0) na += units;
+        else if ((tb == 0 && tj == GT_Q6_K) || tj == tb) tb = tj;
         else { err = "unsupported weight-type mix in one launch"; return false; }
     }
     a.n_pairs = item0;

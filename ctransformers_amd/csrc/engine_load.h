@@ -240,7 +240,7 @@ bool Engine::stage_file(const GgufFile& f, const std::vector<const GgufTensor*>&
 const uint8_t* Engine::staged(const GgufTensor* t) const { return dev_file_ ? dev_file_ + (t->data - file_lo_) : nullptr; }
 
 void Engine::release_staged() {
-    if (dev_file_) { hipFree(dev_file_); dev_file_ = nullptr; }
+    if (dev_file_) { (void)hipFree(dev_file_); dev_file_ = nullptr; }
 }
 
 // LAYOUT_L9 (decode mat-vec, kernels_v9.h) and LAYOUT_R2C4 (prompt chunks, kernels_pg.h) copies.  The matrices of `parts` are placed back to back in ONE device

@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const uint8_t* ac
     // instruction issue (in-kernel stamps: 2 x (181 VALU x 4 + 24 MFMA x 16) cycles per pair of waves and step).
     const int bx = (int)blockIdx.x, grp = (int)blockIdx.y;
     if (bx * NW >= a.n_items) return;   // padding workgroups (whole workgroups: no barrier is left waiting)
-    const int tid = (int)threadIdx.x, lane = lane_id();
+    const int lane = lane_id();
     const int wv = uniform_int(wave_id());
     const int r16 = lane & 15, p = lane >> 4, rr = r16 & 1;
     const int t0 = grp * TG;

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
         n_tot = base + (end < n_eval ? end : n_eval);
     }
     const int np = n_tot & ~31, nl = n_kv - np;
-    const int last_c = np >= 32 ? np - 32 : 0, last_p = n_kv - 1;
+    const int last_c = np >= 32 ? np - 32 : 0;
     const int j = tid & 3, quad = tid >> 2;
     const bool pv_wave = wv >= NWV;
     constexpr int NBUF = PB * NC > VB ? PB * NC : VB;
