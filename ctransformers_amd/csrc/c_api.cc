@@ -222,6 +222,8 @@ long long ctamd_chunk_tokens(ctransformers_llm* llm) { return llm->engine().chun
 long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
 long long ctamd_qa_launches(ctransformers_llm* llm) { return llm->engine().qa_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
+long long ctamd_mm8_launches(void) { return ctamd::mm8_launches(); }
+int ctamd_debug_read_kv(ctransformers_llm* llm, int layer, unsigned short* k, unsigned short* v) { return llm->engine().debug_read_kv(layer, k, v); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
 const char* ctamd_handoff(ctransformers_llm* llm) { return llm->pipe.handoff(); }
 int ctamd_stage_range(ctransformers_llm* llm, int stage, int* layer_begin, int* layer_end) {

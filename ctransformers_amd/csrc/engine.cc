@@ -19,6 +19,7 @@
 #include "kernels_pf.h"
 #include "kernels_pg.h"
 #include "kernels_raw32.h"
+#include "kernels_mm8.h"
 
 namespace ctamd {
 
@@ -30,6 +31,9 @@ namespace ctamd {
             return false;                                                                                    \
         }                                                                                                    \
     } while (0)
+
+// Prompt chunks: the order-free kernels (kernels_mm8.h) unless CT_AMD_PREFILL=exact asks for the bit-identical chunk kernels
+constexpr bool kPrefillFastDefault = false;
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -142,6 +146,8 @@ static long long g_kq_launches = 0;   // test hook (ctamd_kq_launches): K-quant 
 long long kq_launches() { return g_kq_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
 long long pg_launches() { return g_pg_launches; }
+static long long g_mm8_launches = 0;  // test hook (ctamd_mm8_launches): chunk launches of the order-free kernels (kernels_mm8.h)
+long long mm8_launches() { return g_mm8_launches; }
 
 // Two-type launch: how many of a workgroup's sixteen waves walk type group B.  A launch ends with its slowest wave, and a wave's time goes with the
 // bytes of its units: the split with the smallest LARGEST per-wave byte count, ties to the split nearest the groups' byte shares.  (Round 5: the split
@@ -763,6 +769,115 @@ bool Engine::pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
     return true;
 }
 
+// One mat-vec site of a prompt chunk in the order-free form (kernels_mm8.h): the nt activation rows as Q8_K / Q8_0 units in operand order, then one launch per
+// weight type over the LAYOUT_M8 records of the site's jobs.
+bool Engine::mm8_can(const MatvecArgs& m) const {
+    if (!fast_pf_ || !acts8_ || m.njobs < 1) return false;
+    const bool b32 = is_block32(m.job[0].w.type);
+    for (int j = 0; j < m.njobs; ++j) {
+        const DevMat& w = m.job[j].w;
+        if (!w.m8 || is_block32(w.type) != b32 || (b32 && w.type != m.job[0].w.type)) return false;
+        if (w.type == GT_Q4_0) return false;                  // (no instantiation yet: the legacy graphs keep kernels_pf.h)
+        if (m.gateup ? w.M % 16 != 0 : w.M % 32 != 0) return false;   // whole row tiles only
+        const int e = m.job[j].epi;
+        if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_SILU_MUL || e == EPI_GELU || e == EPI_ADD2)) return false;
+    }
+    if (m.gateup && (m.njobs != 1 || m.job[0].epi != EPI_SILU_MUL)) return false;
+    if ((size_t)m8_steps(m.job[0].w.type, m.K) * ((kPfChunk + 31) / 32) * kMm8Unit > acts8_bytes_) return false;
+    return !b32 ? (m.K % 256 == 0 && m.K <= 32768) : (m.K % 32 == 0 && m.K <= 32768);
+}
+
+bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err) {
+    const int ty0 = m.job[0].w.type;
+    const bool b32 = is_block32(ty0);
+    const int ntt = (nt + 31) / 32, ns = m8_steps(ty0, m.K);
+    const dim3 qg((unsigned)(8 * ((nt + 7) / 8))), qb(1024);
+    if (b32) {
+        if (m.K <= 12288) CT_LAUNCH((mm8_quantize_q80_kernel<12288>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, m.norm_b, nt);
+        else CT_LAUNCH((mm8_quantize_q80_kernel<32768>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, m.norm_b, nt);
+    } else if (m.pro == PRO_LAYERNORM) {
+        if (m.K <= 4096) CT_LAUNCH((mm8_quantize_q8k_kernel<4096, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, m.norm_b, nt);
+        else if (m.K <= 12288) CT_LAUNCH((mm8_quantize_q8k_kernel<12288, true>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, m.norm_b, nt);
+        else { err = "LayerNorm prologue on rows above 12288"; return false; }
+    } else if (m.K <= 4096) CT_LAUNCH((mm8_quantize_q8k_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
+    else if (m.K <= 12288) CT_LAUNCH((mm8_quantize_q8k_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
+    else CT_LAUNCH((mm8_quantize_q8k_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
+    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K, GT_Q8_0}) {
+        Mm8Args a;
+        a.m = m;
+        a.acts = acts8_;
+        a.n_tok = nt; a.ntt = ntt; a.nb = ns; a.ld_out = ld_out; a.ld_res = ld_res; a.ld_q = hp_.n_embd;
+        int nj = 0, tile0 = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            if (m.job[j].w.type != ty) continue;
+            a.m.job[nj] = m.job[j];
+            a.m.job[nj].pair0 = tile0;
+            tile0 += m.gateup ? m.job[j].w.M / 16 : m.job[j].w.M / 32;
+            ++nj;
+        }
+        if (nj == 0) continue;
+        for (int j = nj; j < 3; ++j) a.m.job[j] = MatJob();
+        a.m.njobs = nj;
+        a.n_tiles = tile0;
+        // Shape of the launch: NTT token tiles per wave (they share the unpacked weight operands of a K-step) x KS K-slices per workgroup (8 / KS row
+        // tiles, which share the staged activation units).  One workgroup per CU at a time (LDS, registers).  Cost model from in-kernel stamps (7B shapes):
+        // a step = the matrix work of a SIMD's two waves + the part of the step's vector-memory issue that does not hide behind it (the CU takes ~45 bytes
+        // of requests per cycle: the stage copy grows with KS, the weight records with 1 / NTT); a workgroup = its steps + ~6 000 cycles of prologue and
+        // the K-slices' reduction; a launch = rounds of workgroups over the CUs.
+        static const int shapes[4][2] = {{2, 1}, {2, 2}, {2, 4}, {1, 8}};
+        int best = -1;
+        double best_cost = 0.0;
+        const size_t unit = (size_t)mm8_unit_bytes(ty);
+        for (int si = 0; si < 4; ++si) {
+            const int NTTv = shapes[si][0], KSv = shapes[si][1], RW = kMm8Waves / KSv;
+            if (mm8_force_ntt_ && (NTTv != mm8_force_ntt_ || KSv != mm8_force_ks_)) continue;
+            if (!mm8_force_ntt_ && NTTv > 1 && ntt < 2) continue;   // token tiles that do not exist
+            const long long wgs = (long long)((tile0 + RW - 1) / RW) * ((ntt + NTTv - 1) / NTTv);
+            const double rounds = (double)((wgs + chip_cus() - 1) / chip_cus());
+            const double tile_cycles = ty == GT_Q6_K ? 1200.0 : (ty == GT_Q8_0 ? 800.0 : 620.0);
+            const double issue = ((double)KSv * NTTv * unit + (double)kMm8Waves * m8_record_bytes(ty)) / 45.0;
+            const double step = 2.0 * NTTv * tile_cycles + 0.5 * issue;
+            const double cost = rounds * (((ns + KSv - 1) / KSv) * step + 6000.0);
+            if (best < 0 || cost < best_cost) { best = si; best_cost = cost; }
+        }
+        if (best < 0) { err = "CT_AMD_MM8_SHAPE names no instantiated launch shape (2,1 / 2,2 / 2,4 / 1,8)"; return false; }
+        const int NTTv = shapes[best][0], KSv = shapes[best][1], RW = kMm8Waves / KSv;
+        const dim3 grid((unsigned)((tile0 + RW - 1) / RW), (unsigned)((ntt + NTTv - 1) / NTTv)), block(512);
+        const size_t smem = std::max((size_t)2 * KSv * NTTv * unit, (size_t)kMm8Waves * NTTv * 4096);
+        ++g_mm8_launches;
+#ifdef MM8_TRACE
+        a.m.dbg_sink = (float*)trace_buf_;
+        HIP_OK(hipMemsetAsync(trace_buf_, 0, 120 * 8, stream_));
+#endif
+#define MM8L(TYV, NV, KV) do { \
+            auto kfn = mm8_kernel<TYV, NV, KV>; \
+            CT_OPTIN_ONCE(kfn, (size_t)158 * 1024); \
+            CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.acts, a.nb, a.n_tiles, a); } while (0)
+#define MM8T(TYV) do { \
+            if (NTTv == 2 && KSv == 1) MM8L(TYV, 2, 1); else if (NTTv == 2 && KSv == 2) MM8L(TYV, 2, 2); \
+            else if (NTTv == 2) MM8L(TYV, 2, 4); else MM8L(TYV, 1, 8); } while (0)
+        if (ty == GT_Q4_K) MM8T(GT_Q4_K); else if (ty == GT_Q5_K) MM8T(GT_Q5_K); else if (ty == GT_Q6_K) MM8T(GT_Q6_K); else MM8T(GT_Q8_0);
+#undef MM8T
+#undef MM8L
+#ifdef MM8_TRACE
+        {
+            static int shown = 0;
+            if (shown < 12 && nt > 64) {
+                ++shown;
+                HIP_OK(hipStreamSynchronize(stream_));
+                unsigned long long h[120];
+                HIP_OK(hipMemcpy(h, trace_buf_, sizeof h, hipMemcpyDeviceToHost));
+                fprintf(stderr, "mm8_trace type %d shape %d,%d tiles %d ns %d grid %u x %u: prologue %llu;", ty, NTTv, KSv, tile0, ns, grid.x, grid.y, h[1] - h[0]);
+                for (int st = 0; 1 + 5 * st + 5 < 120 && h[1 + 5 * st + 4]; ++st)
+                    fprintf(stderr, " [issue %llu compute %llu wait %llu barrier %llu]", h[2 + 5 * st] - h[1 + 5 * st], h[3 + 5 * st] - h[2 + 5 * st], h[4 + 5 * st] - h[3 + 5 * st], h[5 + 5 * st] - h[4 + 5 * st]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+    }
+    return true;
+}
+
 // One mat-vec site of a prompt chunk: activation images of the nt rows, then the token-batched kernel(s) — kernels_pg.h for
 // K-quant weights (f16 matrix cores), kernels_pf.h for Q8_0 / Q4_0 (4x4x4 int8 matrix cores; dot4 for rows above 16384).
 bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes,
@@ -788,6 +903,13 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
             }
             return true;
         }
+    }
+    static const char* mm8_sites = getenv("CT_AMD_MM8_SITES");   // experiments: only these sites ("qkv,wo,gate_up,down") take the order-free kernels
+    if (mm8_can(m) && (!mm8_sites || strstr(mm8_sites, site))) {
+        prof_begin(site, "mm8", bytes);
+        const bool ok = mm8_matvec(m, x, ldx, nt, ld_out, ld_res, err);
+        prof_end();
+        return ok;
     }
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
@@ -1192,6 +1314,16 @@ int Engine::read_stamps(unsigned long long* out, int max) {
     (void)hipMemcpy(out, stamps_ + 1, (size_t)k * 8, hipMemcpyDeviceToHost);
     (void)hipMemset(stamps_, 0, 8);
     return k;
+}
+
+int Engine::debug_read_kv(int layer, uint16_t* k, uint16_t* v) {
+    if (layer < l0_ || layer >= l1_ || !kcache_ || !vcache_) return -1;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    const int G = hp_.n_embd_gqa();
+    (void)hipMemcpy(k, kcache_ + (size_t)(layer - l0_) * n_ctx_ * G, (size_t)n_ctx_ * G * 2, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(v, vcache_ + (size_t)(layer - l0_) * v_stride_ * G, (size_t)v_stride_ * G * 2, hipMemcpyDeviceToHost);
+    return v_stride_;
 }
 
 bool Engine::decode_burst(int n, double* us_per_token, std::string& err) {

@@ -46,6 +46,7 @@ struct Layer {
 
 long long pg_launches();   // test hook: prompt-chunk launches of kernels_pg.h issued by this process
 long long kq_launches();   // test hook: K-quant decode mat-vec launches (kernels_v9.h) issued by this process
+long long mm8_launches();  // test hook: prompt-chunk launches of the order-free kernels (kernels_mm8.h) issued by this process
 
 class Engine {
    public:
@@ -117,6 +118,8 @@ class Engine {
     int embeddings_size() const { return have_logits_ && !hp_.legacy() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
     int read_stamps(unsigned long long* out, int max);   // measurement only: copies and clears the stamps
+    // tests / measurement only: this stage's fp16 K and V cache of one layer -> host ([n_head_kv][n_ctx][head_dim] and [n_embd_gqa][v_stride]); returns v_stride
+    int debug_read_kv(int layer, uint16_t* k, uint16_t* v);
     long long qa_launches() const { return qa_launches_; }   // fused QKV + attention launches issued (eager launches and graph captures)
     long long spec_hits() const { return spec_hits_; }           // evals served by a speculative continuation step
     long long spec_launched() const { return spec_launched_; }   // continuation steps queued
@@ -147,6 +150,7 @@ class Engine {
     bool upload_matrix(const struct GgufTensor* t, DevMat& m, bool keep_raw, std::string& err);
     bool upload_r2c4(const std::vector<std::pair<const struct GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err);
     bool upload_l9b(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err);
+    bool upload_m8(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err);   // LAYOUT_M8 arenas (kernels_mm8.h), when the handle runs the order-free prompt kernels
     bool upload_f32(const struct GgufTensor* t, float** out, int n, std::string& err);
     bool build_tables(std::string& err);
     bool token_step(bool want_logits, std::string& err);
@@ -157,6 +161,8 @@ class Engine {
     bool run_chunk(int c0, int nt, bool want_logits, std::string& err);    // chunk_step, replayed from a hipGraph where it can be   // prompt chunk of 2..kPfChunk tokens (kernels_pf.h)
     bool pg_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err);
     bool pf_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, const char* site, double bytes, std::string& err);
+    bool mm8_can(const ::MatvecArgs& m) const;   // every job of the site has a LAYOUT_M8 arena the order-free kernels take (kernels_mm8.h)
+    bool mm8_matvec(::MatvecArgs& m, const float* x, int ldx, int nt, int ld_out, int ld_res, std::string& err);
     void launch_attention(uint16_t* kc, uint16_t* vc, int nt = 0);
     void fill_attn_args(::AttnArgsX& ax, uint16_t* kc, uint16_t* vc, int nt);
     bool qa_can(const Layer& L) const;   // this layer's token step takes the fused QKV + attention launch (kernels_qa9.h)
@@ -209,6 +215,12 @@ class Engine {
     long long chunk_tokens_ = 0;
     const char* pg_trace_site_ = nullptr;   // measurement only (CT_AMD_PG_TRACE)
     int pg_force_tg_ = 0;   // tests: 16 / 32 tokens per workgroup
+    // Prompt chunks in the order-free form (kernels_mm8.h; CT_AMD_PREFILL=fast|exact, read at load): the reference's quantization points and exact integer
+    // dots, f32 sums in any order — logits within 1e-3 of the reference instead of bit-identical.  Token steps are untouched.
+    bool fast_pf_ = false;
+    uint8_t* acts8_ = nullptr;    // activation units [K-step][token tile] (kernels_mm8.h)
+    size_t acts8_bytes_ = 0;
+    int mm8_force_ntt_ = 0, mm8_force_ks_ = 0;   // experiments (CT_AMD_MM8_SHAPE="ntt,ks")
     uint8_t* acts_h_ = nullptr;   // stage images (kernels_pg.h): [layout 45 | layout 6]
     size_t acts_h_half_ = 0;
     float* rope_cs_ = nullptr;

@@ -161,6 +161,71 @@ __global__ void __launch_bounds__(256) repack_g4_kernel(int q8, const uint8_t* _
     }
 }
 
+// ---- LAYOUT_M8 (quant.h; kernels_mm8.h) ------------------------------------------------------------------------------------------------------
+// One file-layout K-quant block -> row r (0..31) of a (tile, K-step) record.
+CT_HD static inline void place_m8(int type, uint8_t* rec, int r, const uint8_t* blk) {
+    if (type != GT_Q6_K) {
+        const uint8_t* q = blk + 4;
+        uint32_t sc[8], mn[8];
+        for (int jj = 0; jj < 8; ++jj) {   // reference packing: k_quants.c:306-314
+            if (jj < 4) { sc[jj] = q[jj] & 63; mn[jj] = q[jj + 4] & 63; }
+            else { sc[jj] = (q[jj + 4] & 0xF) | ((q[jj - 4] >> 6) << 4); mn[jj] = (q[jj + 4] >> 4) | ((q[jj] >> 6) << 4); }
+        }
+        const uint32_t W1 = sc[0] | (sc[1] << 6) | (sc[2] << 12) | (sc[3] << 18) | (sc[4] << 24) | ((mn[7] & 3u) << 30);
+        const uint32_t W2 = sc[5] | (sc[6] << 6) | (sc[7] << 12) | (mn[0] << 18) | (mn[1] << 24) | (((mn[7] >> 2) & 3u) << 30);
+        const uint32_t W3 = mn[2] | (mn[3] << 6) | (mn[4] << 12) | (mn[5] << 18) | (mn[6] << 24) | ((mn[7] >> 4) << 30);
+        uint8_t* hdr = rec + r * 16;
+        memcpy(hdr, blk, 4);
+        memcpy(hdr + 4, &W1, 4); memcpy(hdr + 8, &W2, 4); memcpy(hdr + 12, &W3, 4);
+        const uint8_t* qs = blk + (type == GT_Q4_K ? 16 : 48);
+        uint8_t* dq = rec + (type == GT_Q4_K ? 512 : 1536);
+        if (type == GT_Q5_K)
+            for (int c = 0; c < 2; ++c) memcpy(rec + 512 + (c * 32 + r) * 16, blk + 16 + 16 * c, 16);
+        for (int g = 0; g < 4; ++g)
+            for (int c = 0; c < 2; ++c) memcpy(dq + g * 1024 + (c * 32 + r) * 16, qs + 32 * g + 16 * c, 16);
+    } else {   // ql[128] | qh[64] | scales[16] | d
+        for (int h = 0; h < 2; ++h)
+            for (int o = 0; o < 2; ++o)
+                for (int c = 0; c < 2; ++c) memcpy(rec + (2 * h + o) * 1024 + (c * 32 + r) * 16, blk + 64 * h + 32 * o + 16 * c, 16);
+        for (int h = 0; h < 2; ++h)
+            for (int c = 0; c < 2; ++c) memcpy(rec + 4096 + h * 1024 + (c * 32 + r) * 16, blk + 128 + 32 * h + 16 * c, 16);
+        memcpy(rec + 6144 + r * 16, blk + 192, 16);
+        memcpy(rec + 6656 + r * 2, blk + 208, 2);
+    }
+}
+// One file-layout Q8_0 / Q4_0 block -> block jj (0..7) of row r of a (tile, K-step) record.
+CT_HD static inline void place_m8_b32(int type, uint8_t* rec, int r, int jj, const uint8_t* blk) {
+    memcpy(rec + r * 16 + jj * 2, blk, 2);
+    if (type == GT_Q8_0) {
+        for (int c = 0; c < 2; ++c) memcpy(rec + 512 + jj * 1024 + (c * 32 + r) * 16, blk + 2 + 16 * c, 16);
+    } else {
+        memcpy(rec + 512 + jj * 512 + r * 16, blk + 2, 16);
+    }
+}
+// row of the matrix (and which tensor: gate / up of a fused matrix) behind row r of tile `tile`
+CT_HD static inline int m8_row_of(int tile, int r, bool fused, bool& second) {
+    second = fused && r >= 16;
+    return fused ? 16 * tile + (r & 15) : 32 * tile + r;
+}
+__global__ void __launch_bounds__(256) repack_m8_kernel(int type, const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb, uint8_t* __restrict__ dst,
+                                                        int M, int nbf, int n_tiles) {
+    const bool b32 = is_block32(type);
+    const int ns = b32 ? (nbf + 7) / 8 : nbf, per = b32 ? 8 : 1, bb = ggml_block_bytes(type), rec = m8_record_bytes(type);
+    const long long n = (long long)n_tiles * ns * 32 * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int jj = (int)(i % per), r = (int)((i / per) & 31);
+        const long long ts = i / per / 32;
+        const int s = (int)(ts % ns), tile = (int)(ts / ns);
+        bool second;
+        const int row = m8_row_of(tile, r, sb != nullptr, second), b = b32 ? 8 * s + jj : s;
+        if (row >= M || b >= nbf) continue;   // zero rows / zero blocks (the arena is cleared first)
+        const uint8_t* blk = (second ? sb : sa) + ((size_t)row * nbf + b) * bb;
+        uint8_t* rp = dst + (size_t)ts * rec;
+        if (b32) place_m8_b32(type, rp, r, jj, blk);
+        else place_m8(type, rp, r, blk);
+    }
+}
+
 // Load pipeline, stage 1: the byte range of the mapping that holds the tensors in `need` -> device memory, unchanged.  pread() by
 // worker threads straight into pinned slots (no page faults on the mapping, no pageable bounce inside the runtime), one async copy
 // per slot; reading slot k + 1 overlaps the copy of slot k.
@@ -407,6 +472,65 @@ bool Engine::upload_l9b(const std::vector<std::pair<const GgufTensor*, DevMat*>>
     return true;
 }
 
+// LAYOUT_M8 arenas (kernels_mm8.h) of the matrices in `parts`, one allocation; `fuse`: pairs (gate, up) become ONE matrix of tiles
+// (16 gate rows | 16 up rows), described by the pair's DevMat.  Called only where the handle runs the order-free prompt kernels.
+bool Engine::upload_m8(const std::vector<std::pair<const GgufTensor*, DevMat*>>& parts, bool fuse, std::string& err) {
+    struct Plan { const GgufTensor* ta; const GgufTensor* tb; DevMat* m; size_t off; int type, K, M, nbf, ns, n_tiles; };
+    std::vector<Plan> plan;
+    size_t total = 0;
+    for (size_t i = 0; i < parts.size(); i += fuse ? 2 : 1) {
+        const GgufTensor* ta = parts[i].first;
+        const GgufTensor* tb = fuse ? parts[i + 1].first : nullptr;
+        if (!ta || (fuse && !tb)) { err = "missing tensor for the M8 layout"; return false; }
+        if (!(is_kquant(ta->type) || is_block32(ta->type))) return true;   // other types keep the exact forms
+        if (tb && (tb->type != ta->type || tb->ne[0] != ta->ne[0] || tb->ne[1] != ta->ne[1])) { err = "gate/up tensors differ in type or shape"; return false; }
+        Plan p;
+        p.ta = ta; p.tb = tb; p.m = parts[i].second; p.type = ta->type; p.K = (int)ta->ne[0]; p.M = (int)ta->ne[1];
+        p.nbf = p.K / ggml_block_elems(p.type);
+        p.ns = m8_steps(p.type, p.K);
+        if (p.K % ggml_block_elems(p.type) || p.K > 32768) return true;
+        p.n_tiles = tb ? (p.M + 15) / 16 : (p.M + 31) / 32;
+        p.off = total;
+        total += (size_t)p.n_tiles * p.ns * m8_record_bytes(p.type);
+        plan.push_back(p);
+    }
+    if (plan.empty()) return true;
+    uint8_t* d = nullptr;
+    if (!dev_alloc(dev_allocs_, &d, total + 16384, err)) return false;   // + one record: the kernels request a K-step past a tile's last one (clamped, but keep the slack)
+    if (dev_file_) {
+        HIP_OK(hipMemsetAsync(d, 0, total + 16384, stream_));
+        for (const Plan& p : plan) {
+            const long long n = (long long)p.n_tiles * p.ns * 32 * (is_block32(p.type) ? 8 : 1);
+            const unsigned gx = (unsigned)std::min<long long>((n + 255) / 256, 65535LL * 16);
+            CT_LAUNCH(repack_m8_kernel, dim3(gx), dim3(256), stream_, p.type, staged(p.ta), p.tb ? staged(p.tb) : (const uint8_t*)nullptr, d + p.off, p.M, p.nbf, p.n_tiles);
+        }
+    } else {
+        std::vector<uint8_t> st(total, 0);
+        for (const Plan& p : plan) {
+            const bool b32 = is_block32(p.type);
+            const int bb = ggml_block_bytes(p.type), rec = m8_record_bytes(p.type);
+            uint8_t* dst = st.data() + p.off;
+            parallel_rows(p.n_tiles, [&](int t0, int t1) {
+                for (int tile = t0; tile < t1; ++tile)
+                    for (int r = 0; r < 32; ++r) {
+                        bool second;
+                        const int row = m8_row_of(tile, r, p.tb != nullptr, second);
+                        if (row >= p.M) continue;
+                        const uint8_t* src = (second ? p.tb->data : p.ta->data) + (size_t)row * p.nbf * bb;
+                        for (int b = 0; b < p.nbf; ++b) {
+                            if (b32) place_m8_b32(p.type, dst + ((size_t)tile * p.ns + (b >> 3)) * rec, r, b & 7, src + (size_t)b * bb);
+                            else place_m8(p.type, dst + ((size_t)tile * p.ns + b) * rec, r, src + (size_t)b * bb);
+                        }
+                    }
+            });
+        }
+        HIP_OK(hipMemset(d + total, 0, 16384));
+        HIP_OK(hipMemcpy(d, st.data(), total, hipMemcpyHostToDevice));
+    }
+    for (const Plan& p : plan) p.m->m8 = d + p.off;
+    return true;
+}
+
 bool Engine::upload_matrix(const GgufTensor* t, DevMat& m, bool keep_raw, std::string& err) {
     m.type = t->type;
     m.K = (int)t->ne[0];
@@ -585,7 +709,12 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
     if (n_ctx_ > (1 << 20)) { err = "context_length above 1048576 is not supported"; return false; }
 
     HIP_OK(hipStreamCreate(&stream_));
+    {   // CT_AMD_PREFILL=fast: prompt chunks in the order-free form (kernels_mm8.h); exact: the bit-identical chunk kernels (kernels_pg.h / kernels_pf.h)
+        const char* pm = getenv("CT_AMD_PREFILL");
+        fast_pf_ = pm && *pm ? (!strcmp(pm, "fast") || !strcmp(pm, "1")) : kPrefillFastDefault;
+    }
     bool r2_auto = true;   // mat() also makes the matrix's own R2C4 copy (false: the caller places several matrices in one arena)
+    bool m8_auto = true;   // ... and, on a handle with the order-free prompt kernels, its LAYOUT_M8 copy (false: the output head, which only token steps read)
     const GgufTensor* t;
     auto mat = [&](const std::string& name, DevMat& m, int M, int K, bool raw = false) {
         t = f.tensor(name);
@@ -594,6 +723,7 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (!upload_matrix(t, m, raw, err)) return false;
         if (is_kquant(t->type) && r2_auto && !upload_r2c4({{t, &m}}, false, err)) return false;
         if (is_block32(t->type) && r2_auto && !upload_l9b({{t, &m}}, false, err)) return false;
+        if (fast_pf_ && m8_auto && !upload_m8({{t, &m}}, false, err)) return false;
         weight_bytes_ += t->nbytes;
         return true;
     };
@@ -646,7 +776,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (l1_ == hp_.n_layer) {
             if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
             if (!upload_f32(f.tensor("output_norm.bias"), &output_norm_b_, E, err)) return false;
+            m8_auto = false;
             if (!mat("output.weight", output_, V, E)) return false;
+            m8_auto = true;
         }
         if (!dev_alloc(dev_allocs_, &qkv_tmp_, (size_t)(E + 2 * G), err) || !dev_alloc(dev_allocs_, &attn_proj_, (size_t)E, err))
             return false;
@@ -660,7 +792,9 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (!mat(p + "attn_q.weight", L.wq, E, E) || !mat(p + "attn_k.weight", L.wk, G, E) ||
             !mat(p + "attn_v.weight", L.wv, G, E))
             return false;
+        m8_auto = false;   // (the chunk launch reads the fused gate/up matrix: its LAYOUT_M8 copy is made below)
         if (!mat(p + "ffn_gate.weight", L.w_gate, F, E) || !mat(p + "ffn_up.weight", L.w_up, F, E)) return false;
+        m8_auto = true;
         r2_auto = true;
         if (!mat(p + "attn_output.weight", L.wo, E, E) || !mat(p + "ffn_down.weight", L.w_down, E, F)) return false;
         if (L.w_gate.type != L.w_up.type) { err = "ffn_gate/ffn_up type mismatch in layer " + std::to_string(i); return false; }
@@ -683,10 +817,15 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
         if (is_block32(L.w_gate.type) &&
             !upload_l9b({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
             return false;
+        if (fast_pf_ && (is_kquant(L.w_gate.type) || is_block32(L.w_gate.type)) && F % 16 == 0 &&
+            !upload_m8({{f.tensor(p + "ffn_gate.weight"), &L.w_gu}, {f.tensor(p + "ffn_up.weight"), &L.w_gu}}, true, err))
+            return false;
     }
     if (l1_ == hp_.n_layer) {
         if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;
+        m8_auto = false;
         if (!mat("output.weight", output_, V, E)) return false;
+        m8_auto = true;
     }
     }
     if (l0_ > 0 || l1_ < hp_.n_layer)
@@ -788,6 +927,12 @@ bool Engine::alloc_state(std::string& err) {
             acts_h_half_ = (size_t)(std::max(E, F) / 256) * std::max((kPfChunk / 16) * PgStage<16>::BYTES, (kPfChunk / 32) * PgStage<32>::BYTES) + 4096;
             if (!dev_alloc(dev_allocs_, &acts_h_, 2 * acts_h_half_, err)) return false;
             HIP_OK(hipMemset(acts_h_, 0, 2 * acts_h_half_));   // token slots past the chunk's end are read (and their results dropped)
+        }
+        if (fast_pf_) {   // activation units of the order-free kernels: [K-steps of the widest input][token tiles of a chunk]
+            acts8_bytes_ = (size_t)((std::max(E, F) + 255) / 256) * ((kPfChunk + 31) / 32) * kMm8Unit + 4096;
+            if (!dev_alloc(dev_allocs_, &acts8_, acts8_bytes_, err)) return false;
+            HIP_OK(hipMemset(acts8_, 0, acts8_bytes_));
+            if (const char* sh = getenv("CT_AMD_MM8_SHAPE")) { if (sscanf(sh, "%d,%d", &mm8_force_ntt_, &mm8_force_ks_) != 2) mm8_force_ntt_ = mm8_force_ks_ = 0; }
         }
         if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
                              !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))

@@ -54,6 +54,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
             a.job[1].w = L.w_up; a.job[1].pair0 = 0; a.job[1].epi = EPI_SILU_MUL;
             a.njobs = 2; a.gateup = 1; a.n_pairs = F;
             if (L.w_gu.r2) { a.job[0].w = L.w_gu; a.njobs = 1; }   // K-quants: the fused matrix of the decode path (kernels_pg.h)
+            else if (fast_pf_ && L.w_gu.m8) { a.job[0].w = L.w_gu; a.njobs = 1; }   // Q8_0: the fused LAYOUT_M8 matrix (kernels_mm8.h)
             if (!pf_matvec(a, xb_, E, nt, F, 0, "gate_up", (double)(L.w_gate.bytes + L.w_up.bytes), err)) return false;
         }
         {

@@ -386,6 +386,94 @@ DEV uint32_t pk_mul_f16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint
 DEV uint32_t h2_from_int(int v) { const _Float16 h = (_Float16)(short)v; const f16x2 r = {h, h}; return __builtin_bit_cast(uint32_t, r); }
 #endif
 
+// ---- 32x32 matrix cores of the order-free prompt kernels (kernels_mm8.h) -------------------------------------------------------------
+// v_mfma_i32_32x32x32_i8: D[32][32] (+)= A[32][32] * B[32][32], 16 int8 per lane and operand.  Pairing (hardware-checked,
+// tools/experiments/mfma_i8_32x32x32_probe.cpp): byte e of lane (n, c)'s A meets byte e of lane (m, c)'s B (n, m = lane & 31, c = lane >> 5;
+// which k the hardware calls it is irrelevant to an integer sum); lane (m, h) holds D[(i & 3) + 8 (i >> 2) + 4 h][m] in register i.
+// mfma_i8_32x32x32_bias: the same product on top of C = 0x4B400000 in every element — the result bits READ AS FLOATS are 1.5 * 2^23 + sum
+// (|sum| < 2^22), the integer sum as an exact float without a conversion.
+// v_mfma_f32_32x32x16_f16 on integer-valued halves (every product and partial sum an integer below 2^24: exact in any order): 8 halves per lane
+// and operand, same pairing and result map.
+#ifdef CT_EMU
+struct i32x16 {
+    int v[16];
+    int operator[](int i) const { return v[i]; }
+    int& operator[](int i) { return v[i]; }
+};
+struct f32x16 {
+    float v[16];
+    float operator[](int i) const { return v[i]; }
+    float& operator[](int i) { return v[i]; }
+};
+static inline i32x16 mfma_i8_32x32x32_c(u32x4 a, u32x4 b, int c0) {
+    const int lane = (int)(threadIdx.x & 63), m = lane & 31, h = lane >> 5;
+    const uint64_t a01 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a23 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    const uint64_t b01 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b23 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    uint64_t bk[2][2];
+    for (int c = 0; c < 2; ++c) { bk[c][0] = emu_shfl_any(b01, m + 32 * c); bk[c][1] = emu_shfl_any(b23, m + 32 * c); }
+    i32x16 d;
+    for (int i = 0; i < 16; ++i) {
+        const int n = (i & 3) + 8 * (i >> 2) + 4 * h;
+        int s = c0;
+        for (int c = 0; c < 2; ++c) {
+            const uint64_t am[2] = {emu_shfl_any(a01, n + 32 * c), emu_shfl_any(a23, n + 32 * c)};
+            for (int w = 0; w < 2; ++w)
+                for (int e = 0; e < 8; ++e) s += (int)(int8_t)(am[w] >> (8 * e)) * (int)(int8_t)(bk[c][w] >> (8 * e));
+        }
+        d[i] = s;
+    }
+    return d;
+}
+static inline i32x16 mfma_i8_32x32x32(u32x4 a, u32x4 b) { return mfma_i8_32x32x32_c(a, b, 0); }
+static inline i32x16 mfma_i8_32x32x32_acc(u32x4 a, u32x4 b, i32x16 c) {
+    const i32x16 p = mfma_i8_32x32x32_c(a, b, 0);
+    for (int i = 0; i < 16; ++i) c[i] += p[i];
+    return c;
+}
+static inline i32x16 mfma_i8_32x32x32_bias(u32x4 a, u32x4 b) { return mfma_i8_32x32x32_c(a, b, 0x4B400000); }
+static inline f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b) {
+    const int lane = (int)(threadIdx.x & 63), m = lane & 31, h = lane >> 5;
+    const uint64_t a01 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a23 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    const uint64_t b01 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b23 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    uint64_t bk[2][2];
+    for (int c = 0; c < 2; ++c) { bk[c][0] = emu_shfl_any(b01, m + 32 * c); bk[c][1] = emu_shfl_any(b23, m + 32 * c); }
+    f32x16 d;
+    for (int i = 0; i < 16; ++i) {
+        const int n = (i & 3) + 8 * (i >> 2) + 4 * h;
+        double s = 0.0;
+        for (int c = 0; c < 2; ++c) {
+            const uint64_t am[2] = {emu_shfl_any(a01, n + 32 * c), emu_shfl_any(a23, n + 32 * c)};
+            for (int w = 0; w < 2; ++w)
+                for (int e = 0; e < 4; ++e)
+                    s += (double)f16_bits_to_f32((uint16_t)(am[w] >> (16 * e))) * (double)f16_bits_to_f32((uint16_t)(bk[c][w] >> (16 * e)));
+        }
+        d[i] = (float)s;
+    }
+    return d;
+}
+#else
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+DEV i32x16 mfma_i8_32x32x32(u32x4 a, u32x4 b) {
+    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a), __builtin_bit_cast(i32x4v, b), z, 0, 0, 0);
+}
+DEV i32x16 mfma_i8_32x32x32_acc(u32x4 a, u32x4 b, i32x16 c) {
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a), __builtin_bit_cast(i32x4v, b), c, 0, 0, 0);
+}
+DEV i32x16 mfma_i8_32x32x32_bias(u32x4 a, u32x4 b) {
+    constexpr int K = 0x4B400000;
+    const i32x16 z = {K, K, K, K, K, K, K, K, K, K, K, K, K, K, K, K};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a), __builtin_bit_cast(i32x4v, b), z, 0, 0, 0);
+}
+DEV f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b) {
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), z, 0, 0, 0);
+}
+#endif
+
 // ---- f32 matrix core, K = 1 (kernels_pf.h: the block-scale products of the Q8_0 / Q4_0 prompt chunks) --------------------------------
 // v_mfma_f32_4x4x1_16b_f32: sixteen independent rank-1 updates D_b[i][m] = C + A_b[i] * B_b[m] (the lane roles of the int8 4x4x4 form:
 // lane 4b + m gives A_b[m] and B_b[m], holds D_b[i][m] in register i).  With C = 0 and operands whose product is exact in f32 (two
@@ -653,6 +741,8 @@ DEV uint32_t vgpr_const(uint32_t v) { uint32_t r; asm volatile("v_mov_b32 %0, %1
 #ifdef CT_EMU
 static inline void glds16(const void* gsrc, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
 static inline void glds4(const void* gsrc, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 4 * (threadIdx.x & 63), gsrc, 4); }
+static inline void glds16_s(const void* sbase, uint32_t voff, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 16 * (threadIdx.x & 63), (const unsigned char*)sbase + voff, 16); }
+static inline void glds4_s(const void* sbase, uint32_t voff, unsigned char* lds_wave_base) { memcpy(lds_wave_base + 4 * (threadIdx.x & 63), (const unsigned char*)sbase + voff, 4); }
 template <int N> static inline void vm_wait() {}
 template <int N> static inline void sleep_cycles() {}
 #else
@@ -667,6 +757,19 @@ DEV void glds16(const void* gsrc, unsigned char* lds_wave_base) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// The same with the source as (wave-uniform base in scalar registers) + (32-bit lane offset): no 64-bit vector address arithmetic per piece.
+DEV void glds16_s(const void* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase) : "memory");
+}
+DEV void glds4_s(const void* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase) : "memory");
 }
 template <int N> DEV void sleep_cycles() { __builtin_amdgcn_s_sleep(N); }   // N * 64 clocks
 template <int N> DEV void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }

@@ -66,7 +66,7 @@ CT_HD static inline bool is_raw32(int t) { return t == GT_Q4_1 || t == GT_Q5_0 |
 // LAYOUT_G4 (Q8_0 / Q4_0, kernels_q32.h): per 8-row tile and group of 4 consecutive 32-blocks one record with each lane's
 // four dwords contiguous (Q8_0 1088 B, Q4_0 576 B = 8 rows x 4 blocks x the file block size: bytes unchanged).
 // (LAYOUT_TILE8S = 2 was the 8-row tile layout of the retired mat-vec generations 5 / 6.)
-enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5, LAYOUT_F16 = 6, LAYOUT_RAW32 = 7 };   // LAYOUT_F16 / LAYOUT_RAW32: rows as in the file (DevMat::raw; kernels_f16.h, kernels_raw32.h)
+enum { LAYOUT_TILE8S = 2, LAYOUT_G4 = 3, LAYOUT_R2C4 = 4, LAYOUT_L9 = 5, LAYOUT_F16 = 6, LAYOUT_RAW32 = 7, LAYOUT_M8 = 8 };   // LAYOUT_F16 / LAYOUT_RAW32: rows as in the file (DevMat::raw; kernels_f16.h, kernels_raw32.h)
 CT_HD static inline int tile8_record_bytes(int t) { return 8 * ggml_block_bytes(t); }
 // LAYOUT_R2C4 record of the prompt-chunk copy.  Q4_K / Q5_K: 8 x the file block.  Q6_K: the quants are stored UNPACKED-READY for the
 // f16 matrix-core operand (kernels_pg.h): per (slot, p, l) two dwords A, B with the four 6-bit values of vector va(p) / vb(p),
@@ -83,6 +83,25 @@ CT_HD static inline int l9_record_bytes(int t) { return t == GT_Q8_0 ? 1088 : (t
 CT_HD static inline int l9_spu(int t, int K) { return (t == GT_Q8_0 || t == GT_Q4_0) ? ((K >> 5) + 15) >> 4 : ((K >> 8) + 3) >> 2; }
 CT_HD static inline bool is_block32(int t) { return t == GT_Q8_0 || t == GT_Q4_0; }
 
+// LAYOUT_M8 (kernels_mm8.h: the order-free prompt kernels on the 32x32x32 int8 matrix cores): a record = one TILE of 32 rows x one K-STEP of 256
+// elements, every field lane-linear for the wave that owns the tile — lane = 32 c + r reads, in one 16-byte load per piece, what row r contributes to
+// K-chunk c (elements 16c .. 16c+15 of a 32-element sub-block) of the matrix instruction's B operand; a tile's records are consecutive along K.
+// Record bytes = 32 x the file's bytes of 256 elements (the repack moves bytes; the 6-bit scales / mins of Q4_K / Q5_K are re-encoded, same 12 bytes).
+//   Q4_K 4608 B: hdr[32 rows][16] | qs[4 g][64 lanes][16]                 piece g, lane (r, c) = file qs bytes 32g + 16c ..: low nibbles sub-block 2g, high 2g + 1
+//       hdr = f16 d | f16 dmin | W1 | W2 | W3 with the sixteen 6-bit fields one bfe each (m7 in the three spare bit pairs):
+//         W1 = sc0 | sc1<<6 | sc2<<12 | sc3<<18 | sc4<<24 | (m7 & 3)<<30
+//         W2 = sc5 | sc6<<6 | sc7<<12 | m0<<18 | m1<<24 | ((m7>>2) & 3)<<30
+//         W3 = m2 | m3<<6 | m4<<12 | m5<<18 | m6<<24 | (m7>>4)<<30
+//   Q5_K 5632 B: hdr[32][16] | qh[64 lanes][16] | qs[4][64][16]           qh lane (r, c) = file qh bytes 16c ..: bit j of byte e = fifth bit of element 16c + e of sub-block j
+//   Q6_K 6720 B: ql[2 h][2 o][64][16] | qh[2 h][64][16] | sc[32][16] | d[32] f16     ql piece (h, o), lane (r, c) = file ql bytes 64h + 32o + 16c ..; qh piece h = file qh bytes 32h + 16c ..
+//   Q8_0 8704 B (8 blocks): d[32 rows][8] f16 | qs[8 j][64][16]           block j, lane (r, c) = its quants 16c .. 16c+15
+//   Q4_0 4608 B (8 blocks): d[32][8] f16 | qs[8 j][32 rows][16]           both K-chunks of a row read the same 16 bytes (low nibbles: elements 0..15, high: 16..31)
+// The fused gate/up matrix: tile T = gate rows 16T .. 16T+15 (r < 16) and up rows 16T .. 16T+15 (r >= 16).
+CT_HD static inline int m8_record_bytes(int t) {
+    switch (t) { case GT_Q4_K: return 4608; case GT_Q5_K: return 5632; case GT_Q6_K: return 6720; case GT_Q8_0: return 8704; case GT_Q4_0: return 4608; default: return 0; }
+}
+CT_HD static inline int m8_steps(int t, int K) { return (t == GT_Q8_0 || t == GT_Q4_0) ? ((K >> 5) + 7) >> 3 : K >> 8; }   // K-steps of 256 elements per row
+
 // A weight matrix resident on one GPU.  M rows (outputs), K columns (inputs).
 struct DevMat {
     int type = -1;
@@ -92,6 +111,7 @@ struct DevMat {
     const uint8_t* raw = nullptr;  // file layout, kept only for tensors used by row lookup (token_embd)
     const uint8_t* r2 = nullptr;   // LAYOUT_R2C4 records (inside an arena several matrices may share): prompt-chunk kernels
     const uint8_t* r9 = nullptr;   // LAYOUT_L9 records, same arena geometry: decode mat-vec (kernels_v9.h)
+    const uint8_t* m8 = nullptr;   // LAYOUT_M8 records (row tiles of 32): the order-free prompt kernels (kernels_mm8.h); null unless the handle runs them
     int layout = 0;                // LAYOUT_R2C4 (records in r2) / LAYOUT_G4 (records in p[0])
     size_t bytes = 0;           // total device bytes (== file bytes)
 };
