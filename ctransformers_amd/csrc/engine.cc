@@ -851,7 +851,7 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
 #endif
 #define MM8L(TYV, NV, KV) do { \
             auto kfn = mm8_kernel<TYV, NV, KV>; \
-            CT_OPTIN_ONCE(kfn, (size_t)158 * 1024); \
+            CT_OPTIN_ONCE(kfn, (size_t)160 * 1024); \
             CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.acts, a.nb, a.n_tiles, a); } while (0)
 #define MM8T(TYV) do { \
             if (NTTv == 2 && KSv == 1) MM8L(TYV, 2, 1); else if (NTTv == 2 && KSv == 2) MM8L(TYV, 2, 2); \

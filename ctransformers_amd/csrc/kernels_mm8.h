@@ -27,7 +27,7 @@
 #include "kernels_pg.h"
 
 constexpr int kMm8Waves = 8;
-constexpr int kMm8Unit = 9472;    // K-quant activations, one (256-block, token tile): q8[8 j][64 lanes][16] | bsum16 as halves [64 lanes][16] | y.d[32] f32 | 1152 * sum(q8)[32] i32
+constexpr int kMm8Unit = 10240;   // K-quant activations, one (256-block, token tile): q8[8 j][64 lanes][16] | bsum16 as halves [64 lanes][16] | y.d[32] f32 | 1152 * sum(q8)[32] i32 | pad to 1 KB pieces
 constexpr int kMm8UnitB = 9216;   // Q8_0 activations, one (8 blocks, token tile):     q8[8 j][64 lanes][16] | y.d[8 j][32] f32
 CT_HD static inline int mm8_unit_bytes(int type) { return is_block32(type) ? kMm8UnitB : kMm8Unit; }
 
@@ -171,6 +171,15 @@ static inline u32x4 lds16(const uint8_t* p) { u32x4 r; memcpy(&r, p, 16); return
 DEV u32x4 lds16(const uint8_t* p) { return *(const u32x4*)p; }
 #endif
 
+// the sixteen accumulators have their values at this point of the program (a scheduling fence on values)
+DEV void mm8_pin(f32x16& a) {
+#ifndef CT_EMU
+    asm volatile("" : "+v"(a));
+#else
+    (void)a;
+#endif
+}
+
 // acc[i] += p[i] * s for the sixteen results of a matrix instruction (s lane-local: the scale of this lane's row).  NOT through gpu.h's asm mad24: the
 // operands come straight out of a matrix instruction, and hipcc pads the MFMA-write -> VALU-read hazard only for instructions it can see (with the asm
 // form the first multiply-adds read the registers before the product had landed: wrong sums on hardware, right ones in the emulator).  The builtin
@@ -200,8 +209,10 @@ DEV void mm8_yd16(const uint8_t* yd /* f32[32] of the tile */, int lane, float (
 // `feed(slot)`, slot = 8 * token tile + sub-block: the caller's memory requests of this step (the copy of the next stage), spread over the step — issued in
 // one burst at the top they cost every wave of the workgroup ~2 700 cycles in which nothing computes (in-kernel stamps: the CU accepts ~64 bytes of vector
 // memory requests per cycle, and all eight waves ask at once).
+// `R` holds the record of this K-step on entry and the record at `next_rec` (requested, not yet waited for) on return: the K-quant forms request it once
+// their operands are unpacked, the Q8_0 form — whose operands ARE the record's registers — block by block behind the last token tile's use of each.
 template <int TYPE, int NTT, class Feed>
-DEV void mm8_step(const Mm8W<TYPE>& R, const uint8_t* stage, int lane, f32x16 (&acc)[NTT], const Feed& feed) {
+DEV void mm8_step(Mm8W<TYPE>& R, const uint8_t* __restrict__ next_rec, const uint8_t* stage, int lane, f32x16 (&acc)[NTT], const Feed& feed) {
     const int c = lane >> 5;
     if constexpr (TYPE == GT_Q4_K || TYPE == GT_Q5_K) {
         // Digit planes: sc_j = 8 h_j + l_j (h, l in 0..7), B1 = q * h_j, B0 = q * l_j are int8 operands (15 * 7 = 105; Q5_K: 31 * 7 = 217, stored as
@@ -241,6 +252,7 @@ DEV void mm8_step(const Mm8W<TYPE>& R, const uint8_t* stage, int lane, f32x16 (&
                 B1[2 * g + 1][k] = pk_mul_u16(hi, hb) ^ X; B0[2 * g + 1][k] = pk_mul_u16(hi, lb) ^ X;
             }
         }
+        R = mm8_load<TYPE>(next_rec, lane);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const uint8_t* U = stage + tt * UNIT;
@@ -273,6 +285,7 @@ DEV void mm8_step(const Mm8W<TYPE>& R, const uint8_t* stage, int lane, f32x16 (&
                 const float u = fmaf((float)isum, dw, M[i] * ndmw);
                 acc[tt][i] = fmaf(u, da[i], acc[tt][i]);
             }
+            mm8_pin(acc[tt]);
         }
     } else if constexpr (TYPE == GT_Q6_K) {
         constexpr int UNIT = kMm8Unit;
@@ -294,6 +307,7 @@ DEV void mm8_step(const Mm8W<TYPE>& R, const uint8_t* stage, int lane, f32x16 (&
                     const uint32_t q = ((qd & 2 ? lw >> 4 : lw) & 0x0F0F0F0Fu) | (((hw >> (2 * qd)) & 0x03030303u) << 4);
                     B[4 * h + qd][k] = (q + 0x60606060u) ^ 0x80808080u;   // q - 32 per byte (q <= 63: no carry between bytes)
                 }
+        R = mm8_load<TYPE>(next_rec, lane);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const uint8_t* U = stage + tt * UNIT;
@@ -321,50 +335,53 @@ DEV void mm8_step(const Mm8W<TYPE>& R, const uint8_t* stage, int lane, f32x16 (&
             sched_fence();
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[tt][i] = fmaf((float)ai[i] * dw, da[i], acc[tt][i]);
+            mm8_pin(acc[tt]);
         }
     } else {   // Q8_0 / Q4_0: eight 32-blocks, each with its own fp16 scale on both sides
         constexpr int UNIT = kMm8UnitB;
-        u32x4 B[8];
+        const u32x4 dcur = R.d;   // the row's eight block scales (fp16)
+        u32x4 B4[TYPE == GT_Q4_0 ? 8 : 1];
+        if constexpr (TYPE == GT_Q4_0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (TYPE == GT_Q8_0) B[j] = R.q[j];
-            else {
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t n = (c ? R.q[j][k] >> 4 : R.q[j][k]) & 0x0F0F0F0Fu;
-                    B[j][k] = (n + 0x78787878u) ^ 0x80808080u;   // n - 8 per byte
+                    B4[j][k] = (n + 0x78787878u) ^ 0x80808080u;   // n - 8 per byte
                 }
-            }
+            R = mm8_load<TYPE>(next_rec, lane);
         }
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const uint8_t* U = stage + tt * UNIT;
-            u32x4 A = lds16(U + lane * 16);
-            i32x16 pend = mfma_i8_32x32x32_bias(A, B[0]);
-            A = lds16(U + 1024 + lane * 16);
-            sched_fence();
+            // (no hand-made software pipeline here: with the product of block j + 1 issued before the multiply-adds of block j hipcc kept all eight
+            // products and their y.d rows live and spilled ~300 registers; the SIMD's other wave covers the matrix instruction's latency instead)
 #pragma unroll
-            for (int j = 1; j <= 8; ++j) {
-                i32x16 cur = pend;
-                if (j < 8) {
-                    cur = mfma_i8_32x32x32_bias(A, B[j]);
-                    if (j < 7) A = lds16(U + (j + 1) * 1024 + lane * 16);
+            for (int j = 0; j < 8; ++j) {
+                const u32x4 A = lds16(U + j * 1024 + lane * 16);
+                i32x16 p;
+                if constexpr (TYPE == GT_Q4_0) p = mfma_i8_32x32x32_bias(A, B4[j]);
+                else {
+                    p = mfma_i8_32x32x32_bias(A, R.q[j]);
+                    if (tt == NTT - 1) R.q[j] = ld_stream16(next_rec + 512 + j * 1024 + lane * 16);   // this block's registers are free: the next K-step's block
                 }
-                const uint32_t dh = R.d[(j - 1) >> 1];
-                const float dwj = f16_bits_to_f32((uint16_t)(((j - 1) & 1) ? dh >> 16 : dh & 0xFFFFu));
+                const uint32_t dh = dcur[j >> 1];
+                const float dwj = f16_bits_to_f32((uint16_t)((j & 1) ? dh >> 16 : dh & 0xFFFFu));
                 const float nbd = -12582912.0f * dwj;   // exact (13 significant bits)
                 float da[16];
-                mm8_yd16(U + 8192 + (j - 1) * 128, lane, da);
+                mm8_yd16(U + 8192 + j * 128, lane, da);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float u = fmaf(bits_to_f32((uint32_t)pend[i]), dwj, nbd);   // = p * fp16(x.d), rounded once
+                    const float u = fmaf(bits_to_f32((uint32_t)p[i]), dwj, nbd);   // = p * fp16(x.d), rounded once
                     acc[tt][i] = fmaf(u, da[i], acc[tt][i]);
                 }
-                pend = cur;
-                feed(8 * tt + j - 1);
+                mm8_pin(acc[tt]);   // the accumulation of block j happens HERE (left alone hipcc issues the eight products first, sinks the multiply-adds
+                                    // of all blocks behind them and spills the y.d rows it has read on the way: 300 registers)
+                feed(8 * tt + j);
                 sched_fence();
             }
         }
+        if constexpr (TYPE == GT_Q8_0) R.d = ld16(next_rec + (lane & 31) * 16);
     }
 }
 
@@ -380,7 +397,8 @@ __global__ void __launch_bounds__(512, 2) mm8_kernel(const uint8_t* acts0, int n
     kernarg_touch<16 + sizeof(Mm8Args)>();
     CT_DYN_SMEM(smem);
     constexpr int RW = kMm8Waves / KS, SU = KS * NTT, UNIT = (TYPE == GT_Q8_0 || TYPE == GT_Q4_0) ? kMm8UnitB : kMm8Unit, SB = SU * UNIT;
-    constexpr int PP = (UNIT + 1023) / 1024;        // DMA pieces per unit: whole 1 KB pieces, then (K-quants) one 256-byte piece
+    constexpr int PP = UNIT / 1024;                 // DMA pieces per unit (1 KB each: 16 bytes per lane)
+    static_assert(UNIT % 1024 == 0, "units are whole 1 KB pieces");
     constexpr int REC = TYPE == GT_Q4_K ? 4608 : (TYPE == GT_Q5_K ? 5632 : (TYPE == GT_Q6_K ? 6720 : (TYPE == GT_Q8_0 ? 8704 : 4608)));
     const MatvecArgs& m = a.m;
     const int lane = lane_id(), wv = uniform_int(wave_id());
@@ -415,28 +433,28 @@ __global__ void __launch_bounds__(512, 2) mm8_kernel(const uint8_t* acts0, int n
                 int blk = st * KS + k;
                 blk = blk < nb ? blk : nb - 1;
                 const uint8_t* s = src0 + (size_t)blk * step_stride + (size_t)(q < tq_max ? q : 0) * UNIT;
-                if (part * 1024 + 1024 <= UNIT) glds16_s(s + part * 1024, (uint32_t)lane * 16u, buf + u * UNIT + part * 1024);
-                else glds4_s(s + part * 1024, (uint32_t)lane * 4u, buf + u * UNIT + part * 1024);
+                glds16_s(s + part * 1024, (uint32_t)lane * 16u, buf + u * UNIT + part * 1024);
             }
         }
     };
     // the same copy, one piece per call: what mm8_step issues between its sub-blocks (slots 0 .. 8 NTT - 1; the pieces of a wave are spread evenly over them)
     constexpr int NPW = (SU * PP + kMm8Waves - 1) / kMm8Waves, NSLOT = 8 * NTT;
     struct Feeder {
-        const uint8_t* src0; uint8_t* buf; size_t step_stride; int st, nb, tq_max, wv, lane; bool on;
+        const uint8_t* src0; uint8_t* buf; size_t step_stride; int st, nb, tq_max, wv, lane;
         DEV void operator()(int slot) const {
 #pragma unroll
             for (int n = 0; n < NPW; ++n) {
                 if (slot != (n * NSLOT) / NPW) continue;   // (compile-time after unrolling: slot and n are constants at every call site)
-                const int p = n * kMm8Waves + wv;
-                if (on && p < SU * PP) {
-                    const int u = p / PP, part = p - u * PP, k = u / NTT, q = u - k * NTT;
-                    int blk = st * KS + k;
-                    blk = blk < nb ? blk : nb - 1;
-                    const uint8_t* s = src0 + (size_t)blk * step_stride + (size_t)(q < tq_max ? q : 0) * UNIT;
-                    if (part * 1024 + 1024 <= UNIT) glds16_s(s + part * 1024, (uint32_t)lane * 16u, buf + u * UNIT + part * 1024);
-                    else glds4_s(s + part * 1024, (uint32_t)lane * 4u, buf + u * UNIT + part * 1024);
-                }
+                // No branch in here: with one, hipcc sinks the accumulation steps of all eight sub-blocks of the caller behind it and spills every product
+                // (the Q8_0 form: 300 spilled registers).  A piece index past the stage's last piece copies the last piece again; the step behind the last
+                // one copies the last stage again (into the buffer nobody reads any more).
+                int pidx = n * kMm8Waves + wv;
+                pidx = pidx < SU * PP ? pidx : SU * PP - 1;
+                const int u = pidx / PP, part = pidx - u * PP, k = u / NTT, q = u - k * NTT;
+                int blk = st * KS + k;
+                blk = blk < nb ? blk : nb - 1;
+                const uint8_t* s = src0 + (size_t)blk * step_stride + (size_t)(q < tq_max ? q : 0) * UNIT;
+                glds16_s(s + part * 1024, (uint32_t)lane * 16u, buf + u * UNIT + part * 1024);
             }
         }
     };
@@ -458,17 +476,15 @@ __global__ void __launch_bounds__(512, 2) mm8_kernel(const uint8_t* acts0, int n
         uint8_t* cur = smem + (st & 1) * SB;
         MM8_STAMP();
         // the copy of step st + 1 goes into the buffer step st - 1 read (every wave has passed that step's barrier), piece by piece from inside the step
-        const Feeder feed = {src0, smem + ((st + 1) & 1) * SB, step_stride, st + 1, nb, tq_max, wv, lane, st + 1 < nsteps};
+        const Feeder feed = {src0, smem + ((st + 1) & 1) * SB, step_stride, st + 1 < nsteps ? st + 1 : st, nb, tq_max, wv, lane};
         const int bnext = bcur + KS;
-        const Mm8W<TYPE> Rn = mm8_load<TYPE>(wrec + (size_t)(bnext < nb ? bnext : nb - 1) * REC, lane);
         MM8_STAMP();
-        if (bcur < nb) mm8_step<TYPE, NTT>(R, cur + ks * NTT * UNIT, lane, acc, feed);
+        if (bcur < nb) mm8_step<TYPE, NTT>(R, wrec + (size_t)(bnext < nb ? bnext : nb - 1) * REC, cur + ks * NTT * UNIT, lane, acc, feed);
         else {   // a K-slice without a block in the last step: its share of the copy still goes out
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl) feed(sl);
         }
         MM8_STAMP();
-        R = Rn;
         bcur = bnext;
         vm_wait<0>();      // the copy (and the next weights) have landed ...
         mm8_landed<TYPE>(R);
