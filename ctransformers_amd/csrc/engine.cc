@@ -783,7 +783,7 @@ bool Engine::mm8_can(const MatvecArgs& m) const {
         if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_SILU_MUL || e == EPI_GELU || e == EPI_ADD2)) return false;
     }
     if (m.gateup && (m.njobs != 1 || m.job[0].epi != EPI_SILU_MUL)) return false;
-    if ((size_t)m8_steps(m.job[0].w.type, m.K) * ((kPfChunk + 31) / 32) * kMm8Unit > acts8_bytes_) return false;
+    if ((size_t)m8_steps(m.job[0].w.type, m.K) * ((pf_cap_ + 31) / 32) * kMm8Unit > acts8_bytes_) return false;
     return !b32 ? (m.K % 256 == 0 && m.K <= 32768) : (m.K % 32 == 0 && m.K <= 32768);
 }
 
@@ -911,6 +911,7 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
         prof_end();
         return ok;
     }
+    if (nt > kPfChunk) { err = "prompt chunk above 128 tokens at a site without the order-free kernels"; return false; }
     prof_begin(site, "matvec_pf", bytes);
     const dim3 qg((unsigned)nt), qb(1024);
     if (m.job[0].w.layout == LAYOUT_G4) {   // Q8_0 / Q4_0 weights: Q8_0 activation images, kernels_pf.h
@@ -987,7 +988,15 @@ bool Engine::pf_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_ou
 // of a chunk shape seen before are replayed from a graph: the first use of a shape runs eagerly (it also performs the
 // one-time dynamic-LDS opt-ins), the second captures.
 bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
-    chunk_below_128_ = req_past_ + c0 + nt <= 128;   // positions of this chunk: [n_past + c0, n_past + c0 + nt)
+    // attn_chunk_tile_kernel applies when every position of the chunk lies below 128 AND so does the end of the reference batch its tokens belong to: the
+    // V*P dot of a token runs over the positions of its whole batch (masked ones with probability zero, llama.cpp:2373-2378), and the kernel keeps 128
+    // positions of V and 160-float probability rows in LDS.  (Round 6: the second condition was missing — a request longer than 128 tokens evaluated as ONE
+    // reference batch, batch_size > 128, zeroed probabilities past its row's end in the first chunk and differed from the reference build.)
+    {
+        const int bs = h_scalars_[3], idx_last = c0 + nt - 1;
+        const int end = bs > 0 ? std::min(req_n_, (idx_last / bs + 1) * bs) : req_n_;
+        chunk_below_128_ = req_past_ + c0 + nt <= 128 && req_past_ + end <= 128;   // positions of this chunk: [n_past + c0, n_past + c0 + nt)
+    }
 #ifndef CT_EMU
     if (use_graph_ && !prof_ && !only_site_) {
         // the attention kernel depends on the flag; a pipeline stage (not the whole model) copies its rows from / to the hand-off

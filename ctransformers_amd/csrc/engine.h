@@ -211,7 +211,9 @@ class Engine {
     float *qkv_tmp_b_ = nullptr, *attn_proj_b_ = nullptr;   // falcon chunks: fused QKV rows, Wo output
     bool pf_ok_ = false;    // llama architecture, every layer matrix a K-quant in the tile layout, K <= 12288
     int pf_min_ = 2;        // chunks shorter than this run token by token
-    int pf_chunk_ = 128;    // tokens per chunk_step (<= kPfChunk; CT_AMD_PF_CHUNK lowers it)
+    int pf_chunk_ = 128;    // tokens per chunk_step (<= pf_cap_; CT_AMD_PF_CHUNK lowers it)
+    int pf_cap_ = 128;      // rows of the chunk scratch: kPfChunk, or kPfChunkFast where every site of the graph takes the order-free kernels (kernels_mm8.h),
+                            // whose launches fill the chip better with more token tiles
     long long chunk_tokens_ = 0;
     const char* pg_trace_site_ = nullptr;   // measurement only (CT_AMD_PG_TRACE)
     int pg_force_tg_ = 0;   // tests: 16 / 32 tokens per workgroup

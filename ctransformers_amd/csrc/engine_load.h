@@ -913,9 +913,21 @@ bool Engine::alloc_state(std::string& err) {
     }
     if (pf_ok_) {
         pf_min_ = std::max(2, env_int("CT_AMD_PF_MIN", 2));
-        pf_chunk_ = std::max(pf_min_, std::min(kPfChunk, env_int("CT_AMD_PF_CHUNK", kPfChunk)));
-        if (!dev_alloc(dev_allocs_, &xb_, (size_t)kPfChunk * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)kPfChunk * E, err) ||
-            !dev_alloc(dev_allocs_, &hb_, (size_t)kPfChunk * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)kPfChunk * E, err))
+        pf_cap_ = kPfChunk;
+        if (fast_pf_ && !hp_.legacy()) {   // every mat-mul site of every layer on the order-free kernels: chunks of up to kPfChunkFast tokens
+            bool all = true;
+            auto ok8 = [&](const DevMat& w, bool gu) { return w.m8 && w.type != GT_Q4_0 && (gu ? w.M % 16 == 0 : w.M % 32 == 0) && w.K <= 32768; };
+            for (int i = l0_; i < l1_ && all; ++i) {
+                const Layer& L = layers_[i];
+                if (hp_.falcon()) all = ok8(L.wqkv, false) && ok8(L.wo, false) && ok8(L.w_up, false) && ok8(L.w_down, false);
+                else all = ok8(L.wq, false) && ok8(L.wk, false) && ok8(L.wv, false) && ok8(L.wo, false) && ok8(L.w_gu, true) && ok8(L.w_down, false) &&
+                           is_block32(L.wq.type) == is_block32(L.wk.type) && is_block32(L.wq.type) == is_block32(L.wv.type);
+            }
+            if (all) pf_cap_ = std::max(kPfChunk, std::min(kPfChunkFast, env_int("CT_AMD_PF_CAP", kPfChunkFast)) & ~31);
+        }
+        pf_chunk_ = std::max(pf_min_, std::min(pf_cap_, env_int("CT_AMD_PF_CHUNK", pf_cap_)));
+        if (!dev_alloc(dev_allocs_, &xb_, (size_t)pf_cap_ * E, err) || !dev_alloc(dev_allocs_, &attn_out_b_, (size_t)pf_cap_ * E, err) ||
+            !dev_alloc(dev_allocs_, &hb_, (size_t)pf_cap_ * F, err) || !dev_alloc(dev_allocs_, &q_f16_b_, (size_t)pf_cap_ * E, err))
             return false;
         pg_force_tg_ = env_int("CT_AMD_PG_TG", 0);
         if (!kq_model) {   // Q8_0 activation images of the Q8_0 / Q4_0 chunk kernel
@@ -929,13 +941,13 @@ bool Engine::alloc_state(std::string& err) {
             HIP_OK(hipMemset(acts_h_, 0, 2 * acts_h_half_));   // token slots past the chunk's end are read (and their results dropped)
         }
         if (fast_pf_) {   // activation units of the order-free kernels: [K-steps of the widest input][token tiles of a chunk]
-            acts8_bytes_ = (size_t)((std::max(E, F) + 255) / 256) * ((kPfChunk + 31) / 32) * kMm8Unit + 4096;
+            acts8_bytes_ = (size_t)((std::max(E, F) + 255) / 256) * ((pf_cap_ + 31) / 32) * kMm8Unit + 4096;
             if (!dev_alloc(dev_allocs_, &acts8_, acts8_bytes_, err)) return false;
             HIP_OK(hipMemset(acts8_, 0, acts8_bytes_));
             if (const char* sh = getenv("CT_AMD_MM8_SHAPE")) { if (sscanf(sh, "%d,%d", &mm8_force_ntt_, &mm8_force_ks_) != 2) mm8_force_ntt_ = mm8_force_ks_ = 0; }
         }
-        if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * (E + 2 * G), err) ||
-                             !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)kPfChunk * E, err)))
+        if (hp_.falcon() && (!dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)pf_cap_ * (E + 2 * G), err) ||
+                             !dev_alloc(dev_allocs_, &attn_proj_b_, (size_t)pf_cap_ * E, err)))
             return false;
         if (hp_.legacy() && !dev_alloc(dev_allocs_, &qkv_tmp_b_, (size_t)kPfChunk * 3 * E, err)) return false;
     }

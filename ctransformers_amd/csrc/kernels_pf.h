@@ -21,6 +21,7 @@
 #include "kernels_q32.h"
 
 constexpr int kPfTokens = 8;    // tokens per workgroup (register accumulators per lane: 2 x 8)
+constexpr int kPfChunkFast = 512;   // chunk size where every site runs the order-free kernels (kernels_mm8.h): more token tiles per launch
 constexpr int kPfChunk = 128;   // tokens per chunk_step (8 groups of 16 on the matrix-core path): the per-chunk launches of Wo,
                                 // the quantize kernels and attention are shared by more tokens (64 -> 128: +11 %)
 

@@ -38,13 +38,24 @@ if __name__ == "__main__":
     ftype = sys.argv[2] if len(sys.argv) > 2 else "Q4_K_M"
     n_prompt = int(sys.argv[3]) if len(sys.argv) > 3 else 128
     mm8_check.model_path(shape, ftype)
-    for mode in ("exact", "fast"):
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", mode, shape, ftype, str(n_prompt)], check=True)
+    # KV_A / KV_B = "mode[:chunk]" override the pair (e.g. "exact:64" against "exact:128": the bit-identical kernels do not depend on the chunking)
+    pair = [os.environ.get("KV_A", "exact"), os.environ.get("KV_B", "fast")]
+    for i, spec in enumerate(pair):
+        mode, _, chunk = spec.partition(":")
+        env = dict(os.environ)
+        if chunk:
+            env["CT_AMD_PF_CHUNK"] = chunk
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", mode, shape, ftype, str(n_prompt)], check=True, env=env)
+        os.replace("/tmp/mm8_kv_%s.npz" % mode, "/tmp/mm8_kv_%d.npz" % i)
+    os.replace("/tmp/mm8_kv_0.npz", "/tmp/mm8_kv_exact.npz"); os.replace("/tmp/mm8_kv_1.npz", "/tmp/mm8_kv_fast.npz")
     a, b = np.load("/tmp/mm8_kv_exact.npz"), np.load("/tmp/mm8_kv_fast.npz")
     for key in a.files:
         x, y = a[key].view(np.float16).astype(np.float64), b[key].view(np.float16).astype(np.float64)
         d = np.abs(x - y)
         nz = d > 0
         ulp = np.abs(a[key].astype(np.int64) - b[key].astype(np.int64))   # fp16 bit patterns of the same sign differ by their ulp distance
+        if key == "k1" and os.environ.get("KV_PER_POS"):
+            per = d.max(axis=(0, 2)) / np.abs(x).max()   # [pos]
+            print("k1 per-position max diff (x1000):", " ".join("%d" % int(1000 * v) for v in per))
         print("%-4s %9d values, %7d differ (%.4f %%), max |diff| / max |x| %.3g, max ulp distance %d, share of differing values more than 1 ulp apart %.4f" %
               (key, x.size, int(nz.sum()), 100.0 * nz.mean(), d.max() / np.abs(x).max(), int(ulp.max()), float((ulp[nz] > 1).mean()) if nz.any() else 0.0))
