@@ -777,7 +777,6 @@ bool Engine::mm8_can(const MatvecArgs& m) const {
     for (int j = 0; j < m.njobs; ++j) {
         const DevMat& w = m.job[j].w;
         if (!w.m8 || is_block32(w.type) != b32 || (b32 && w.type != m.job[0].w.type)) return false;
-        if (w.type == GT_Q4_0) return false;                  // (no instantiation yet: the legacy graphs keep kernels_pf.h)
         if (m.gateup ? w.M % 16 != 0 : w.M % 32 != 0) return false;   // whole row tiles only
         const int e = m.job[j].epi;
         if (!(e == EPI_STORE || e == EPI_ADD || e == EPI_ROPE_Q || e == EPI_ROPE_K || e == EPI_V || e == EPI_SILU_MUL || e == EPI_GELU || e == EPI_ADD2)) return false;
@@ -802,7 +801,7 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
     } else if (m.K <= 4096) CT_LAUNCH((mm8_quantize_q8k_kernel<4096, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
     else if (m.K <= 12288) CT_LAUNCH((mm8_quantize_q8k_kernel<12288, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
     else CT_LAUNCH((mm8_quantize_q8k_kernel<32768, false>), qg, qb, stream_, x, ldx, m.norm_w, m.K, m.pro, m.eps, acts8_, ntt, (const float*)nullptr, nt);
-    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K, GT_Q8_0}) {
+    for (const int ty : {GT_Q4_K, GT_Q5_K, GT_Q6_K, GT_Q8_0, GT_Q4_0}) {
         Mm8Args a;
         a.m = m;
         a.acts = acts8_;
@@ -834,7 +833,7 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
             if (!mm8_force_ntt_ && NTTv > 1 && ntt < 2) continue;   // token tiles that do not exist
             const long long wgs = (long long)((tile0 + RW - 1) / RW) * ((ntt + NTTv - 1) / NTTv);
             const double rounds = (double)((wgs + chip_cus() - 1) / chip_cus());
-            const double tile_cycles = ty == GT_Q6_K ? 1200.0 : (ty == GT_Q8_0 ? 800.0 : 620.0);
+            const double tile_cycles = ty == GT_Q6_K ? 1200.0 : (is_block32(ty) ? 800.0 : 620.0);
             const double issue = ((double)KSv * NTTv * unit + (double)kMm8Waves * m8_record_bytes(ty)) / 45.0;
             const double step = 2.0 * NTTv * tile_cycles + 0.5 * issue;
             const double cost = rounds * (((ns + KSv - 1) / KSv) * step + 6000.0);
@@ -856,7 +855,7 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
 #define MM8T(TYV) do { \
             if (NTTv == 2 && KSv == 1) MM8L(TYV, 2, 1); else if (NTTv == 2 && KSv == 2) MM8L(TYV, 2, 2); \
             else if (NTTv == 2) MM8L(TYV, 2, 4); else MM8L(TYV, 1, 8); } while (0)
-        if (ty == GT_Q4_K) MM8T(GT_Q4_K); else if (ty == GT_Q5_K) MM8T(GT_Q5_K); else if (ty == GT_Q6_K) MM8T(GT_Q6_K); else MM8T(GT_Q8_0);
+        if (ty == GT_Q4_K) MM8T(GT_Q4_K); else if (ty == GT_Q5_K) MM8T(GT_Q5_K); else if (ty == GT_Q6_K) MM8T(GT_Q6_K); else if (ty == GT_Q8_0) MM8T(GT_Q8_0); else MM8T(GT_Q4_0);
 #undef MM8T
 #undef MM8L
 #ifdef MM8_TRACE

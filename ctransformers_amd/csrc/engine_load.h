@@ -916,7 +916,7 @@ bool Engine::alloc_state(std::string& err) {
         pf_cap_ = kPfChunk;
         if (fast_pf_ && !hp_.legacy()) {   // every mat-mul site of every layer on the order-free kernels: chunks of up to kPfChunkFast tokens
             bool all = true;
-            auto ok8 = [&](const DevMat& w, bool gu) { return w.m8 && w.type != GT_Q4_0 && (gu ? w.M % 16 == 0 : w.M % 32 == 0) && w.K <= 32768; };
+            auto ok8 = [&](const DevMat& w, bool gu) { return w.m8 && (gu ? w.M % 16 == 0 : w.M % 32 == 0) && w.K <= 32768; };
             for (int i = l0_; i < l1_ && all; ++i) {
                 const Layer& L = layers_[i];
                 if (hp_.falcon()) all = ok8(L.wqkv, false) && ok8(L.wo, false) && ok8(L.w_up, false) && ok8(L.w_down, false);

@@ -75,7 +75,7 @@ def ref():
 _HEAVY_FIRST = ("test_edge_requests_match_reference_build", "test_matvec9_ragged_and_wide_rows", "test_chunk_attention_across_position_tiles",
                 "test_mpt_on_emulator_build", "test_reference_package_drives_this_library", "test_reference_hf_transformers_shim",
                 "test_wide_rows_on_emulator_build", "test_starcoder_on_emulator_build", "test_wide_k_rows", "test_inprocess_pipeline_equals_reference",
-                "test_gloo_pipeline", "test_stage_chain_micro_batches")
+                "test_gloo_pipeline", "test_stage_chain_micro_batches", "test_one_reference_batch_of_140_tokens_on_the_emulator")
 
 
 def pytest_collection_modifyitems(config, items):

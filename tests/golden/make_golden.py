@@ -72,6 +72,23 @@ def model_golden(name, ftype, seed, shape="llama-tiny", quantizer=None):
     print(name, "greedy head:", toks[:8])
 
 
+def big_batch_golden():
+    """Requests longer than 128 tokens evaluated as ONE reference batch (batch_size > 128): every token's V*P dot runs over the whole batch
+    (llama.cpp:2373-2378).  tiny-q4km-refq-batch.npz: logits for a 140-token request (batch 160, context 192: the emulator's size) and a 200-token
+    one (batch 256, context 320)."""
+    path = os.path.join(HERE, "tiny-q4km-refq.gguf")
+    out = {}
+    for n, bs, ctx in ((140, 160, 192), (200, 256, 320)):
+        r = ref.open_llm(path, context_length=ctx, batch_size=bs, threads=4)
+        toks = synth.prompt_tokens(n, 512)
+        r.eval(toks)
+        out["logits_%d" % n] = r.logits.to_numpy().copy()
+        out["prompt_%d" % n] = np.array(toks, dtype=np.int32)
+        out["cfg_%d" % n] = np.array([bs, ctx], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "tiny-q4km-refq-batch.npz"), **out)
+    print("tiny-q4km-refq-batch: ok")
+
+
 def ops_golden():
     rng = np.random.default_rng(2024)
     ops = ref.GgmlOps()
@@ -189,6 +206,8 @@ if __name__ == "__main__":
     # either sign, make_qkx1_quants' scale searches) — what files in the field hold; tools/synth.py's numpy quantizers never emit those
     if not only or "tiny-q4km-refq" in only:
         model_golden("tiny-q4km-refq", "Q4_K_M", 13, "llama-tiny", quantizer="reference")
+    if not only or "batch" in only:
+        big_batch_golden()
     if not only or "ops" in only:
         ops_golden()
     if not only or "falcon_ops" in only:
