@@ -202,6 +202,8 @@ def other_configs():
             continue
         res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
                         prefill_tok_s=d["prefill_tok_s"], prefill_2k_tok_s=d.get("prefill_2k_tok_s"), decode_tok_s_at_2k=d.get("decode_tok_s_at_2k"),
+                        prefill_fast_tok_s=(d.get("prefill_fast") or {}).get("tok_s"), prefill_fast_2k_tok_s=(d.get("prefill_fast") or {}).get("tok_s_2k"),
+                        prefill_fast_logits_rel_diff=(d.get("prefill_fast") or {}).get("logits_rel_diff_vs_default"),
                         load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
                         bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
         if (cfg in (4, 5) or big == "1") and os.environ.get("CTAMD_BENCH_KEEP_BIG") != "1":   # 7 / 25 / 49 GB of scratch disk: one file at a time, none left behind
@@ -211,6 +213,51 @@ def other_configs():
                 except OSError:
                     pass
     return res
+
+
+def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_context):
+    """The order-free prompt kernels (CT_AMD_PREFILL=fast: ctransformers_amd/csrc/kernels_mm8.h) on fresh handles of the same file: steady-state prompt
+    rates at 128, 512 and 2048 tokens, and how far their results are from the default (bit-identical) kernels' — logits of the 128-token prompt and the
+    greedy continuation.  Opt-in: the default keeps the reference's bits (DESIGN.md 5b says why 1e-3 is out of reach for any other summation order)."""
+    os.environ["CT_AMD_PREFILL"] = "fast"
+    try:
+        h = LLM(MODEL, config=Config(context_length=N_CTX_2K if long_context else 640, batch_size=2048, gpu_layers=1000))
+        rates = {}
+        for n in (128, 512) + ((N_PROMPT_2K,) if long_context else ()):
+            p = synth.prompt_tokens(n, n_vocab)
+            h._context = []
+            h.eval(p)
+            h._context = []
+            h.eval(p)
+            h._context = []
+            t0 = time.perf_counter()
+            h.eval(p)
+            rates[n] = round(n / (time.perf_counter() - t0), 1)
+        del h
+        h = LLM(MODEL, config=Config(context_length=N_CTX, batch_size=N_PROMPT, gpu_layers=1000))   # the headline's own handle shape for the comparison
+        h.eval(prompt)
+        t = h.sample(top_k=1, repetition_penalty=1.0)
+        lg = np.array(h.logits.to_numpy(), copy=True)
+        same = 0
+        for want in exact_greedy:
+            if int(t) != want:
+                break
+            same += 1
+            h.eval([t])
+            t = h.sample(top_k=1, repetition_penalty=1.0)
+        del h
+    finally:
+        os.environ.pop("CT_AMD_PREFILL", None)
+    tops = round(rates[128] * pf_flop / 1e12, 1) if pf_flop else None
+    return dict(tok_s=rates[128], tok_s_512=rates[512], tok_s_2k=rates.get(N_PROMPT_2K), chunk_tokens=512, opt_in="CT_AMD_PREFILL=fast",
+                kernel="mm8_kernel<TYPE,NTT,KS> (v_mfma_i32_32x32x32_i8: Q4_K / Q5_K scales as two int8 digit planes inside the accumulation, Q6_K masked K-chunks, "
+                       "Q8_0 float scales; Q8_K / Q8_0 activations as the reference quantizes them; f32 sums in free order)",
+                tops=tops, mfma_i8_peak_tops=5000, frac=round(tops / 5000.0, 4) if tops else None, frac_of_f16_peak=round(tops / 2500.0, 4) if tops else None,
+                logits_rel_diff_vs_default=float(np.abs(lg - exact_logits).max() / np.abs(exact_logits).max()),
+                greedy_steps_compared=len(exact_greedy), greedy_steps_identical=same,
+                note="same quantization points and exact integer dots as the reference, another f32 summation order: K / V rows of the first layer within an fp16 ulp, "
+                     "logits within the reference's own int8 quantization noise (~4e-2 of the largest logit on this synthetic model), NOT within 1e-3 — hence opt-in; "
+                     "MFMA-busy counters: profiles/r06_mm8_pmc.txt")
 
 
 def stage_ranges(llm):
@@ -245,6 +292,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 3, 4 and 5")
     ap.add_argument("--no-long-context", action="store_true", help="skip the 2048-token prompt / decode-at-2k measurement")
+    ap.add_argument("--no-fast-prefill", action="store_true", help="skip the order-free prompt kernels' numbers (prefill_fast)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2: the headline)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-vocab", type=int, default=32000, help=argparse.SUPPRESS)
@@ -320,9 +368,12 @@ def main():
     llm.eval(prompt)
     prefill_s = time.perf_counter() - t0
     tok = llm.sample(top_k=1, repetition_penalty=1.0)
+    exact_logits = np.array(llm.logits.to_numpy(), copy=True)   # (the order-free prompt kernels are compared with these below)
+    exact_greedy = [int(tok)]
     for _ in range(a.warmup):
         llm.eval([tok])
         tok = llm.sample(top_k=1, repetition_penalty=1.0)
+        exact_greedy.append(int(tok))
     steps = min(a.steps, N_CTX - N_PROMPT - a.warmup - 1)
     # llm.eval() returns only after the library synchronised its stream(s); the logits stay in HBM (lazy outputs: they cross the
     # bus when ctransformers_llm_logits_data is called) and a greedy sample() returns the device-side first-maximum — 4 bytes per
@@ -429,6 +480,8 @@ def main():
         out["long_context"] = dict(n_prompt=N_PROMPT_2K, context_length=N_CTX_2K, batch_size=N_PROMPT, decode_steps=N_DECODE_2K,
                                    decode_positions="%d..%d" % (N_PROMPT_2K + 4, N_PROMPT_2K + 4 + N_DECODE_2K - 1))
         del h
+    if n_gpus == 1 and n_stages == 1 and not a.no_fast_prefill:
+        out["prefill_fast"] = fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, not a.no_long_context)
     if issue is not None:
         out["config"]["host_issue"] = issue
     if n_stages > 1:
