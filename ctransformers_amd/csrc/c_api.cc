@@ -223,6 +223,11 @@ long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
 long long ctamd_qa_launches(ctransformers_llm* llm) { return llm->engine().qa_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 long long ctamd_mm8_launches(void) { return ctamd::mm8_launches(); }
+long long ctamd_resident_replays(ctransformers_llm* llm) {   // requests evaluated a second time after a residency give-up, summed over the stages
+    long long n = 0;
+    for (int s = 0; s < llm->pipe.n_stages(); ++s) n += llm->pipe.stage(s).resident_replays();
+    return n;
+}
 int ctamd_debug_read_kv(ctransformers_llm* llm, int layer, unsigned short* k, unsigned short* v) { return llm->engine().debug_read_kv(layer, k, v); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }
 const char* ctamd_handoff(ctransformers_llm* llm) { return llm->pipe.handoff(); }

@@ -1108,6 +1108,41 @@ bool Engine::drain_spec(std::string& err) {
 }
 #endif
 
+void Engine::disable_resident_forms() {
+    if (!fuse_qa_ && !attn_share_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);   // nothing of the graphs below (a queued continuation step included) is in flight any more
+    fuse_qa_ = false;
+    attn_share_ = false;
+#ifndef CT_EMU
+    if (graph_step_) { (void)hipGraphExecDestroy(graph_step_); graph_step_ = nullptr; }
+    if (graph_step_head_) { (void)hipGraphExecDestroy(graph_step_head_); graph_step_head_ = nullptr; }
+    for (int b = 0; b < 2; ++b) {
+        if (graph_cont_[b]) { (void)hipGraphExecDestroy(graph_cont_[b]); graph_cont_[b] = nullptr; }
+        if (ev_step_[b]) { (void)hipEventDestroy(ev_step_[b]); ev_step_[b] = nullptr; }
+    }
+    spec_inflight_ = false;
+    ev_pending_ = false;
+#endif
+    h_scalars_[n_ctx_ + 14] = 0;   // (a step that was still running when the word was read may have raised it again)
+}
+
+bool Engine::resident_timeout() {
+    if (!h_scalars_ || h_scalars_[n_ctx_ + 14] == 0) return false;
+    const bool had = fuse_qa_ || attn_share_;
+    disable_resident_forms();
+    h_scalars_[n_ctx_ + 14] = 0;
+    if (had) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "ctransformers_amd: a launch that needs its whole grid resident gave up (another process or handle on this GPU?); "
+                            "this handle continues with the forms that need no residency, the request is evaluated again\n");
+        }
+    }
+    return true;
+}
+
 bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
     if (l0_ != 0 || l1_ != hp_.n_layer) { err = "this handle is a pipeline stage: use eval_stage"; return false; }
 #ifndef CT_EMU
@@ -1123,19 +1158,33 @@ bool Engine::eval(const int* tokens, int n, int n_past, std::string& err, int ba
             if (n_past + 1 < n_ctx_ && !launch_spec(b ^ 1, n_past + 1, err)) return false;   // the guess after this one, before waiting
             HIP_OK(hipEventSynchronize(ev_step_[b]));
             HIP_OK(hipGetLastError());
-            cur_buf_ = b;
-            have_logits_ = true;
-            outputs_on_host_ = false;
-            last_token_ = tokens[0];
-            last_pos_ = n_past;
-            last_pick_ = h_scalars_[n_ctx_ + 12 + b];
-            return true;
+            if (!resident_timeout()) {
+                cur_buf_ = b;
+                have_logits_ = true;
+                outputs_on_host_ = false;
+                last_token_ = tokens[0];
+                last_pos_ = n_past;
+                last_pick_ = h_scalars_[n_ctx_ + 12 + b];
+                return true;
+            }
+            // the queued step (or the one behind it) gave up on residency: its outputs are not valid — this token is evaluated again below, the normal way
+            --spec_hits_;
+            ++resident_replays_;
         }
         // not what was guessed: the queued step finishes first (stream order); what it wrote is a KV position nobody has evaluated
         // and the other output buffer
     }
     spec_want_ = armed && n == 1 && n_past + 1 < n_ctx_ && spec_possible();
 #endif
+    const long long replays0 = resident_replays_;
+    if (eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch)) return true;
+    if (resident_replays_ == replays0) return false;   // some other failure
+    // req_wait switched the handle to the forms that need no residency and drained the stream: the same request once more (every KV row it wrote is
+    // written again; a continuation step is not queued this time)
+#ifndef CT_EMU
+    spec_want_ = false;
+#endif
+    err.clear();
     return eval_stage(tokens, n, n_past, nullptr, nullptr, err, batch);
 }
 
@@ -1233,21 +1282,11 @@ bool Engine::req_wait(int n, int n_past, std::string& err) {
 #else
     HIP_OK(hipStreamSynchronize(stream_));
 #endif
-    if (h_scalars_[n_ctx_ + 14] != 0) {   // a sweep of the fused QKV + attention launch gave up (kernels_qa9.h): its workgroups were not all resident
-        h_scalars_[n_ctx_ + 14] = 0;
-        fuse_qa_ = false;                 // the handle goes on with the two-launch form and the recomputed score rows (the graphs are captured again)
-        attn_share_ = false;
-#ifndef CT_EMU
-        if (graph_step_) { (void)hipGraphExecDestroy(graph_step_); graph_step_ = nullptr; }
-        if (graph_step_head_) { (void)hipGraphExecDestroy(graph_step_head_); graph_step_head_ = nullptr; }
-        for (int b = 0; b < 2; ++b) {
-            if (graph_cont_[b]) { (void)hipGraphExecDestroy(graph_cont_[b]); graph_cont_[b] = nullptr; }
-            if (ev_step_[b]) { (void)hipEventDestroy(ev_step_[b]); ev_step_[b] = nullptr; }
-        }
-        spec_inflight_ = false;
-#endif
+    if (dbg_qa_timeout_ > 0 && (fuse_qa_ || attn_share_) && --dbg_qa_timeout_ == 0) h_scalars_[n_ctx_ + 14] = 1;   // tests: as if a sweep had given up
+    if (resident_timeout()) {
+        ++resident_replays_;
         err = "a decode launch whose workgroups hand data to each other (fused QKV + attention, shared score rows) timed out waiting for workgroups of "
-              "its own grid (is the device shared?): this eval's results are invalid; the handle continues with the forms that need no residency";
+              "its own grid (is the device shared?): the request is evaluated again with the forms that need no residency";
         return false;
     }
     have_logits_ = l1_ == hp_.n_layer;

@@ -115,6 +115,14 @@ class Engine {
     // launch prepared them), and an eval that asks for exactly it only waits for its event.  Anything else the caller does is served
     // as before (the speculative step wrote a KV position nobody has evaluated yet and a logits buffer nobody reads).
     void note_sample(bool device_greedy) { greedy_armed_ = device_greedy; }
+    // Launches whose workgroups wait for each other (fused QKV + attention, shared score rows: kernels_qa9.h / kernels_attn9.h) need their whole grid
+    // resident; on a shared device a sweep may give up and raise a pinned word.  The reference never fails an eval because the machine is shared
+    // (models/llm.h:40-54), so: the stage switches to the forms that need no residency (for good) and the caller REPLAYS the request — every position it
+    // wrote is simply written again (KV overwrite semantics).  resident_timeout(): the word was raised since the last call (the stream is drained, the
+    // forms are off, the word is clear); disable_resident_forms(): the same switch without a timeout (pipeline stages whose device also runs a stream wait).
+    bool resident_timeout();
+    void disable_resident_forms();
+    long long resident_replays() const { return resident_replays_; }
     int embeddings_size() const { return have_logits_ && !hp_.legacy() ? hp_.n_embd : 0; }   // legacy models expose none (models/llm.h:73)
     size_t weight_bytes() const { return weight_bytes_; }
     int read_stamps(unsigned long long* out, int max);   // measurement only: copies and clears the stamps
@@ -268,6 +276,8 @@ class Engine {
     uint32_t* xs_ = nullptr;          // the shared score rows: [n_head][n_ctx] granules
     int cur_layer_ = 0;               // layer whose launches are being issued (tags of the in-launch exchanges)
     long long qa_launches_ = 0;
+    long long resident_replays_ = 0;   // requests evaluated a second time after a residency give-up
+    int dbg_qa_timeout_ = 0;           // tests (CT_AMD_DBG_QA_TIMEOUT=N): the N-th wait of this handle behaves as if a sweep had given up
     unsigned* pick_ws_ = nullptr;     // head launch: one 64-bit key per wave, [workgroup][16] (kernels_v9.h:v9_pick_store)
     int cur_buf_ = 0;
     void select_out(int buf) { d_logits_ = d_logits2_[buf]; d_emb_ = d_logits_ + hp_.n_vocab; d_argmax_ = d_argmax2_[buf]; pick_host_ = pick_host2_[buf]; }

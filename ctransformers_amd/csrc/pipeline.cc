@@ -224,13 +224,22 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
         }
     }
     if (!err.empty()) return false;
-    for (size_t s = 0; s + 1 < dev_.size(); ++s) {   // direct peer copies where the link allows them (hipMemcpyPeerAsync works either way)
-        if (dev_[s] == dev_[s + 1]) continue;
+    // direct peer stores where the link allows them AND the mapping was really established (hipMemcpyPeerAsync works either way): a boundary whose
+    // hipDeviceEnablePeerAccess failed for another reason than "already enabled" keeps the copy + event form — a store into an unmapped peer
+    // buffer would be a GPU fault, not a fallback
+    std::vector<char> peer_ok(dev_.size() > 1 ? dev_.size() - 1 : 0, 0);
+    for (size_t s = 0; s + 1 < dev_.size(); ++s) {
+        if (dev_[s] == dev_[s + 1]) { peer_ok[s] = 1; continue; }
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) == hipSuccess && can) {
             (void)hipSetDevice(dev_[s]);
-            (void)hipDeviceEnablePeerAccess(dev_[s + 1], 0);
-            (void)hipGetLastError();   // "already enabled" is fine
+            const hipError_t pe = hipDeviceEnablePeerAccess(dev_[s + 1], 0);
+#ifndef CT_EMU
+            peer_ok[s] = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+#else
+            peer_ok[s] = pe == hipSuccess;
+#endif
+            (void)hipGetLastError();
         }
     }
     ev_.assign(dev_.size(), {});
@@ -259,17 +268,12 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
         for (size_t s = 0; s < dev_.size(); ++s)
             for (size_t t = s + 1; t < dev_.size(); ++t) distinct = distinct && dev_[s] != dev_[t];
         flag_mode_ = hm && *hm ? !strcmp(hm, "flag") : distinct;
-        for (size_t s = 0; flag_mode_ && s + 1 < dev_.size(); ++s) {
-            if (dev_[s] == dev_[s + 1]) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) != hipSuccess || !can) flag_mode_ = false;
-        }
+        const bool rows_of_float4 = st_[0]->hparams().n_embd % 4 == 0;   // handoff_rows_kernel moves 16-byte pieces
+        if (!rows_of_float4) flag_mode_ = false;
+        for (size_t s = 0; flag_mode_ && s + 1 < dev_.size(); ++s)
+            if (!peer_ok[s]) flag_mode_ = false;
         direct_.assign(dev_.size() - 1, 0);
-        for (size_t s = 0; s + 1 < dev_.size(); ++s) {
-            int can = dev_[s] == dev_[s + 1] ? 1 : 0;
-            if (!can && hipDeviceCanAccessPeer(&can, dev_[s], dev_[s + 1]) != hipSuccess) can = 0;
-            direct_[s] = can && (st_[0]->hparams().n_embd % 4 == 0) ? 1 : 0;
-        }
+        for (size_t s = 0; s + 1 < dev_.size(); ++s) direct_[s] = peer_ok[s] && rows_of_float4 ? 1 : 0;
         flag_.assign(dev_.size() - 1, nullptr);
         prod_.assign(dev_.size() - 1, nullptr);
         issued_.assign(dev_.size() - 1, 0u);
@@ -282,6 +286,20 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
             (void)hipMemset(prod_[s], 0, 256);
         }
         for (size_t s = 0; s < dev_.size(); ++s) { (void)hipSetDevice(dev_[s]); (void)hipDeviceSynchronize(); }
+        // First contact (the flag form has never met two physical devices in this project's history): one row of known values through every boundary —
+        // peer-mapped stores, system-scope sequence word, the consumer stream's wait — before a user's eval depends on it.  A boundary that does not
+        // deliver within two seconds, or delivers other bytes, sends the whole pipeline back to the copy + event form (CT_AMD_HANDOFF=flag does not
+        // override a failed check).
+        if (flag_mode_ && !handoff_self_check()) {
+            fprintf(stderr, "ctransformers_amd: the in-stream hand-off (peer stores + stream wait) failed its self-check; stages hand over by copy + event\n");
+            flag_mode_ = false;
+        }
+        // A stage that WAITS for a hand-off has the runtime's polling wave on its device while it waits: one CU less than the grid of the fused
+        // QKV + attention launch and of the shared score rows needs (they assume every workgroup resident: kernels_qa9.h) — their sweeps would time out
+        // and the eval be replayed (Engine::resident_timeout).  Decided here, once: consumer stages of the flag form run the forms that need no residency;
+        // stage 0 (no wait on its device) keeps them.
+        for (size_t s = 1; flag_mode_ && s < st_.size(); ++s)
+            if (dev_[s] != dev_[s - 1]) st_[s]->disable_resident_forms();
     }
 #endif
     // Tokens per micro-batch of a prompt.  A (stage, micro-batch) unit of a 7B costs 1.96 / 2.6 / 4.0 ms x 2 / stages at 32 / 64 / 128
@@ -292,6 +310,42 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
     if (mb && atoi(mb) > 0) micro_batch_ = atoi(mb);
     return true;
 }
+
+#ifndef CT_EMU
+bool Pipeline::handoff_self_check() {
+    const int E = st_[0]->hparams().n_embd;
+    std::vector<float> pat((size_t)E), back((size_t)E);
+    const char* dbg_fail = getenv("CT_AMD_DBG_HANDOFF_FAIL");   // tests: the check runs and then reports a mismatch
+    for (size_t s = 0; s + 1 < st_.size(); ++s) {
+        if (shares_stream((int)s)) continue;   // (stream order: no flag on this boundary)
+        for (int i = 0; i < E; ++i) pat[(size_t)i] = (float)((i * 2654435761u + 97u * (unsigned)s) & 0xFFFFFF) * (1.0f / 4096.0f) - 1024.0f;
+        if (hipSetDevice(dev_[s]) != hipSuccess || hipMemcpy(st_[s]->xio(), pat.data(), (size_t)E * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+        if (hipSetDevice(dev_[s + 1]) != hipSuccess || hipMemset(st_[s + 1]->xio(), 0, (size_t)E * 4) != hipSuccess) return false;
+        ++issued_[s];
+        // consumer first: its stream waits for the sequence number, then brings the row back
+        if (hipStreamWaitValue32(st_[s + 1]->stream(), flag_[s], issued_[s], hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) return false;
+        if (hipMemcpyAsync(back.data(), st_[s + 1]->xio(), (size_t)E * 4, hipMemcpyDeviceToHost, st_[s + 1]->stream()) != hipSuccess) return false;
+        (void)hipSetDevice(dev_[s]);
+        hipLaunchKernelGGL(handoff_rows_kernel, dim3(1), dim3(256), 0, st_[s]->stream(), (const float4*)st_[s]->xio(), (float4*)st_[s + 1]->xio(), E / 4, flag_[s], prod_[s],
+                           (int*)nullptr, 0, 0, 0, 0, (const int*)nullptr);
+        (void)hipSetDevice(dev_[s + 1]);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool done = false;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
+            if (hipStreamQuery(st_[s + 1]->stream()) == hipSuccess) { done = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        (void)hipGetLastError();
+        if (!done) {   // release the waiting stream by hand, then give up on the form
+            (void)hipMemcpy(flag_[s], &issued_[s], 4, hipMemcpyHostToDevice);
+            (void)hipStreamSynchronize(st_[s + 1]->stream());
+            return false;
+        }
+        if (memcmp(pat.data(), back.data(), (size_t)E * 4) != 0) return false;
+    }
+    return !(dbg_fail && *dbg_fail == '1');
+}
+#endif
 
 #define PIPE_OK(expr)                                                                                        \
     do {                                                                                                     \
@@ -305,7 +359,25 @@ bool Pipeline::load(const std::string& path, int context_length, int gpu_layers,
 bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int batch) {
     if (st_.size() == 1) return st_[0]->eval(tokens, n, n_past, err, batch);
     if (n <= 0) return true;
-    if (eval_stages(tokens, n, n_past, err, batch)) return true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (eval_stages(tokens, n, n_past, err, batch)) return true;
+        drain_after_failure();
+        // A stage whose resident launch forms gave up (Engine::resident_timeout: the device is shared) has switched them off; eval_stages stopped at the
+        // first such stage, so every stage is asked — their words would otherwise fail the next evals one after another — and the request is evaluated
+        // once more (every KV row it wrote is written again).  The reference never fails an eval for this reason (models/llm.h:40-54).
+        bool lost = false;
+        for (auto& st : st_) lost = st->resident_timeout() || lost;
+        if (!lost || attempt == 1) return false;
+#ifndef CT_EMU
+        if (step_graph_) { (void)hipGraphExecDestroy(step_graph_); step_graph_ = nullptr; }
+#endif
+        err.clear();
+    }
+    return false;
+}
+
+// a host-side failure in the middle of a request
+void Pipeline::drain_after_failure() {
     // a host-side failure in the middle of a request: the stages already fed keep running and writing into the next stage's hand-off
     // buffer and KV cache — drain every stream before the caller sees the error, so that a retry does not overlap stale work
 #ifndef CT_EMU
@@ -324,7 +396,6 @@ bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int 
         (void)hipSetDevice(dev_[s]);
         (void)hipStreamSynchronize(st_[s]->stream());
     }
-    return false;
 }
 
 // A decode step of stages that share one stream: see step_graph_ (pipeline.h).  taken = false: the caller goes the per-stage way.

@@ -54,6 +54,8 @@ class Pipeline {
 
    private:
     bool eval_stages(const int* tokens, int n, int n_past, std::string& err, int batch);
+    bool handoff_self_check();    // load time, hand-off form "flag" on distinct devices: a known row through every boundary (false: use copy + event)
+    void drain_after_failure();   // every stage's stream idle (and a pending flag hand-off released) before the caller sees an error or the request is replayed
     std::vector<std::unique_ptr<Engine>> st_;
     std::vector<int> dev_;
     std::vector<std::pair<int, int>> ranges_;
