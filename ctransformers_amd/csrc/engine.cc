@@ -1005,7 +1005,7 @@ bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
         auto it = chunk_graphs_.find(key);
         if (it == chunk_graphs_.end() && chunk_seen_[key]++ >= 1) {
             hipGraph_t g = nullptr;
-            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             const bool ok = chunk_step(c0, nt, want_logits, err);
             const hipError_t e = hipStreamEndCapture(stream_, &g);
             if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
@@ -1045,7 +1045,7 @@ bool Engine::ensure_graphs(std::string& err) {
     if (graph_step_) return true;
     for (int head = 0; head < 2; ++head) {
         hipGraph_t g = nullptr;
-        HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+        HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         const bool ok = token_step(head == 1, err);
         hipError_t e = hipStreamEndCapture(stream_, &g);
         if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
@@ -1062,7 +1062,7 @@ bool Engine::ensure_graphs(std::string& err) {
             hipGraph_t g = nullptr;
             select_out(b);
             cont_mode_ = true;
-            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeGlobal));
+            HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             const bool ok = token_step(true, err);
             hipError_t e = hipStreamEndCapture(stream_, &g);
             cont_mode_ = false;

@@ -322,13 +322,14 @@ bool Pipeline::handoff_self_check() {
         if (hipSetDevice(dev_[s]) != hipSuccess || hipMemcpy(st_[s]->xio(), pat.data(), (size_t)E * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
         if (hipSetDevice(dev_[s + 1]) != hipSuccess || hipMemset(st_[s + 1]->xio(), 0, (size_t)E * 4) != hipSuccess) return false;
         ++issued_[s];
-        // consumer first: its stream waits for the sequence number, then brings the row back
-        if (hipStreamWaitValue32(st_[s + 1]->stream(), flag_[s], issued_[s], hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) return false;
-        if (hipMemcpyAsync(back.data(), st_[s + 1]->xio(), (size_t)E * 4, hipMemcpyDeviceToHost, st_[s + 1]->stream()) != hipSuccess) return false;
+        // producer first, as eval_stages queues them (two streams of ONE device may share a hardware queue: a wait queued ahead of the kernel it waits
+        // for would never be released); then the consumer's stream waits for the sequence number and brings the row back
         (void)hipSetDevice(dev_[s]);
         hipLaunchKernelGGL(handoff_rows_kernel, dim3(1), dim3(256), 0, st_[s]->stream(), (const float4*)st_[s]->xio(), (float4*)st_[s + 1]->xio(), E / 4, flag_[s], prod_[s],
                            (int*)nullptr, 0, 0, 0, 0, (const int*)nullptr);
         (void)hipSetDevice(dev_[s + 1]);
+        if (hipStreamWaitValue32(st_[s + 1]->stream(), flag_[s], issued_[s], hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) return false;
+        if (hipMemcpyAsync(back.data(), st_[s + 1]->xio(), (size_t)E * 4, hipMemcpyDeviceToHost, st_[s + 1]->stream()) != hipSuccess) return false;
         const auto t0 = std::chrono::steady_clock::now();
         bool done = false;
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
@@ -422,7 +423,7 @@ bool Pipeline::eval_one_graph(const int* tokens, int n_past, std::string& err, i
         if (!st_[s]->req_begin(tokens, 1, n_past, batch, err, s == 0)) return false;
     if (!step_graph_) {
         hipGraph_t g = nullptr;
-        PIPE_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+        PIPE_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         bool ok = true;
         for (int s = 0; s < S && ok; ++s) {
             ok = st_[s]->capture_step(s == S - 1, err);

@@ -89,15 +89,18 @@ def _model_7b_2l():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(180)
 def test_two_threads_decode_on_one_gpu():
     """Two host threads, a handle each, 7B widths (the fused launch's grid = every CU): both greedy chains equal the chain a handle decodes alone.  Whether a
     sweep gives up depends on how the hardware interleaves the two grids; if one does, the request is replayed — never a failed eval."""
     path = _model_7b_2l()
     toks = synth.prompt_tokens(40, 32000)
+    create = threading.Lock()   # (handles are created one at a time: the reference's library is single-threaded per handle, models/llm.h; loads are not what is tested)
 
     def chain(out, idx, n):
         try:
-            m = LLM(path, config=Config(context_length=256, batch_size=64))
+            with create:
+                m = LLM(path, config=Config(context_length=256, batch_size=64))
             m.eval(toks)
             seq, lg = [], []
             for _ in range(n):
@@ -126,6 +129,7 @@ def test_two_threads_decode_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(180)
 def test_decode_beside_a_long_prompt():
     """One handle decodes while another thread's handle evaluates a 2k-token prompt (every CU busy with chunk kernels): the decoded chain is the lone chain's."""
     path = _model_7b_2l()
