@@ -148,12 +148,22 @@ def test_bit_identical_to_reference_build(ref, tmp_path, shape, ftype, n_prompt,
         assert np.array_equal(r.embeddings.to_numpy(), m.embeddings.to_numpy())
 
 
+def bench_file(config):
+    """The file `bench.py --config N` times (same path, same generator, same seed): block pools out of the reference's own ggml_quantize_chunk where
+    oracle/_ref travelled with the snapshot ("refq"), this repo's numpy quantizers otherwise ("r2") — the timed bytes are the checked bytes."""
+    import bench
+    shape, ftype, p = bench.CONFIGS[config]
+    if not os.path.exists(p):
+        (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p + ".tmp", shape, ftype, seed=1234, quantizer=bench.QUANTIZER)
+        os.replace(p + ".tmp", p)
+    return shape, ftype, p
+
+
 @pytest.fixture(scope="module")
 def model_7b(tmp_path_factory):
-    p = os.environ.get("CTAMD_BENCH_MODEL", "/tmp/ctamd_llama2_7b_q4km_r2.gguf")
-    if not os.path.exists(p):
-        synth.write_llama_gguf(p, "llama-2-7b", "Q4_K_M", seed=1234)
-    return p
+    if os.environ.get("CTAMD_BENCH_MODEL"):
+        return os.environ["CTAMD_BENCH_MODEL"]
+    return bench_file(2)[2]
 
 
 def test_full_7b_properties_and_reference(ref, model_7b):
@@ -236,9 +246,7 @@ def test_chunk_path_repeatable_on_full_7b(ref, model_7b):
 def test_config3_full_size_q8_0(ref, tmp_path_factory):
     """BASELINE.json configs[2]: the full 32-layer Llama-2-7B Q8_0 file — 128-token prompt + 32 greedy tokens against the reference
     build (kernels_q32.h decode, the dot4 chunk kernels for the prompt)."""
-    p = "/tmp/ctamd_llama2_7b_q80_r2.gguf"
-    if not os.path.exists(p):
-        synth.write_llama_gguf(p, "llama-2-7b", "Q8_0", seed=1234)
+    p = bench_file(3)[2]
     toks = synth.prompt_tokens(128, 32000)
     m = open_hip(p, context_length=256, batch_size=128)
     r = ref.open_llm(p, context_length=256, batch_size=128, threads=16)
@@ -250,6 +258,28 @@ def test_config3_full_size_q8_0(ref, tmp_path_factory):
         t = int(a.argmax())
         r.eval([t])
         m.eval([t])
+    os.remove(p)
+
+
+def test_full_7b_numpy_quantized_blocks(ref):
+    """The one full-size case on this repo's own numpy quantizers (tools/synth.py) — the other full-size tests read the files bench.py times, whose blocks
+    come out of the reference's ggml_quantize_chunk: an 8-token prompt + 4 greedy steps of the 32-layer Q4_K_M file against the reference build."""
+    p = "/tmp/ctamd_llama2_7b_q4km_r2.gguf"
+    if not os.path.exists(p):
+        synth.write_llama_gguf(p + ".tmp", "llama-2-7b", "Q4_K_M", seed=1234, quantizer=None)
+        os.replace(p + ".tmp", p)
+    m = open_hip(p, context_length=64, batch_size=8)
+    r = ref.open_llm(p, context_length=64, batch_size=8, threads=16)
+    toks = synth.prompt_tokens(8, 32000)
+    m.eval(toks)
+    r.eval(toks)
+    for i in range(4):
+        a, b = r.logits.to_numpy(), m.logits.to_numpy()
+        assert np.array_equal(a, b), "step %d" % i
+        t = int(a.argmax())
+        r.eval([t])
+        m.eval([t])
+    del m, r
     os.remove(p)
 
 
@@ -267,9 +297,7 @@ def test_big_config_full_size(ref, config):
     """BASELINE.json configs[3] / configs[4] at FULL size on one GPU: the 60-layer Falcon-40B Q4_K_M / 80-layer Llama-2-70B Q5_K_M file
     (the ones `bench.py --config 4|5` times), an 8-token prompt + 4 greedy steps, every logits vector bit-identical to the reference CPU
     build on the same file.  (The 2-layer models of test_reference_build_parity cover the same widths on every run.)"""
-    shape, ftype, p = {4: ("falcon-40b", "Q4_K_M", "/tmp/ctamd_falcon_40b_q4km_r2.gguf"), 5: ("llama-2-70b", "Q5_K_M", "/tmp/ctamd_llama2_70b_q5km_r2.gguf")}[config]
-    if not os.path.exists(p):
-        (synth.write_falcon_gguf if shape.startswith("falcon") else synth.write_llama_gguf)(p, shape, ftype, seed=1234)
+    shape, ftype, p = bench_file(config)
     m = open_hip(p, context_length=64, batch_size=8)
     r = ref.open_llm(p, context_length=64, batch_size=8, threads=32)
     toks = synth.prompt_tokens(8, m.vocab_size)
