@@ -141,7 +141,6 @@ static bool kq_can(const MatvecArgs& a) {
     return true;
 }
 
-static thread_local int g_last_kq_grid = 0;   // workgroups of the issuing thread's last generation-9 launch (Engine::launch_pick: key slots of the head launch)
 static long long g_kq_launches = 0;   // test hook (ctamd_kq_launches): K-quant decode mat-vec launches (kernels_v9.h) of this process
 long long kq_launches() { return g_kq_launches; }
 static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk launches on the f16 matrix cores (kernels_pg.h)
@@ -223,7 +222,7 @@ static bool launch_matvec_kq(MatvecArgs& a, hipStream_t s, std::string& err) {
     // records — ffn_down, 2048 row pairs of eleven records — so that the whole unit is in flight: 10.8 us against 8.8 us per launch.  A CU
     // with eight streaming waves is served at about 8.6 B/cycle whatever their requests in flight, with sixteen at 10.7: DESIGN.md 5.)
     const dim3 grid((unsigned)gx), block(1024);
-    g_last_kq_grid = gx;
+    a.grid_out = gx;   // (Engine::launch_pick: the head launch's workgroups = its key slots)
     if (a.pick_ws && gx > 2048) { err = "head launch with more than 2048 workgroups"; return false; }
     {
         if (a.emb_out && (tb != 0 || a.K > 16384)) { err = "emb_out on a mixed-type or wide launch"; return false; }
@@ -424,12 +423,13 @@ void Engine::set_head_fold(MatvecArgs& a, bool cont) {
     head_cont_ = cont && l0_ == 0 && tok_embd_.raw && fold_on_ == 1 && ggml_row_bytes(tok_embd_.type, hp_.n_embd) <= (size_t)64 * 1024;
 }
 // behind a folding head launch: the pick's second half (+ the continuation of a greedy chain where the head said so)
-void Engine::launch_pick() {
-    if (!head_folds()) return;
+void Engine::launch_pick(const MatvecArgs& head) {
+    if (!head_folds() || !head.pick_ws || head.grid_out <= 0) return;
+    head_folded_ = true;   // this handle's head launches leave keys: req_logits launches no argmax
     const bool c = head_cont_;
     const size_t rb = c ? (size_t)ggml_row_bytes(tok_embd_.type, hp_.n_embd) + 16 : 16;
     CT_OPTIN_ONCE(pick_cont_kernel, (size_t)80 * 1024);
-    CT_LAUNCH_DYN(pick_cont_kernel, dim3(1), dim3(1024), rb, stream_, (const unsigned long long*)pick_ws_, 16 * g_last_kq_grid, d_argmax_, pick_host_, c ? d_state_ : (int*)nullptr,
+    CT_LAUNCH_DYN(pick_cont_kernel, dim3(1), dim3(1024), rb, stream_, (const unsigned long long*)pick_ws_, 16 * head.grid_out, d_argmax_, pick_host_, c ? d_state_ : (int*)nullptr,
               c ? x_ : (float*)nullptr, (const uint8_t*)tok_embd_.raw, tok_embd_.type, hp_.n_embd);
 }
 
@@ -1239,7 +1239,7 @@ bool Engine::req_range(int c0, int nt, bool last_of_request, std::string& err) {
 bool Engine::req_logits(std::string& err) {
     if (l1_ != hp_.n_layer) { err = "logits live on the last stage"; return false; }
     HIP_OK(hipSetDevice(device_));
-    if (!head_folds()) {   // (a folding head launch wrote the pick into the pinned word itself)
+    if (!head_folded_) {   // (a folding head launch — every head launch of a handle folds or none does — wrote the pick into the pinned word itself)
         CT_LAUNCH(argmax_first_kernel, dim3(1), dim3(1024), stream_, (const float*)d_logits_, hp_.n_vocab, d_argmax_);
         HIP_OK(hipMemcpyAsync(&h_scalars_[n_ctx_ + 12], d_argmax_, 4, hipMemcpyDeviceToHost, stream_));
     }

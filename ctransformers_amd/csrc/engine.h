@@ -283,7 +283,8 @@ class Engine {
     void select_out(int buf) { d_logits_ = d_logits2_[buf]; d_emb_ = d_logits_ + hp_.n_vocab; d_argmax_ = d_argmax2_[buf]; pick_host_ = pick_host2_[buf]; }
     bool head_folds() const;          // the head launch picks the greedy token itself (no argmax launch, no 4-byte copy)
     void set_head_fold(::MatvecArgs& a, bool cont);
-    void launch_pick();
+    void launch_pick(const ::MatvecArgs& head);   // behind the head launch `head` (its grid = the key slots)
+    bool head_folded_ = false;        // a head launch of this handle has left per-wave keys and been followed by pick_cont_kernel (set where that is launched or captured)
     int stamps_level_ = 0;
     unsigned long long* stamps_ = nullptr;   // measurement only (CT_AMD_STAMPS=1): wall-clock stamps at the start and end of every token step
     bool head_cont_ = false;          // the head launch being issued belongs to a token step that advanced the cursor before it

@@ -70,7 +70,7 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
         else CT_LAUNCH((layernorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, (const float*)output_norm_b_,
                        d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
-        if (a.pick_ws) launch_pick();
+        if (a.pick_ws) launch_pick(a);
     }
     CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
     return true;
@@ -190,7 +190,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
             if (!run_matvec(a, err)) return false;
             prof_end();
         }
-        if (a.pick_ws && !only_site_) launch_pick();
+        if (a.pick_ws && !only_site_) launch_pick(a);
     }
     if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
     return true;

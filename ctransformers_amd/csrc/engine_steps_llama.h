@@ -74,7 +74,7 @@ bool Engine::chunk_step(int c0, int nt, bool want_logits, std::string& err) {
         if (kq_can(a)) { a.emb_out = d_emb_; set_head_fold(a, false); }   // the head launch stores the final-norm output from its prologue and picks the greedy token
         else CT_LAUNCH((rmsnorm_f32_kernel<256>), dim3(1), dim3(256), stream_, xl, (const float*)output_norm_, d_emb_, E, hp_.rms_eps);
         if (!run_matvec(a, err)) return false;
-        if (a.pick_ws) launch_pick();
+        if (a.pick_ws) launch_pick(a);
     }
     CT_LAUNCH(advance_state_n_kernel, dim3(1), dim3(64), stream_, d_state_, nt);
     return true;
@@ -214,7 +214,7 @@ bool Engine::token_step(bool want_logits, std::string& err) {
             prof_end();
         }
         if (stamps_ && stamps_level_ > 1) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 8ull);
-        if (a.pick_ws && !only_site_) launch_pick();
+        if (a.pick_ws && !only_site_) launch_pick(a);
     }
     if (!only_site_ && !bumped) CT_LAUNCH(advance_state_kernel, dim3(1), dim3(64), stream_, d_state_, n_ctx_);
     if (stamps_) CT_LAUNCH(stamp_kernel, dim3(1), dim3(1), stream_, stamps_, 2ull);

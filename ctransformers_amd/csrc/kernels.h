@@ -89,6 +89,7 @@ struct MatvecArgs {
     // Greedy pick, first half (kernels_v9.h:v9_pick_store; the EMB instantiations): every wave of the head launch leaves the first maximum
     // of ITS logits rows as a 64-bit key in pick_ws[workgroup][wave]; pick_cont_kernel finishes.  Null: no pick.
     unsigned* pick_ws;
+    int grid_out;              // host side only: workgroups of the launch these arguments went out with (set by the launch helper)
     float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
     int dbg;                   // measurement only (CT_AMD_DBG / ctamd_trace_site): bit 32 = write in-kernel s_memtime stamps to dbg_sink
 };
