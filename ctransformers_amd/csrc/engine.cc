@@ -545,6 +545,14 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
     const int hd = hp_.head_dim();
     AttnArgsX ax = AttnArgsX();
     fill_attn_args(ax, kc, vc, nt);
+    if (nt > 0 && fast_pf_ && !alibi_ && (hd == 128 || hd == 64) && env_int("CT_AMD_ATTN_MM", 1) != 0) {
+        // order-free prompt chunks: K.Q and V.P on the f16 matrix cores (kernels_mm8.h:attn_mm_kernel), any context length
+        const dim3 gm((unsigned)hp_.n_head, (unsigned)((nt + 31) / 32));
+        const size_t sm = (size_t)8 * 32 * 12 + (size_t)8 * 16 * 64 * 4;
+        if (hd == 128) { auto kfn = attn_mm_kernel<128>; CT_LAUNCH_DYN(kfn, gm, dim3(512), sm, stream_, ax, nt); }
+        else { auto kfn = attn_mm_kernel<64>; CT_LAUNCH_DYN(kfn, gm, dim3(512), sm, stream_, ax, nt); }
+        return;
+    }
     const dim3 ag((unsigned)hp_.n_head, (unsigned)(hd / 64), (unsigned)std::max(1, nt));   // nt > 0: the tokens of a prompt chunk
     const size_t smem = (size_t)((n_ctx_ + 63) & ~63) * 4;   // the probability row
 #define ATTN(NTV, HDV, ALLV, GRID) do { \
@@ -1371,6 +1379,15 @@ int Engine::debug_read_kv(int layer, uint16_t* k, uint16_t* v) {
     (void)hipMemcpy(k, kcache_ + (size_t)(layer - l0_) * n_ctx_ * G, (size_t)n_ctx_ * G * 2, hipMemcpyDeviceToHost);
     (void)hipMemcpy(v, vcache_ + (size_t)(layer - l0_) * v_stride_ * G, (size_t)v_stride_ * G * 2, hipMemcpyDeviceToHost);
     return v_stride_;
+}
+
+// Test hook: the attention output rows of the last chunk launched (last layer of this stage), n_tok x n_embd floats.
+int Engine::debug_read_attn_out(float* dst, int n_tok) {
+    if (!attn_out_b_ || n_tok < 1 || n_tok > pf_cap_) return -1;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    (void)hipMemcpy(dst, attn_out_b_, (size_t)n_tok * hp_.n_embd * 4, hipMemcpyDeviceToHost);
+    return hp_.n_embd;
 }
 
 bool Engine::decode_burst(int n, double* us_per_token, std::string& err) {

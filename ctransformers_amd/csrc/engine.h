@@ -128,6 +128,7 @@ class Engine {
     int read_stamps(unsigned long long* out, int max);   // measurement only: copies and clears the stamps
     // tests / measurement only: this stage's fp16 K and V cache of one layer -> host ([n_head_kv][n_ctx][head_dim] and [n_embd_gqa][v_stride]); returns v_stride
     int debug_read_kv(int layer, uint16_t* k, uint16_t* v);
+    int debug_read_attn_out(float* dst, int n_tok);
     long long qa_launches() const { return qa_launches_; }   // fused QKV + attention launches issued (eager launches and graph captures)
     long long spec_hits() const { return spec_hits_; }           // evals served by a speculative continuation step
     long long spec_launched() const { return spec_launched_; }   // continuation steps queued

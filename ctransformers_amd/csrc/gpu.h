@@ -431,7 +431,15 @@ static inline i32x16 mfma_i8_32x32x32_acc(u32x4 a, u32x4 b, i32x16 c) {
     return c;
 }
 static inline i32x16 mfma_i8_32x32x32_bias(u32x4 a, u32x4 b) { return mfma_i8_32x32x32_c(a, b, 0x4B400000); }
+static inline f32x16 mfma_f16_32x32x16_acc(u32x4 a, u32x4 b, f32x16 c);
 static inline f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b) {
+    f32x16 z;
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return mfma_f16_32x32x16_acc(a, b, z);
+}
+// (the sum of the sixteen products and C in double, rounded once: what the hardware does inside the instruction is not specified beyond "f32 accumulate" —
+// callers are the order-free kernels, whose results do not depend on it beyond an f32 rounding)
+static inline f32x16 mfma_f16_32x32x16_acc(u32x4 a, u32x4 b, f32x16 c0) {
     const int lane = (int)(threadIdx.x & 63), m = lane & 31, h = lane >> 5;
     const uint64_t a01 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a23 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
     const uint64_t b01 = (uint64_t)b[0] | ((uint64_t)b[1] << 32), b23 = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
@@ -440,7 +448,7 @@ static inline f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b) {
     f32x16 d;
     for (int i = 0; i < 16; ++i) {
         const int n = (i & 3) + 8 * (i >> 2) + 4 * h;
-        double s = 0.0;
+        double s = (double)c0[i];
         for (int c = 0; c < 2; ++c) {
             const uint64_t am[2] = {emu_shfl_any(a01, n + 32 * c), emu_shfl_any(a23, n + 32 * c)};
             for (int w = 0; w < 2; ++w)
@@ -471,6 +479,10 @@ DEV f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b) {
     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), z, 0, 0, 0);
+}
+DEV f32x16 mfma_f16_32x32x16_acc(u32x4 a, u32x4 b, f32x16 c) {
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
 }
 #endif
 
@@ -546,6 +558,7 @@ struct u32x2 {
     uint32_t& operator[](int i) { return v[i]; }
 };
 static inline u32x2 ld_stream8(const void* p) { u32x2 r; memcpy(&r, p, 8); return r; }
+static inline u32x2 ld8(const void* p) { u32x2 r; memcpy(&r, p, 8); return r; }
 static inline uint32_t ld_stream4(const void* p) { uint32_t r; memcpy(&r, p, 4); return r; }
 static inline int bfe_i32(uint32_t v, int off, int width) { return (int)(v << (32 - off - width)) >> (32 - width); }
 static inline uint32_t pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -558,6 +571,7 @@ DEV float wave_read_lane(float v, int src) {
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 DEV u32x2 ld_stream8(const void* p) { return __builtin_nontemporal_load((const u32x2*)p); }
+DEV u32x2 ld8(const void* p) { return *(const u32x2*)p; }
 DEV uint32_t ld_stream4(const void* p) { return __builtin_nontemporal_load((const uint32_t*)p); }
 DEV int bfe_i32(uint32_t v, int off, int width) { return __builtin_amdgcn_sbfe((int)v, off, width); }
 // the low bytes of four words as one word (three v_perm_b32)

@@ -560,3 +560,169 @@ __global__ void __launch_bounds__(512, 2) mm8_kernel(const uint8_t* acts0, int n
         }
     }
 }
+
+// ---- prompt attention of the order-free form ------------------------------------------------------------------------------------------------------
+// The reference's chain per (head, token) (llama.cpp:2352-2378): K.Q dots of fp16 rows with f32 sums, * 1/sqrt(head_dim) in f32,
+// causal mask, softmax = max, table_exp_f16[fp16(s - max)], the sum in double, * (float)(1 / sum) in f32; the probabilities rounded to fp16, V.P dots of
+// fp16 rows with f32 sums.  Kept here: every one of those roundings (the fp16 ones and the f32 scale / normalisation), the exact max, the exact double sum
+// (fp16 addends are multiples of 2^-24: any order is exact).  Given up: the order of the f32 sums inside the two dot products, which run on
+// v_mfma_f32_32x32x16_f16 (products of two halves are exact in f32).
+// A workgroup = (head, 32 tokens), eight waves; wave w takes the position tiles w, w + 8, .. of 32 positions up to the tile's last visible position.
+//   scores, transposed: D = K_tile (A operand: lane = position) x Q_tile (B operand: lane = token) — lane (token, c) then holds, in register i, the score
+//   of position (i & 3) + 8 (i >> 2) + 4 c of the tile: sixteen probabilities of ITS token, which after rounding to fp16 ARE the A operand of the V.P
+//   product (lane = token, eight k-slots per matrix instruction = registers 0..7 / 8..15) with no exchange between lanes; the V operand (lane = channel)
+//   reads the matching positions as two 8-byte pieces per instruction.
+// The probability rows are never stored: pass 1 computes the scores for the row maxima, pass 2 again for the sums, pass 3 again for the V.P product — the
+// K.Q product is a quarter of a percent of the matrix cores' time at these sizes, the table look-ups of passes 2 and 3 are what the kernel costs.  No
+// context limit (nothing in LDS grows with it).  Masked positions contribute p = 0 as in the reference (expf(-inf) entry); V of positions this request has
+// not written yet is not read as numbers (zeroed in the operand: a stale Inf times 0 would poison the sum).
+template <int HD>
+__global__ void __launch_bounds__(512) attn_mm_kernel(const AttnArgsX a, int n_tok) {
+    kernarg_touch<sizeof(AttnArgsX)>();
+    constexpr int NS = HD / 16, NCT = HD / 32, NW = 8;
+    CT_DYN_SMEM(smem);   // [NW][32] floats (maxima) | [NW][32] doubles (sums) | [NW][16][64] floats (one channel tile's partial results)
+    float* s_max = (float*)smem;
+    double* s_sum = (double*)(smem + NW * 32 * 4);
+    float* s_red = (float*)(smem + NW * 32 * 12);
+    const int lane = lane_id(), wv = uniform_int(wave_id()), tk = lane & 31, c = lane >> 5;
+    const int h = (int)blockIdx.x, t0 = (int)blockIdx.y * 32;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const int pos0 = *a.pos;
+    const int tok_ld = t0 + tk < n_tok ? t0 + tk : n_tok - 1;            // (a tile's surplus tokens compute the last token again; nothing of it is stored)
+    const int my_last = pos0 + t0 + tk;                                   // the last position this lane's token sees
+    const int last = pos0 + (t0 + 31 < n_tok ? t0 + 31 : n_tok - 1);      // the last position any token of the tile sees (written by this chunk's QKV launch)
+    const int ntiles = last / 32 + 1;
+    u32x4 Q[NS];
+    {
+        const uint16_t* qrow = a.q_f16 + (size_t)tok_ld * a.q_stride + (size_t)h * HD + 8 * c;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) Q[s] = ld16(qrow + 16 * s);
+    }
+    const uint16_t* kb = a.kcache + (size_t)hk * a.n_ctx * HD;
+    const float scale = a.kq_scale;
+    auto load_k = [&](int pt, u32x4 (&Kf)[NS]) {
+        int p = pt * 32 + tk;
+        p = p < last ? p : last;                                          // (rows behind the last written one: read the last one, masked below)
+        const uint16_t* kr = kb + (size_t)p * HD + 8 * c;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) Kf[s] = ld16(kr + 16 * s);
+    };
+    auto scores = [&](int pt, const u32x4 (&Kf)[NS], float (&S)[16]) {
+        f32x16 D = mfma_f16_32x32x16(Kf[0], Q[0]);
+#pragma unroll
+        for (int s = 1; s < NS; ++s) D = mfma_f16_32x32x16_acc(Kf[s], Q[s], D);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = pt * 32 + (i & 3) + 8 * (i >> 2) + 4 * c;
+            S[i] = p <= my_last ? D[i] * scale : -INFINITY;
+        }
+    };
+    // pass 1: the row maxima
+    float mx = -INFINITY;
+    {
+        u32x4 Kc[NS], Kn[NS];
+        if (wv < ntiles) load_k(wv, Kc);
+        for (int pt = wv; pt < ntiles; pt += NW) {
+            if (pt + NW < ntiles) load_k(pt + NW, Kn);
+            float S[16];
+            scores(pt, Kc, S);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[i]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Kc[s] = Kn[s];
+        }
+    }
+    mx = fmaxf(mx, lane_xor32(mx));
+    if (c == 0) s_max[wv * 32 + tk] = mx;
+    __syncthreads();
+    mx = s_max[tk];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, s_max[w * 32 + tk]);
+    // pass 2: the sums of the exponentials (double: exact in any order)
+    double sum = 0.0;
+    {
+        u32x4 Kc[NS], Kn[NS];
+        if (wv < ntiles) load_k(wv, Kc);
+        for (int pt = wv; pt < ntiles; pt += NW) {
+            if (pt + NW < ntiles) load_k(pt + NW, Kn);
+            float S[16];
+            scores(pt, Kc, S);
+            float e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(S[i] - mx)]);   // (masked: fp16(-inf) -> the table's 0)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += (double)e[i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Kc[s] = Kn[s];
+        }
+    }
+    sum += lane_xor32(sum);
+    if (c == 0) s_sum[wv * 32 + tk] = sum;
+    __syncthreads();
+    sum = s_sum[tk];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += s_sum[w * 32 + tk];
+    const float inv = (float)(1.0 / sum);
+    // pass 3: probabilities as fp16, V.P on the matrix cores
+    f32x16 O[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[ct][i] = 0.0f;
+    {
+        const uint16_t* vb = a.vcache + ((size_t)hk * HD + tk) * a.v_stride + 4 * c;   // lane (channel tk of a tile, c): positions 4 c + {0..3, 8..11, 16..19, 24..27}
+        u32x4 Kc[NS], Kn[NS];
+        if (wv < ntiles) load_k(wv, Kc);
+        for (int pt = wv; pt < ntiles; pt += NW) {
+            if (pt + NW < ntiles) load_k(pt + NW, Kn);
+            u32x2 V[NCT][4];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) V[ct][g] = ld8(vb + (size_t)ct * 32 * a.v_stride + pt * 32 + 8 * g);
+            if (pt * 32 + 31 > last) {   // the tile holds positions nobody has written in this request: zero them in the operand (wave-uniform branch)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nv = last - (pt * 32 + 8 * g + 4 * c) + 1;   // valid halves of this piece
+                    const uint32_t m0 = nv >= 2 ? 0xFFFFFFFFu : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? 0xFFFFFFFFu : (nv == 3 ? 0xFFFFu : 0u);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) { V[ct][g][0] &= m0; V[ct][g][1] &= m1; }
+                }
+            }
+            float S[16];
+            scores(pt, Kc, S);
+            uint32_t P[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float e0 = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(S[2 * i] - mx)]);
+                const float e1 = f16_bits_to_f32(a.exp_tab[f32_to_f16_bits(S[2 * i + 1] - mx)]);
+                P[i] = (uint32_t)f32_to_f16_bits(e0 * inv) | ((uint32_t)f32_to_f16_bits(e1 * inv) << 16);
+            }
+            const u32x4 PA0 = {P[0], P[1], P[2], P[3]}, PA1 = {P[4], P[5], P[6], P[7]};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const u32x4 VB0 = {V[ct][0][0], V[ct][0][1], V[ct][1][0], V[ct][1][1]}, VB1 = {V[ct][2][0], V[ct][2][1], V[ct][3][0], V[ct][3][1]};
+                O[ct] = mfma_f16_32x32x16_acc(PA0, VB0, O[ct]);
+                O[ct] = mfma_f16_32x32x16_acc(PA1, VB1, O[ct]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Kc[s] = Kn[s];
+        }
+    }
+    // the waves' partial results meet in LDS, one channel tile at a time: lane (channel, c) register i = token (i & 3) + 8 (i >> 2) + 4 c
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_red[(wv * 16 + i) * 64 + lane] = O[ct][i];
+        __syncthreads();
+        for (int idx = (int)threadIdx.x; idx < 16 * 64; idx += 512) {
+            const int i = idx >> 6, ln = idx & 63;
+            float r = s_red[idx];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) r += s_red[w * 16 * 64 + idx];
+            const int tok = t0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+            if (tok < n_tok) a.out[(size_t)tok * a.out_stride + (size_t)h * HD + ct * 32 + (ln & 31)] = r;
+        }
+    }
+}

@@ -104,6 +104,44 @@ def test_one_reference_batch_of_140_tokens_on_the_emulator(emu_lib, monkeypatch)
     assert np.array_equal(m.logits.to_numpy(), g["logits_140"])
 
 
+def _attn_out(m, n_tok):
+    f = m._lib.ctamd_debug_read_attn_out
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    buf = np.zeros(n_tok * 16384, np.float32)
+    E = f(m._llm, buf.ctypes.data, n_tok)
+    assert E > 0
+    return buf[:n_tok * E].reshape(n_tok, E).copy()
+
+
+def _attention_forms(path, lib, n_tok, ctx, monkeypatch, past=0):
+    """Attention output rows of a ONE-layer model's last chunk, order-free mat-muls in both runs (identical Q / K / V), the bit-identical chunk attention
+    kernels (CT_AMD_ATTN_MM=0) against attn_mm_kernel."""
+    out = []
+    for mm in ("0", "1"):
+        monkeypatch.setenv("CT_AMD_ATTN_MM", mm)
+        m = _open(path, lib, True, monkeypatch, context_length=ctx, batch_size=max(n_tok, past, 8))
+        toks = synth.prompt_tokens(past + n_tok, m.vocab_size)
+        if past:
+            m.eval(toks[:past])
+        m.eval(toks[past:])
+        out.append((_attn_out(m, n_tok), m.logits.to_numpy().copy()))
+        del m
+    (a, la), (b, lb) = out
+    return float(np.abs(a - b).max() / np.abs(a).max()), float(np.abs(la - lb).max() / np.abs(la).max()), a, b
+
+
+@pytest.mark.parametrize("n_tok,past", [(5, 0), (70, 0), (33, 40)])
+def test_matrix_core_prompt_attention_on_the_emulator(emu_lib, n_tok, past, tmp_path, monkeypatch):
+    """attn_mm_kernel keeps every rounding of the reference's chain except the order of the f32 sums inside the K.Q and V.P dots: its output rows differ from
+    the bit-identical kernels' by a few f32 ulp, plus an fp16 ulp of single probabilities where a score moved across a rounding boundary (2^-11 of that
+    probability's share).  Ragged tiles: 5 and 70 tokens (tiles of 32), a chunk that starts at position 40."""
+    shape = dict(synth.LLAMA_SHAPES["llama-tiny"], n_layer=1)
+    path = str(tmp_path / "tiny1l.gguf")
+    synth.write_llama_gguf(path, shape, "Q4_K_M", seed=3)
+    rel, rel_logits, a, b = _attention_forms(path, emu_lib, n_tok, 128, monkeypatch, past)
+    assert np.isfinite(b).all() and rel < 2e-3, rel
+
+
 # ---- MI355X ---------------------------------------------------------------------------------------------------------------------------------------
 
 def _model(shape, ftype, tag):
@@ -172,3 +210,19 @@ def test_reference_batch_above_128_tokens(ref, batch_size, monkeypatch):
         m2 = LLM(path, config=Config(**cfg))
         m2.eval(toks)
         assert np.array_equal(m2.logits.to_numpy(), want), chunk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n_tok,past", [("llama-7b-2l", 128, 0), ("llama-7b-2l", 300, 0), ("llama-7b-2l", 77, 1000), ("llama-70b-2l", 160, 200)])
+def test_matrix_core_prompt_attention(shape, n_tok, past, tmp_path, monkeypatch):
+    """The same on the GPU at head size 128: 7B widths (32 heads) and 70B widths (64 heads on 8 K/V heads), one layer; whole tiles, ragged tiles, a chunk
+    behind 1000 earlier positions (the waves' position tiles, the masked diagonal tiles, the zeroed V tail)."""
+    hp = dict(synth.LLAMA_SHAPES[shape], n_layer=1)
+    path = "/tmp/ctamd_fast_attn_%s_1l.gguf" % shape.replace("-", "_")
+    if not os.path.exists(path):
+        synth.write_llama_gguf(path + ".tmp", hp, "Q4_K_M", seed=11)
+        os.replace(path + ".tmp", path)
+    rel, rel_logits, a, b = _attention_forms(path, None, n_tok, 1536, monkeypatch, past)
+    print("attn_mm_kernel vs the bit-identical chunk attention, %s, %d tokens behind %d: rows differ by %.3g of the largest, logits by %.3g" %
+          (shape, n_tok, past, rel, rel_logits))
+    assert np.isfinite(b).all() and rel < 2e-3, rel
