@@ -852,10 +852,6 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
         const dim3 grid((unsigned)((tile0 + RW - 1) / RW), (unsigned)((ntt + NTTv - 1) / NTTv)), block(512);
         const size_t smem = std::max((size_t)2 * KSv * NTTv * unit, (size_t)kMm8Waves * NTTv * 4096);
         ++g_mm8_launches;
-#ifdef MM8_TRACE
-        a.m.dbg_sink = (float*)trace_buf_;
-        HIP_OK(hipMemsetAsync(trace_buf_, 0, 120 * 8, stream_));
-#endif
 #define MM8L(TYV, NV, KV) do { \
             auto kfn = mm8_kernel<TYV, NV, KV>; \
             CT_OPTIN_ONCE(kfn, (size_t)160 * 1024); \
@@ -866,21 +862,6 @@ bool Engine::mm8_matvec(MatvecArgs& m, const float* x, int ldx, int nt, int ld_o
         if (ty == GT_Q4_K) MM8T(GT_Q4_K); else if (ty == GT_Q5_K) MM8T(GT_Q5_K); else if (ty == GT_Q6_K) MM8T(GT_Q6_K); else if (ty == GT_Q8_0) MM8T(GT_Q8_0); else MM8T(GT_Q4_0);
 #undef MM8T
 #undef MM8L
-#ifdef MM8_TRACE
-        {
-            static int shown = 0;
-            if (shown < 12 && nt > 64) {
-                ++shown;
-                HIP_OK(hipStreamSynchronize(stream_));
-                unsigned long long h[120];
-                HIP_OK(hipMemcpy(h, trace_buf_, sizeof h, hipMemcpyDeviceToHost));
-                fprintf(stderr, "mm8_trace type %d shape %d,%d tiles %d ns %d grid %u x %u: prologue %llu;", ty, NTTv, KSv, tile0, ns, grid.x, grid.y, h[1] - h[0]);
-                for (int st = 0; 1 + 5 * st + 5 < 120 && h[1 + 5 * st + 4]; ++st)
-                    fprintf(stderr, " [issue %llu compute %llu wait %llu barrier %llu]", h[2 + 5 * st] - h[1 + 5 * st], h[3 + 5 * st] - h[2 + 5 * st], h[4 + 5 * st] - h[3 + 5 * st], h[5 + 5 * st] - h[4 + 5 * st]);
-                fprintf(stderr, "\n");
-            }
-        }
-#endif
     }
     return true;
 }

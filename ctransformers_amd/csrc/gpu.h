@@ -196,11 +196,7 @@ static inline u32x4 ld_stream16(const void* p) { u32x4 r; memcpy(&r, p, 16); ret
 static inline u32x4 ld16(const void* p) { u32x4 r; memcpy(&r, p, 16); return r; }
 #else
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifdef LD_STREAM_PLAIN   // experiment: default cache policy on the weight stream
-DEV u32x4 ld_stream16(const void* p) { return *(const u32x4*)p; }
-#else
 DEV u32x4 ld_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
-#endif
 DEV u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 #endif
 

@@ -464,33 +464,20 @@ __global__ void __launch_bounds__(512, 2) mm8_kernel(const uint8_t* acts0, int n
     vm_wait<0>();
     mm8_landed<TYPE>(R);
     __syncthreads();
-#ifdef MM8_TRACE
-    unsigned long long* trc = (bx == 0 && tg == 0 && wv == MM8_TRACE && lane == 0 && m.dbg_sink) ? (unsigned long long*)m.dbg_sink : nullptr;
-    int tri = 0;
-#define MM8_STAMP() do { if (trc && tri < 120) trc[tri++] = clock64_dev(); } while (0)
-#else
-#define MM8_STAMP() do {} while (0)
-#endif
-    MM8_STAMP();
     for (int st = 0; st < nsteps; ++st) {
         uint8_t* cur = smem + (st & 1) * SB;
-        MM8_STAMP();
         // the copy of step st + 1 goes into the buffer step st - 1 read (every wave has passed that step's barrier), piece by piece from inside the step
         const Feeder feed = {src0, smem + ((st + 1) & 1) * SB, step_stride, st + 1 < nsteps ? st + 1 : st, nb, tq_max, wv, lane};
         const int bnext = bcur + KS;
-        MM8_STAMP();
         if (bcur < nb) mm8_step<TYPE, NTT>(R, wrec + (size_t)(bnext < nb ? bnext : nb - 1) * REC, cur + ks * NTT * UNIT, lane, acc, feed);
         else {   // a K-slice without a block in the last step: its share of the copy still goes out
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl) feed(sl);
         }
-        MM8_STAMP();
         bcur = bnext;
         vm_wait<0>();      // the copy (and the next weights) have landed ...
         mm8_landed<TYPE>(R);
-        MM8_STAMP();
         __syncthreads();   // ... and every wave knows: the next step reads what this one copied
-        MM8_STAMP();
     }
     // the K-slices' partial results meet in LDS: [wave][tile][register][lane]
     float* red = (float*)smem;

@@ -101,9 +101,6 @@ DEV void patch_f16(u32x4& v, int elem, uint32_t h) {   // fp16 element `elem` (0
 // of every 32-step): the same thirty-two fma chains, the same reduction tree (the j exchanges two lane bits up, t_m = S[m] + S[m + 4] is the
 // exchange between the halves), half the instructions per wave and step — the lone V*P wave of a workgroup was 3 800 of the attention
 // phase's 8 600 cycles at 200 positions.
-#ifndef QA_EXP
-#define QA_EXP 0   // bisecting builds (tools/experiments): 1 = no granule publish in the mat-vec phase, 2 = no attention phase compiled (both need CT_AMD_QA_PHASE1=1)
-#endif
 #ifndef QA_VB
 #define QA_VB 6   // V chunk slots per V*P lane: 4 -> 773.3, 6 -> 776.1, 8 (six registers spilled) -> 765.8 tok/s over 256 steps (positions 144..400), alternating on one box
 #endif
@@ -172,16 +169,13 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
         it.g0 = rec + 2 * (off + wl);
         it.gstep = 2 * gw;
         if constexpr (TB != 0) {
-            if (wv < a.nwA) v9_run<TA, MAXK, true, NS, false, QA_EXP != 1>(a, SM, a.baseA, 0, it, lane, wv, pro);
-            else v9_run<TB, MAXK, true, NS, false, QA_EXP != 1>(a, SM, a.baseB, a.n_groupA, it, lane, wv, pro);
+            if (wv < a.nwA) v9_run<TA, MAXK, true, NS, false, true>(a, SM, a.baseA, 0, it, lane, wv, pro);
+            else v9_run<TB, MAXK, true, NS, false, true>(a, SM, a.baseB, a.n_groupA, it, lane, wv, pro);
         } else {
-            v9_run<TA, MAXK, false, NS, false, QA_EXP != 1>(a, SM, a.baseA, 0, it, lane, wv, pro);
+            v9_run<TA, MAXK, false, NS, false, true>(a, SM, a.baseA, 0, it, lane, wv, pro);
         }
     }
     if (q.phase & 1) return;
-#if QA_EXP == 2
-    return;
-#endif
     // the map, the cursor {step, pos, n_past + n, batch} and the tag: computed / read again here rather than carried through the mat-vec phase
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id());
     const Map M2 = map_of(uniform_int(opaque_int((int)blockIdx.x)));
