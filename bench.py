@@ -249,15 +249,18 @@ def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_cont
     finally:
         os.environ.pop("CT_AMD_PREFILL", None)
     tops = round(rates[128] * pf_flop / 1e12, 1) if pf_flop else None
+    tops_512 = round(rates[512] * pf_flop / 1e12, 1) if pf_flop else None
     return dict(tok_s=rates[128], tok_s_512=rates[512], tok_s_2k=rates.get(N_PROMPT_2K), chunk_tokens=512, opt_in="CT_AMD_PREFILL=fast",
                 kernel="mm8_kernel<TYPE,NTT,KS> (v_mfma_i32_32x32x32_i8: Q4_K / Q5_K scales as two int8 digit planes inside the accumulation, Q6_K masked K-chunks, "
-                       "Q8_0 float scales; Q8_K / Q8_0 activations as the reference quantizes them; f32 sums in free order)",
-                tops=tops, mfma_i8_peak_tops=5000, frac=round(tops / 5000.0, 4) if tops else None, frac_of_f16_peak=round(tops / 2500.0, 4) if tops else None,
+                       "Q8_0 float scales; Q8_K / Q8_0 activations as the reference quantizes them; f32 sums in free order) + attn_mm_kernel<HD> "
+                       "(v_mfma_f32_32x32x16_f16 for K.Q and V.P, the reference's fp16 / f32 roundings, exact max and double sum)",
+                tops=tops, tops_512=tops_512, mfma_i8_peak_tops=5000, frac=round(tops / 5000.0, 4) if tops else None,
+                frac_of_f16_peak=round(tops / 2500.0, 4) if tops else None, frac_512_of_f16_peak=round(tops_512 / 2500.0, 4) if tops_512 else None,
                 logits_rel_diff_vs_default=float(np.abs(lg - exact_logits).max() / np.abs(exact_logits).max()),
                 greedy_steps_compared=len(exact_greedy), greedy_steps_identical=same,
                 note="same quantization points and exact integer dots as the reference, another f32 summation order: K / V rows of the first layer within an fp16 ulp, "
                      "logits within the reference's own int8 quantization noise (~4e-2 of the largest logit on this synthetic model), NOT within 1e-3 — hence opt-in; "
-                     "MFMA-busy counters: profiles/r06_mm8_pmc.txt")
+                     "MFMA-busy counters: profiles/r06_mm8_pmc_128tok.txt, profiles/r06_mm8_pmc_512tok.txt")
 
 
 def stage_ranges(llm):

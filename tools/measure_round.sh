@@ -4,12 +4,14 @@
 # MFMA-busy of the prompt chunks), in-kernel traces (mat-vec sites, fused QKV + attention launch), in-stream stamps (token-step gaps, pipeline hops),
 # per-site prefill timings, attention context scaling, the in-process pipeline on the one GPU (2 / 4 / 8 stages), the hand-off probe, legacy architectures.
 # Summaries land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-M=/tmp/ctamd_llama2_7b_q4km_r2.gguf
+# the file bench.py times: block pools from the reference's quantizer where oracle/_ref travelled with the snapshot (bench.py:_ref_quantizer)
+if [ -f oracle/_ref/libctransformers_ref.so ]; then M=/tmp/ctamd_llama2_7b_q4km_refq.gguf; else M=/tmp/ctamd_llama2_7b_q4km_r2.gguf; fi
+export CTAMD_BENCH_MODEL=$M
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
+timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
 timeout 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1
 timeout 2400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for S in 2 4 8; do
@@ -41,6 +43,14 @@ timeout 300 python tools/gpu_sites.py final > $O/v9_sites_7b_q4km.json 2> $O/sit
 ( timeout 300 python tools/ctx_scaling.py llama-7b-2l; timeout 300 python tools/ctx_scaling.py; echo "CT_AMD_ATTN_SHARE=0"; CT_AMD_ATTN_SHARE=0 timeout 300 python tools/ctx_scaling.py llama-7b-2l; CT_AMD_ATTN_SHARE=0 timeout 300 python tools/ctx_scaling.py ) > $O/ctx_scaling.txt 2>&1
 timeout 300 python tools/prefill_sweep.py $M 8 16 32 64 128 > $O/prefill_sweep_7b_q4km.txt 2>&1
 timeout 600 python tools/legacy_speed.py > $O/legacy_arch_speed.txt 2>&1
+# the order-free prompt form (CT_AMD_PREFILL=fast): rates against the bit-identical form, kernel shares, SQ counters at 128- and 512-token prompts
+( for n in 128 512 2048; do timeout 300 python tools/mm8_check.py llama-2-7b Q4_K_M $n 8 2304; done
+  for n in 128 512 2048; do timeout 400 python tools/mm8_check.py llama-2-7b Q8_0 $n 8 2304; done
+  timeout 400 python tools/mm8_check.py llama-70b-2l Q5_K_M 2048 8 2304; timeout 400 python tools/mm8_check.py falcon-7b-2l Q4_K_M 512 8 2304 ) > $O/prefill_fast_rates.txt 2>&1
+( cd /tmp; for n in 128 512; do CT_AMD_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_fast$n -o fast -- python $R/tools/mm8_check.py --worker fast llama-2-7b Q4_K_M $n 2 2304 > $R/$O/prof_fast$n.log 2>&1; done )
+for n in 128 512; do python tools/prof_summary.py $O/prof_fast$n > $O/kernel_stats_fast_${n}tok_7b_q4km.txt 2>&1; done
+timeout 900 bash tools/pmc_mm8.sh $O/pmc_mm8_128 llama-2-7b Q4_K_M 128 > $O/pmc_mm8_128.log 2>&1; cp $O/pmc_mm8_128/mm8_pmc.txt $O/mm8_pmc_128tok.txt 2>/dev/null
+timeout 900 bash tools/pmc_mm8.sh $O/pmc_mm8_512 llama-2-7b Q4_K_M 512 > $O/pmc_mm8_512.log 2>&1; cp $O/pmc_mm8_512/mm8_pmc.txt $O/mm8_pmc_512tok.txt 2>/dev/null
 python - <<PY
 import json
 for n in ("bench_default", "bench_gpus2_inprocess_one_gpu", "bench_gpus4_inprocess_one_gpu", "bench_gpus8_inprocess_one_gpu", "bench_gpus8_events_one_gpu", "bench_gpus4_flag_one_gpu"):
@@ -54,5 +64,5 @@ for n in ("bench_default", "bench_gpus2_inprocess_one_gpu", "bench_gpus4_inproce
     except Exception as e:
         print(n, "failed", e)
 PY
-tail -3 $O/pytest_gpu.txt; tail -1 $O/smoke.txt; head -14 $O/kernel_stats_7b_q4km.txt; head -6 $O/token_step_timeline.txt; cat $O/prefill_sweep_7b_q4km.txt; head -c 600 $O/v9_pmc_traffic.json; echo; cat $O/ctx_scaling.txt; cat $O/pipeline_stamps.txt $O/token_step_stamps.txt
-find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete; rm -rf $O/pmc_mfma/p1 $O/pmc_mfma/p2 $O/pmc_mfma/p3
+tail -3 $O/pytest_gpu.txt; tail -1 $O/smoke.txt; head -14 $O/kernel_stats_7b_q4km.txt; head -6 $O/token_step_timeline.txt; cat $O/prefill_sweep_7b_q4km.txt; head -c 600 $O/v9_pmc_traffic.json; echo; cat $O/ctx_scaling.txt; cat $O/pipeline_stamps.txt $O/token_step_stamps.txt; cat $O/prefill_fast_rates.txt; head -12 $O/kernel_stats_fast_128tok_7b_q4km.txt; cat $O/mm8_pmc_512tok.txt | grep -E 'dispatches'
+find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete; rm -rf $O/pmc_mfma/p1 $O/pmc_mfma/p2 $O/pmc_mfma/p3 $O/pmc_mm8_128/p1 $O/pmc_mm8_128/p2 $O/pmc_mm8_512/p1 $O/pmc_mm8_512/p2
