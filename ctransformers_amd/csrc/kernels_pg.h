@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(NW * 64, 2) matmul_pg_kernel(const uint8_t* ac
         for (int c = 0; c < VP; ++c) glds16((SRC) + (size_t)(c * NW + wv) * 1024 + lane16, (DST) + (size_t)(c * NW + wv) * 1024); \
         _Pragma("unroll") \
         for (int c = 0; c < ST::TAILP; ++c) glds4((SRC) + ST::SUMS + (size_t)(c * NW + wv) * 256 + lane4, (DST) + ST::SUMS + (size_t)(c * NW + wv) * 256); } while (0)
-    // Three LDS buffers (rotating byte offsets; all below 64 KB, the reach of the DMA's M0 base) and ONE barrier per step, in its
+    // Three LDS buffers (rotating byte offsets; all below 64 KB — round 6: M0 reaches all 160 KB, tools/experiments/lds_dma_reach.cpp; kernels_mm8.h uses it) and ONE barrier per step, in its
     // middle (behind AVX lane 3).  Stage b + 2 is requested in the second half of step b, waited for (vmcnt) right before the barrier
     // of step b + 1 and first read at the top of step b + 2:
     //   landing  an LDS-DMA takes ~1.1 us under load, about a step: waited for inside its own step it IS the step time;

@@ -161,7 +161,7 @@ def bench_file(config):
 
 @pytest.fixture(scope="module")
 def model_7b(tmp_path_factory):
-    if os.environ.get("CTAMD_BENCH_MODEL"):
+    if os.environ.get("CTAMD_BENCH_MODEL") and os.path.exists(os.environ["CTAMD_BENCH_MODEL"]):
         return os.environ["CTAMD_BENCH_MODEL"]
     return bench_file(2)[2]
 

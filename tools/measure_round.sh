@@ -9,10 +9,10 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 # the file bench.py times: block pools from the reference's quantizer where oracle/_ref travelled with the snapshot (bench.py:_ref_quantizer)
 if [ -f oracle/_ref/libctransformers_ref.so ]; then M=/tmp/ctamd_llama2_7b_q4km_refq.gguf; else M=/tmp/ctamd_llama2_7b_q4km_r2.gguf; fi
-export CTAMD_BENCH_MODEL=$M
 export TMPDIR=/tmp
 timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
 timeout 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1
+export CTAMD_BENCH_MODEL=$M   # (behind the suite: its fixtures write the files themselves)
 timeout 2400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for S in 2 4 8; do
   D=$(python -c "print(','.join(['0'] * $S))")
@@ -46,7 +46,7 @@ timeout 600 python tools/legacy_speed.py > $O/legacy_arch_speed.txt 2>&1
 # the order-free prompt form (CT_AMD_PREFILL=fast): rates against the bit-identical form, kernel shares, SQ counters at 128- and 512-token prompts
 ( for n in 128 512 2048; do timeout 300 python tools/mm8_check.py llama-2-7b Q4_K_M $n 8 2304; done
   for n in 128 512 2048; do timeout 400 python tools/mm8_check.py llama-2-7b Q8_0 $n 8 2304; done
-  timeout 400 python tools/mm8_check.py llama-70b-2l Q5_K_M 2048 8 2304; timeout 400 python tools/mm8_check.py falcon-7b-2l Q4_K_M 512 8 2304 ) > $O/prefill_fast_rates.txt 2>&1
+  timeout 400 python tools/mm8_check.py llama-70b-2l Q5_K_M 2048 8 2304; timeout 400 python tools/mm8_check.py falcon-40b-2l Q4_K_M 512 8 2304 ) > $O/prefill_fast_rates.txt 2>&1
 ( cd /tmp; for n in 128 512; do CT_AMD_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_fast$n -o fast -- python $R/tools/mm8_check.py --worker fast llama-2-7b Q4_K_M $n 2 2304 > $R/$O/prof_fast$n.log 2>&1; done )
 for n in 128 512; do python tools/prof_summary.py $O/prof_fast$n > $O/kernel_stats_fast_${n}tok_7b_q4km.txt 2>&1; done
 timeout 900 bash tools/pmc_mm8.sh $O/pmc_mm8_128 llama-2-7b Q4_K_M 128 > $O/pmc_mm8_128.log 2>&1; cp $O/pmc_mm8_128/mm8_pmc.txt $O/mm8_pmc_128tok.txt 2>/dev/null
