@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libctransformers_emu.so")
+EMU_LIB = os.environ.get("CTAMD_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libctransformers_emu.so")   # (CTAMD_EMU_LIB: a sanitizer build of the same sources)
 HIP_LIB = os.path.join(ROOT, "ctransformers_amd", "lib", "libctransformers.so")
 
 
