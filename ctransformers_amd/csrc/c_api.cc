@@ -48,6 +48,7 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
         fprintf(stderr, "Model type '%s' is not supported.\n", model_type);
         return nullptr;
     }
+    std::lock_guard<std::recursive_mutex> legacy(ctamd::capture_mutex());   // loads copy on the legacy stream: not while another thread captures (engine.h)
     ctransformers_llm* llm = nullptr;
     try {   // nothing may propagate across the C boundary: a malformed file makes create return NULL (as the reference does)
     llm = new ctransformers_llm;
@@ -73,7 +74,10 @@ ctransformers_llm* ctransformers_llm_create(const char* model_path, const char* 
     }
 }
 
-void ctransformers_llm_delete(ctransformers_llm* llm) { delete llm; }
+void ctransformers_llm_delete(ctransformers_llm* llm) {
+    std::lock_guard<std::recursive_mutex> legacy(ctamd::capture_mutex());   // hipFree synchronizes the device: not while another thread captures (engine.h)
+    delete llm;
+}
 
 int ctransformers_llm_tokenize(ctransformers_llm* llm, const char* text, bool add_bos_token, int* output) {
     const std::vector<int> t = llm->engine().vocab().tokenize(text, add_bos_token);

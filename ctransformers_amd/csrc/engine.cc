@@ -40,6 +40,11 @@ static int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
+std::recursive_mutex& capture_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 Engine::~Engine() { free_all(); }
 
 bool Engine::adopt_stream(hipStream_t s) {
@@ -994,9 +999,11 @@ bool Engine::run_chunk(int c0, int nt, bool want_logits, std::string& err) {
         auto it = chunk_graphs_.find(key);
         if (it == chunk_graphs_.end() && chunk_seen_[key]++ >= 1) {
             hipGraph_t g = nullptr;
+            std::unique_lock<std::recursive_mutex> cap(capture_mutex());
             HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             const bool ok = chunk_step(c0, nt, want_logits, err);
             const hipError_t e = hipStreamEndCapture(stream_, &g);
+            cap.unlock();
             if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
             if (e != hipSuccess) { err = std::string("hipStreamEndCapture (chunk) failed: ") + hipGetErrorString(e); return false; }
             hipGraphExec_t ex = nullptr;
@@ -1034,9 +1041,11 @@ bool Engine::ensure_graphs(std::string& err) {
     if (graph_step_) return true;
     for (int head = 0; head < 2; ++head) {
         hipGraph_t g = nullptr;
+        std::unique_lock<std::recursive_mutex> cap(capture_mutex());
         HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         const bool ok = token_step(head == 1, err);
         hipError_t e = hipStreamEndCapture(stream_, &g);
+        cap.unlock();
         if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
         if (e != hipSuccess) { err = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e); return false; }
         hipGraphExec_t ex = nullptr;
@@ -1051,9 +1060,11 @@ bool Engine::ensure_graphs(std::string& err) {
             hipGraph_t g = nullptr;
             select_out(b);
             cont_mode_ = true;
+            std::unique_lock<std::recursive_mutex> cap(capture_mutex());
             HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             const bool ok = token_step(true, err);
             hipError_t e = hipStreamEndCapture(stream_, &g);
+            cap.unlock();
             cont_mode_ = false;
             select_out(0);
             if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
@@ -1251,7 +1262,9 @@ bool Engine::req_logits(std::string& err) {
 void Engine::fetch_outputs() {
     if (outputs_on_host_ || !have_logits_) return;
     (void)hipSetDevice(device_);
-    (void)hipMemcpy(h_logits_, d_logits2_[cur_buf_], ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost);
+    // (on the handle's own stream: a copy on the legacy stream would collide with a capture another thread has open, engine.h:capture_mutex)
+    (void)hipMemcpyAsync(h_logits_, d_logits2_[cur_buf_], ((size_t)hp_.n_vocab + hp_.n_embd) * 4, hipMemcpyDeviceToHost, stream_);
+    (void)hipStreamSynchronize(stream_);
     outputs_on_host_ = true;
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,12 @@ struct Layer {
 long long pg_launches();   // test hook: prompt-chunk launches of kernels_pg.h issued by this process
 long long kq_launches();   // test hook: K-quant decode mat-vec launches (kernels_v9.h) issued by this process
 long long mm8_launches();  // test hook: prompt-chunk launches of the order-free kernels (kernels_mm8.h) issued by this process
+
+// Process-wide and recursive: a stream capture (hipStreamCaptureModeThreadLocal) tolerates other threads' launches on their own streams, but not an operation
+// on the legacy stream or a device-wide synchronization anywhere in the process while it is open (hipMemcpy / hipMemset / hipFree of a load or a delete in
+// another thread: "operation would make the legacy stream depend on a capturing blocking stream", and the capture is lost).  Handle creation and deletion
+// hold this mutex from start to end, every capture holds it from Begin to End; the eval path itself makes no legacy-stream call.
+std::recursive_mutex& capture_mutex();
 
 class Engine {
    public:

@@ -379,6 +379,7 @@ bool Pipeline::eval(const int* tokens, int n, int n_past, std::string& err, int 
 
 // a host-side failure in the middle of a request
 void Pipeline::drain_after_failure() {
+    std::lock_guard<std::recursive_mutex> legacy(capture_mutex());   // (the releases below are copies on the legacy stream)
     // a host-side failure in the middle of a request: the stages already fed keep running and writing into the next stage's hand-off
     // buffer and KV cache — drain every stream before the caller sees the error, so that a retry does not overlap stale work
 #ifndef CT_EMU
@@ -423,6 +424,7 @@ bool Pipeline::eval_one_graph(const int* tokens, int n_past, std::string& err, i
         if (!st_[s]->req_begin(tokens, 1, n_past, batch, err, s == 0)) return false;
     if (!step_graph_) {
         hipGraph_t g = nullptr;
+        std::unique_lock<std::recursive_mutex> cap(capture_mutex());
         PIPE_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         bool ok = true;
         for (int s = 0; s < S && ok; ++s) {
@@ -432,6 +434,7 @@ bool Pipeline::eval_one_graph(const int* tokens, int n_past, std::string& err, i
                                    (float4*)st_[s + 1]->xio(), E / 4, (unsigned*)nullptr, (unsigned*)nullptr, st_[s + 1]->state_dev(), 0, 0, 0, 0, (const int*)st_[s]->state_dev());
         }
         hipError_t e = hipStreamEndCapture(stream, &g);
+        cap.unlock();
         if (!ok || e != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
             if (ok) err = std::string("hipStreamEndCapture (pipeline step) failed: ") + hipGetErrorString(e);

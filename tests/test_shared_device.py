@@ -95,12 +95,12 @@ def test_two_threads_decode_on_one_gpu():
     sweep gives up depends on how the hardware interleaves the two grids; if one does, the request is replayed — never a failed eval."""
     path = _model_7b_2l()
     toks = synth.prompt_tokens(40, 32000)
-    create = threading.Lock()   # (handles are created one at a time: the reference's library is single-threaded per handle, models/llm.h; loads are not what is tested)
 
     def chain(out, idx, n):
         try:
-            with create:
-                m = LLM(path, config=Config(context_length=256, batch_size=64))
+            # (created concurrently: a load copies on the legacy stream, which must not meet a graph capture of the other thread — the library
+            # serialises creation, deletion and captures process-wide, engine.h:capture_mutex)
+            m = LLM(path, config=Config(context_length=256, batch_size=64))
             m.eval(toks)
             seq, lg = [], []
             for _ in range(n):
