@@ -454,7 +454,7 @@ def main():
                           tops=round(out["prefill_tok_s"] * pf_flop / 1e12, 1) if pf_flop else None, mfma_f16_peak_tops=2500,
                           bound=("valu + mfma issue" if kq else "valu issue") + " (the exact f32 chain step per block, AVX lane, row and token)")
     out["prefill"]["frac"] = round(out["prefill"]["tops"] / 2500.0, 4) if out["prefill"]["tops"] else None
-    out["prefill"]["frac_note"] = "tops / dense f16 MFMA peak; MFMA-busy counters of the chunk kernels: profiles/r05_prefill_mfma_pmc.txt"
+    out["prefill"]["frac_note"] = "tops / dense f16 MFMA peak; MFMA-busy counters of the chunk kernels: profiles/r06_prefill_mfma_pmc.txt"
     if n_gpus == 1 and not a.no_long_context:
         # BASELINE configs[4] says "2k-ctx prefill": a 2048-token prompt at context 2304 (batch_size 128, as the 128-token prompt), then 32
         # greedy steps at positions 2048.. — for every config, on a fresh handle (the context length is fixed at load)

@@ -2,7 +2,7 @@
 (ctamd_profile_decode, include/ctransformers_amd_ext.h) folded into the `roofline` object of the bench JSON line."""
 import ctypes
 
-PMC_FILE = "r05_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
+PMC_FILE = "r06_v9_pmc_traffic.json"   # the committed separate-pass PMC summary `traffic` is read from (profiles/)
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 MATVEC_SITES = ("qkv", "wo", "gate_up", "lm_head")  # the K=4096 instantiation of the dominant kernel
 KERNEL = "matvec_v9_kernel<16384,TA,TB,LN> at K = 4096 (QKV, Wo, gate+up, lm_head launch sites; `down` is the same kernel at K = 11008)"
