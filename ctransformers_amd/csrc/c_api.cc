@@ -232,6 +232,7 @@ long long ctamd_resident_replays(ctransformers_llm* llm) {   // requests evaluat
     for (int s = 0; s < llm->pipe.n_stages(); ++s) n += llm->pipe.stage(s).resident_replays();
     return n;
 }
+int ctamd_falcon_fold(ctransformers_llm* llm) { return llm->engine().falcon_fold() ? 1 : 0; }
 int ctamd_debug_read_attn_out(ctransformers_llm* llm, float* dst, int n_tok) { return llm->engine().debug_read_attn_out(dst, n_tok); }
 int ctamd_debug_read_kv(ctransformers_llm* llm, int layer, unsigned short* k, unsigned short* v) { return llm->engine().debug_read_kv(layer, k, v); }
 int ctamd_n_stages(ctransformers_llm* llm) { return llm->pipe.n_stages(); }

@@ -40,6 +40,7 @@ struct Layer {
     float* attn_norm2 = nullptr;
     float* attn_norm2_b = nullptr;
     DevMat wqkv;
+    DevMat wq_v, wk_v, wv_v;   // falcon with folded rows (Engine::falcon_fold_): the Q / K / V row ranges of wqkv's LAYOUT_L9 arena as three jobs of one launch
     // gpt2 (gpt2.cc:391-699): second norm (ln_2) reuses ffn_norm + ffn_norm_b; row biases of the four mat-muls
     float* ffn_norm_b = nullptr;
     float *b_qkv = nullptr, *b_wo = nullptr, *b_up = nullptr, *b_down = nullptr;
@@ -136,6 +137,7 @@ class Engine {
     // tests / measurement only: this stage's fp16 K and V cache of one layer -> host ([n_head_kv][n_ctx][head_dim] and [n_embd_gqa][v_stride]); returns v_stride
     int debug_read_kv(int layer, uint16_t* k, uint16_t* v);
     int debug_read_attn_out(float* dst, int n_tok);
+    bool falcon_fold() const { return falcon_fold_; }
     long long qa_launches() const { return qa_launches_; }   // fused QKV + attention launches issued (eager launches and graph captures)
     long long spec_hits() const { return spec_hits_; }           // evals served by a speculative continuation step
     long long spec_launched() const { return spec_launched_; }   // continuation steps queued
@@ -252,6 +254,9 @@ class Engine {
     bool stage_file(const class GgufFile& f, const std::vector<const struct GgufTensor*>& need, std::string& err);
     void release_staged();
     const uint8_t* staged(const struct GgufTensor* t) const;
+    bool falcon_fold_ = false;           // falcon: attn_qkv rows permuted at load (NEOX pairs adjacent), RoPE + fp16 Q + KV append in the QKV launch's epilogue
+    uint8_t* perm_scratch_ = nullptr;    // load only
+    size_t perm_scratch_bytes_ = 0;
     uint8_t* dev_file_ = nullptr;        // [file_lo_, file_hi_) of the mapping, on the device; freed at the end of load()
     const uint8_t* file_lo_ = nullptr;
     const uint8_t* file_hi_ = nullptr;

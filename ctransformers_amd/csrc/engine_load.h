@@ -161,6 +161,18 @@ __global__ void __launch_bounds__(256) repack_g4_kernel(int q8, const uint8_t* _
     }
 }
 
+// falcon: the rows of attn_qkv (file layout, staged on the device) reordered inside every Q and K head so that the NEOX rotation pair (i, i + head_dim / 2)
+// becomes rows (2i, 2i + 1) — the row pair the mat-vec kernels finish in neighbouring lanes (kernels_v9.h epilogue, MatvecArgs::rope_neox).  Every layout is
+// built from the reordered copy; V rows keep their places.  One workgroup per destination row, 2-byte pieces (row bytes are even for every block type).
+__global__ void __launch_bounds__(256) falcon_permute_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int row_bytes, int n_rope_rows, int hd) {
+    const int r = (int)blockIdx.x;
+    int sr = r;
+    if (r < n_rope_rows) { const int p = r % hd; sr = r - p + (p >> 1) + ((p & 1) ? (hd >> 1) : 0); }
+    const uint16_t* s = (const uint16_t*)(src + (size_t)sr * row_bytes);
+    uint16_t* d = (uint16_t*)(dst + (size_t)r * row_bytes);
+    for (int i = (int)threadIdx.x; i < row_bytes / 2; i += 256) d[i] = s[i];
+}
+
 // ---- LAYOUT_M8 (quant.h; kernels_mm8.h) ------------------------------------------------------------------------------------------------------
 // One file-layout K-quant block -> row r (0..31) of a (tile, K-step) record.
 CT_HD static inline void place_m8(int type, uint8_t* rec, int r, const uint8_t* blk) {
@@ -305,6 +317,7 @@ bool Engine::stage_file(const GgufFile& f, const std::vector<const GgufTensor*>&
 const uint8_t* Engine::staged(const GgufTensor* t) const { return dev_file_ ? dev_file_ + (t->data - file_lo_) : nullptr; }
 
 void Engine::release_staged() {
+    if (perm_scratch_) { (void)hipFree(perm_scratch_); perm_scratch_ = nullptr; perm_scratch_bytes_ = 0; }
     if (dev_file_) { (void)hipFree(dev_file_); dev_file_ = nullptr; }
 }
 
@@ -769,9 +782,36 @@ bool Engine::load(const std::string& path, int context_length, int gpu_layers, s
                 if (!upload_f32(f.tensor(p + "attn_norm_2.weight"), &L.attn_norm2, E, err)) return false;
                 if (!upload_f32(f.tensor(p + "attn_norm_2.bias"), &L.attn_norm2_b, E, err)) return false;
             }
+            {   // RoPE, fp16 Q and the KV append in the QKV launch's epilogue (token steps): needs the NEOX pairs in neighbouring rows — reorder the staged
+                // tensor before any layout is built from it (file bytes on the device only: CT_AMD_GPU_REPACK=0 keeps the separate launch)
+                const GgufTensor* tq = f.tensor(p + "attn_qkv.weight");
+                const int hd = hp_.head_dim();
+                const bool types_ok = tq && (is_kquant(tq->type) || tq->type == GT_Q8_0 || tq->type == GT_Q4_0);
+                if (i == l0_) falcon_fold_ = dev_file_ && types_ok && hd % 2 == 0 && (E % 2 == 0) && (G % 2 == 0) && env_int("CT_AMD_FALCON_FOLD", 1) != 0;
+                if (falcon_fold_ && !types_ok) { err = "attn_qkv weight types differ between layers in a way the folded QKV epilogue does not take"; return false; }
+                if (falcon_fold_) {
+                    if (tq->ne[0] != E || tq->ne[1] != E + 2 * G) { err = "bad shape for " + p + "attn_qkv.weight"; return false; }
+                    const size_t row_bytes = tq->nbytes / (size_t)(E + 2 * G);
+                    if (perm_scratch_bytes_ < tq->nbytes) {
+                        if (perm_scratch_) { HIP_OK(hipStreamSynchronize(stream_)); (void)hipFree(perm_scratch_); perm_scratch_ = nullptr; }
+                        HIP_OK(hipMalloc((void**)&perm_scratch_, tq->nbytes));
+                        perm_scratch_bytes_ = tq->nbytes;
+                    }
+                    uint8_t* st = const_cast<uint8_t*>(staged(tq));
+                    HIP_OK(hipMemcpyAsync(perm_scratch_, st, tq->nbytes, hipMemcpyDeviceToDevice, stream_));
+                    CT_LAUNCH(falcon_permute_rows_kernel, dim3((unsigned)(E + 2 * G)), dim3(256), stream_, (const uint8_t*)perm_scratch_, st, (int)row_bytes, E + G, hd);
+                }
+            }
             if (!mat(p + "attn_qkv.weight", L.wqkv, E + 2 * G, E) || !mat(p + "attn_output.weight", L.wo, E, E) ||
                 !mat(p + "ffn_up.weight", L.w_up, F, E) || !mat(p + "ffn_down.weight", L.w_down, E, F))
                 return false;
+            if (falcon_fold_) {
+                if (!L.wqkv.r9) { err = "attn_qkv without a LAYOUT_L9 arena"; return false; }
+                const size_t unit_bytes = (size_t)l9_spu(L.wqkv.type, E) * l9_record_bytes(L.wqkv.type);
+                L.wq_v = L.wqkv; L.wq_v.M = E; L.wq_v.bytes = L.wqkv.bytes / (size_t)(E + 2 * G) * (size_t)E;
+                L.wk_v = L.wqkv; L.wk_v.M = G; L.wk_v.r9 = L.wqkv.r9 + (size_t)(E / 2) * unit_bytes; L.wk_v.bytes = L.wqkv.bytes / (size_t)(E + 2 * G) * (size_t)G;
+                L.wv_v = L.wqkv; L.wv_v.M = G; L.wv_v.r9 = L.wqkv.r9 + (size_t)((E + G) / 2) * unit_bytes; L.wv_v.bytes = L.wk_v.bytes;
+            }
         }
         if (l1_ == hp_.n_layer) {
             if (!upload_f32(f.tensor("output_norm.weight"), &output_norm_, E, err)) return false;

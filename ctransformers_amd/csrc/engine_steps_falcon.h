@@ -38,7 +38,7 @@ bool Engine::chunk_step_falcon(int c0, int nt, bool want_logits, std::string& er
         if (site_on("rope_store"))
             CT_LAUNCH(falcon_rope_store_kernel, dim3((unsigned)(hp_.n_head + 2 * hp_.n_head_kv), (unsigned)nt), dim3((unsigned)(hd / 2)), stream_,
                       (const float*)qkv_tmp_b_, q_f16_b_, kc, vc, (const float*)rope_cs_, d_pos, hp_.n_head, hp_.n_head_kv, hd, n_ctx_,
-                      v_stride_);
+                      v_stride_, falcon_fold_ ? 1 : 0);
         if (site_on("attn_fused")) launch_attention(kc, vc, nt);
         {   // Wo, kept apart: the residual is added after the MLP
             MatvecArgs a = base;
@@ -117,7 +117,12 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
             a.norm_w = L.attn_norm2 ? L.attn_norm2 : L.attn_norm;
             a.norm_b = L.attn_norm2 ? L.attn_norm2_b : L.attn_norm_b;
             a.out = qkv_tmp_;
-            set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            if (falcon_fold_) {   // NEOX RoPE, fp16 Q and the KV append in this launch's epilogue (rows reordered at load): no falcon_rope_store_kernel launch
+                a.rope_neox = 1; a.q_f16 = q_f16_; a.kcache = kc; a.vcache = vc;
+                set_jobs(a, {{&L.wq_v, EPI_ROPE_Q}, {&L.wk_v, EPI_ROPE_K}, {&L.wv_v, EPI_V}});
+            } else {
+                set_jobs(a, {{&L.wqkv, EPI_STORE}});
+            }
             apply_trace(a, "qkv");
             if (site_on("qkv")) {
                 prof_begin("qkv", "matvec", (double)L.wqkv.bytes);
@@ -125,11 +130,11 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
                 prof_end();
             }
         }
-        if (site_on("rope_store")) {
+        if (!falcon_fold_ && site_on("rope_store")) {
             prof_begin("rope_store", "falcon_rope_store_kernel", 0.0);
             CT_LAUNCH(falcon_rope_store_kernel, dim3((unsigned)(hp_.n_head + 2 * hp_.n_head_kv)), dim3((unsigned)(hd / 2)), stream_,
                       (const float*)qkv_tmp_, q_f16_, kc, vc, (const float*)rope_cs_, d_pos, hp_.n_head, hp_.n_head_kv, hd, n_ctx_,
-                      v_stride_);
+                      v_stride_, 0);
             prof_end();
         }
         if (site_on("attn_fused")) {

@@ -89,6 +89,8 @@ struct MatvecArgs {
     // Greedy pick, first half (kernels_v9.h:v9_pick_store; the EMB instantiations): every wave of the head launch leaves the first maximum
     // of ITS logits rows as a 64-bit key in pick_ws[workgroup][wave]; pick_cont_kernel finishes.  Null: no pick.
     unsigned* pick_ws;
+    int rope_neox;             // EPI_ROPE_Q / EPI_ROPE_K on a matrix whose rows were permuted at load so that the NEOX pair (i, i + head_dim / 2) of a head sits in rows
+                               // (2i, 2i + 1) (falcon, engine_load.h:falcon_permute_rows_kernel): the pair rotates by the NEOX formulas and is stored at its ORIGINAL rows
     int grid_out;              // host side only: workgroups of the launch these arguments went out with (set by the launch helper)
     float* dbg_sink;           // measurement only: always-valid scratch the ablation paths may write to
     int dbg;                   // measurement only (CT_AMD_DBG / ctamd_trace_site): bit 32 = write in-kernel s_memtime stamps to dbg_sink
@@ -207,7 +209,8 @@ __global__ void __launch_bounds__(NT) rmsnorm_f32_kernel(const float* __restrict
 // grid = n_head + 2*n_head_kv (one head each), head_dim/2 threads.
 __global__ void falcon_rope_store_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ q_f16, uint16_t* __restrict__ kcache,
                                          uint16_t* __restrict__ vcache, const float* __restrict__ rope_cs, const int* __restrict__ pos_p,
-                                         int n_head, int n_head_kv, int head_dim, int n_ctx, int v_stride) {
+                                         int n_head, int n_head_kv, int head_dim, int n_ctx, int v_stride, int perm) {
+    // perm: the Q and K rows arrive in the load-time order of MatvecArgs::rope_neox (pair (i, i + half) in rows (2i, 2i + 1)); V rows are never permuted
     // blockIdx.y: token inside a prompt chunk (rows of n_head + 2 n_head_kv heads in qkv, n_head heads in q_f16), else 0
     const int hh = (int)blockIdx.x, i = (int)threadIdx.x, half = head_dim >> 1, tok = (int)blockIdx.y, pos = *pos_p + tok;
     if (i >= half) return;
@@ -220,7 +223,7 @@ __global__ void falcon_rope_store_kernel(const float* __restrict__ qkv, uint16_t
         return;
     }
     const float cs = rope_cs[((size_t)pos * half + i) * 2 + 0], sn = rope_cs[((size_t)pos * half + i) * 2 + 1];
-    const float x0 = src[i], x1 = src[i + half];
+    const float x0 = src[perm ? 2 * i : i], x1 = src[perm ? 2 * i + 1 : i + half];
     const float o0 = fmaf(x0, cs, -(x1 * sn)), o1 = fmaf(x0, sn, x1 * cs);
     if (hh < n_head) {
         q_f16[(size_t)hh * head_dim + i] = f32_to_f16_bits(o0);

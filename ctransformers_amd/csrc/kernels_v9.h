@@ -838,6 +838,13 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
         a.out[e_r] = (e_bias + res) + e_res;
     } else if (e_epi == EPI_BIAS_GELU) {
         a.out[e_r] = f16_bits_to_f32(a.gelu_tab[f32_to_f16_bits(e_bias + res)]);
+    } else if (a.rope_neox) {   // falcon: rows (2i, 2i + 1) hold the NEOX pair (i, i + head_dim / 2) of their head (rows permuted at load); the reference build
+                                // evaluates out[i] = fma(x0, cos, -(x1 * sin)), out[i + n/2] = fma(x0, sin, x1 * cos) (ggml.c:12543-12561, oracle/mirror.c:mir_rope_neox)
+        const float o = (e_r & 1) ? fmaf(other, e_cs.y, res * e_cs.x) : fmaf(res, e_cs.x, -(other * e_cs.y));
+        const int p = e_r % a.head_dim;
+        const int r_orig = e_r - p + (p >> 1) + ((p & 1) ? (a.head_dim >> 1) : 0);
+        if (e_epi == EPI_ROPE_Q) a.q_f16[r_orig] = f32_to_f16_bits(o);
+        else a.kcache[kcache_off(pos, r_orig, a.head_dim, a.n_ctx)] = f32_to_f16_bits(o);
     } else {   // EPI_ROPE_Q / EPI_ROPE_K: the pair (2u, 2u + 1) is one rotation (reference ggml.c:12536-12537, fma forms of the build)
         const float o = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
         if (e_epi == EPI_ROPE_Q) a.q_f16[e_r] = f32_to_f16_bits(o);

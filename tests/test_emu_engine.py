@@ -48,6 +48,38 @@ def test_logits_bit_identical_to_reference(emu_lib, name, steps):
         assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1]), "step %d" % i
 
 
+def falcon_fold(m):
+    import ctypes
+    f = m._lib.ctamd_falcon_fold
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    return int(f(m._llm))
+
+
+@pytest.mark.parametrize("name", ["falcon-tiny-q4km", "falcon-tiny7-q4km"])
+def test_falcon_rope_and_kv_append_in_the_qkv_launch(emu_lib, name, monkeypatch):
+    """Round 6: the rows of attn_qkv are reordered at load (NEOX pair (i, i + head_dim / 2) -> rows (2i, 2i + 1)), so the token step's QKV launch rotates, rounds
+    to fp16 and appends K / V in its own epilogue (MatvecArgs::rope_neox) — one launch per layer less; prompt chunks read the same reordered rows through
+    falcon_rope_store_kernel's `perm` form.  On by default; CT_AMD_FALCON_FOLD=0 and CT_AMD_GPU_REPACK=0 keep the separate launch: the same bits
+    (the golden logits of the reference build, llama.cpp:2652-2700)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    for env, want in ((None, 1), ("CT_AMD_FALCON_FOLD", 0), ("CT_AMD_GPU_REPACK", 0)):
+        if env:
+            monkeypatch.setenv(env, "0")
+        m = open_emu(emu_lib, name)
+        assert falcon_fold(m) == want
+        m.eval(list(g["prompt"])[:3])          # three tokens through a chunk, the rest one by one through token steps
+        for t in list(g["prompt"])[3:]:
+            m.eval([int(t)])
+        assert np.array_equal(m.logits.to_numpy(), g["logits"][0])
+        for i in range(3):
+            t = m.sample(top_k=1, repetition_penalty=1.0)
+            assert t == int(g["greedy"][i])
+            m.eval([t])
+            assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1])
+        if env:
+            monkeypatch.delenv(env)
+
+
 def qa_launches(m):
     """Fused QKV + attention launches this handle has issued (kernels_qa9.h)."""
     import ctypes
