@@ -259,7 +259,8 @@ def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_cont
                 logits_rel_diff_vs_default=float(np.abs(lg - exact_logits).max() / np.abs(exact_logits).max()),
                 greedy_steps_compared=len(exact_greedy), greedy_steps_identical=same,
                 note="same quantization points and exact integer dots as the reference, another f32 summation order: K / V rows of the first layer within an fp16 ulp, "
-                     "logits within the reference's own int8 quantization noise (~4e-2 of the largest logit on this synthetic model), NOT within 1e-3 — hence opt-in; "
+                     "logits within the reference's own int8 quantization noise (~4e-2 of the largest logit on this synthetic model; the reference CPU build differs from ITSELF "
+                     "by 3e-2 when its batch_size changes: profiles/r06_reference_self_difference.txt), NOT within 1e-3 — hence opt-in; "
                      "MFMA-busy counters: profiles/r06_mm8_pmc_128tok.txt, profiles/r06_mm8_pmc_512tok.txt")
 
 
