@@ -213,14 +213,17 @@ def test_reference_batch_above_128_tokens(ref, batch_size, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,n_tok,past", [("llama-7b-2l", 128, 0), ("llama-7b-2l", 300, 0), ("llama-7b-2l", 77, 1000), ("llama-70b-2l", 160, 200)])
+@pytest.mark.parametrize("shape,n_tok,past", [("llama-7b-2l", 128, 0), ("llama-7b-2l", 300, 0), ("llama-7b-2l", 77, 1000), ("llama-70b-2l", 160, 200),
+                                              ("falcon-40b-2l", 200, 300)])
 def test_matrix_core_prompt_attention(shape, n_tok, past, tmp_path, monkeypatch):
-    """The same on the GPU at head size 128: 7B widths (32 heads) and 70B widths (64 heads on 8 K/V heads), one layer; whole tiles, ragged tiles, a chunk
-    behind 1000 earlier positions (the waves' position tiles, the masked diagonal tiles, the zeroed V tail)."""
-    hp = dict(synth.LLAMA_SHAPES[shape], n_layer=1)
+    """The same on the GPU: head size 128 at 7B widths (32 heads) and 70B widths (64 heads on 8 K/V heads), head size 64 at Falcon-40B widths (128 heads on
+    8 K/V heads, the falcon graph), one layer; whole tiles, ragged tiles, a chunk behind 1000 earlier positions (the waves' position tiles, the masked
+    diagonal tiles, the zeroed V tail)."""
+    falcon = shape.startswith("falcon")
+    hp = dict((synth.FALCON_SHAPES if falcon else synth.LLAMA_SHAPES)[shape], n_layer=1)
     path = "/tmp/ctamd_fast_attn_%s_1l.gguf" % shape.replace("-", "_")
     if not os.path.exists(path):
-        synth.write_llama_gguf(path + ".tmp", hp, "Q4_K_M", seed=11)
+        (synth.write_falcon_gguf if falcon else synth.write_llama_gguf)(path + ".tmp", hp, "Q4_K_M", seed=11)
         os.replace(path + ".tmp", path)
     rel, rel_logits, a, b = _attention_forms(path, None, n_tok, 1536, monkeypatch, past)
     print("attn_mm_kernel vs the bit-identical chunk attention, %s, %d tokens behind %d: rows differ by %.3g of the largest, logits by %.3g" %
