@@ -69,6 +69,18 @@ const char* ctamd_handoff(ctransformers_llm* llm);
 /* Host microseconds the one issuing thread of the in-process pipeline has spent queueing stage `stage`'s launches, event waits and peer
    copies since the handle was created; *evals = the multi-stage evals counted (0.0 for a single-stage handle). */
 double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals);
+/* Round 6 test hooks.
+   ctamd_mm8_launches: chunk launches of the order-free prompt kernels (csrc/kernels_mm8.h; CT_AMD_PREFILL=fast) issued by this process.
+   ctamd_resident_replays: requests this handle evaluated a second time after a launch that needs its whole grid resident gave up (the device was shared);
+     the eval that hit it still returned true.
+   ctamd_falcon_fold: 1 if this (falcon) handle rotates / stores Q, K, V in the QKV launch's epilogue (attn_qkv rows reordered at load).
+   ctamd_debug_read_kv: fp16 K rows [n_head_kv][n_ctx][head_dim] and V rows [n_embd_gqa][stride] of one layer to host memory; returns the V row stride.
+   ctamd_debug_read_attn_out: the attention output rows (n_tok x n_embd floats) of the last prompt chunk launched; returns n_embd. */
+long long ctamd_mm8_launches(void);
+long long ctamd_resident_replays(ctransformers_llm* llm);
+int ctamd_falcon_fold(ctransformers_llm* llm);
+int ctamd_debug_read_kv(ctransformers_llm* llm, int layer, unsigned short* k, unsigned short* v);
+int ctamd_debug_read_attn_out(ctransformers_llm* llm, float* dst, int n_tok);
 #ifdef __cplusplus
 }
 #endif
