@@ -191,3 +191,30 @@ def test_failed_handoff_self_check_falls_back_to_events(monkeypatch):
         f.restype, f.argtypes = C.c_char_p, [C.c_void_p]
         assert f(m._llm) == want, f(m._llm)
         _greedy(m, g, 6)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(240)
+def test_handles_created_used_and_deleted_from_four_threads():
+    """Four host threads, each three times: create a handle, evaluate the golden prompt, decode eight greedy steps with every logits vector fetched, delete it —
+    while the other threads are anywhere in the same cycle (loads copy on the legacy stream, first steps capture graphs, deletes synchronize the device:
+    the library serialises those three process-wide, engine.h:capture_mutex).  Every chain is the golden chain, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
+    path = os.path.join(GOLDEN, "tiny-q4km.gguf")
+    errs = []
+
+    def worker():
+        try:
+            for _ in range(3):
+                m = LLM(path, config=Config(context_length=96, batch_size=8))
+                _greedy(m, g, 8)
+                del m
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker) for _ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
