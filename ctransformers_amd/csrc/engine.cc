@@ -444,10 +444,12 @@ void Engine::launch_pick(const MatvecArgs& head) {
 // contexts up to 1024, and a device on which the attention grid (n_head x channel groups <= CUs, one 1024-thread workgroup per CU) is
 // resident as a whole: the workgroups of a KV head wait for each other's rows (kernels_qa9.h: co-residency).
 bool Engine::qa_can(const Layer& L) const {
-    if (!fuse_qa_ || hp_.falcon() || hp_.legacy() || !xq_) return false;
+    if (!fuse_qa_ || hp_.legacy() || !xq_) return false;
+    if (hp_.falcon() && !falcon_fold_) return false;   // (falcon: the three row ranges of attn_qkv as jobs, NEOX pairs as row pairs: engine_load.h)
     const int hd = hp_.head_dim(), E = hp_.n_embd;
     if (!(hd == 128 || hd == 64) || E > 16384 || n_ctx_ > 1024 || hp_.n_head % hp_.n_head_kv) return false;
-    const DevMat *q = &L.wq, *k = &L.wk, *v = &L.wv;
+    if (hp_.falcon() && hd != 64) return false;        // (the LayerNorm instantiations: head size 64, every falcon model's)
+    const DevMat *q = hp_.falcon() ? &L.wq_v : &L.wq, *k = hp_.falcon() ? &L.wk_v : &L.wk, *v = hp_.falcon() ? &L.wv_v : &L.wv;
     if (!q->r9 || !k->r9 || !v->r9 || q->type != k->type || !(q->type == GT_Q4_K || q->type == GT_Q5_K)) return false;
     if (!(v->type == q->type || v->type == GT_Q6_K)) return false;
     if (k->r9 != q->r9 + (size_t)((q->M + 1) / 2) * l9_spu(q->type, E) * l9_record_bytes(q->type)) return false;
@@ -460,7 +462,7 @@ bool Engine::qa_can(const Layer& L) const {
     int ng = hd / 16;
     while (ng > hd / 64 && hp_.n_head * ng > cus) ng >>= 1;
     const int pvw = hd / ng / 16;
-    if (hp_.n_head * ng > cus || !(pvw == 1 || (pvw == 2 && hd == 128))) return false;
+    if (hp_.n_head * ng > cus || !(pvw == 1 || (pvw == 2 && (hd == 128 || hp_.falcon())))) return false;
     // at most two units per wave (kernels_qa9.h:QaItems): the group's (rep + 2) * hd / 2 units over its rep * ng workgroups of sixteen waves —
     // with a second weight type for v, the waves are split by bytes and either part may be as small as one wave per workgroup
     const int rep = hp_.n_head / hp_.n_head_kv, NG = rep * ng;
@@ -509,13 +511,13 @@ bool Engine::launch_qkv_attn(MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, 
     ++g_kq_launches;
     ++qa_launches_;
 #ifdef CT_EMU
-#define QAL(TAV, TBV, HDV, NWVV) do { \
-        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2)>; \
+#define QAL(TAV, TBV, HDV, NWVV, ...) do { \
+        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2), ##__VA_ARGS__>; \
         qa.phase = 1; CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); \
         qa.phase = 2; CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); } while (0)
 #else
-#define QAL(TAV, TBV, HDV, NWVV) do { \
-        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2)>; \
+#define QAL(TAV, TBV, HDV, NWVV, ...) do { \
+        auto kfn = qkv_attn9_kernel<TAV, TBV, HDV, NWVV, (TBV == 0 ? V9_NS_K : V9_NS_K2), ##__VA_ARGS__>; \
         CT_OPTIN_ONCE(kfn, (size_t)150 * 1024); \
         CT_LAUNCH_DYN(kfn, grid, block, smem, stream_, a.x, a.norm_w, a.K, a.pro, a, qa); } while (0)
 #endif
@@ -523,6 +525,11 @@ bool Engine::launch_qkv_attn(MatvecArgs& a, uint16_t* kc, uint16_t* vc, int il, 
         if (hd == 64) QAL(TAV, TBV, 64, 14); \
         else if (pvw == 1) QAL(TAV, TBV, 128, 14); \
         else QAL(TAV, TBV, 128, 12); } while (0)   /* 16 - (channels per workgroup) / 8 score waves (kernels_qa9.h) */
+    if (a.pro == PRO_LAYERNORM) {   // falcon: one weight type, head size 64, 16 or 32 channels per workgroup
+        if (tb != 0 || hd != 64) { err = "fused QKV + attention launch: LayerNorm form with a second weight type or a head size other than 64"; return false; }
+        if (ta == GT_Q4_K) { if (pvw == 1) QAL(GT_Q4_K, 0, 64, 14, true); else QAL(GT_Q4_K, 0, 64, 12, true); }
+        else { if (pvw == 1) QAL(GT_Q5_K, 0, 64, 14, true); else QAL(GT_Q5_K, 0, 64, 12, true); }
+    } else
     if (ta == GT_Q4_K) { if (tb) QAT(GT_Q4_K, GT_Q6_K); else QAT(GT_Q4_K, 0); }
     else { if (tb) QAT(GT_Q5_K, GT_Q6_K); else QAT(GT_Q5_K, 0); }
 #undef QAT

@@ -917,7 +917,7 @@ bool Engine::alloc_state(std::string& err) {
     d_tokens_ = d_state_ + 4;
     HIP_OK(hipMemset(d_state_, 0, ((size_t)n_ctx_ + 8) * 4));   // [4 + n_ctx]: the token epoch (kernels_qa9.h)
     dbg_qa_timeout_ = env_int("CT_AMD_DBG_QA_TIMEOUT", 0);
-    fuse_qa_ = env_int("CT_AMD_FUSE_QA", 1) != 0 && !hp_.falcon() && !hp_.legacy();
+    fuse_qa_ = env_int("CT_AMD_FUSE_QA", 1) != 0 && !hp_.legacy() && (!hp_.falcon() || falcon_fold_);
     if (fuse_qa_) {
         const size_t words = (size_t)(hp_.n_head + 2 * hp_.n_head_kv) * (hp_.head_dim() / 2) * 2;
         if (!dev_alloc(dev_allocs_, &xq_, words + 16, err)) return false;

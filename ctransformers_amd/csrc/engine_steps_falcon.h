@@ -111,6 +111,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
         cur_layer_ = il;
         uint16_t* kc = kcache_ + (size_t)(il - l0_) * n_ctx_ * G;
         uint16_t* vc = vcache_ + (size_t)(il - l0_) * v_stride_ * G;
+        bool fused_qa = false;
         {   // LayerNorm -> Q8_K -> fused QKV rows (f32, un-rotated)
             MatvecArgs a = base;
             a.K = E; a.pro = PRO_LAYERNORM; a.x = x_;
@@ -124,7 +125,11 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
                 set_jobs(a, {{&L.wqkv, EPI_STORE}});
             }
             apply_trace(a, "qkv");
-            if (site_on("qkv")) {
+            fused_qa = falcon_fold_ && qa_can(L) && !only_site_ && !prof_ && (!trace_site_ || !strcmp(trace_site_, "qa"));
+            if (fused_qa) {   // ... and the attention in the same launch (kernels_qa9.h, LayerNorm form)
+                if (trace_site_) { a.dbg |= 32; a.dbg_sink = (float*)(trace_buf_ + 256); }
+                if (!launch_qkv_attn(a, kc, vc, il, err)) return false;
+            } else if (site_on("qkv")) {
                 prof_begin("qkv", "matvec", (double)L.wqkv.bytes);
                 if (!run_matvec(a, err)) return false;
                 prof_end();
@@ -137,7 +142,7 @@ bool Engine::token_step_falcon(bool want_logits, std::string& err) {
                       v_stride_, 0);
             prof_end();
         }
-        if (site_on("attn_fused")) {
+        if (!fused_qa && site_on("attn_fused")) {
             prof_begin("attn_fused", "attn_fused_exact_kernel", 0.0);
             launch_attention(kc, vc);
             prof_end();

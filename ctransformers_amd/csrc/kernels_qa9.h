@@ -104,7 +104,9 @@ DEV void patch_f16(u32x4& v, int elem, uint32_t h) {   // fp16 element `elem` (0
 #ifndef QA_VB
 #define QA_VB 6   // V chunk slots per V*P lane: 4 -> 773.3, 6 -> 776.1, 8 (six registers spilled) -> 765.8 tok/s over 256 steps (positions 144..400), alternating on one box
 #endif
-template <int TA, int TB, int HD, int NWV, int NS>
+// LN (falcon graph, llama.cpp:2652-2700): LayerNorm prologue; with MatvecArgs::rope_neox the q / k granule u of a head carries the NEOX pair
+// (row u | row u + HD / 2) of the reordered matrix — the sweep parks its halves at elements u and u + HD / 2, so the K.Q dot reads the vectors in file order.
+template <int TA, int TB, int HD, int NWV, int NS, bool LN = false>
 __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const float* nw0, int K0, int pro0, const MatvecArgs a, const QaArgs q) {   // (leading scalars: kernels_v9.h:matvec_v9_kernel)
     constexpr int MAXK = 16384;
     constexpr int PB = 2, VB = QA_VB;
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
         const int rep = M1.rep, hk = M1.hk, NG = M1.NG, gidx = M1.gidx, lu_all = M1.lu_all;
         uint32_t* rec = q.xq + (size_t)hk * lu_all * 2;
         auto pro = [&](bool trc, unsigned long long (&ts)[4]) __attribute__((always_inline)) {
-            pro9_finish<MAXK, false, false, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K, 16>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, nullptr, wv, lane, trc, ts);
+            pro9_finish<MAXK, LN, false, TB == 0, TA == GT_Q6_K || TB == GT_Q6_K, 16>(SM.L, P, a.norm_w, a.norm_b, a.K, a.pro, a.eps, nullptr, wv, lane, trc, ts);
         };
         const int uq = rep * (HD / 2), uk = HD / 2;            // q / k units of the group
         const int nq_all = a.job[1].pair0, nqk_all = a.job[2].pair0;
@@ -250,8 +252,18 @@ __global__ void __launch_bounds__(1024) qkv_attn9_kernel(const float* x0, const 
             for (int t = 0; t < 3; ++t) ok = ok && tg[t] == tag;
             if (__ballot(!ok) == 0ull) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (gi[t] >= 0) QS.xw[lane + 64 * t] = dat[t];
+                for (int t = 0; t < 3; ++t) {
+                    const int i = lane + 64 * t;
+                    if (gi[t] < 0) continue;
+                    if (LN && a.rope_neox && i < 2 * nqg) {   // q / k granule u of the head: elements u and u + HD / 2 of the vector
+                        uint16_t* v16 = reinterpret_cast<uint16_t*>(QS.xw) + (i < nqg ? 0 : HD);
+                        const int u = i < nqg ? i : i - nqg;
+                        v16[u] = (uint16_t)(dat[t] & 0xFFFFu);
+                        v16[u + HD / 2] = (uint16_t)(dat[t] >> 16);
+                    } else {
+                        QS.xw[i] = dat[t];
+                    }
+                }
                 break;
             }
 #ifdef CT_EMU

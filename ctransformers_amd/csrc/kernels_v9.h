@@ -818,7 +818,10 @@ DEV void v9_run(const MatvecArgs& a, SmemV9<MAXK>& SM, const uint8_t* base, int 
     if constexpr (XQ) {   // fused QKV + attention launch: the pair's two fp16 results as one tagged granule (kernels_qa9.h); a QKV unit is a whole
                           // row pair, so both lanes of a pair are here
         float val = res;
-        if (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K) val = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
+        if (e_epi == EPI_ROPE_Q || e_epi == EPI_ROPE_K) {
+            if (a.rope_neox) val = (e_r & 1) ? fmaf(other, e_cs.y, res * e_cs.x) : fmaf(res, e_cs.x, -(other * e_cs.y));   // (the NEOX pair of a reordered row pair: below)
+            else val = (e_r & 1) ? fmaf(res, e_cs.x, other * e_cs.y) : fmaf(res, e_cs.x, -(other * e_cs.y));
+        }
         const uint32_t hb = f32_to_f16_bits(val), ho = lane_xor1(hb);
         if ((lane & 1) == 0) items.publish(lane >> 1, hb | (ho << 16));
     }

@@ -79,6 +79,8 @@ def test_falcon_rope_and_kv_append_in_the_qkv_launch(emu_lib, name, monkeypatch)
             assert t == int(g["greedy"][i])
             m.eval([t])
             assert np.array_equal(m.logits.to_numpy(), g["logits"][i + 1])
+        # ... and with the rows reordered the token steps take the fused QKV + attention launch (kernels_qa9.h, LayerNorm form): four launches per layer
+        assert (qa_launches(m) > 0) == bool(want)
         if env:
             monkeypatch.delenv(env)
 
