@@ -65,6 +65,7 @@ CONFIG = 2
 CONFIGS = {2: ("llama-2-7b", "Q4_K_M", "/tmp/ctamd_llama2_7b_q4km_%s.gguf" % _QTAG), 3: ("llama-2-7b", "Q8_0", "/tmp/ctamd_llama2_7b_q80_%s.gguf" % _QTAG),
            4: ("falcon-40b", "Q4_K_M", "/tmp/ctamd_falcon_40b_q4km_%s.gguf" % _QTAG), 5: ("llama-2-70b", "Q5_K_M", "/tmp/ctamd_llama2_70b_q5km_%s.gguf" % _QTAG)}
 N_PROMPT_2K, N_CTX_2K, N_DECODE_2K = 2048, 2304, 32
+SETTLE_S = 0.75   # untimed prompt evaluations in front of the steady-state measurements (main())
 
 
 def shape_dims():
@@ -367,6 +368,13 @@ def main():
     prefill_cold_s = time.perf_counter() - t0
     llm._context = []
     llm.eval(prompt)            # second pass: the library captures the hipGraph of each chunk shape on its second use
+    # settle: SETTLE_S seconds of untimed prompt evaluations before anything steady-state is timed.  The first process on a fresh box measured 4 - 6 % low
+    # once in six runs of round 6 (decode 720 against 752 - 768 tok/s, the same box 767 minutes later: profiles/r06_bench_default_last_run.json) with only
+    # ~45 ms of GPU work in front of the timed loop; the W warm-up steps of the contract follow as before.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < SETTLE_S:
+        llm._context = []
+        llm.eval(prompt)
     llm._context = []
     t0 = time.perf_counter()
     llm.eval(prompt)
@@ -435,7 +443,7 @@ def main():
                            if SHAPE == "llama-2-7b" and FTYPE == "Q4_K_M" else "BASELINE config %d: %s %s, all layers on %d x MI355X, 128-tok prefill + %d warm-up + %d timed greedy decode steps, ctx 512" % (a.config, SHAPE, FTYPE, n_gpus, a.warmup, steps),
                            shape=SHAPE, ftype=FTYPE, n_prompt=N_PROMPT, parallelism=par, stages=n_stages, layer_ranges=ranges,
                            devices=os.environ.get("CT_AMD_DEVICES", "0"), ranks=world, model_cached=cached,
-                           handoff=HANDOFF, rccl_ranks=rccl_ranks,
+                           handoff=HANDOFF, rccl_ranks=rccl_ranks, settle_s=SETTLE_S,
                            decode_form=dict(launches_per_layer=4 if fused_qa else 5, fused_qkv_attention=fused_qa,
                                             greedy_chain=dict(steps_served_by_a_queued_step=spec_hits, steps_queued_ahead=int(_sl.value),
                                                               note="the timed loop is eval + sample(top_k=1): after a device-side greedy pick the engine queues the "
