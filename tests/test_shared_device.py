@@ -48,13 +48,14 @@ def test_forced_give_up_is_replayed_on_the_emulator(emu_lib, nth, monkeypatch):
 # ---- MI355X ---------------------------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nth", [2, 3, 6])
-def test_forced_give_up_is_replayed(nth, monkeypatch):
-    """The same on the HIP build: graph replays, queued continuation steps of a greedy chain (the give-up is noticed on a continuation step for nth = 6)."""
+@pytest.mark.parametrize("name,nth", [("tiny-q4km", 2), ("tiny-q4km", 3), ("tiny-q4km", 6), ("falcon-tiny-q4km", 3), ("falcon-tiny7-q4km", 6)])
+def test_forced_give_up_is_replayed(name, nth, monkeypatch):
+    """The same on the HIP build: graph replays, queued continuation steps of a greedy chain (the give-up is noticed on a continuation step for nth = 6);
+    the llama graph and the falcon graph (round 6: its token steps take the fused launch too, and fall back to the five-launch form)."""
     monkeypatch.setenv("CT_AMD_DBG_QA_TIMEOUT", str(nth))
-    g = np.load(os.path.join(GOLDEN, "tiny-q4km.npz"))
-    m = LLM(os.path.join(GOLDEN, "tiny-q4km.gguf"), config=Config(context_length=96, batch_size=8))
-    _greedy(m, g, 20)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = LLM(os.path.join(GOLDEN, name + ".gguf"), config=Config(context_length=96, batch_size=8))
+    _greedy(m, g, min(20, len(g["greedy"]) - 1))
     assert _replays(m) == 1
 
 
