@@ -204,6 +204,7 @@ def other_configs():
         res.append(dict(config=cfg, workload=d["config"]["workload"], decode_tok_s=d["value"], ms_per_step=d["ms_per_step"], steps=d["steps"],
                         prefill_tok_s=d["prefill_tok_s"], prefill_2k_tok_s=d.get("prefill_2k_tok_s"), decode_tok_s_at_2k=d.get("decode_tok_s_at_2k"),
                         prefill_fast_tok_s=(d.get("prefill_fast") or {}).get("tok_s"), prefill_fast_2k_tok_s=(d.get("prefill_fast") or {}).get("tok_s_2k"),
+                        decode_fast_attn_tok_s_at_2k=(d.get("prefill_fast") or {}).get("decode_tok_s_at_2k"),
                         prefill_fast_logits_rel_diff=(d.get("prefill_fast") or {}).get("logits_rel_diff_vs_default"),
                         load_s=d["load_s"], frac_of_8TBps_per_token=d["token_roofline"]["frac_of_8TBps"],
                         bytes_per_token=d["token_roofline"]["bytes_per_token"], model_cached=d["config"]["model_cached"]))
@@ -221,6 +222,8 @@ def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_cont
     rates at 128, 512 and 2048 tokens, and how far their results are from the default (bit-identical) kernels' — logits of the 128-token prompt and the
     greedy continuation.  Opt-in: the default keeps the reference's bits (DESIGN.md 5b says why 1e-3 is out of reach for any other summation order)."""
     os.environ["CT_AMD_PREFILL"] = "fast"
+    os.environ["CT_AMD_DECODE_ATTN"] = "fast"   # (only the first handle below decodes beyond 1024 positions: the order-free decode attention's rate at 2k)
+    d2k = None
     try:
         h = LLM(MODEL, config=Config(context_length=N_CTX_2K if long_context else 640, batch_size=2048, gpu_layers=1000))
         rates = {}
@@ -234,6 +237,16 @@ def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_cont
             t0 = time.perf_counter()
             h.eval(p)
             rates[n] = round(n / (time.perf_counter() - t0), 1)
+        if long_context:   # token steps behind the 2048-token prompt, as `decode_tok_s_at_2k` measures them for the default kernels
+            tk = h.sample(top_k=1, repetition_penalty=1.0)
+            for _ in range(4):
+                h.eval([tk])
+                tk = h.sample(top_k=1, repetition_penalty=1.0)
+            t0 = time.perf_counter()
+            for _ in range(N_DECODE_2K):
+                h.eval([tk])
+                tk = h.sample(top_k=1, repetition_penalty=1.0)
+            d2k = round(N_DECODE_2K / (time.perf_counter() - t0), 2)
         del h
         h = LLM(MODEL, config=Config(context_length=N_CTX, batch_size=N_PROMPT, gpu_layers=1000))   # the headline's own handle shape for the comparison
         h.eval(prompt)
@@ -249,9 +262,11 @@ def fast_prefill(prompt, n_vocab, exact_logits, exact_greedy, pf_flop, long_cont
         del h
     finally:
         os.environ.pop("CT_AMD_PREFILL", None)
+        os.environ.pop("CT_AMD_DECODE_ATTN", None)
     tops = round(rates[128] * pf_flop / 1e12, 1) if pf_flop else None
     tops_512 = round(rates[512] * pf_flop / 1e12, 1) if pf_flop else None
     return dict(tok_s=rates[128], tok_s_512=rates[512], tok_s_2k=rates.get(N_PROMPT_2K), chunk_tokens=512, opt_in="CT_AMD_PREFILL=fast",
+                decode_tok_s_at_2k=d2k, decode_opt_in="CT_AMD_DECODE_ATTN=fast (attn_decode9_free_kernel: the V*P steps of a channel split over the workgroup's waves)",
                 kernel="mm8_kernel<TYPE,NTT,KS> (v_mfma_i32_32x32x32_i8: Q4_K / Q5_K scales as two int8 digit planes inside the accumulation, Q6_K masked K-chunks, "
                        "Q8_0 float scales; Q8_K / Q8_0 activations as the reference quantizes them; f32 sums in free order) + attn_mm_kernel<HD> "
                        "(v_mfma_f32_32x32x16_f16 for K.Q and V.P, the reference's fp16 / f32 roundings, exact max and double sum)",

@@ -227,6 +227,7 @@ long long ctamd_kq_launches(void) { return ctamd::kq_launches(); }
 long long ctamd_qa_launches(ctransformers_llm* llm) { return llm->engine().qa_launches(); }
 long long ctamd_pg_launches(void) { return ctamd::pg_launches(); }
 long long ctamd_mm8_launches(void) { return ctamd::mm8_launches(); }
+long long ctamd_attn_free_launches(void) { return ctamd::attn_free_launches(); }
 long long ctamd_resident_replays(ctransformers_llm* llm) {   // requests evaluated a second time after a residency give-up, summed over the stages
     long long n = 0;
     for (int s = 0; s < llm->pipe.n_stages(); ++s) n += llm->pipe.stage(s).resident_replays();

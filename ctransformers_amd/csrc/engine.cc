@@ -152,6 +152,8 @@ static long long g_pg_launches = 0;   // test hook (ctamd_pg_launches): chunk la
 long long pg_launches() { return g_pg_launches; }
 static long long g_mm8_launches = 0;  // test hook (ctamd_mm8_launches): chunk launches of the order-free kernels (kernels_mm8.h)
 long long mm8_launches() { return g_mm8_launches; }
+static long long g_attn_free_launches = 0;   // test hook (ctamd_attn_free_launches): order-free decode attention launches (kernels_attn9.h)
+long long attn_free_launches() { return g_attn_free_launches; }
 
 // Two-type launch: how many of a workgroup's sixteen waves walk type group B.  A launch ends with its slowest wave, and a wave's time goes with the
 // bytes of its units: the split with the smallest LARGEST per-wave byte count, ties to the split nearest the groups' byte shares.  (Round 5: the split
@@ -688,8 +690,20 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
 #ifdef CT_EMU
             share = false;   // (the test build runs workgroups one after the other: a gather would wait for ever)
 #endif
+            if (share) { ax.xs = xs_; ax.epoch = (const unsigned*)(d_state_ + 4 + n_ctx_); ax.err = qa_err_; ax.layer = cur_layer_ & 255; }
+            if (attn_free_) {   // CT_AMD_DECODE_ATTN=fast: every wave a score wave and a V*P wave, the V*P steps of a channel split over the waves
+                ++g_attn_free_launches;
+#define ATTN9F(HDV, SHV) do { \
+                auto kfn = attn_decode9_free_kernel<HDV, SHV>; \
+                CT_OPTIN_ONCE(kfn, (size_t)kMaxCtxFused * 4); \
+                CT_LAUNCH_DYN(kfn, g9, dim3(512), smem, stream_, ax.pos - 1, ng, ax.n_head, ax.n_head_kv, ax); } while (0)
+                if (hd == 128) { if (share) ATTN9F(128, true); else ATTN9F(128, false); }
+                else { if (share) ATTN9F(64, true); else ATTN9F(64, false); }
+#undef ATTN9FV
+#undef ATTN9F
+                return;
+            }
             if (share) {
-                ax.xs = xs_; ax.epoch = (const unsigned*)(d_state_ + 4 + n_ctx_); ax.err = qa_err_; ax.layer = cur_layer_ & 255;
                 if (hd == 128) ATTN9D(128, true); else ATTN9D(64, true);
             } else if (hd == 128) ATTN9D(128, false); else ATTN9D(64, false);
 #undef ATTN9D
@@ -1384,6 +1398,12 @@ int Engine::debug_read_kv(int layer, uint16_t* k, uint16_t* v) {
 
 // Test hook: the attention output rows of the last chunk launched (last layer of this stage), n_tok x n_embd floats.
 int Engine::debug_read_attn_out(float* dst, int n_tok) {
+    if (n_tok == 0 && attn_out_) {   // the last token step's row (its last layer's attention output)
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemcpy(dst, attn_out_, (size_t)hp_.n_embd * 4, hipMemcpyDeviceToHost);
+        return hp_.n_embd;
+    }
     if (!attn_out_b_ || n_tok < 1 || n_tok > pf_cap_) return -1;
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);

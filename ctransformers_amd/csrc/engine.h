@@ -48,6 +48,7 @@ struct Layer {
 
 long long pg_launches();   // test hook: prompt-chunk launches of kernels_pg.h issued by this process
 long long kq_launches();   // test hook: K-quant decode mat-vec launches (kernels_v9.h) issued by this process
+long long attn_free_launches();   // test hook: order-free decode attention launches (kernels_attn9.h:attn_decode9_free_kernel) issued by this process
 long long mm8_launches();  // test hook: prompt-chunk launches of the order-free kernels (kernels_mm8.h) issued by this process
 
 // Process-wide and recursive: a stream capture (hipStreamCaptureModeThreadLocal) tolerates other threads' launches on their own streams, but not an operation
@@ -285,6 +286,7 @@ class Engine {
     uint32_t* xq_ = nullptr;          // fused QKV + attention launch: the KV-head groups' exchange records (kernels_qa9.h)
     int* qa_err_ = nullptr;           // device view of the pinned word h_scalars_[n_ctx_ + 14] a timed-out sweep raises
     bool fuse_qa_ = true;             // CT_AMD_FUSE_QA (read at load)
+    bool attn_free_ = false;          // CT_AMD_DECODE_ATTN=fast (opt-in): order-free V*P in the long-context decode attention (kernels_attn9.h:attn_decode9_free_kernel)
     bool attn_share_ = true;          // CT_AMD_ATTN_SHARE: long-context decode attention shares one score row per head (kernels_attn9.h)
     uint32_t* xs_ = nullptr;          // the shared score rows: [n_head][n_ctx] granules
     int cur_layer_ = 0;               // layer whose launches are being issued (tags of the in-launch exchanges)

@@ -899,7 +899,11 @@ bool Engine::warm_up(std::string& err) {
 
 bool Engine::alloc_state(std::string& err) {
     const int E = hp_.n_embd, G = hp_.n_embd_gqa(), F = hp_.n_ff, V = hp_.n_vocab;
-    v_stride_ = (n_ctx_ + 31) / 32 * 32;  // V rows (one per channel) start 16-byte aligned
+    // V rows (one per channel): 16-byte aligned, and NOT a power of two apart — with a context of 2^k positions the rows of a head would sit exactly
+    // 2^(k+1) bytes apart and a token step's short reads of all of them (4096 rows x 280 bytes at position 140 of a 7B) fall on a fraction of the
+    // memory channels: 64 halves of padding measured +0.9 % decode on the 7B (763.9 -> 771.4 tok/s; 32 .. 320 all within 0.3 % of it;
+    // profiles/r06_v_row_padding.txt).  CT_AMD_V_PAD overrides (halves, multiples of 32).
+    v_stride_ = (n_ctx_ + 31) / 32 * 32 + std::max(0, env_int("CT_AMD_V_PAD", 64)) / 32 * 32;
     const size_t k_elems = (size_t)(l1_ - l0_) * n_ctx_ * G, v_elems = (size_t)(l1_ - l0_) * v_stride_ * G;
     if (!dev_alloc(dev_allocs_, &kcache_, k_elems, err) || !dev_alloc(dev_allocs_, &vcache_, v_elems + 64, err)) return false;
     HIP_OK(hipMemset(kcache_, 0, k_elems * 2));
@@ -924,6 +928,10 @@ bool Engine::alloc_state(std::string& err) {
         HIP_OK(hipMemset(xq_, 0, (words + 16) * 4));
     }
     attn_share_ = env_int("CT_AMD_ATTN_SHARE", 1) != 0 && !hp_.legacy();
+    {   // order-free V*P of the long-context decode attention: opt-in, like the order-free prompt kernels (the default stays bit-identical)
+        const char* da = getenv("CT_AMD_DECODE_ATTN");
+        attn_free_ = da && (!strcmp(da, "fast") || !strcmp(da, "1")) && !hp_.legacy();
+    }
     if (attn_share_ && n_ctx_ > 1024 && n_ctx_ <= kMaxCtxFused) {   // (the deep form of the decode attention: contexts above 1024)
         const size_t words = (size_t)hp_.n_head * n_ctx_ * 2;
         if (!dev_alloc(dev_allocs_, &xs_, words + 16, err)) return false;

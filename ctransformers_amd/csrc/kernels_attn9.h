@@ -321,3 +321,251 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int
     if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
     if (trace) tr[6] = clock64_dev();
 }
+
+// ---- order-free decode attention (CT_AMD_DECODE_ATTN=fast, opt-in; long-context form only) ----
+// The bit-identical kernel above keeps the reference's V*P order: per (head, channel) ONE chain of fma steps over the positions in file order,
+// so one wave walks a channel group's whole V slice (62 dependent ring steps at 2001 positions, three memory round trips behind the softmax).
+// Here every rounding POINT of the reference stays — the K.Q dot per position in its lane order (scores bit-identical), the fp16 input of the
+// exp table, the exact double sum, the fp16 probabilities, f32 fma steps of 32 positions, the scalar double tail — and only the ORDER in which
+// the 32-position steps of a channel meet is given up: the workgroup's eight waves are ALL score waves and ALL V*P waves; wave (cg, s) owns
+// the chunk pairs s, s + SPL, s + 2 SPL, .. of channel group cg (SPL = 8 / channel groups) and requests its first sixteen chunks right behind its K rows
+// — at 2001 positions that is the workgroup's whole V slice, landed long before the probabilities exist; the SPL partial sums of a channel meet in
+// slice order, in double, and the scalar tail (its own chain from 0.0, run by the last slice's wave beside the others' fma steps) is added last.
+// Same grid, same workgroup map, same shared score row (SHARE) and the same residency contract as attn_decode9_kernel<.., SHARE>.
+// Measured at 2001 positions (7B / 70B widths, us per launch; bit-identical form 15.0 / 14.2): single chunks per wave 14.8 / 13.7; chunk PAIRS (2 m, 2 m + 1:
+// the two halves of a 128-byte line of a V row, what is built) 14.3 / 13.2; the non-temporal hint on the K / V requests 16.6 / 17.5 (the two half-line
+// requests of a line no longer meet in L1).  Where the time is (in-kernel stamps, profiles/r06_decode_attn_free.txt): the K / V bytes arrive at
+// ~4 TB/s (7B: 128 KB per CU; 70B widths: 256 KB per CU, seven eighths of it out of L2 — every query head of a group fetches the group's rows again),
+// then the row gather (2.5 us), the softmax with its table look-ups (2 us), V*P (1 us) and the meeting of the slices (1.2 us).
+template <int HD, bool SHARE>
+__global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0, int ng, int n_head, int n_head_kv, const AttnArgsX a) {
+    kernarg_touch<24 + sizeof(AttnArgsX)>();
+    constexpr int NWV = 8, NT = 64 * NWV, NQ = NT / 4;   // every wave computes scores: 128 positions per slot
+    constexpr int NC = HD / 32, PB = 2, VB = 16;
+    CT_DYN_SMEM(smem_raw);
+    float* prob = reinterpret_cast<float*>(smem_raw);
+    __shared__ double red[NWV];
+    __shared__ float redf[NWV];
+    __shared__ float part[NWV][16];
+    __shared__ double tailp[4][16];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = uniform_int(wave_id()), j = tid & 3, quad = tid >> 2;
+    int h, grp;
+    {
+        const int b = (int)blockIdx.x, rep = n_head / n_head_kv;
+        if ((n_head_kv & 7) == 0) {
+            const int i = b >> 3, per = rep * ng;
+            const int hkv = (b & 7) + 8 * (i / per), r = (i / ng) % rep;
+            h = hkv * rep + r; grp = i % ng;
+        } else { h = b / ng; grp = b - h * ng; }
+    }
+    const bool trace = a.trace && blockIdx.x == 0 && lane == 0;   // measurement only (tools/attn_trace_ctx.py): stamps of workgroup 0's waves
+    unsigned long long* tr = a.trace + 16 * wv;
+    if (trace) tr[0] = clock64_dev();
+    const int hk = h / (n_head / n_head_kv);
+    const int CG = HD / ng / 16, SPL = NWV / CG;   // channel groups of 16 in this workgroup (1, 2 or 4), position slices per group
+    const int cg = wv % CG, s = wv / CG;
+    // ---- requests that do not depend on the cursor: the query, this wave's first VB chunks of V, (no SHARE) the first K rows ----
+    const uint16_t* kbase = a.kcache + (size_t)hk * a.n_ctx * HD + 8 * j;
+    const int d = grp * (HD / ng) + cg * 16 + (lane >> 2);
+    const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
+    u32x4 vb[VB], kb[PB * NC], qv[NC], tailv[4];
+    auto chunk_of = [&](int k) __attribute__((always_inline)) { return 2 * (s + SPL * (k >> 1)) + (k & 1); };   // this wave's k-th chunk: pairs 2 m, 2 m + 1
+    // Request order = return order (a wave's loads come back in issue order): the query and the K rows are what the first dependent work waits for, so
+    // they go out in front of the bulk of V; only VSPEC chunks of V leave before the cursor is known (they cost nothing: the scalar load is in flight).
+    constexpr int VSPEC = 4;
+    {
+        const uint16_t* qrow = a.q_f16 + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qv[c] = ld16(qrow + 32 * c + 8 * j);
+    }
+    if constexpr (!SHARE) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            int p = u * NQ + quad;
+            p = p < a.n_ctx ? p : a.n_ctx - 1;
+            const uint16_t* krow = kbase + (size_t)p * HD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kb[u * NC + c] = ld16(krow + 32 * c);
+        }
+    }
+    auto vreq = [&](int u) __attribute__((always_inline)) {
+        const int off = 32 * chunk_of(u);
+        vb[u] = ld16(vrow + (off + 32 <= a.v_stride ? off : a.v_stride - 32) + 8 * j);
+    };
+#pragma unroll
+    for (int u = 0; u < VSPEC; ++u) vreq(u);
+    int cur[4];
+    uint32_t tag = 0u;
+    if constexpr (SHARE) tag = (((uint32_t)sload_i32x4_and(cur0, cur, (const int*)a.epoch) + 1u) << 8) | (uint32_t)a.layer;
+    else sload_i32x4(cur0, cur);
+    const int n_kv = cur[1] + 1;
+    int n_tot = cur[2];
+    if (cur[3] > 0) {   // the reference batch this token belongs to (attn_fused_exact_kernel)
+        const int idx = cur[0], base = cur[1] - cur[0];
+        const int end = (idx / cur[3] + 1) * cur[3], n_eval = n_tot - base;
+        n_tot = base + (end < n_eval ? end : n_eval);
+    }
+    const int np = n_tot & ~31, nl = n_kv - np, nchunk = np >> 5;
+    const int last_c = np >= 32 ? np - 32 : 0, last_p = n_kv - 1;
+    const int per = SHARE ? (n_kv + ng - 1) / ng : n_kv;
+    const int p0 = SHARE ? grp * per : 0, p1 = SHARE ? (p0 + per < n_kv ? p0 + per : n_kv) : n_kv;
+    if constexpr (SHARE) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int p = p0 + u * NQ + quad;
+            const uint16_t* krow = kbase + (size_t)(p < last_p ? p : last_p) * HD;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kb[u * NC + c] = ld16(krow + 32 * c);
+        }
+    }
+    // The exp table's negative half (64 KB; every softmax input is <= 0) is touched once per XCD — workgroups 0 .. 7 sit on the eight XCDs — so that
+    // the look-ups behind the row maximum find it in their L2: between two layers 100+ MB of weights and K / V rows have passed through it.
+    const uint32_t warm = *(const uint32_t*)(a.exp_tab + 0x8000 + (blockIdx.x < 8u ? 64 * tid : 0));   // (unconditional: no branch around a load)
+#pragma unroll
+    for (int u = VSPEC; u < VB; ++u) vreq(u);
+    if (s == SPL - 1) {   // the tail positions' values (the row is padded: np + 31 stays inside the cache); the last slice's wave runs the tail
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tailv[c] = ld16(vrow + np + 8 * c);
+    }
+    if (trace) { tr[1] = clock64_dev(); tr[7] = (unsigned long long)n_kv; }
+    // ---- scores (per position: the bit-identical kernel's) ----
+    float mx = -INFINITY;
+    {
+        auto slot = [&](int u, int base, auto REQ) __attribute__((always_inline)) {
+            const int p = base + u * NQ + quad;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fma8_hh(acc, kb[u * NC + c], qv[c]);
+            if constexpr (decltype(REQ)::value) {
+                const int pn = p + NQ * PB;
+                const uint16_t* krow = kbase + (size_t)(pn < last_p ? pn : last_p) * HD;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kb[u * NC + c] = ld16(krow + 32 * c);
+            }
+            const float sc = f16dot_reduce_exact(acc, j) * a.kq_scale;
+            if constexpr (SHARE) {
+                if (p < p1 && j == 0) st_granule(a.xs + ((size_t)h * a.n_ctx + p) * 2, f32_to_bits(sc), tag);
+            } else if (p < n_kv) {
+                mx = fmaxf(mx, sc);
+                if (j == 0) prob[p] = sc;
+            }
+        };
+        int base = p0;
+        for (; base + NQ * PB < p1; base += NQ * PB) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) slot(u, base, A9Req<true>{});
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) slot(u, base, A9Req<false>{});
+    }
+    if (trace) tr[2] = clock64_dev();
+    if constexpr (SHARE) {   // gather the head's row (attn_decode9_kernel<.., SHARE>)
+        const uint32_t* row = a.xs + (size_t)h * a.n_ctx * 2;
+        const unsigned long long t0 = wall_ticks();
+        (void)t0;
+        bool gave_up = false;
+        for (int i0 = 0; i0 < n_kv && !gave_up; i0 += 8 * NT) {
+            for (;;) {
+                uint32_t dat[8], tg[8];
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * NT + tid;
+                    dat[u] = 0u; tg[u] = tag;
+                    if (i < n_kv) ld_granule(row + 2 * i, dat[u], tg[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ok = ok && tg[u] == tag;
+                if (__ballot(!ok) == 0ull) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * NT + tid;
+                        if (i < n_kv) { const float sc = bits_to_f32(dat[u]); prob[i] = sc; mx = fmaxf(mx, sc); }
+                    }
+                    break;
+                }
+#ifdef CT_EMU
+                emu::spin_yield();
+#else
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_ticks() - t0 > 2000000ull) { if (lane == 0) *a.err = 1; gave_up = true; break; }
+#endif
+            }
+        }
+    }
+    mx = fmaxf(mx, lane_xor1(mx)); mx = fmaxf(mx, lane_xor2(mx));
+    mx = fmaxf(mx, lane_xor4(mx)); mx = fmaxf(mx, lane_xor8(mx)); mx = fmaxf(mx, lane_xor16(mx)); mx = fmaxf(mx, lane_xor32(mx));
+    if (lane == 0) redf[wv] = mx;
+    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, redf[w]);
+    if (trace) tr[3] = clock64_dev();
+#ifndef CT_EMU
+    asm volatile("" :: "v"(warm));   // (the touch is a real load: its value is "used" here, long after it has landed)
+#else
+    (void)warm;
+#endif
+    // ---- softmax: fp16 exp table, exact double sum, fp16 probabilities ----
+    double sum = 0.0;
+    constexpr int SB = 4;
+    for (int i0 = 0; i0 < n_kv; i0 += NT * SB) {
+        uint16_t e16[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { const int i = i0 + u * NT + tid; e16[u] = i < n_kv ? a.exp_tab[f32_to_f16_bits(prob[i] - mx)] : (uint16_t)0; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * NT + tid;
+            if (i < n_kv) { const float e = f16_bits_to_f32(e16[u]); prob[i] = e; sum += (double)e; }
+        }
+    }
+    sum = wave_sum_fast(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) tot += red[w];
+    const float inv = (float)(1.0 / tot);
+    for (int i = tid; i < n_kv; i += NT) prob[i] = f16_bits_to_f32(f32_to_f16_bits(prob[i] * inv));
+    for (int i = n_kv + tid; i < np; i += NT) prob[i] = 0.0f;   // masked columns of this batch
+    __syncthreads();
+    if (trace) tr[4] = clock64_dev();
+    // ---- V*P: this wave's chunks s, s + SPL, .. of its sixteen channels (a quad per channel) ----
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int npair = nchunk > 2 * s ? (nchunk - 2 * s + 2 * SPL - 1) / (2 * SPL) : 0;   // pairs of this wave whose first chunk exists
+    const int nk = npair > 0 ? 2 * npair - (2 * (s + SPL * (npair - 1)) + 1 >= nchunk ? 1 : 0) : 0;   // its chunks
+    auto step = [&](int u, int k) __attribute__((always_inline)) {
+        const float* pr = &prob[32 * chunk_of(k) + 8 * j];
+        float pc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) pc[l] = pr[l];
+        fma8_hf(acc, vb[u], pc);
+    };
+    int k0 = 0;
+    for (; k0 + VB < nk; k0 += VB) {   // every chunk of this round exists and more follow: each slot is re-requested (clamped to the last chunk)
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            step(u, k0 + u);
+            const int in = 32 * chunk_of(k0 + u + VB);
+            vb[u] = ld16(vrow + (in < last_c ? in : last_c) + 8 * j);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VB; ++u)
+        if (k0 + u < nk) step(u, k0 + u);
+    const float res = f16dot_reduce_exact(acc, j);
+    if (trace) tr[5] = clock64_dev();
+    if (j == 0) part[wv][lane >> 2] = res;
+    if (s == SPL - 1) {   // the scalar tail: its own chain from 0.0 (with no 32-position step at all that IS the reference's sum)
+        double tl = 0.0;
+        if (nl > 0) tl = f16_tail32(tl, tailv, prob + np, nl);
+        if (j == 0) tailp[cg][lane >> 2] = tl;
+    }
+    __syncthreads();
+    if (s != 0) return;
+    double sumf = (double)part[cg][lane >> 2];
+    for (int t = 1; t < SPL; ++t) sumf += (double)part[cg + CG * t][lane >> 2];
+    sumf += tailp[cg][lane >> 2];
+    if (j == 0) a.out[(size_t)h * HD + d] = (float)sumf;
+    if (trace) tr[6] = clock64_dev();
+}

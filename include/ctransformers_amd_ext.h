@@ -75,8 +75,12 @@ double ctamd_stage_issue_us(ctransformers_llm* llm, int stage, long long* evals)
      the eval that hit it still returned true.
    ctamd_falcon_fold: 1 if this (falcon) handle rotates / stores Q, K, V in the QKV launch's epilogue (attn_qkv rows reordered at load).
    ctamd_debug_read_kv: fp16 K rows [n_head_kv][n_ctx][head_dim] and V rows [n_embd_gqa][stride] of one layer to host memory; returns the V row stride.
-   ctamd_debug_read_attn_out: the attention output rows (n_tok x n_embd floats) of the last prompt chunk launched; returns n_embd. */
+   ctamd_debug_read_attn_out: the attention output rows (n_tok x n_embd floats) of the last prompt chunk launched; returns n_embd.
+     n_tok = 0: the one row of the last token step (its last layer's attention output).
+   ctamd_attn_free_launches: launches of the order-free long-context decode attention (csrc/kernels_attn9.h:attn_decode9_free_kernel;
+     CT_AMD_DECODE_ATTN=fast, opt-in) issued by this process. */
 long long ctamd_mm8_launches(void);
+long long ctamd_attn_free_launches(void);
 long long ctamd_resident_replays(ctransformers_llm* llm);
 int ctamd_falcon_fold(ctransformers_llm* llm);
 int ctamd_debug_read_kv(ctransformers_llm* llm, int layer, unsigned short* k, unsigned short* v);

@@ -28,7 +28,7 @@ def _mm8_launches(m):
 def _kv(m, layer, n_ctx, G, head_dim, n_pos):
     """fp16 K rows [kv head][pos][head_dim] and V rows [channel][pos] of one layer, the first n_pos positions."""
     k = np.zeros(n_ctx * G, np.uint16)
-    v = np.zeros(((n_ctx + 31) // 32 * 32) * G, np.uint16)
+    v = np.zeros(((n_ctx + 31) // 32 * 32 + 512) * G, np.uint16)   # (the library pads the rows: it returns the stride)
     f = m._lib.ctamd_debug_read_kv
     f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     vs = f(m._llm, layer, k.ctypes.data, v.ctypes.data)

@@ -23,10 +23,10 @@ def worker(mode, shape, ftype, n_prompt):
     for il in LAYERS:
         if il >= hp["n_layer"]:
             continue
-        k = np.zeros(512 * G, np.uint16); v = np.zeros(512 * G, np.uint16)
+        k = np.zeros(512 * G, np.uint16); v = np.zeros((512 + 512) * G, np.uint16)   # (rows are padded: the call returns the stride)
         vs = f(m._llm, il, k.ctypes.data, v.ctypes.data)
         out["k%d" % il] = k.reshape(-1, 512, hp["n_embd"] // hp["n_head"])[:, :n_prompt, :].copy()
-        out["v%d" % il] = v.reshape(G, vs)[:, :n_prompt].copy()
+        out["v%d" % il] = v[:G * vs].reshape(G, vs)[:, :n_prompt].copy()
     np.savez("/tmp/mm8_kv_%s.npz" % mode, **out)
 
 
