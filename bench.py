@@ -45,7 +45,7 @@ from ctransformers_amd import measure
 from tools import synth  # noqa: E402
 from ctransformers_amd.llm import LLM, Config  # noqa: E402
 
-N_PROMPT, N_DECODE, N_CTX = 128, 256, 512
+N_PROMPT, N_DECODE, N_CTX = 128, 256, int(os.environ.get("CTAMD_BENCH_CTX", "512"))   # (CTAMD_BENCH_CTX: layout experiments only; the headline is 512)
 def _ref_quantizer():
     """BASELINE.md 3 quantizes with ggml_quantize_chunk: where the reference build travelled with the snapshot (oracle/_ref exports it) the
     block pools of the synthetic files come from it; else from this repo's numpy quantizers (tools/synth.py)."""
