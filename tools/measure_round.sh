@@ -42,6 +42,7 @@ timeout 300 python tools/gpu_sites.py final > $O/v9_sites_7b_q4km.json 2> $O/sit
 ( timeout 300 python tools/gpu_trace.py; timeout 300 python tools/qa_trace.py ) > $O/v9_inkernel_trace_7b_q4km.txt 2> $O/trace.err
 ( timeout 300 python tools/ctx_scaling.py llama-7b-2l; timeout 300 python tools/ctx_scaling.py; echo "CT_AMD_ATTN_SHARE=0"; CT_AMD_ATTN_SHARE=0 timeout 300 python tools/ctx_scaling.py llama-7b-2l; CT_AMD_ATTN_SHARE=0 timeout 300 python tools/ctx_scaling.py ) > $O/ctx_scaling.txt 2>&1
 timeout 300 python tools/prefill_sweep.py $M 8 16 32 64 128 > $O/prefill_sweep_7b_q4km.txt 2>&1
+( timeout 600 python tools/ctx_scaling_free.py; timeout 300 python tools/attn_trace_free.py ) 2>&1 | grep -v amdgpu.ids > $O/decode_attn_free.txt   # order-free decode attention (CT_AMD_DECODE_ATTN=fast)
 timeout 600 python tools/legacy_speed.py > $O/legacy_arch_speed.txt 2>&1
 # the order-free prompt form (CT_AMD_PREFILL=fast): rates against the bit-identical form, kernel shares, SQ counters at 128- and 512-token prompts
 ( for n in 128 512 2048; do timeout 300 python tools/mm8_check.py llama-2-7b Q4_K_M $n 8 2304; done
