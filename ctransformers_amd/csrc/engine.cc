@@ -700,6 +700,7 @@ void Engine::launch_attention(uint16_t* kc, uint16_t* vc, int nt) {
                 if (hd == 128) { if (share) ATTN9F(128, true); else ATTN9F(128, false); }
                 else { if (share) ATTN9F(64, true); else ATTN9F(64, false); }
 #undef ATTN9FV
+#undef ATTN9FV
 #undef ATTN9F
                 return;
             }

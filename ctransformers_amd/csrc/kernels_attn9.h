@@ -328,15 +328,18 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int
 // Here every rounding POINT of the reference stays — the K.Q dot per position in its lane order (scores bit-identical), the fp16 input of the
 // exp table, the exact double sum, the fp16 probabilities, f32 fma steps of 32 positions, the scalar double tail — and only the ORDER in which
 // the 32-position steps of a channel meet is given up: the workgroup's eight waves are ALL score waves and ALL V*P waves; wave (cg, s) owns
-// the chunk pairs s, s + SPL, s + 2 SPL, .. of channel group cg (SPL = 8 / channel groups) and requests its first sixteen chunks right behind its K rows
-// — at 2001 positions that is the workgroup's whole V slice, landed long before the probabilities exist; the SPL partial sums of a channel meet in
+// the chunk pairs s, s + SPL, s + 2 SPL, .. of channel group cg (SPL = 8 / channel groups) and requests its first sixteen chunks as soon as its scores
+// are computed — at 2001 positions that is the workgroup's whole V slice, landed before the probabilities exist; the SPL partial sums of a channel meet in
 // slice order, in double, and the scalar tail (its own chain from 0.0, run by the last slice's wave beside the others' fma steps) is added last.
 // Same grid, same workgroup map, same shared score row (SHARE) and the same residency contract as attn_decode9_kernel<.., SHARE>.
-// Measured at 2001 positions (7B / 70B widths, us per launch; bit-identical form 15.0 / 14.2): single chunks per wave 14.8 / 13.7; chunk PAIRS (2 m, 2 m + 1:
-// the two halves of a 128-byte line of a V row, what is built) 14.3 / 13.2; the non-temporal hint on the K / V requests 16.6 / 17.5 (the two half-line
-// requests of a line no longer meet in L1).  Where the time is (in-kernel stamps, profiles/r06_decode_attn_free.txt): the K / V bytes arrive at
-// ~4 TB/s (7B: 128 KB per CU; 70B widths: 256 KB per CU, seven eighths of it out of L2 — every query head of a group fetches the group's rows again),
-// then the row gather (2.5 us), the softmax with its table look-ups (2 us), V*P (1 us) and the meeting of the slices (1.2 us).
+// Measured at 2001 positions (7B / 70B / Falcon-40B widths, us per launch, same box; bit-identical form 15.0 / 14.0 / 14.2): V requested at kernel entry,
+// single chunks per wave 14.8 / 13.7 / -; chunk PAIRS (2 m, 2 m + 1: the two halves of a 128-byte line of a V row) 14.3 / 13.2 / 13.6; pairs with the
+// non-temporal hint on the K / V requests 16.6 / 17.5 (the two half-line requests of a line no longer meet in L1); pairs requested behind the row gather
+// 14.0 / 12.9 / 13.2; pairs requested behind the wave's scores (what is built) 13.5 / 12.1 / 12.7; the same with four K-row slots per quad 13.6 / 12.3 / 12.3.
+// At 1025 positions the built form and the bit-identical one are level (11.0 / 10.5 / 10.6 against 10.7 / 11.2 / 10.8).  Where the rest of the time is
+// (in-kernel stamps, profiles/r06_decode_attn_free.txt): the K / V bytes arrive at ~4 TB/s (7B: 128 KB per CU; 70B widths: 256 KB per CU, seven eighths
+// of it out of L2 — every query head of a group fetches the group's rows again), then the row gather (2.5 us), the softmax with its table look-ups (2 us),
+// V*P (1 us) and the meeting of the slices (1.2 us).
 template <int HD, bool SHARE>
 __global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0, int ng, int n_head, int n_head_kv, const AttnArgsX a) {
     kernarg_touch<24 + sizeof(AttnArgsX)>();
@@ -370,9 +373,7 @@ __global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0,
     const uint16_t* vrow = a.vcache + ((size_t)hk * HD + d) * a.v_stride;
     u32x4 vb[VB], kb[PB * NC], qv[NC], tailv[4];
     auto chunk_of = [&](int k) __attribute__((always_inline)) { return 2 * (s + SPL * (k >> 1)) + (k & 1); };   // this wave's k-th chunk: pairs 2 m, 2 m + 1
-    // Request order = return order (a wave's loads come back in issue order): the query and the K rows are what the first dependent work waits for, so
-    // they go out in front of the bulk of V; only VSPEC chunks of V leave before the cursor is known (they cost nothing: the scalar load is in flight).
-    constexpr int VSPEC = 4;
+    // Request order: the query and the K rows first — they are what the first dependent work waits for; V follows behind the scores (below).
     {
         const uint16_t* qrow = a.q_f16 + (size_t)h * HD;
 #pragma unroll
@@ -392,8 +393,6 @@ __global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0,
         const int off = 32 * chunk_of(u);
         vb[u] = ld16(vrow + (off + 32 <= a.v_stride ? off : a.v_stride - 32) + 8 * j);
     };
-#pragma unroll
-    for (int u = 0; u < VSPEC; ++u) vreq(u);
     int cur[4];
     uint32_t tag = 0u;
     if constexpr (SHARE) tag = (((uint32_t)sload_i32x4_and(cur0, cur, (const int*)a.epoch) + 1u) << 8) | (uint32_t)a.layer;
@@ -421,8 +420,6 @@ __global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0,
     // The exp table's negative half (64 KB; every softmax input is <= 0) is touched once per XCD — workgroups 0 .. 7 sit on the eight XCDs — so that
     // the look-ups behind the row maximum find it in their L2: between two layers 100+ MB of weights and K / V rows have passed through it.
     const uint32_t warm = *(const uint32_t*)(a.exp_tab + 0x8000 + (blockIdx.x < 8u ? 64 * tid : 0));   // (unconditional: no branch around a load)
-#pragma unroll
-    for (int u = VSPEC; u < VB; ++u) vreq(u);
     if (s == SPL - 1) {   // the tail positions' values (the row is padded: np + 31 stays inside the cache); the last slice's wave runs the tail
 #pragma unroll
         for (int c = 0; c < 4; ++c) tailv[c] = ld16(vrow + np + 8 * c);
@@ -458,6 +455,11 @@ __global__ void __launch_bounds__(512) attn_decode9_free_kernel(const int* cur0,
 #pragma unroll
         for (int u = 0; u < PB; ++u) slot(u, base, A9Req<false>{});
     }
+    // The V chunks leave HERE, behind this wave's score computation: a CU keeps about 32 KB of requests in flight, and V requested at kernel entry (the
+    // first form of this kernel) took that budget from the K rows of the waves that start a little later — their scores, and with them the whole head's
+    // row gather, ended 4 000 cycles late.  Behind the scores the V bytes travel beside the gather and the softmax, which wait on latency, not bandwidth.
+#pragma unroll
+    for (int u = 0; u < VB; ++u) vreq(u);
     if (trace) tr[2] = clock64_dev();
     if constexpr (SHARE) {   // gather the head's row (attn_decode9_kernel<.., SHARE>)
         const uint32_t* row = a.xs + (size_t)h * a.n_ctx * 2;
