@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(MAXT) attn_decode9_kernel(const int* cur0, int
 // Measured at 2001 positions (7B / 70B / Falcon-40B widths, us per launch, same box; bit-identical form 15.0 / 14.0 / 14.2): V requested at kernel entry,
 // single chunks per wave 14.8 / 13.7 / -; chunk PAIRS (2 m, 2 m + 1: the two halves of a 128-byte line of a V row) 14.3 / 13.2 / 13.6; pairs with the
 // non-temporal hint on the K / V requests 16.6 / 17.5 (the two half-line requests of a line no longer meet in L1); pairs requested behind the row gather
-// 14.0 / 12.9 / 13.2; pairs requested behind the wave's scores (what is built) 13.5 / 12.1 / 12.7; the same with four K-row slots per quad 13.6 / 12.3 / 12.3.
+// 14.0 / 12.9 / 13.2; pairs requested behind the wave's scores (what is built) 13.5 / 12.1 / 12.7; the same with four K-row slots per quad 13.6 / 12.3 / 12.3; with FOUR score
+// waves of four slots (the other four waves wait at a barrier before their V requests) 13.3 / 11.7 / 12.8 — and 0.5 us slower at 1025 positions.
 // At 1025 positions the built form and the bit-identical one are level (11.0 / 10.5 / 10.6 against 10.7 / 11.2 / 10.8).  Where the rest of the time is
 // (in-kernel stamps, profiles/r06_decode_attn_free.txt): the K / V bytes arrive at ~4 TB/s (7B: 128 KB per CU; 70B widths: 256 KB per CU, seven eighths
 // of it out of L2 — every query head of a group fetches the group's rows again), then the row gather (2.5 us), the softmax with its table look-ups (2 us),
